@@ -38,6 +38,12 @@ extern "C" {
 
 #define SFMBA_ABI_VERSION 1
 
+#if defined(__GNUC__)
+#define SFMBA_API __attribute__((visibility("default")))
+#else
+#define SFMBA_API
+#endif
+
 /* ceres::TerminationType values the reference tests against (BA.cpp:182). */
 enum {
     SFMBA_CONVERGENCE    = 0,
@@ -112,11 +118,11 @@ typedef struct sfmba_iteration {
 
 typedef struct sfmba_problem sfmba_problem;   /* opaque, device-resident problem */
 
-void        sfmba_options_default(sfmba_options* opt);
-int         sfmba_abi_version(void);
-const char* sfmba_last_error(void);
+SFMBA_API void        sfmba_options_default(sfmba_options* opt);
+SFMBA_API int         sfmba_abi_version(void);
+SFMBA_API const char* sfmba_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime missing). */
-int         sfmba_device_count(void);
+SFMBA_API int         sfmba_device_count(void);
 
 /*
  * One-shot solve == the ceres::Problem build + ceres::Solve of BA.cpp:109-179.
@@ -124,7 +130,7 @@ int         sfmba_device_count(void);
  * shim applies the reference's "discard unless CONVERGENCE" rule (BA.cpp:182-185).
  * trace may be NULL; at most trace_cap rows are written, *trace_len receives the count.
  */
-int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3,
+SFMBA_API int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3,
                 int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                 double* focal, const sfmba_options* opt, sfmba_summary* summary,
                 sfmba_iteration* trace, int trace_cap, int* trace_len);
@@ -134,46 +140,46 @@ int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3,
  * across calls -- used by bench.py (inputs resident before the timed region) and by
  * the incremental caller (SfM.cpp:464-466 re-runs BA after every added view).
  */
-int  sfmba_problem_create(int device, int precision,
+SFMBA_API int  sfmba_problem_create(int device, int precision,
                           int n_cam, const double* cam6, int n_pt, const double* pt3,
                           int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                           double focal, sfmba_problem** out);
 /* Restore the parameters given at create time (device-to-device copy). */
-int  sfmba_problem_reset(sfmba_problem* p);
+SFMBA_API int  sfmba_problem_reset(sfmba_problem* p);
 /* Overwrite the current parameters from host arrays (full-size arrays, as at create). */
-int  sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double* pt3, double focal);
-int  sfmba_problem_solve(sfmba_problem* p, const sfmba_options* opt, sfmba_summary* summary,
+SFMBA_API int  sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double* pt3, double focal);
+SFMBA_API int  sfmba_problem_solve(sfmba_problem* p, const sfmba_options* opt, sfmba_summary* summary,
                          sfmba_iteration* trace, int trace_cap, int* trace_len);
-int  sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double* focal);
-void sfmba_problem_destroy(sfmba_problem* p);
+SFMBA_API int  sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double* focal);
+SFMBA_API void sfmba_problem_destroy(sfmba_problem* p);
 /* The HIP stream all kernels of this problem are launched on (hipStream_t as void*). */
-void* sfmba_problem_stream(sfmba_problem* p);
+SFMBA_API void* sfmba_problem_stream(sfmba_problem* p);
 /* Dimension of the reduced camera system: 6 * (#cameras with observations) + 1. */
-int  sfmba_problem_reduced_dim(const sfmba_problem* p);
+SFMBA_API int  sfmba_problem_reduced_dim(const sfmba_problem* p);
 
 /*
  * Kernel-level entry points (parity tests call these through the C ABI).
  *   residuals_out : [2*n_obs] in the caller's observation order
  *   cost_out      : 1/2 sum r^2
  */
-int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double* cost_out);
+SFMBA_API int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double* cost_out);
 /*
  * Jacobian blocks at the current parameters, UNSCALED, caller's observation order:
  *   jc [n_obs][2][6], jp [n_obs][2][3], jf [n_obs][2].  Any pointer may be NULL.
  */
-int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double* jf);
+SFMBA_API int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double* jf);
 /*
  * Damped, Jacobi-scaled reduced camera system at the current parameters for trust-region
  * radius `radius`:  S [dim*dim] row-major (symmetric, both triangles filled), rhs [dim],
  * scale [dim] = Jacobi column scaling of the reduced unknowns (cameras in ascending active
  * order, focal last).  jacobi_scaling follows opt (NULL = defaults).
  */
-int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, double radius,
+SFMBA_API int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, double radius,
                                 double* S, double* rhs, double* scale);
 /* Dense SPD solve on the device (the reduced-system solver in isolation): A [n*n] row-major
  * symmetric, b [n] -> x [n].  method = SFMBA_LINEAR_*.  Returns SFMBA_OK and *info = 0 on success,
  * *info = k > 0 if the leading minor of order k is not positive definite. */
-int sfmba_dense_spd_solve(int device, int n, const double* A, const double* b, double* x,
+SFMBA_API int sfmba_dense_spd_solve(int device, int n, const double* A, const double* b, double* x,
                           int method, double pcg_tol, int pcg_max_iters, int* info, int* iters);
 
 /*
@@ -184,14 +190,14 @@ int sfmba_dense_spd_solve(int device, int n, const double* A, const double* b, d
  * All buffers are DEVICE pointers owned by the problem (wrap them as torch tensors for
  * torch.distributed); everything is enqueued on sfmba_problem_stream().
  */
-int     sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt);
-int64_t sfmba_shard_reduce_len(const sfmba_problem* p);       /* doubles in reduce_buf */
-void*   sfmba_shard_reduce_buf(sfmba_problem* p);             /* packed partial S | rhs | scalars */
-void*   sfmba_shard_scalars_buf(sfmba_problem* p);            /* 8 doubles: trial cost, model change, norms */
-int     sfmba_shard_partial_build(sfmba_problem* p);          /* linearise own points, partial S/rhs/scalars */
-int     sfmba_shard_solve_update(sfmba_problem* p);           /* after all-reduce #1: solve, back-substitute, trial cost */
-int     sfmba_shard_finish(sfmba_problem* p, int* done);      /* after all-reduce #2: accept/reject, convergence */
-int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);
+SFMBA_API int     sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt);
+SFMBA_API int64_t sfmba_shard_reduce_len(const sfmba_problem* p);       /* doubles in reduce_buf */
+SFMBA_API void*   sfmba_shard_reduce_buf(sfmba_problem* p);             /* packed partial S | rhs | scalars */
+SFMBA_API void*   sfmba_shard_scalars_buf(sfmba_problem* p);            /* 8 doubles: trial cost, model change, norms */
+SFMBA_API int     sfmba_shard_partial_build(sfmba_problem* p);          /* linearise own points, partial S/rhs/scalars */
+SFMBA_API int     sfmba_shard_solve_update(sfmba_problem* p);           /* after all-reduce #1: solve, back-substitute, trial cost */
+SFMBA_API int     sfmba_shard_finish(sfmba_problem* p, int* done);      /* after all-reduce #2: accept/reject, convergence */
+SFMBA_API int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);
 
 #ifdef __cplusplus
 }

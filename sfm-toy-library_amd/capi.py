@@ -1,0 +1,198 @@
+"""ctypes binding of the C ABI in include/sfmba.h (libsfmba_hip.so, built from csrc/).
+
+This is the only way Python code (tests, bench.py, the sharded driver) reaches the product: through
+the same extern "C" entry points the C++ shim in host/ calls.  If the shared library has not been
+built, or no HIP device is present, calls fail loudly -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from .structs import SfmbaOptions, SfmbaSummary, SfmbaIteration
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsfmba_hip.so")
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+# every extern "C" symbol include/sfmba.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "sfmba_options_default", "sfmba_abi_version", "sfmba_last_error", "sfmba_device_count", "sfmba_solve",
+    "sfmba_problem_create", "sfmba_problem_reset", "sfmba_problem_set_params", "sfmba_problem_solve",
+    "sfmba_problem_get_params", "sfmba_problem_destroy", "sfmba_problem_stream", "sfmba_problem_reduced_dim",
+    "sfmba_problem_eval_residuals", "sfmba_problem_eval_jacobian", "sfmba_problem_build_reduced",
+    "sfmba_dense_spd_solve", "sfmba_shard_begin", "sfmba_shard_reduce_len", "sfmba_shard_reduce_buf",
+    "sfmba_shard_scalars_buf", "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish",
+    "sfmba_shard_end",
+]
+
+
+class SfmbaError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SfmbaError("%s is missing: build it with `make -C %s` (or __graft_entry__.build()); "
+                             "the MI355X back end has no CPU fallback" % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        L = C.CDLL(LIB_PATH)
+        L.sfmba_last_error.restype = C.c_char_p
+        L.sfmba_problem_stream.restype = C.c_void_p
+        L.sfmba_shard_reduce_buf.restype = C.c_void_p
+        L.sfmba_shard_scalars_buf.restype = C.c_void_p
+        L.sfmba_shard_reduce_len.restype = C.c_int64
+        for name in ("sfmba_problem_reset", "sfmba_problem_set_params", "sfmba_problem_solve", "sfmba_problem_get_params",
+                     "sfmba_problem_destroy", "sfmba_problem_stream", "sfmba_problem_reduced_dim",
+                     "sfmba_problem_eval_residuals", "sfmba_problem_eval_jacobian", "sfmba_problem_build_reduced",
+                     "sfmba_shard_begin", "sfmba_shard_reduce_len", "sfmba_shard_reduce_buf", "sfmba_shard_scalars_buf",
+                     "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish", "sfmba_shard_end"):
+            getattr(L, name).argtypes = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SfmbaError("sfmba rc=%d: %s" % (rc, (lib().sfmba_last_error() or b"").decode()))
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def device_count():
+    return int(lib().sfmba_device_count())
+
+
+def default_options(**overrides):
+    o = SfmbaOptions()
+    lib().sfmba_options_default(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _trace_rows(trace, n, cap):
+    return [trace[i].as_dict() for i in range(min(n, cap))]
+
+
+def solve(prob, opt=None, trace_cap=1024):
+    """One-shot sfmba_solve on host arrays.  Returns (cam6, pt3, focal, summary, trace); prob untouched."""
+    cam6, pt3 = _d(prob.cam6).copy(), _d(prob.pt3).copy()
+    oc, op, oxy = _i(prob.obs_cam), _i(prob.obs_pt), _d(prob.obs_xy)
+    focal = C.c_double(prob.focal)
+    opt = opt or default_options()
+    summ = SfmbaSummary()
+    trace = (SfmbaIteration * trace_cap)()
+    tl = C.c_int(0)
+    _check(lib().sfmba_solve(C.c_int(prob.n_cam), _p(cam6, _dp), C.c_int(prob.n_pt), _p(pt3, _dp), C.c_int64(prob.n_obs),
+                             _p(oc, _ip), _p(op, _ip), _p(oxy, _dp), C.byref(focal), C.byref(opt), C.byref(summ),
+                             trace, C.c_int(trace_cap), C.byref(tl)))
+    return cam6, pt3, focal.value, summ.as_dict(), _trace_rows(trace, tl.value, trace_cap)
+
+
+def dense_spd_solve(A, b, method=0, tol=1e-12, max_iters=0, device=0):
+    A, b = _d(A), _d(b)
+    n = b.shape[0]
+    x = np.zeros(n)
+    info, iters = C.c_int(0), C.c_int(0)
+    _check(lib().sfmba_dense_spd_solve(C.c_int(device), C.c_int(n), _p(A, _dp), _p(b, _dp), _p(x, _dp), C.c_int(method),
+                                       C.c_double(tol), C.c_int(max_iters), C.byref(info), C.byref(iters)))
+    return x, info.value, iters.value
+
+
+class Problem:
+    """Device-resident problem (sfmba_problem_*)."""
+
+    def __init__(self, prob, precision=0, device=0):
+        self.n_cam, self.n_pt, self.n_obs = prob.n_cam, prob.n_pt, prob.n_obs
+        cam6, pt3 = _d(prob.cam6), _d(prob.pt3)
+        oc, op, oxy = _i(prob.obs_cam), _i(prob.obs_pt), _d(prob.obs_xy)
+        self._h = C.c_void_p()
+        self._template = (cam6.copy(), pt3.copy())
+        _check(lib().sfmba_problem_create(C.c_int(device), C.c_int(precision), C.c_int(prob.n_cam), _p(cam6, _dp),
+                                          C.c_int(prob.n_pt), _p(pt3, _dp), C.c_int64(prob.n_obs), _p(oc, _ip), _p(op, _ip),
+                                          _p(oxy, _dp), C.c_double(prob.focal), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().sfmba_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self):
+        return lib().sfmba_problem_stream(self._h)
+
+    @property
+    def reduced_dim(self):
+        return int(lib().sfmba_problem_reduced_dim(self._h))
+
+    def reset(self):
+        _check(lib().sfmba_problem_reset(self._h))
+
+    def set_params(self, cam6, pt3, focal):
+        cam6, pt3 = _d(cam6), _d(pt3)
+        _check(lib().sfmba_problem_set_params(self._h, _p(cam6, _dp), _p(pt3, _dp), C.c_double(focal)))
+
+    def get_params(self):
+        cam6, pt3 = self._template[0].copy(), self._template[1].copy()
+        focal = C.c_double(0.0)
+        _check(lib().sfmba_problem_get_params(self._h, _p(cam6, _dp), _p(pt3, _dp), C.byref(focal)))
+        return cam6, pt3, focal.value
+
+    def solve(self, opt=None, trace_cap=1024):
+        opt = opt or default_options()
+        summ = SfmbaSummary()
+        trace = (SfmbaIteration * trace_cap)()
+        tl = C.c_int(0)
+        _check(lib().sfmba_problem_solve(self._h, C.byref(opt), C.byref(summ), trace, C.c_int(trace_cap), C.byref(tl)))
+        return summ.as_dict(), _trace_rows(trace, tl.value, trace_cap)
+
+    def eval_residuals(self):
+        res = np.zeros(2 * self.n_obs)
+        cost = C.c_double(0.0)
+        _check(lib().sfmba_problem_eval_residuals(self._h, _p(res, _dp), C.byref(cost)))
+        return res.reshape(-1, 2), cost.value
+
+    def eval_jacobian(self):
+        n = self.n_obs
+        jc, jp, jf = np.zeros(12 * n), np.zeros(6 * n), np.zeros(2 * n)
+        _check(lib().sfmba_problem_eval_jacobian(self._h, _p(jc, _dp), _p(jp, _dp), _p(jf, _dp)))
+        return jc.reshape(n, 2, 6), jp.reshape(n, 2, 3), jf.reshape(n, 2)
+
+    def build_reduced(self, radius, opt=None):
+        d = self.reduced_dim
+        S, rhs, scale = np.zeros(d * d), np.zeros(d), np.zeros(d)
+        opt = opt or default_options()
+        _check(lib().sfmba_problem_build_reduced(self._h, C.byref(opt), C.c_double(radius), _p(S, _dp), _p(rhs, _dp), _p(scale, _dp)))
+        return S.reshape(d, d), rhs, scale

@@ -1,0 +1,105 @@
+// ba_kernels.h -- host-visible declarations of the bundle-adjustment kernels (ba_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfmba {
+
+// Accumulator slots inside LMState::acc (zeroed by k_lm_control / hipMemsetAsync).
+enum {
+    ACC_TRIAL_COST = 0,   // sum r^2 at the trial point (x2 of the cost)
+    ACC_MODEL = 1,        // model_cost_change
+    ACC_STEP2 = 2,        // ||x - x_trial||^2
+    ACC_XNEW2 = 3,        // ||x_trial||^2
+    ACC_BAD_TRIAL = 4,    // != 0: non-finite residual at the trial point
+    ACC_GMAX = 5,         // max |g| (bit pattern, atomicMax)
+    ACC_BAD_LIN = 6,      // != 0: non-finite value in the linearisation
+    ACC_LIN_COST = 7,     // sum r^2 at the linearisation point
+    ACC_COUNT = 8
+};
+
+// Device-resident Levenberg-Marquardt state (TrustRegionMinimizer + LevenbergMarquardtStrategy
+// bookkeeping [Ceres-upstream]).  One instance per problem, in HBM.
+struct LMState {
+    int cur;                  // parameter buffer holding the accepted point (0/1)
+    int iter;                 // LM iterations taken
+    int termination;          // -1 running, else SFMBA_* termination type
+    int message;              // message id (host maps to text)
+    int consecutive_invalid;
+    int successful, unsuccessful, residual_evals, jacobian_evals, linear_iters;
+    int x_is_new;             // the current linearisation is at a freshly accepted point
+    int lin_info;             // dense solver status of this iteration (0 ok)
+    int last_step_successful;
+    int pad0;
+    double cost, x_norm, radius, decrease_factor, gmax;
+    double focal[2];
+    double fscale;            // Jacobi scale of the focal column
+    double acc[ACC_COUNT];
+    // options (copied from sfmba_options at solve start)
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double max_radius, min_radius, min_relative_decrease, min_diag, max_diag;
+    int max_consecutive_invalid;
+    int pad1;
+};
+
+enum {
+    MSG_NONE = 0, MSG_GRADIENT_TOL, MSG_PARAMETER_TOL, MSG_FUNCTION_TOL, MSG_MIN_RADIUS,
+    MSG_INVALID_STEPS, MSG_INITIAL_EVAL_FAILED, MSG_EVAL_FAILED, MSG_MAX_ITERS, MSG_MAX_TIME
+};
+
+struct TraceRow {   // same layout as sfmba_iteration
+    int iteration, step_is_valid, step_is_successful, linear_iters;
+    double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+};
+
+// Static structure of a problem, all device pointers (built once on the host, see sfmba_api.cpp).
+struct DeviceStructure {
+    int ncam, npt, nobs;      // active cameras / points, observations
+    int d, ld;                // reduced dim 6*ncam+1, padded leading dimension (multiple of 64)
+    const int* pt_ptr;        // [npt+1] point-major CSR
+    const int* obs_cam;       // [nobs] camera slot, point-major order (ascending inside a point)
+    const void* obs_xy;       // [nobs] float2 or double2, point-major order
+    const int* cam_ptr;       // [ncam+1] camera-major CSR
+    const int* cam_obs;       // [nobs] point-major position q of each camera-major entry
+    const int* cam_obs_pt;    // [nobs] point slot of that entry
+    int nchunk;
+    const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), window index}
+    int win_cams;             // cameras per LDS column window
+};
+
+struct DeviceBuffers {
+    double* cam[2];           // [ncam][6]
+    double* pts[2];           // [npt][3]
+    double* camtab[2];        // [ncam][CT_STRIDE]
+    double* steptab;          // [ncam][ST_STRIDE]
+    double* cscale;           // [6*ncam] Jacobi scale of the camera columns
+    double* pscale;           // [npt][3]
+    void* Y;                  // [nobs][YREC] float or double
+    double* pt_t;             // [npt][3] L^-1 b_p
+    double* pt_yf;            // [npt][3] L^-1 E_f
+    double* S;                // [ld*ld] reduced system: upper triangle of the row-major matrix
+    double* rhs;              // [ld]  (overwritten by the solution)
+    double* udiag;            // [ld]  diag(J~^T J~) of the reduced unknowns, undamped
+    double* bc;               // [ld]  scaled gradient of the reduced unknowns
+    LMState* st;
+    TraceRow* trace;
+    int trace_cap;
+};
+
+template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
+void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling);
+template <typename T> void launch_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_eval_residuals(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
+                                                 const int* perm, double* res_out, double* cost_out);
+template <typename T> void launch_eval_jacobian(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
+                                                const int* obs_pt, const int* perm, double* jc, double* jp, double* jf);
+void launch_mirror_scale(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* S_full, double* scale_out);
+
+size_t build_lds_bytes(const DeviceStructure& ds);
+
+}  // namespace sfmba

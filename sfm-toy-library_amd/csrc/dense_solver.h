@@ -1,0 +1,38 @@
+// dense_solver.h -- dense SPD solve of the reduced camera system on the device.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sfmba {
+
+constexpr int CHOL_NB = 64;
+
+// Workspace of the reduced-system solver (allocated once per problem).
+struct DenseSolver {
+    int ld = 0;               // padded dimension (multiple of CHOL_NB, > d)
+    int d = 0;                // true dimension
+    double* minv = nullptr;   // [ld/NB][NB*NB] inverse-transposed diagonal blocks (L_kk^-T)
+    double* y = nullptr;      // [ld] work vector of the back substitution
+    // PCG
+    double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
+    double* vec = nullptr;    // [6*ld] x r z p q b
+    double* binv = nullptr;   // [ld*6] inverses of the 6x6 diagonal blocks (+1x1 focal)
+    double* scal = nullptr;   // [8] rz, pq, bnorm2, rnorm2, ...
+    int* flags = nullptr;     // [4] done, iters
+    int* h_flags = nullptr;   // pinned host mirror
+};
+
+int  dense_solver_create(DenseSolver* ws, int d, int ld);
+void dense_solver_destroy(DenseSolver* ws);
+
+// Padded leading dimension for a reduced system of dimension d (room for the augmented rhs row).
+inline int dense_padded_dim(int d) { return ((d + 1 + CHOL_NB - 1) / CHOL_NB) * CHOL_NB; }
+
+// Cholesky: S holds the UPPER triangle of the row-major matrix (== lower triangle, column-major),
+// padded to ld with an identity diagonal.  rhs[0..d) is overwritten by the solution.
+// *info_dev (device int) is set to k>0 if the leading minor k is not positive definite.
+void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev);
+
+// Block-Jacobi PCG on the same storage.  Returns the number of iterations (host sync inside).
+int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev);
+
+}  // namespace sfmba

@@ -1,0 +1,681 @@
+// sfmba_api.hip -- C ABI of include/sfmba.h: problem structure build, HBM residency, LM driver.
+//
+// Host-side counterpart of what adjustBundle() does between BA.cpp:142 (AddResidualBlock loop) and
+// BA.cpp:179 (ceres::Solve): the observation list is regrouped once per problem (point-major CSR
+// for the point pass, camera-major CSR for the reduced-system pass), uploaded, and every LM
+// iteration is then a fixed sequence of kernels on one private HIP stream.  The accept/reject
+// logic runs on the device (k_lm_control); the host only reads the small LMState back once per
+// iteration to learn whether to stop.
+//
+// There is NO CPU fallback in this file: without a HIP device every entry point returns
+// SFMBA_ERR_NO_DEVICE.
+#include "../../include/sfmba.h"
+#include "ba_kernels.h"
+#include "dense_solver.h"
+#include "sfmba_device.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace sfmba;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int rc, const std::string& msg) { g_last_error = msg; return rc; }
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(SFMBA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+double now_seconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+const char* message_text(int id) {
+    switch (id) {
+        case MSG_GRADIENT_TOL: return "Gradient tolerance reached.";
+        case MSG_PARAMETER_TOL: return "Parameter tolerance reached.";
+        case MSG_FUNCTION_TOL: return "Function tolerance reached.";
+        case MSG_MIN_RADIUS: return "Minimum trust region radius reached.";
+        case MSG_INVALID_STEPS: return "Number of consecutive invalid steps more than max_num_consecutive_invalid_steps.";
+        case MSG_INITIAL_EVAL_FAILED: return "Initial residual and Jacobian evaluation failed.";
+        case MSG_EVAL_FAILED: return "Residual and Jacobian evaluation failed.";
+        case MSG_MAX_ITERS: return "Maximum number of iterations reached.";
+        case MSG_MAX_TIME: return "Maximum solver time reached.";
+        default: return "";
+    }
+}
+
+template <typename T> hipError_t dev_alloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1)); }
+
+template <typename T> hipError_t dev_upload(T** p, const std::vector<T>& v) {
+    hipError_t e = dev_alloc(p, v.size());
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(*p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+    return e;
+}
+
+__global__ void k_fill(double* p, size_t n, double v) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) p[e] = v;
+}
+
+}  // namespace
+
+struct sfmba_problem {
+    int device = 0;
+    int precision = SFMBA_PRECISION_F64;
+    hipStream_t stream = nullptr;
+    int n_cam_full = 0, n_pt_full = 0;
+    int64_t n_obs = 0;
+    std::vector<int> acam_id, apt_id;     // active slot -> caller index
+    std::vector<int> perm;                // point-major position -> caller observation index
+    DeviceStructure ds = {};
+    DeviceBuffers db = {};
+    DenseSolver solver;
+    // owned device arrays behind ds
+    int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;
+    int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
+    void* d_obs_xy = nullptr;
+    int4* d_chunks = nullptr;
+    double *d_cam0 = nullptr, *d_pts0 = nullptr;  // parameters given at create time
+    double focal0 = 0.0;
+    double *d_sys = nullptr;                      // S | rhs | udiag | bc (contiguous)
+    int* d_info = nullptr;
+    LMState* h_state = nullptr;                   // pinned
+    int cur = 0;                                  // which buffer holds the current parameters
+    double focal = 0.0;
+    bool empty = false;                           // no observations
+    // sharded-mode state
+    sfmba_options shard_opt;
+    bool shard_active = false;
+    double shard_t0 = 0.0;
+    int shard_phase = 0;
+};
+
+namespace {
+
+int check_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SFMBA_ERR_NO_DEVICE, "no HIP device available: the MI355X back end has no CPU fallback");
+    if (device < 0 || device >= n) return fail(SFMBA_ERR_INVALID_ARG, "device index out of range");
+    return SFMBA_OK;
+}
+
+void init_state(sfmba_problem* p, LMState& st, const sfmba_options& o) {
+    std::memset(&st, 0, sizeof(st));
+    st.cur = p->cur;
+    st.iter = 0;
+    st.termination = -1;
+    st.x_is_new = 1;
+    st.radius = o.initial_radius;
+    st.decrease_factor = 2.0;
+    st.focal[p->cur] = p->focal;
+    st.focal[p->cur ^ 1] = p->focal;
+    st.fscale = 1.0;
+    st.function_tolerance = o.function_tolerance;
+    st.gradient_tolerance = o.gradient_tolerance;
+    st.parameter_tolerance = o.parameter_tolerance;
+    st.max_radius = o.max_radius;
+    st.min_radius = o.min_radius;
+    st.min_relative_decrease = o.min_relative_decrease;
+    st.min_diag = o.min_lm_diagonal;
+    st.max_diag = o.max_lm_diagonal;
+    st.max_consecutive_invalid = o.max_consecutive_invalid_steps;
+}
+
+int upload_state(sfmba_problem* p, const LMState& st) {
+    *p->h_state = st;
+    HIP_TRY(hipMemcpyAsync(p->db.st, p->h_state, sizeof(LMState), hipMemcpyHostToDevice, p->stream));
+    return SFMBA_OK;
+}
+
+int download_state(sfmba_problem* p) {
+    HIP_TRY(hipMemcpyAsync(p->h_state, p->db.st, sizeof(LMState), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return SFMBA_OK;
+}
+
+int ensure_trace(sfmba_problem* p, int rows) {
+    if (rows <= p->db.trace_cap) return SFMBA_OK;
+    if (p->db.trace) (void)hipFree(p->db.trace);
+    p->db.trace = nullptr;
+    p->db.trace_cap = 0;
+    HIP_TRY(dev_alloc(&p->db.trace, (size_t)rows));
+    p->db.trace_cap = rows;
+    return SFMBA_OK;
+}
+
+template <typename T>
+void launch_linearise_setup(sfmba_problem* p, int jacobi) {
+    const size_t n = 6 * (size_t)p->ds.ncam;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
+    launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
+    launch_xnorm(p->stream, p->ds, p->db);
+    launch_iter0(p->stream, p->ds, p->db);
+    launch_colnorm<T>(p->stream, p->ds, p->db, jacobi);
+    launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
+}
+
+template <typename T>
+int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, sfmba_iteration* trace, int trace_cap, int* trace_len) {
+    sfmba_summary sum;
+    std::memset(&sum, 0, sizeof(sum));
+    if (trace_len) *trace_len = 0;
+    if (p->empty) {
+        sum.termination = SFMBA_CONVERGENCE;
+        std::snprintf(sum.message, sizeof(sum.message), "Function tolerance reached. No non-constant parameter blocks found.");
+        if (summary) *summary = sum;
+        return SFMBA_OK;
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    const int want_rows = std::min(std::max(o.max_iters, 0) + 2, 1 << 16);
+    int rc = ensure_trace(p, want_rows);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    const double t0 = now_seconds();
+
+    LMState st;
+    init_state(p, st, o);
+    rc = upload_state(p, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
+    launch_linearise_setup<T>(p, o.jacobi_scaling);
+
+    int term = -1, msg = MSG_NONE;
+    int host_iter = 0;
+    for (;;) {
+        if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
+        if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
+        launch_build<T>(p->stream, p->ds, p->db);
+        launch_finalize(p->stream, p->ds, p->db);
+        if (o.linear_solver == SFMBA_LINEAR_PCG) {
+            const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info);
+            if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+            sum.linear_iters += it;
+        } else {
+            dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info);
+        }
+        // hand the dense-solver status to the control kernel
+        HIP_TRY(hipMemcpyAsync(&p->db.st->lin_info, p->d_info, sizeof(int), hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
+        launch_update<T>(p->stream, p->ds, p->db);
+        launch_control(p->stream, p->ds, p->db);
+        rc = download_state(p);
+        if (rc) return rc;
+        host_iter = p->h_state->iter;
+        if (o.verbose) {
+            std::fprintf(stderr, "[sfmba] it %3d cost %.12e |g|inf %.3e radius %.3e term %d\n", p->h_state->iter, p->h_state->cost,
+                         p->h_state->gmax, p->h_state->radius, p->h_state->termination);
+        }
+        if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; break; }
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    rc = download_state(p);
+    if (rc) return rc;
+    const LMState& hs = *p->h_state;
+    p->cur = hs.cur;
+    p->focal = hs.focal[hs.cur];
+    sum.termination = term;
+    sum.iterations = hs.iter;
+    sum.successful_steps = hs.successful;
+    sum.unsuccessful_steps = hs.unsuccessful;
+    sum.residual_evals = hs.residual_evals;
+    sum.jacobian_evals = hs.jacobian_evals;
+    sum.final_cost = hs.cost;
+    sum.seconds = now_seconds() - t0;
+    std::snprintf(sum.message, sizeof(sum.message), "%s", message_text(msg));
+    // trace rows
+    const int rows = std::min(hs.iter + 1, p->db.trace_cap);
+    std::vector<TraceRow> tr((size_t)std::max(rows, 1));
+    HIP_TRY(hipMemcpy(tr.data(), p->db.trace, sizeof(TraceRow) * (size_t)rows, hipMemcpyDeviceToHost));
+    sum.initial_cost = rows > 0 ? tr[0].cost : hs.cost;
+    if (trace && trace_cap > 0) {
+        const int n = std::min(rows, trace_cap);
+        static_assert(sizeof(TraceRow) == sizeof(sfmba_iteration), "trace row layout");
+        std::memcpy(trace, tr.data(), sizeof(TraceRow) * (size_t)n);
+    }
+    if (trace_len) *trace_len = rows;
+    if (summary) *summary = sum;
+    return SFMBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sfmba_options_default(sfmba_options* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->max_iters = 500;               // BA.cpp:174
+    o->max_seconds = 10.0;            // BA.cpp:176
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->initial_radius = 1e4;
+    o->max_radius = 1e16;
+    o->min_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->jacobi_scaling = 1;
+    o->max_consecutive_invalid_steps = 5;
+    o->linear_solver = SFMBA_LINEAR_CHOLESKY;
+    o->precision = SFMBA_PRECISION_F64;
+    o->pcg_tolerance = 1e-10;
+    o->pcg_max_iters = 0;
+    o->verbose = 0;
+}
+
+int sfmba_abi_version(void) { return SFMBA_ABI_VERSION; }
+
+const char* sfmba_last_error(void) { return g_last_error.c_str(); }
+
+int sfmba_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void sfmba_problem_destroy(sfmba_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    dense_solver_destroy(&p->solver);
+    void* frees[] = { p->d_pt_ptr, p->d_obs_cam, p->d_cam_ptr, p->d_cam_obs, p->d_cam_obs_pt, p->d_obs_pt, p->d_obs_xy, p->d_chunks,
+                      p->d_cam0, p->d_pts0, p->d_sys, p->d_info, p->db.cam[0], p->db.cam[1], p->db.pts[0], p->db.pts[1],
+                      p->db.camtab[0], p->db.camtab[1], p->db.steptab, p->db.cscale, p->db.pscale, p->db.Y, p->db.pt_t, p->db.pt_yf,
+                      p->db.st, p->db.trace };
+    for (void* f : frees) if (f) (void)hipFree(f);
+    if (p->h_state) (void)hipHostFree(p->h_state);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int sfmba_problem_create(int device, int precision, int n_cam, const double* cam6, int n_pt, const double* pt3,
+                         int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                         double focal, sfmba_problem** out) {
+    if (!out) return fail(SFMBA_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_cam < 0 || n_pt < 0 || n_obs < 0 || n_obs >= (int64_t)1 << 31) return fail(SFMBA_ERR_INVALID_ARG, "bad sizes");
+    if (precision != SFMBA_PRECISION_F64 && precision != SFMBA_PRECISION_F32J) return fail(SFMBA_ERR_INVALID_ARG, "bad precision");
+    if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs > 0 && (!obs_cam || !obs_pt || !obs_xy)))
+        return fail(SFMBA_ERR_INVALID_ARG, "NULL array");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+
+    sfmba_problem* p = new sfmba_problem();
+    p->device = device;
+    p->precision = precision;
+    p->n_cam_full = n_cam; p->n_pt_full = n_pt; p->n_obs = n_obs;
+    p->focal0 = p->focal = focal;
+    struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
+
+    // ---- structure (host) ----
+    std::vector<int> cam_slot((size_t)n_cam, -1), pt_slot((size_t)n_pt, -1);
+    for (int64_t k = 0; k < n_obs; ++k) {
+        if (obs_cam[k] < 0 || obs_cam[k] >= n_cam || obs_pt[k] < 0 || obs_pt[k] >= n_pt)
+            return fail(SFMBA_ERR_INVALID_ARG, "observation index out of range");
+        cam_slot[obs_cam[k]] = 0;
+        pt_slot[obs_pt[k]] = 0;
+    }
+    for (int j = 0; j < n_cam; ++j) if (cam_slot[j] == 0) { cam_slot[j] = (int)p->acam_id.size(); p->acam_id.push_back(j); }
+    for (int i = 0; i < n_pt; ++i) if (pt_slot[i] == 0) { pt_slot[i] = (int)p->apt_id.size(); p->apt_id.push_back(i); }
+    const int ncam = (int)p->acam_id.size(), npt = (int)p->apt_id.size(), nobs = (int)n_obs;
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LMState), hipHostMallocDefault));
+    if (nobs == 0) {
+        p->empty = true;
+        guard.p = nullptr;
+        *out = p;
+        return SFMBA_OK;
+    }
+
+    std::vector<int> pt_ptr((size_t)npt + 1, 0);
+    for (int k = 0; k < nobs; ++k) pt_ptr[(size_t)pt_slot[obs_pt[k]] + 1]++;
+    for (int i = 0; i < npt; ++i) pt_ptr[(size_t)i + 1] += pt_ptr[i];
+    std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1);
+    std::vector<int> pm_cam((size_t)nobs), pm_pt((size_t)nobs);
+    p->perm.resize((size_t)nobs);
+    for (int k = 0; k < nobs; ++k) {
+        const int i = pt_slot[obs_pt[k]];
+        const int q = fill[i]++;
+        pm_cam[q] = cam_slot[obs_cam[k]];
+        pm_pt[q] = i;
+        p->perm[q] = k;
+    }
+    // ascending camera slot inside each point (stable insertion sort: segments are short)
+    for (int i = 0; i < npt; ++i) {
+        for (int a = pt_ptr[i] + 1; a < pt_ptr[(size_t)i + 1]; ++a) {
+            const int c = pm_cam[a], pk = p->perm[a];
+            int b = a - 1;
+            while (b >= pt_ptr[i] && pm_cam[b] > c) { pm_cam[b + 1] = pm_cam[b]; p->perm[b + 1] = p->perm[b]; --b; }
+            pm_cam[b + 1] = c; p->perm[b + 1] = pk;
+        }
+    }
+    std::vector<int> cam_ptr((size_t)ncam + 1, 0);
+    for (int q = 0; q < nobs; ++q) cam_ptr[(size_t)pm_cam[q] + 1]++;
+    for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] += cam_ptr[j];
+    std::vector<int> cfill(cam_ptr.begin(), cam_ptr.end() - 1);
+    std::vector<int> cam_obs((size_t)nobs), cam_obs_pt((size_t)nobs);
+    for (int q = 0; q < nobs; ++q) {
+        const int e = cfill[pm_cam[q]]++;
+        cam_obs[e] = q;
+        cam_obs_pt[e] = pm_pt[q];
+    }
+    // chunks of the camera pass: (camera, entry range, column window)
+    const int lds_budget_doubles = 7200;                       // 36*win_cams doubles <= ~56 KB
+    const int win_cams = std::max(1, std::min(ncam, lds_budget_doubles / 36));
+    const int nwin = (ncam + win_cams - 1) / win_cams;
+    int chunk_len = (int)std::max<int64_t>(256, ((int64_t)nobs + 1023) / 1024);
+    chunk_len = ((chunk_len + 255) / 256) * 256;
+    std::vector<int4> chunks;
+    for (int j = 0; j < ncam; ++j) {
+        for (int w = j / win_cams; w < nwin; ++w)
+            for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
+                int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = w;
+                chunks.push_back(c);
+            }
+    }
+
+    // ---- upload ----
+    HIP_TRY(dev_upload(&p->d_pt_ptr, pt_ptr));
+    HIP_TRY(dev_upload(&p->d_obs_cam, pm_cam));
+    HIP_TRY(dev_upload(&p->d_cam_ptr, cam_ptr));
+    HIP_TRY(dev_upload(&p->d_cam_obs, cam_obs));
+    HIP_TRY(dev_upload(&p->d_cam_obs_pt, cam_obs_pt));
+    HIP_TRY(dev_upload(&p->d_chunks, chunks));
+    {
+        std::vector<int> both((size_t)2 * nobs);
+        std::copy(pm_pt.begin(), pm_pt.end(), both.begin());
+        std::copy(p->perm.begin(), p->perm.end(), both.begin() + nobs);
+        HIP_TRY(dev_upload(&p->d_obs_pt, both));
+        p->d_perm = p->d_obs_pt + nobs;
+    }
+    if (precision == SFMBA_PRECISION_F32J) {
+        std::vector<float> xy((size_t)2 * nobs);
+        for (int q = 0; q < nobs; ++q) { xy[2 * (size_t)q] = (float)obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = (float)obs_xy[2 * (size_t)p->perm[q] + 1]; }
+        float* d = nullptr;
+        HIP_TRY(dev_upload(&d, xy));
+        p->d_obs_xy = d;
+    } else {
+        std::vector<double> xy((size_t)2 * nobs);
+        for (int q = 0; q < nobs; ++q) { xy[2 * (size_t)q] = obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = obs_xy[2 * (size_t)p->perm[q] + 1]; }
+        double* d = nullptr;
+        HIP_TRY(dev_upload(&d, xy));
+        p->d_obs_xy = d;
+    }
+    std::vector<double> cam0((size_t)6 * ncam), pts0((size_t)3 * npt);
+    for (int j = 0; j < ncam; ++j) std::memcpy(&cam0[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
+    for (int i = 0; i < npt; ++i) std::memcpy(&pts0[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
+    HIP_TRY(dev_upload(&p->d_cam0, cam0));
+    HIP_TRY(dev_upload(&p->d_pts0, pts0));
+
+    DeviceStructure& ds = p->ds;
+    ds.ncam = ncam; ds.npt = npt; ds.nobs = nobs;
+    ds.d = 6 * ncam + 1;
+    ds.ld = dense_padded_dim(ds.d);
+    ds.pt_ptr = p->d_pt_ptr; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
+    ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt;
+    ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks; ds.win_cams = win_cams;
+
+    DeviceBuffers& db = p->db;
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(dev_alloc(&db.cam[b], (size_t)6 * ncam));
+        HIP_TRY(dev_alloc(&db.pts[b], (size_t)3 * npt));
+        HIP_TRY(dev_alloc(&db.camtab[b], (size_t)CT_STRIDE * ncam));
+    }
+    HIP_TRY(dev_alloc(&db.steptab, (size_t)ST_STRIDE * ncam));
+    HIP_TRY(dev_alloc(&db.cscale, (size_t)6 * ncam));
+    HIP_TRY(dev_alloc(&db.pscale, (size_t)3 * npt));
+    const size_t ybytes = (size_t)nobs * YREC * (precision == SFMBA_PRECISION_F32J ? sizeof(float) : sizeof(double));
+    HIP_TRY(hipMalloc(&db.Y, ybytes));
+    HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
+    HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
+    const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld;
+    HIP_TRY(dev_alloc(&p->d_sys, sys_len));
+    db.S = p->d_sys;
+    db.rhs = db.S + (size_t)ds.ld * ds.ld;
+    db.udiag = db.rhs + ds.ld;
+    db.bc = db.udiag + ds.ld;
+    HIP_TRY(dev_alloc(&db.st, 1));
+    HIP_TRY(dev_alloc(&p->d_info, 1));
+    db.trace = nullptr; db.trace_cap = 0;
+    if (dense_solver_create(&p->solver, ds.d, ds.ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
+
+    // opt in to the dynamic LDS the camera pass needs
+    rc = sfmba_problem_reset(p);
+    if (rc) return rc;
+    guard.p = nullptr;
+    *out = p;
+    return SFMBA_OK;
+}
+
+int sfmba_problem_reset(sfmba_problem* p) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    p->focal = p->focal0;
+    p->cur = 0;
+    if (p->empty) return SFMBA_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpyAsync(p->db.cam[0], p->d_cam0, sizeof(double) * 6 * (size_t)p->ds.ncam, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->db.pts[0], p->d_pts0, sizeof(double) * 3 * (size_t)p->ds.npt, hipMemcpyDeviceToDevice, p->stream));
+    sfmba_options o;
+    sfmba_options_default(&o);
+    LMState st;
+    init_state(p, st, o);
+    return upload_state(p, st);
+}
+
+int sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double* pt3, double focal) {
+    if (!p || !cam6 || !pt3) return fail(SFMBA_ERR_INVALID_ARG, "NULL argument");
+    p->focal = focal;
+    p->cur = 0;
+    if (p->empty) return SFMBA_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<double> cam((size_t)6 * p->ds.ncam), pts((size_t)3 * p->ds.npt);
+    for (int j = 0; j < p->ds.ncam; ++j) std::memcpy(&cam[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
+    for (int i = 0; i < p->ds.npt; ++i) std::memcpy(&pts[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(p->db.cam[0], cam.data(), sizeof(double) * cam.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->db.pts[0], pts.data(), sizeof(double) * pts.size(), hipMemcpyHostToDevice));
+    sfmba_options o;
+    sfmba_options_default(&o);
+    LMState st;
+    init_state(p, st, o);
+    return upload_state(p, st);
+}
+
+int sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double* focal) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (focal) *focal = p->focal;
+    if (p->empty) return SFMBA_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (cam6) {
+        std::vector<double> cam((size_t)6 * p->ds.ncam);
+        HIP_TRY(hipMemcpy(cam.data(), p->db.cam[p->cur], sizeof(double) * cam.size(), hipMemcpyDeviceToHost));
+        for (int j = 0; j < p->ds.ncam; ++j) std::memcpy(cam6 + 6 * (size_t)p->acam_id[j], &cam[6 * (size_t)j], 6 * sizeof(double));
+    }
+    if (pt3) {
+        std::vector<double> pts((size_t)3 * p->ds.npt);
+        HIP_TRY(hipMemcpy(pts.data(), p->db.pts[p->cur], sizeof(double) * pts.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < p->ds.npt; ++i) std::memcpy(pt3 + 3 * (size_t)p->apt_id[i], &pts[3 * (size_t)i], 3 * sizeof(double));
+    }
+    return SFMBA_OK;
+}
+
+int sfmba_problem_solve(sfmba_problem* p, const sfmba_options* opt, sfmba_summary* summary,
+                        sfmba_iteration* trace, int trace_cap, int* trace_len) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    sfmba_options o;
+    if (opt) o = *opt; else sfmba_options_default(&o);
+    if (p->precision == SFMBA_PRECISION_F32J) return run_solve<float>(p, o, summary, trace, trace_cap, trace_len);
+    return run_solve<double>(p, o, summary, trace, trace_cap, trace_len);
+}
+
+void* sfmba_problem_stream(sfmba_problem* p) { return p ? (void*)p->stream : nullptr; }
+
+int sfmba_problem_reduced_dim(const sfmba_problem* p) { return p && !p->empty ? p->ds.d : 0; }
+
+int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3, int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt,
+                const double* obs_xy, double* focal, const sfmba_options* opt, sfmba_summary* summary,
+                sfmba_iteration* trace, int trace_cap, int* trace_len) {
+    if (!focal) return fail(SFMBA_ERR_INVALID_ARG, "focal is NULL");
+    sfmba_options o;
+    if (opt) o = *opt; else sfmba_options_default(&o);
+    const double t0 = now_seconds();
+    sfmba_problem* p = nullptr;
+    int rc = sfmba_problem_create(0, o.precision, n_cam, cam6, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, *focal, &p);
+    if (rc) return rc;
+    const double setup = now_seconds() - t0;
+    sfmba_summary sum;
+    rc = sfmba_problem_solve(p, &o, &sum, trace, trace_cap, trace_len);
+    if (rc == SFMBA_OK && sum.termination != SFMBA_FAILURE) rc = sfmba_problem_get_params(p, cam6, pt3, focal);
+    else if (rc == SFMBA_OK) rc = sfmba_problem_get_params(p, cam6, pt3, focal);
+    sum.setup_seconds = setup;
+    if (summary) *summary = sum;
+    sfmba_problem_destroy(p);
+    return rc;
+}
+
+// ---- kernel-level entry points ----------------------------------------------------------------
+int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double* cost_out) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (cost_out) *cost_out = 0.0;
+    if (p->empty) return SFMBA_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    double *d_res = nullptr, *d_cost = nullptr;
+    HIP_TRY(dev_alloc(&d_res, (size_t)2 * p->ds.nobs));
+    HIP_TRY(dev_alloc(&d_cost, 1));
+    HIP_TRY(hipMemsetAsync(d_cost, 0, sizeof(double), p->stream));
+    const size_t n = 6 * (size_t)p->ds.ncam;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
+    launch_cam_setup<double>(p->stream, p->ds, p->db, p->cur);
+    if (p->precision == SFMBA_PRECISION_F32J) launch_eval_residuals<float>(p->stream, p->ds, p->db, p->d_obs_pt, d_res, d_cost);
+    else launch_eval_residuals<double>(p->stream, p->ds, p->db, p->d_obs_pt, d_res, d_cost);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (residuals_out) HIP_TRY(hipMemcpy(residuals_out, d_res, sizeof(double) * 2 * (size_t)p->ds.nobs, hipMemcpyDeviceToHost));
+    if (cost_out) HIP_TRY(hipMemcpy(cost_out, d_cost, sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_res); (void)hipFree(d_cost);
+    return SFMBA_OK;
+}
+
+int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double* jf) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->empty) return SFMBA_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t n = (size_t)p->ds.nobs;
+    double *d_jc = nullptr, *d_jp = nullptr, *d_jf = nullptr;
+    if (jc) HIP_TRY(dev_alloc(&d_jc, 12 * n));
+    if (jp) HIP_TRY(dev_alloc(&d_jp, 6 * n));
+    if (jf) HIP_TRY(dev_alloc(&d_jf, 2 * n));
+    const size_t nc = 6 * (size_t)p->ds.ncam;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, nc, 1.0);
+    launch_cam_setup<double>(p->stream, p->ds, p->db, p->cur);
+    if (p->precision == SFMBA_PRECISION_F32J) launch_eval_jacobian<float>(p->stream, p->ds, p->db, p->d_obs_pt, p->d_perm, d_jc, d_jp, d_jf);
+    else launch_eval_jacobian<double>(p->stream, p->ds, p->db, p->d_obs_pt, p->d_perm, d_jc, d_jp, d_jf);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (jc) HIP_TRY(hipMemcpy(jc, d_jc, sizeof(double) * 12 * n, hipMemcpyDeviceToHost));
+    if (jp) HIP_TRY(hipMemcpy(jp, d_jp, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+    if (jf) HIP_TRY(hipMemcpy(jf, d_jf, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+    if (d_jc) (void)hipFree(d_jc);
+    if (d_jp) (void)hipFree(d_jp);
+    if (d_jf) (void)hipFree(d_jf);
+    return SFMBA_OK;
+}
+
+int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, double radius, double* S, double* rhs, double* scale) {
+    if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
+    sfmba_options o;
+    if (opt) o = *opt; else sfmba_options_default(&o);
+    HIP_TRY(hipSetDevice(p->device));
+    LMState st;
+    init_state(p, st, o);
+    st.radius = radius;
+    int rc = upload_state(p, st);
+    if (rc) return rc;
+    rc = ensure_trace(p, 4);
+    if (rc) return rc;
+    if (p->precision == SFMBA_PRECISION_F32J) { launch_linearise_setup<float>(p, o.jacobi_scaling); launch_build<float>(p->stream, p->ds, p->db); }
+    else { launch_linearise_setup<double>(p, o.jacobi_scaling); launch_build<double>(p->stream, p->ds, p->db); }
+    launch_finalize(p->stream, p->ds, p->db);
+    const int d = p->ds.d;
+    double *d_full = nullptr, *d_scale = nullptr;
+    HIP_TRY(dev_alloc(&d_full, (size_t)d * d));
+    HIP_TRY(dev_alloc(&d_scale, (size_t)d));
+    launch_mirror_scale(p->stream, p->ds, p->db, d_full, d_scale);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (S) HIP_TRY(hipMemcpy(S, d_full, sizeof(double) * (size_t)d * d, hipMemcpyDeviceToHost));
+    if (rhs) HIP_TRY(hipMemcpy(rhs, p->db.rhs, sizeof(double) * (size_t)d, hipMemcpyDeviceToHost));
+    if (scale) HIP_TRY(hipMemcpy(scale, d_scale, sizeof(double) * (size_t)d, hipMemcpyDeviceToHost));
+    (void)hipFree(d_full); (void)hipFree(d_scale);
+    return SFMBA_OK;
+}
+
+int sfmba_dense_spd_solve(int device, int n, const double* A, const double* b, double* x, int method,
+                          double pcg_tol, int pcg_max_iters, int* info, int* iters) {
+    if (n <= 0 || !A || !b || !x) return fail(SFMBA_ERR_INVALID_ARG, "bad arguments");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    const int ld = dense_padded_dim(n);
+    std::vector<double> Ap((size_t)ld * ld, 0.0), bp((size_t)ld, 0.0);
+    for (int r = 0; r < n; ++r) for (int c = r; c < n; ++c) Ap[(size_t)r * ld + c] = A[(size_t)r * n + c];
+    for (int e = n; e < ld; ++e) Ap[(size_t)e * ld + e] = 1.0;
+    std::memcpy(bp.data(), b, sizeof(double) * (size_t)n);
+    double *dA = nullptr, *db_ = nullptr;
+    int* dinfo = nullptr;
+    HIP_TRY(dev_upload(&dA, Ap));
+    HIP_TRY(dev_upload(&db_, bp));
+    HIP_TRY(dev_alloc(&dinfo, 1));
+    HIP_TRY(hipMemset(dinfo, 0, sizeof(int)));
+    DenseSolver ws;
+    if (dense_solver_create(&ws, n, ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int it = 0;
+    if (method == SFMBA_LINEAR_PCG) it = dense_pcg_solve(s, &ws, dA, db_, pcg_tol > 0 ? pcg_tol : 1e-10, pcg_max_iters, dinfo);
+    else dense_cholesky_solve(s, &ws, dA, db_, dinfo);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(x, db_, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    int hinfo = 0;
+    HIP_TRY(hipMemcpy(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) *info = hinfo;
+    if (iters) *iters = it;
+    dense_solver_destroy(&ws);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(dA); (void)hipFree(db_); (void)hipFree(dinfo);
+    return SFMBA_OK;
+}
+
+// ---- sharded (multi-GPU) API --------------------------------------------------------------------
+// reduce_buf = [S (ld*ld) | rhs (ld) | udiag (ld) | bc (ld)] : one all-reduce(SUM) covers the reduced
+// system, its right-hand side, the undamped diagonal and the scaled gradient.  The scalar block is
+// LMState::acc (trial cost, model change, norms) -- see ba_kernels.h.
+int64_t sfmba_shard_reduce_len(const sfmba_problem* p) {
+    return p && !p->empty ? (int64_t)p->ds.ld * p->ds.ld + 3 * (int64_t)p->ds.ld : 0;
+}
+void* sfmba_shard_reduce_buf(sfmba_problem* p) { return p ? (void*)p->d_sys : nullptr; }
+void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p && p->db.st ? (void*)p->db.st->acc : nullptr; }
+
+int sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt) {
+    (void)p; (void)opt;
+    return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build");
+}
+int sfmba_shard_partial_build(sfmba_problem* p) { (void)p; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
+int sfmba_shard_solve_update(sfmba_problem* p) { (void)p; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
+int sfmba_shard_finish(sfmba_problem* p, int* done) { (void)p; (void)done; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
+int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) { (void)p; (void)summary; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
+
+}  // extern "C"

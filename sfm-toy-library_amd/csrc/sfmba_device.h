@@ -1,0 +1,139 @@
+// sfmba_device.h -- device-side camera model shared by the bundle-adjustment kernels (gfx950).
+//
+// Model (reference SfMToyLib/SfMBundleAdjustmentUtils.cpp:58-97, SimpleReprojectionError):
+//   p = Rot(w) X + t ;  r = f * (p.x/p.z, p.y/p.z) - obs
+// with ceres::AngleAxisRotatePoint semantics for Rot(w) [Ceres-upstream]: exact Rodrigues when
+// theta^2 > DBL_EPSILON, first-order X + w x X otherwise.
+// The reference differentiates this functor with Jet<double,10>; here the 2x6 / 2x3 / 2x1 blocks
+// are analytic:
+//   Aproj = (f/pz) [[1,0,-xp],[0,1,-yp]]          (xp = px/pz, yp = py/pz)
+//   d r/d t = Aproj ; d r/d X = Aproj R ; d r/d f = (xp, yp)
+//   d r/d w = Aproj G,  G = -R [X]x K'   with K' = (w w^T + (R^T - I)[w]x)/theta^2   (theta^2 > eps)
+//                       G = -[X]x                                                    (theta^2 <= eps)
+// K' depends on the camera only, so it is tabulated per camera together with R and t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+namespace sfmba {
+
+// ---- per-camera table (doubles), rebuilt by k_cam_setup whenever camera parameters change ----
+constexpr int CT_R = 0;        // R[9] row-major
+constexpr int CT_T = 9;        // t[3]
+constexpr int CT_K = 12;       // K'[9] row-major (identity when small-angle)
+constexpr int CT_SMALL = 21;   // 1.0 if theta^2 <= DBL_EPSILON
+constexpr int CT_SCALE = 22;   // Jacobi column scale of the 6 camera parameters
+constexpr int CT_STRIDE = 28;
+
+// ---- per-camera step table used by the back-substitution / trial-point kernel ----
+constexpr int ST_R = 0;        // R[9] at the current point
+constexpr int ST_T = 9;        // t[3]
+constexpr int ST_KV = 12;      // K' * dw  (dw = unscaled rotation step); dw itself when small-angle
+constexpr int ST_DT = 15;      // dt (unscaled translation step)
+constexpr int ST_SMALL = 18;
+constexpr int ST_RN = 19;      // R[9] at the trial point
+constexpr int ST_TN = 28;      // t[3] at the trial point
+constexpr int ST_STRIDE = 32;
+
+// One padded record per observation written by the point pass and read by the camera pass:
+// Y = A~^T B~ L^-T (6x3, row-major) + the camera slot of the observation.
+constexpr int YREC = 20;       // 18 values + cam slot (as int bits) + pad  -> 16-byte aligned in fp32 and fp64
+
+template <typename T> struct ObsXY;
+template <> struct ObsXY<float>  { typedef float2 type; };
+template <> struct ObsXY<double> { typedef double2 type; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Block-wide sum of `v`; result valid in thread 0.  `scratch` holds >= blockDim.x/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) s += scratch[i];
+    }
+    return s;
+}
+
+// atomic max on non-negative doubles through their bit pattern (monotone for x >= 0; NaN maps high)
+__device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (v != v) bits = 0x7ff8000000000000ull;
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), bits);
+}
+
+// Projection in fp64: p = R X + t, returns xp, yp, 1/pz.  `cam` points at a camera table row.
+struct Proj {
+    double xp, yp, iz;
+};
+
+template <typename CamPtr>
+__device__ __forceinline__ Proj project_point(CamPtr cam, int roff, int toff, const double X[3]) {
+    const double px = cam[roff + 0] * X[0] + cam[roff + 1] * X[1] + cam[roff + 2] * X[2] + cam[toff + 0];
+    const double py = cam[roff + 3] * X[0] + cam[roff + 4] * X[1] + cam[roff + 5] * X[2] + cam[toff + 1];
+    const double pz = cam[roff + 6] * X[0] + cam[roff + 7] * X[1] + cam[roff + 8] * X[2] + cam[toff + 2];
+    Proj pr;
+    pr.iz = 1.0 / pz;
+    pr.xp = px * pr.iz;
+    pr.yp = py * pr.iz;
+    return pr;
+}
+
+// Unscaled point block B = Aproj R (2x3) in precision T.
+template <typename T, typename CamPtr>
+__device__ __forceinline__ void point_block(CamPtr cam, const Proj& pr, double focal, T B[6]) {
+    const T fz = (T)(focal * pr.iz), xp = (T)pr.xp, yp = (T)pr.yp;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const T r0 = (T)cam[CT_R + c], r1 = (T)cam[CT_R + 3 + c], r2 = (T)cam[CT_R + 6 + c];
+        B[c] = fz * (r0 - xp * r2);
+        B[3 + c] = fz * (r1 - yp * r2);
+    }
+}
+
+// Unscaled camera block A (2x6) = [Aproj G | Aproj] given B = Aproj R (G = -R [X]x K'  =>  Aproj G = -B [X]x K').
+template <typename T, typename CamPtr>
+__device__ __forceinline__ void camera_block(CamPtr cam, const Proj& pr, double focal, const double Xd[3],
+                                             const T B[6], T A[12]) {
+    const T fz = (T)(focal * pr.iz), xp = (T)pr.xp, yp = (T)pr.yp;
+    const T X0 = (T)Xd[0], X1 = (T)Xd[1], X2 = (T)Xd[2];
+    if (cam[CT_SMALL] != 0.0) {
+        // G = -[X]x ;  Aproj G, Aproj = fz [[1,0,-xp],[0,1,-yp]] ; [X]x = [[0,-X2,X1],[X2,0,-X0],[-X1,X0,0]]
+        // row0 of Aproj [X]x = fz * ( -xp*(-X1) , -X2 - xp*X0 , X1 )   -> careful expansion below
+        const T a00 = fz, a02 = -fz * xp, a11 = fz, a12 = -fz * yp;
+        // (Aproj [X]x)[r][c] = sum_m Aproj[r][m] [X]x[m][c]
+        const T m00 = a02 * (-X1), m01 = a00 * (-X2) + a02 * X0, m02 = a00 * X1;
+        const T m10 = a11 * X2 + a12 * (-X1), m11 = a12 * X0, m12 = a11 * (-X0);
+        A[0] = -m00; A[1] = -m01; A[2] = -m02;
+        A[6] = -m10; A[7] = -m11; A[8] = -m12;
+    } else {
+        // M = [X]x K' : column c = X x K'[:,c]
+        T M[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const T k0 = (T)cam[CT_K + c], k1 = (T)cam[CT_K + 3 + c], k2 = (T)cam[CT_K + 6 + c];
+            M[c] = X1 * k2 - X2 * k1;
+            M[3 + c] = X2 * k0 - X0 * k2;
+            M[6 + c] = X0 * k1 - X1 * k0;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            A[c] = -(B[0] * M[c] + B[1] * M[3 + c] + B[2] * M[6 + c]);
+            A[6 + c] = -(B[3] * M[c] + B[4] * M[3 + c] + B[5] * M[6 + c]);
+        }
+    }
+    A[3] = fz;   A[4] = (T)0; A[5] = -fz * xp;
+    A[9] = (T)0; A[10] = fz;  A[11] = -fz * yp;
+}
+
+}  // namespace sfmba

@@ -1,0 +1,59 @@
+"""Generates the committed solver fixtures: problem dumps (tests/golden/*.sfmba) and the oracle's
+results on them and on the seeded synthetic configs (tests/golden/solver_golden.json).
+
+The reference cannot be run here (needs Ceres + OpenCV), so these vectors come from the
+CPU oracle (oracle/sfmba_oracle.c), whose camera model is pinned to the reference's own fixture
+(tests/test_oracle_kat.py) and whose LM loop is cross-checked against scipy (tests/test_oracle_solver.py).
+Run from the repo root:  python tests/golden/make_solver_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import sfm_toy_library_amd as sfm          # noqa: E402
+from oracle import oracle_py as oracle     # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def entry(prob, opt):
+    cam, pt, f, summ, trace = oracle.solve(prob, opt)
+    res0, cost0 = oracle.eval_residuals(prob)
+    return dict(n_cam=prob.n_cam, n_pt=prob.n_pt, n_obs=prob.n_obs,
+                initial_cost=summ["initial_cost"], final_cost=summ["final_cost"],
+                iterations=summ["iterations"], successful_steps=summ["successful_steps"],
+                termination=summ["termination_name"], focal=f,
+                rms_px=float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)),
+                residual_checksum=float(np.sum(res0 * np.arange(1, res0.size + 1).reshape(res0.shape) % 7)),
+                trace_cost=[r["cost"] for r in trace], trace_radius=[r["trust_region_radius"] for r in trace],
+                cam0_final=cam[0].tolist(), pt0_final=pt[0].tolist())
+
+
+def main():
+    opt = sfm.SfmbaOptions.defaults(max_seconds=0.0)
+    out = {}
+    for name in ("tiny", "small"):
+        prob = sfm.make_problem(name)
+        sfm.save_problem(os.path.join(HERE, name + ".sfmba"), prob)
+        out[name] = entry(prob, opt)
+    # a harder start (rejected steps) on the dumped small problem
+    prob = sfm.make_problem("small", seed=5)
+    prob.cam6[1:, 3:] += 0.3
+    prob.pt3 += 0.2 * np.random.default_rng(0).normal(size=prob.pt3.shape)
+    sfm.save_problem(os.path.join(HERE, "small_far.sfmba"), prob)
+    out["small_far"] = entry(prob, opt)
+    for name in ("crazyhorse_like", "cfg2"):
+        out[name] = entry(sfm.make_problem(name), opt)
+    out["cfg4.0"] = entry(sfm.make_problem("cfg4", sub=0), opt)
+    with open(os.path.join(HERE, "solver_golden.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for k, v in out.items():
+        print(k, v["iterations"], v["termination"], v["final_cost"], v["rms_px"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/sfmba.h declares, agrees with the ctypes struct mirrors, and refuses to run without a GPU
+(no compute calls here; the parity tests proper are the -m gpu tests)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as ge
+    ge.build_hip()
+    from sfm_toy_library_amd import capi as c
+    return c
+
+
+def test_library_exports_every_declared_symbol(capi):
+    header = open(os.path.join(ROOT, "include", "sfmba.h")).read()
+    declared = re.findall(r"SFMBA_API[^;(]*?(sfmba_\w+)\(", header)
+    assert sorted(set(declared)) == sorted(capi.SYMBOLS)
+    L = capi.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.sfmba_abi_version() == 1
+
+
+def test_default_options_match_reference_values(capi, sfm, oracle):
+    o = capi.default_options()
+    ref = sfm.SfmbaOptions.defaults()
+    orc = sfm.SfmbaOptions()
+    oracle.lib().sfmba_oracle_options_default(C.byref(orc))
+    for name, _ in sfm.SfmbaOptions._fields_:
+        assert getattr(o, name) == getattr(ref, name) == getattr(orc, name), name
+    assert o.max_iters == 500 and o.max_seconds == 10.0        # BA.cpp:174,176
+
+
+def test_struct_sizes_match_header(capi, sfm):
+    # natural C layout of the header structs on x86-64
+    assert C.sizeof(sfm.SfmbaIteration) == 4 * 4 + 6 * 8
+    assert C.sizeof(sfm.SfmbaSummary) == 7 * 4 + 4 + 4 * 8 + 128
+    assert C.sizeof(sfm.SfmbaOptions) == 8 + 10 * 8 + 4 * 4 + 8 + 2 * 4
+
+
+def test_no_cpu_fallback_without_device(capi, sfm):
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    prob = sfm.make_problem("tiny")
+    with pytest.raises(capi.SfmbaError, match="no HIP device"):
+        capi.Problem(prob)
+    with pytest.raises(capi.SfmbaError, match="no HIP device"):
+        capi.solve(prob)
+    with pytest.raises(capi.SfmbaError, match="no HIP device"):
+        capi.dense_spd_solve(np.eye(3), np.ones(3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sfm-toy-library_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle_py" not in text and "libsfmba_oracle" not in text and "sfmba_oracle_" not in text, fn
+
+
+def test_problem_dump_roundtrip(sfm, tmp_path):
+    prob = sfm.make_problem("tiny")
+    path = tmp_path / "p.sfmba"
+    sfm.save_problem(path, prob)
+    back = sfm.load_problem(path)
+    for a in ("cam6", "pt3", "obs_cam", "obs_pt", "obs_xy"):
+        assert np.array_equal(getattr(prob, a), getattr(back, a))
+    assert back.focal == prob.focal
+
+
+def test_synthetic_generator_is_deterministic_and_matches_spec(sfm):
+    a, b = sfm.make_problem("cfg2"), sfm.make_problem("cfg2")
+    assert np.array_equal(a.obs_xy, b.obs_xy) and np.array_equal(a.cam6, b.cam6)
+    assert (a.n_cam, a.n_pt, a.n_obs) == (20, 5000, 30000)
+    assert np.array_equal(a.cam6[0], [0, 0, 0, 0, 0, 5.0])                     # identity first camera
+    assert np.array_equal(a.obs_xy.astype(np.float32).astype(np.float64), a.obs_xy)   # Point2f-representable
+    assert np.all(np.diff(a.obs_pt) >= 0)                                      # point-major
+    same_pt = np.diff(a.obs_pt) == 0
+    assert np.all(np.diff(a.obs_cam)[same_pt] > 0)                             # ascending view inside a point
+    s0, s1 = a.shard_points(0, 2), a.shard_points(1, 2)
+    assert s0.n_obs + s1.n_obs == a.n_obs and s0.n_pt + s1.n_pt == a.n_pt
