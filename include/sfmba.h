@@ -158,6 +158,18 @@ SFMBA_API void* sfmba_problem_stream(sfmba_problem* p);
 SFMBA_API int  sfmba_problem_reduced_dim(const sfmba_problem* p);
 
 /*
+ * Per-kernel timing with HIP events recorded on the problem's own stream around every launch
+ * (bench.py's `roofline` object).  set_profiling resets the counters.
+ */
+typedef struct sfmba_kernel_time {
+    char    name[32];
+    double  total_us;
+    int64_t launches;
+} sfmba_kernel_time;
+SFMBA_API int sfmba_problem_set_profiling(sfmba_problem* p, int enable);
+SFMBA_API int sfmba_problem_get_profile(sfmba_problem* p, sfmba_kernel_time* out, int cap, int* n);
+
+/*
  * Kernel-level entry points (parity tests call these through the C ABI).
  *   residuals_out : [2*n_obs] in the caller's observation order
  *   cost_out      : 1/2 sum r^2

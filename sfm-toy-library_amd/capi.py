@@ -25,8 +25,12 @@ SYMBOLS = [
     "sfmba_problem_eval_residuals", "sfmba_problem_eval_jacobian", "sfmba_problem_build_reduced",
     "sfmba_dense_spd_solve", "sfmba_shard_begin", "sfmba_shard_reduce_len", "sfmba_shard_reduce_buf",
     "sfmba_shard_scalars_buf", "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish",
-    "sfmba_shard_end",
+    "sfmba_shard_end", "sfmba_problem_set_profiling", "sfmba_problem_get_profile",
 ]
+
+
+class _KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_us", C.c_double), ("launches", C.c_int64)]
 
 
 class SfmbaError(RuntimeError):
@@ -177,6 +181,20 @@ class Problem:
         tl = C.c_int(0)
         _check(lib().sfmba_problem_solve(self._h, C.byref(opt), C.byref(summ), trace, C.c_int(trace_cap), C.byref(tl)))
         return summ.as_dict(), _trace_rows(trace, tl.value, trace_cap)
+
+    def set_profiling(self, enable):
+        _check(lib().sfmba_problem_set_profiling(self._h, C.c_int(1 if enable else 0)))
+
+    def get_profile(self):
+        """{kernel: {total_us, launches, avg_us}} measured with HIP events on the solver's stream."""
+        buf = (_KernelTime * 64)()
+        n = C.c_int(0)
+        _check(lib().sfmba_problem_get_profile(self._h, buf, C.c_int(64), C.byref(n)))
+        out = {}
+        for i in range(min(n.value, 64)):
+            k = buf[i]
+            out[k.name.decode()] = dict(total_us=k.total_us, launches=int(k.launches), avg_us=k.total_us / max(1, k.launches))
+        return out
 
     def eval_residuals(self):
         res = np.zeros(2 * self.n_obs)

@@ -89,9 +89,13 @@ struct DeviceBuffers {
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
 void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling);
-template <typename T> void launch_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_cam_schur(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-template <typename T> void launch_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+void launch_post_lin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_eval_residuals(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,

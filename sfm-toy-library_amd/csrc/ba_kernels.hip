@@ -508,25 +508,34 @@ __global__ __launch_bounds__(BLK) void k_cam_schur(DeviceStructure ds, DeviceBuf
     }
 }
 
+static bool use_lds_table(const DeviceStructure& ds, int stride) { return (size_t)ds.ncam * stride * sizeof(double) <= 56 * 1024; }
+
 size_t build_lds_bytes(const DeviceStructure& ds) {
     return sizeof(double) * (size_t)(36 * ds.win_cams + (BLK / 64) * NRED);
 }
 
-static bool use_lds_table(const DeviceStructure& ds, int stride) { return (size_t)ds.ncam * stride * sizeof(double) <= 56 * 1024; }
+void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+    // S | rhs | udiag | bc are contiguous; only the upper triangle of S is ever read, but a flat memset is cheapest
+    (void)hipMemsetAsync(db.S, 0, sizeof(double) * ((size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld), s);
+}
 
 template <typename T>
-void launch_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    // zero S (upper part is all that is read, but a flat memset is cheapest), rhs, udiag, bc: contiguous
-    (void)hipMemsetAsync(db.S, 0, sizeof(double) * ((size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld), s);
+void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     const dim3 grid((ds.npt + BLK - 1) / BLK);
     if (use_lds_table(ds, CT_STRIDE))
         hipLaunchKernelGGL((k_point_build<T, true>), grid, dim3(BLK), sizeof(double) * ds.ncam * CT_STRIDE, s, ds, db);
     else
         hipLaunchKernelGGL((k_point_build<T, false>), grid, dim3(BLK), 0, s, ds, db);
+}
+template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+
+template <typename T>
+void launch_cam_schur(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     hipLaunchKernelGGL(k_cam_schur<T>, dim3(ds.nchunk), dim3(BLK), build_lds_bytes(ds), s, ds, db);
 }
-template void launch_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-template void launch_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_cam_schur<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_cam_schur<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 
 // ------------------------------------------------------------------------------------------
 // finalize: damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding
@@ -584,6 +593,8 @@ __global__ void k_post_lin(DeviceStructure ds, DeviceBuffers db) {
 
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     hipLaunchKernelGGL(k_finalize, dim3((ds.ld + 255) / 256), dim3(256), 0, s, ds, db);
+}
+void launch_post_lin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     hipLaunchKernelGGL(k_post_lin, dim3(1), dim3(1), 0, s, ds, db);
 }
 
@@ -773,17 +784,20 @@ __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, Device
     }
 }
 
-template <typename T>
-void launch_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     hipLaunchKernelGGL(k_cam_update, dim3((ds.ncam + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db);
+}
+
+template <typename T>
+void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     const dim3 grid((ds.npt + BLK - 1) / BLK);
     if (use_lds_table(ds, ST_STRIDE))
         hipLaunchKernelGGL((k_point_update<T, true>), grid, dim3(BLK), sizeof(double) * ds.ncam * ST_STRIDE, s, ds, db);
     else
         hipLaunchKernelGGL((k_point_update<T, false>), grid, dim3(BLK), 0, s, ds, db);
 }
-template void launch_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-template void launch_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 
 // ------------------------------------------------------------------------------------------
 // LM control: the accept/reject logic of ceres::internal::TrustRegionMinimizer::Minimize()
@@ -847,12 +861,12 @@ __global__ void k_lm_control(DeviceBuffers db) {
                     st->unsuccessful++;
                     report_cost = cand;
                 }
-                if (st->radius <= st->min_radius && st->termination == -1 && !row.step_is_successful) {
-                    st->termination = SFMBA_CONVERGENCE;
-                    st->message = MSG_MIN_RADIUS;
-                }
             }
         }
+    }
+    if (st->termination == -1 && st->radius <= st->min_radius) {
+        st->termination = SFMBA_CONVERGENCE;
+        st->message = MSG_MIN_RADIUS;
     }
     row.cost = report_cost;
     row.trust_region_radius = st->radius;

@@ -1,6 +1,7 @@
 // dense_solver.h -- dense SPD solve of the reduced camera system on the device.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "profiler.h"
 
 namespace sfmba {
 
@@ -30,9 +31,9 @@ inline int dense_padded_dim(int d) { return ((d + 1 + CHOL_NB - 1) / CHOL_NB) * 
 // Cholesky: S holds the UPPER triangle of the row-major matrix (== lower triangle, column-major),
 // padded to ld with an identity diagonal.  rhs[0..d) is overwritten by the solution.
 // *info_dev (device int) is set to k>0 if the leading minor k is not positive definite.
-void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev);
+void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof = nullptr);
 
 // Block-Jacobi PCG on the same storage.  Returns the number of iterations (host sync inside).
-int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev);
+int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof = nullptr);
 
 }  // namespace sfmba

@@ -181,17 +181,23 @@ __global__ __launch_bounds__(256) void k_chol_backstep(const double* __restrict_
     if (tid < NB) y[ib + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
-void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev) {
+void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof) {
     const int ld = ws->ld, d = ws->d, nblk = ld / NB;
-    hipLaunchKernelGGL(k_augment, dim3((d + 255) / 256), dim3(256), 0, s, S, ld, d, rhs);
+    { ProfScope ps(prof, KID_CHOL_AUGMENT, s);
+      hipLaunchKernelGGL(k_augment, dim3((d + 255) / 256), dim3(256), 0, s, S, ld, d, rhs); }
     for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(256), 0, s, S, ld, k, d, ws->minv, info_dev);
+        { ProfScope ps(prof, KID_CHOL_PANEL, s);
+          hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(256), 0, s, S, ld, k, d, ws->minv, info_dev); }
         const int m = nblk - k - 1;
-        if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k);
+        if (m > 0) { ProfScope ps(prof, KID_CHOL_UPDATE, s);
+          hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k); }
     }
-    hipLaunchKernelGGL(k_extract_y, dim3((ld + 255) / 256), dim3(256), 0, s, S, ld, d, ws->y);
-    for (int k = nblk - 1; k >= 0; --k)
+    { ProfScope ps(prof, KID_CHOL_EXTRACT, s);
+      hipLaunchKernelGGL(k_extract_y, dim3((ld + 255) / 256), dim3(256), 0, s, S, ld, d, ws->y); }
+    for (int k = nblk - 1; k >= 0; --k) {
+        ProfScope ps(prof, KID_CHOL_BACKSTEP, s);
         hipLaunchKernelGGL(k_chol_backstep, dim3(k + 1), dim3(256), 0, s, S, ld, k, ws->minv, ws->y, rhs, d);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,21 +342,24 @@ __global__ void k_copy_vec(int d, const double* __restrict__ src, double* __rest
     if (e < d) dst[e] = src[e];
 }
 
-int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev) {
+int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof) {
     const int ld = ws->ld, d = ws->d;
     if (!ws->Sfull) {
         if (hipMalloc(&ws->Sfull, sizeof(double) * (size_t)ld * ld) != hipSuccess) return -1;
     }
     if (max_iters <= 0) max_iters = 4 * d;
+    { ProfScope ps(prof, KID_PCG_SETUP, s);
     hipLaunchKernelGGL(k_mirror_full, dim3((d + 255) / 256, d), dim3(256), 0, s, S, ld, d, ws->Sfull);
     hipLaunchKernelGGL(k_block_inverse, dim3(((d - 1) / 6 + 1 + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
-    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, s, d, ld, rhs, ws->vec, ws->binv, ws->scal, ws->flags);
+    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, s, d, ld, rhs, ws->vec, ws->binv, ws->scal, ws->flags); }
     int it = 0;
     const int batch = 8;
     while (it < max_iters) {
         const int n = (max_iters - it) < batch ? (max_iters - it) : batch;
         for (int b = 0; b < n; ++b) {
-            hipLaunchKernelGGL(k_pcg_matvec, dim3((d + 3) / 4), dim3(256), 0, s, d, ld, ws->Sfull, ws->vec, ws->scal, ws->flags);
+            { ProfScope ps(prof, KID_PCG_MATVEC, s);
+            hipLaunchKernelGGL(k_pcg_matvec, dim3((d + 3) / 4), dim3(256), 0, s, d, ld, ws->Sfull, ws->vec, ws->scal, ws->flags); }
+            ProfScope ps2(prof, KID_PCG_UPDATE, s);
             hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), 0, s, d, ld, ws->vec, ws->binv, ws->scal, ws->flags, tol * tol);
         }
         it += n;

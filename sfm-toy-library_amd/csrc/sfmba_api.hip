@@ -12,6 +12,7 @@
 #include "../../include/sfmba.h"
 #include "ba_kernels.h"
 #include "dense_solver.h"
+#include "profiler.h"
 #include "sfmba_device.h"
 
 #include <algorithm>
@@ -101,6 +102,7 @@ struct sfmba_problem {
     bool shard_active = false;
     double shard_t0 = 0.0;
     int shard_phase = 0;
+    Profiler prof;
 };
 
 namespace {
@@ -191,27 +193,32 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     rc = upload_state(p, st);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
-    launch_linearise_setup<T>(p, o.jacobi_scaling);
+    { ProfScope ps(p->prof.on ? &p->prof : nullptr, KID_SETUP, p->stream); launch_linearise_setup<T>(p, o.jacobi_scaling); }
 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
-        launch_build<T>(p->stream, p->ds, p->db);
-        launch_finalize(p->stream, p->ds, p->db);
+        Profiler* prof = p->prof.on ? &p->prof : nullptr;
+        { ProfScope ps(prof, KID_ZERO, p->stream); launch_zero_system(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_POINT_BUILD, p->stream); launch_point_build<T>(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_CAM_SCHUR, p->stream); launch_cam_schur<T>(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_POST_LIN, p->stream); launch_post_lin(p->stream, p->ds, p->db); }
         if (o.linear_solver == SFMBA_LINEAR_PCG) {
-            const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info);
+            const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof);
             if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             sum.linear_iters += it;
         } else {
-            dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info);
+            dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, prof);
         }
         // hand the dense-solver status to the control kernel
         HIP_TRY(hipMemcpyAsync(&p->db.st->lin_info, p->d_info, sizeof(int), hipMemcpyDeviceToDevice, p->stream));
         HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
-        launch_update<T>(p->stream, p->ds, p->db);
-        launch_control(p->stream, p->ds, p->db);
+        { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, p->db); }
         rc = download_state(p);
         if (rc) return rc;
         host_iter = p->h_state->iter;
@@ -224,6 +231,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     HIP_TRY(hipStreamSynchronize(p->stream));
     rc = download_state(p);
     if (rc) return rc;
+    if (p->prof.on) p->prof.collect();
     const LMState& hs = *p->h_state;
     p->cur = hs.cur;
     p->focal = hs.focal[hs.cur];
@@ -297,6 +305,7 @@ void sfmba_problem_destroy(sfmba_problem* p) {
                       p->db.camtab[0], p->db.camtab[1], p->db.steptab, p->db.cscale, p->db.pscale, p->db.Y, p->db.pt_t, p->db.pt_yf,
                       p->db.st, p->db.trace };
     for (void* f : frees) if (f) (void)hipFree(f);
+    p->prof.destroy();
     if (p->h_state) (void)hipHostFree(p->h_state);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -454,7 +463,6 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     db.trace = nullptr; db.trace_cap = 0;
     if (dense_solver_create(&p->solver, ds.d, ds.ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
 
-    // opt in to the dynamic LDS the camera pass needs
     rc = sfmba_problem_reset(p);
     if (rc) return rc;
     guard.p = nullptr;
@@ -549,6 +557,29 @@ int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3, int64_t n_obs, c
     return rc;
 }
 
+int sfmba_problem_set_profiling(sfmba_problem* p, int enable) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    p->prof.reset();
+    p->prof.on = enable != 0;
+    return SFMBA_OK;
+}
+
+int sfmba_problem_get_profile(sfmba_problem* p, sfmba_kernel_time* out, int cap, int* n) {
+    if (!p || !n) return fail(SFMBA_ERR_INVALID_ARG, "NULL argument");
+    int k = 0;
+    for (int id = 0; id < KID_COUNT; ++id) {
+        if (p->prof.count[id] == 0) continue;
+        if (out && k < cap) {
+            std::snprintf(out[k].name, sizeof(out[k].name), "%s", kernel_name(id));
+            out[k].total_us = 1e3 * p->prof.total_ms[id];
+            out[k].launches = p->prof.count[id];
+        }
+        ++k;
+    }
+    *n = k;
+    return SFMBA_OK;
+}
+
 // ---- kernel-level entry points ----------------------------------------------------------------
 int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double* cost_out) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
@@ -607,9 +638,20 @@ int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, doub
     if (rc) return rc;
     rc = ensure_trace(p, 4);
     if (rc) return rc;
-    if (p->precision == SFMBA_PRECISION_F32J) { launch_linearise_setup<float>(p, o.jacobi_scaling); launch_build<float>(p->stream, p->ds, p->db); }
-    else { launch_linearise_setup<double>(p, o.jacobi_scaling); launch_build<double>(p->stream, p->ds, p->db); }
+    launch_zero_system(p->stream, p->ds, p->db);
+    if (p->precision == SFMBA_PRECISION_F32J) {
+        launch_linearise_setup<float>(p, o.jacobi_scaling);
+        launch_zero_system(p->stream, p->ds, p->db);
+        launch_point_build<float>(p->stream, p->ds, p->db);
+        launch_cam_schur<float>(p->stream, p->ds, p->db);
+    } else {
+        launch_linearise_setup<double>(p, o.jacobi_scaling);
+        launch_zero_system(p->stream, p->ds, p->db);
+        launch_point_build<double>(p->stream, p->ds, p->db);
+        launch_cam_schur<double>(p->stream, p->ds, p->db);
+    }
     launch_finalize(p->stream, p->ds, p->db);
+    launch_post_lin(p->stream, p->ds, p->db);
     const int d = p->ds.d;
     double *d_full = nullptr, *d_scale = nullptr;
     HIP_TRY(dev_alloc(&d_full, (size_t)d * d));
