@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--workload", default="cfg3", help="name in synthetic.CONFIGS (default: the BASELINE metric config)")
     ap.add_argument("--linear", default="cholesky", choices=["cholesky", "pcg"])
     ap.add_argument("--precision", default="f32j", choices=["f32j", "f64"])
+    ap.add_argument("--pcg-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="LM iterations of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = min(nproc,16))")
@@ -53,9 +54,9 @@ def cpu_baseline(prob_name, seed_sub, args, gpu_rms):
     """Host restatement of the reference CPU path (oracle = Ceres-equivalent LM + DENSE_SCHUR, NOT Ceres),
     timed on a bounded sample: the same problem, a capped number of LM iterations."""
     threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     import sfm_toy_library_amd as sfm
     from oracle import oracle_py as oracle           # checker/baseline only -- never part of the product path
+    oracle.set_num_threads(threads)
     prob = sfm.make_problem(prob_name, sub=seed_sub)
     iters = args.cpu_iters or (2 if prob.n_obs >= 500000 else 50)
     opt = sfm.SfmbaOptions.defaults(max_seconds=0.0, max_iters=iters)
@@ -113,7 +114,7 @@ def main():
     sub = rank if world > 1 else None
     prob = sfm.make_problem(args.workload, sub=sub)
     P = capi.Problem(prob, precision=precision, device=local_rank)
-    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear)
+    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol)
 
     def barrier():
         torch.cuda.synchronize()
@@ -124,7 +125,7 @@ def main():
     for _ in range(args.warmup):
         P.reset()
         P.solve(opt)
-    P.set_profiling(True)
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, no instrumentation ----
     barrier()
     t0 = time.perf_counter()
     iters = res_evals = jac_evals = lin_iters = 0
@@ -138,6 +139,15 @@ def main():
         lin_iters += summ["linear_iters"]
     barrier()
     dt = time.perf_counter() - t0
+    # ---- the same K steps again with every launch bracketed by HIP events on the solver's stream:
+    # per-kernel average launch durations for the roofline object (not part of `value`) ----
+    P.set_profiling(True)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        P.reset()
+        P.solve(opt)
+    barrier()
+    dt_prof = time.perf_counter() - t1
     profile = P.get_profile()
     P.set_profiling(False)
 
@@ -183,6 +193,7 @@ def main():
                                        "achieved_GBps": b_iter * (g_iters / world) / g_dt / 1e9,
                                        "frac_of_8TBps": b_iter * (g_iters / world) / g_dt / 8.0e12}
         line["roofline"] = roofline_entry(profile, prob, precision)
+        line["ms_per_step_with_event_bracketing"] = 1e3 * dt_prof / args.steps
         line["kernel_profile_us"] = {k: round(v["avg_us"], 2) for k, v in profile.items()}
         line["kernel_profile_share"] = {k: round(v["total_us"] / max(1e-9, sum(x["total_us"] for x in profile.values())), 4)
                                         for k, v in profile.items()}
@@ -220,14 +231,18 @@ def roofline_entry(profile, prob, precision):
 
 def kernel_models(n_obs, n_pt, n_cam, d, t):
     """Algorithmic bytes (or flops) per launch of each kernel; derivations in DESIGN.md."""
-    yrec = 20 * t
+    yrec = 16 * t
+    npair = n_obs * (n_obs / max(n_pt, 1) - 1) / 2      # pairs of observations of one point, a < b
     nb = 64
     nblk = (d + 1 + nb - 1) // nb
     return {
         "point_build": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_obs * yrec + n_pt * (24 + 24 + 48 + 4),
-                        "note": "reads obs (cam idx + xy), points, scales; writes Y records + per-point t, y_f"},
-        "cam_schur": {"bound": "hbm", "bytes": n_obs * (8 + 2 * t + yrec) + n_pt * 72 + 8 * d * d // 2,
-                      "note": "reads camera-major lists, obs, Y once, points; writes upper S once (k-fold re-read of Y is non-algorithmic)"},
+                        "note": "reads obs (cam idx + xy), points, scales; writes one packed record per obs + per-point t, y_f"},
+        "schur_pairs": {"bound": "hbm", "bytes": n_obs * yrec + 8 * npair + 8 * d * d // 2,
+                        "note": "reads every record once and the pair list once, writes the upper triangle of S once "
+                                "(each record is in fact gathered ~k-1 times from L2/MALL: non-algorithmic re-reads)"},
+        "cam_diag": {"bound": "hbm", "bytes": n_obs * (8 + 2 * t + yrec) + n_pt * 48,
+                     "note": "reads camera-major index lists, obs, records, per-point t / y_f"},
         "point_update": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_pt * (24 + 24 + 24 + 4),
                          "note": "reads obs, points, scales; writes trial points"},
         "chol_update": {"bound": "mfma", "flops": 2.0 * d * d * d / 3.0 / max(nblk - 1, 1), "peak_tflops": 78.6,

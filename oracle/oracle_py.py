@@ -54,6 +54,10 @@ def num_threads():
     return int(lib().sfmba_oracle_num_threads())
 
 
+def set_num_threads(n):
+    lib().sfmba_oracle_set_num_threads(C.c_int(int(n)))
+
+
 def rotation_matrix_to_angle_axis_f(R):
     """R: 3x3 (row-major numpy) -> float32 angle-axis, float arithmetic (BA.cpp:126)."""
     Rcm = np.ascontiguousarray(np.asarray(R, dtype=np.float32).T)   # column-major bytes of R

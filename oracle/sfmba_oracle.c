@@ -1068,6 +1068,16 @@ ORACLE_API void sfmba_oracle_options_default(sfmba_options* o) {
     o->verbose = 0;
 }
 
+/* OMP_NUM_THREADS is read once when libgomp initialises (torch may have done that already), so the
+ * bench sets the thread count of the CPU baseline explicitly. */
+ORACLE_API void sfmba_oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORACLE_API int sfmba_oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

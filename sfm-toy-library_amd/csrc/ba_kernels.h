@@ -62,9 +62,18 @@ struct DeviceStructure {
     const int* cam_ptr;       // [ncam+1] camera-major CSR
     const int* cam_obs;       // [nobs] point-major position q of each camera-major entry
     const int* cam_obs_pt;    // [nobs] point slot of that entry
+    const int* obs_pt;        // [nobs] point slot, point-major order
     int nchunk;
-    const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), window index}
-    int win_cams;             // cameras per LDS column window
+    const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), 0}
+    // camera-pair lists of the reduced-system pass: block b = (ja <= jb); pairs sorted by block
+    int nblock;
+    const int2* blk_cams;     // [nblock] {ja, jb}
+    const int* blk_ptr;       // [nblock+1]
+    const int2* pairs;        // [npair] {qa, qb} point-major positions of two observations of one point, qa < qb
+    int npairwg;
+    const int2* pwg_blocks;   // [npairwg] {first block, #blocks <= 4} per workgroup of the pair pass (XCD-grouped rows)
+    int npwg;
+    const int* pwg_ptr;       // [npwg+1] point ranges of the point-pass workgroups (<= 256 observations each)
 };
 
 struct DeviceBuffers {
@@ -81,6 +90,7 @@ struct DeviceBuffers {
     double* rhs;              // [ld]  (overwritten by the solution)
     double* udiag;            // [ld]  diag(J~^T J~) of the reduced unknowns, undamped
     double* bc;               // [ld]  scaled gradient of the reduced unknowns
+    double* facc;             // [4]   focal-focal accumulators: S_ff, rhs_f, udiag_f, bc_f (atomics)
     LMState* st;
     TraceRow* trace;
     int trace_cap;
@@ -91,7 +101,8 @@ void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers&
 template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling);
 void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-template <typename T> void launch_cam_schur(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_post_lin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
@@ -104,6 +115,5 @@ template <typename T> void launch_eval_jacobian(hipStream_t s, const DeviceStruc
                                                 const int* obs_pt, const int* perm, double* jc, double* jp, double* jf);
 void launch_mirror_scale(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* S_full, double* scale_out);
 
-size_t build_lds_bytes(const DeviceStructure& ds);
 
 }  // namespace sfmba

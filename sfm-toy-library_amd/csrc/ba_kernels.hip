@@ -145,8 +145,6 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
     __shared__ double scratch[BLK / 64];
     const int4 ch = ds.chunks[blockIdx.x];
     const int j = ch.x;
-    const int wlo = ch.w * ds.win_cams;
-    if (!(wlo <= j && j < wlo + ds.win_cams)) return;   // only the primary window chunk of each range
     const int cur = db.st->cur;
     const double* ct = db.camtab[cur] + (size_t)j * CT_STRIDE;
     const double focal = db.st->focal[cur];
@@ -215,37 +213,102 @@ __device__ __forceinline__ void load_obs(const void* base, int q, double& ox, do
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: point pass.  One thread per point.
+// Packed per-observation record written by the point pass (16 values = 64 B in fp32, one 128-B
+// line in fp64):  [0..5] A_w = Aproj G (2x3, unscaled)  [6] fz = f/pz  [7] xp  [8] yp
+//                 [9..14] C = B~ L^-T (2x3)             [15] camera slot (bit pattern)
+// The whitened Schur block of two observations a, b of one point is
+//   Y_a Y_b^T = S_a A_a^T (C_a C_b^T) A_b S_b,   A = [A_w | Aproj],  S = Jacobi scale of the camera.
 // ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void store_rec(T* Yout, int q, const T rec[YREC]) {
+    T* dst = Yout + (size_t)q * YREC;
+    if (sizeof(T) == 4) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const float* rf = reinterpret_cast<const float*>(rec);
+#pragma unroll
+        for (int v = 0; v < YREC / 4; ++v) d4[v] = make_float4(rf[4 * v], rf[4 * v + 1], rf[4 * v + 2], rf[4 * v + 3]);
+    } else {
+        double2* d2 = reinterpret_cast<double2*>(dst);
+        const double* rd = reinterpret_cast<const double*>(rec);
+#pragma unroll
+        for (int v = 0; v < YREC / 2; ++v) d2[v] = make_double2(rd[2 * v], rd[2 * v + 1]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void load_rec(const T* Y, int q, T rec[YREC]) {
+    const T* src = Y + (size_t)q * YREC;
+    if (sizeof(T) == 4) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float* rf = reinterpret_cast<float*>(rec);
+#pragma unroll
+        for (int v = 0; v < YREC / 4; ++v) { const float4 x = s4[v]; rf[4 * v] = x.x; rf[4 * v + 1] = x.y; rf[4 * v + 2] = x.z; rf[4 * v + 3] = x.w; }
+    } else {
+        const double2* s2 = reinterpret_cast<const double2*>(src);
+        double* rd = reinterpret_cast<double*>(rec);
+#pragma unroll
+        for (int v = 0; v < YREC / 2; ++v) { const double2 x = s2[v]; rd[2 * v] = x.x; rd[2 * v + 1] = x.y; }
+    }
+}
+
+// unscaled camera block A (2x6, row-major) from a record
+template <typename T>
+__device__ __forceinline__ void rec_camera_block(const T rec[YREC], T A[12]) {
+    A[0] = rec[0]; A[1] = rec[1]; A[2] = rec[2];
+    A[3] = rec[6]; A[4] = (T)0; A[5] = -rec[6] * rec[7];
+    A[6] = rec[3]; A[7] = rec[4]; A[8] = rec[5];
+    A[9] = (T)0; A[10] = rec[6]; A[11] = -rec[6] * rec[8];
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: point pass.  A group of 8 lanes owns one point: the lanes stride over the point's observations
+// (8 consecutive 8/16-byte records per load -> coalesced), the per-point sums are finished with three
+// xor-shuffles, every lane then holds V, b_p, E_f and factors the 3x3 block redundantly.  No
+// __syncthreads inside the loop: waves run independently, the only LDS use is the camera table that
+// each (persistent) workgroup stages once.
+// ------------------------------------------------------------------------------------------
+#define CT_LDS 22    // camera-table columns staged in LDS: R, t, K', small-angle flag
+#define GRP 8        // lanes per point
+
+__device__ __forceinline__ double group_sum8(double v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
 template <typename T, bool LDS_TAB>
 __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceBuffers db) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ double scratch[BLK / 64];
+    double* ltab = reinterpret_cast<double*>(smem_raw);
     const LMState* st = db.st;
     const int cur = st->cur;
     const double* gtab = db.camtab[cur];
-    const double* tab = gtab;
     if (LDS_TAB) {
-        double* ltab = reinterpret_cast<double*>(smem_raw);
-        for (int e = threadIdx.x; e < ds.ncam * CT_STRIDE; e += blockDim.x) ltab[e] = gtab[e];
+        for (int e = threadIdx.x; e < ds.ncam * CT_LDS; e += blockDim.x) ltab[e] = gtab[(size_t)(e / CT_LDS) * CT_STRIDE + e % CT_LDS];
         __syncthreads();
-        tab = ltab;
     }
+    const double* tab = LDS_TAB ? ltab : gtab;
+    const int tstride = LDS_TAB ? CT_LDS : CT_STRIDE;
     const double focal = st->focal[cur];
     const T fscale = (T)st->fscale;
     const double radius = st->radius;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < ds.npt;
-
+    const double* pts = db.pts[cur];
+    T* Yout = reinterpret_cast<T*>(db.Y);
+    const int l = threadIdx.x & (GRP - 1);
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / GRP;
+    const int ngroups = gridDim.x * blockDim.x / GRP;
     double lin_cost = 0.0, sff = 0.0, rhsf = 0.0, gmax = 0.0, bad = 0.0;
-    if (active) {
-        const double* P = db.pts[cur] + 3 * (size_t)i;
-        const double X[3] = { P[0], P[1], P[2] };
-        const T sp[3] = { (T)db.pscale[3 * i], (T)db.pscale[3 * i + 1], (T)db.pscale[3 * i + 2] };
+
+    for (int i = group; i < ds.npt; i += ngroups) {
+        const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
+        const double spd[3] = { db.pscale[3 * (size_t)i], db.pscale[3 * (size_t)i + 1], db.pscale[3 * (size_t)i + 2] };
+        const T sp[3] = { (T)spd[0], (T)spd[1], (T)spd[2] };
         const int q0 = ds.pt_ptr[i], q1 = ds.pt_ptr[i + 1];
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 }, Ef[3] = { 0, 0, 0 };
-        for (int q = q0; q < q1; ++q) {
-            const double* ct = tab + (size_t)ds.obs_cam[q] * CT_STRIDE;
+        for (int q = q0 + l; q < q1; q += GRP) {
+            const double* ct = tab + (size_t)ds.obs_cam[q] * tstride;
             double ox, oy;
             load_obs<T>(ds.obs_xy, q, ox, oy);
             const Proj pr = project_point(ct, CT_R, CT_T, X);
@@ -268,274 +331,304 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
                 Ef[c] += (double)(B[c] * g0 + B[3 + c] * g1);
             }
         }
-        // unscaled gradient of the point block (for the gradient-tolerance test)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c] / (double)sp[c]));
+        for (int c = 0; c < 6; ++c) V[c] = group_sum8(V[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { bp[c] = group_sum8(bp[c]); Ef[c] = group_sum8(Ef[c]); }
         // LM damping D^2 = clamp(diag(J~^T J~)) / radius   [LevenbergMarquardtStrategy::ComputeStep]
         V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
         V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
         V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
         double Li[6];
         const bool pd = chol3_inverse(V, Li);
-        const double t0 = Li[0] * bp[0];
-        const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
-        const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
-        const double y0 = Li[0] * Ef[0];
-        const double y1 = Li[1] * Ef[0] + Li[2] * Ef[1];
-        const double y2 = Li[3] * Ef[0] + Li[4] * Ef[1] + Li[5] * Ef[2];
-        db.pt_t[3 * i] = t0; db.pt_t[3 * i + 1] = t1; db.pt_t[3 * i + 2] = t2;
-        db.pt_yf[3 * i] = y0; db.pt_yf[3 * i + 1] = y1; db.pt_yf[3 * i + 2] = y2;
-        sff = -(y0 * y0 + y1 * y1 + y2 * y2);
-        rhsf = -(y0 * t0 + y1 * t1 + y2 * t2);
-        if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2) || !finite_d(lin_cost)) bad = 1.0;
-
-        // second sweep: Y_a = A~_a^T (B~_a L^-T), 6x3 per observation
+        if (l == 0) {
+            const double t0 = Li[0] * bp[0];
+            const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
+            const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
+            const double y0 = Li[0] * Ef[0];
+            const double y1 = Li[1] * Ef[0] + Li[2] * Ef[1];
+            const double y2 = Li[3] * Ef[0] + Li[4] * Ef[1] + Li[5] * Ef[2];
+            db.pt_t[3 * (size_t)i] = t0; db.pt_t[3 * (size_t)i + 1] = t1; db.pt_t[3 * (size_t)i + 2] = t2;
+            db.pt_yf[3 * (size_t)i] = y0; db.pt_yf[3 * (size_t)i + 1] = y1; db.pt_yf[3 * (size_t)i + 2] = y2;
+            sff -= y0 * y0 + y1 * y1 + y2 * y2;
+            rhsf -= y0 * t0 + y1 * t1 + y2 * t2;
+            if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2)) bad = 1.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c] / spd[c]));
+        }
+        // second sweep: one packed record per observation
         const T l00 = (T)Li[0], l10 = (T)Li[1], l11 = (T)Li[2], l20 = (T)Li[3], l21 = (T)Li[4], l22 = (T)Li[5];
-        T* Yout = reinterpret_cast<T*>(db.Y);
-        for (int q = q0; q < q1; ++q) {
+        for (int q = q0 + l; q < q1; q += GRP) {
             const int j = ds.obs_cam[q];
-            const double* ct = tab + (size_t)j * CT_STRIDE;
+            const double* ct = tab + (size_t)j * tstride;
             const Proj pr = project_point(ct, CT_R, CT_T, X);
             T B[6], A[12];
             point_block<T>(ct, pr, focal, B);
             camera_block<T>(ct, pr, focal, X, B, A);
-            T C[6];   // C = B~ L^-T : C[r][c] = sum_m B~[r][m] Linv[c][m]
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const T b0 = B[3 * r] * sp[0], b1 = B[3 * r + 1] * sp[1], b2 = B[3 * r + 2] * sp[2];
-                C[3 * r + 0] = b0 * l00;
-                C[3 * r + 1] = b0 * l10 + b1 * l11;
-                C[3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
-            }
             T rec[YREC];
+            rec[0] = A[0]; rec[1] = A[1]; rec[2] = A[2]; rec[3] = A[6]; rec[4] = A[7]; rec[5] = A[8];
+            rec[6] = (T)(focal * pr.iz); rec[7] = (T)pr.xp; rec[8] = (T)pr.yp;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const T s = (T)ct[CT_SCALE + a];
-                const T a0 = A[a] * s, a1 = A[6 + a] * s;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) rec[3 * a + c] = a0 * C[c] + a1 * C[3 + c];
+            for (int r = 0; r < 2; ++r) {   // C = B~ L^-T
+                const T b0 = B[3 * r] * sp[0], b1 = B[3 * r + 1] * sp[1], b2 = B[3 * r + 2] * sp[2];
+                rec[9 + 3 * r + 0] = b0 * l00;
+                rec[9 + 3 * r + 1] = b0 * l10 + b1 * l11;
+                rec[9 + 3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
             }
-            if (sizeof(T) == 4) { rec[18] = (T)__int_as_float(j); } else { rec[18] = (T)__longlong_as_double((long long)j); }
-            rec[19] = (T)0;
-            T* dst = Yout + (size_t)q * YREC;
-            if (sizeof(T) == 4) {
-                float4* d4 = reinterpret_cast<float4*>(dst);
-                const float* rf = reinterpret_cast<const float*>(rec);
-#pragma unroll
-                for (int v = 0; v < 5; ++v) d4[v] = make_float4(rf[4 * v], rf[4 * v + 1], rf[4 * v + 2], rf[4 * v + 3]);
-            } else {
-                double2* d2 = reinterpret_cast<double2*>(dst);
-                const double* rd = reinterpret_cast<const double*>(rec);
-#pragma unroll
-                for (int v = 0; v < 10; ++v) d2[v] = make_double2(rd[2 * v], rd[2 * v + 1]);
-            }
+            if (sizeof(T) == 4) rec[15] = (T)__int_as_float(j); else rec[15] = (T)__longlong_as_double((long long)j);
+            store_rec<T>(Yout, q, rec);
         }
     }
+    if (!finite_d(lin_cost)) bad = 1.0;
     // block reductions -> global accumulators
     const double c_sum = block_sum(lin_cost, scratch);
     const double f_sum = block_sum(sff, scratch);
     const double r_sum = block_sum(rhsf, scratch);
     const double b_sum = block_sum(bad, scratch);
     const double gm = wave_max(gmax);
-    if ((threadIdx.x & 63) == 0) atomic_max_nonneg(&db.st->acc[ACC_GMAX], gm);
+    if ((threadIdx.x & 63) == 0 && gm > 0.0) atomic_max_nonneg(&db.st->acc[ACC_GMAX], gm);
     if (threadIdx.x == 0) {
         atomicAdd(&db.st->acc[ACC_LIN_COST], c_sum);
-        atomicAdd(&db.S[(size_t)(ds.d - 1) * ds.ld + (ds.d - 1)], f_sum);
-        atomicAdd(&db.rhs[ds.d - 1], r_sum);
+        atomicAdd(&db.facc[0], f_sum);
+        atomicAdd(&db.facc[1], r_sum);
         if (b_sum != 0.0) atomicAdd(&db.st->acc[ACC_BAD_LIN], b_sum);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: camera pass.  One block per (camera, range of its observations, column window).
-// The 6 x (6*win_cams) row block of S is accumulated in LDS with ds_add_f64, then flushed.
+// K2a: reduced-system pass over camera pairs.  One wave per 6x6 block (ja < jb, plus the rare
+// same-camera duplicates on the diagonal): the pairs of observations (one of camera ja, one of
+// camera jb, same point) were listed once on the host, so the block is the plain sum
+//   -S_a [ sum_pairs A_a^T (C_a C_b^T) A_b ] S_b
+// -- no atomics, every block written exactly once per iteration (empty blocks are written as zero:
+// the in-place Cholesky destroyed the previous contents).  Workgroups are grouped so that all
+// blocks of one block-row run on one XCD (blockIdx % 8): the records of camera ja stay in that L2.
 // ------------------------------------------------------------------------------------------
+template <int N, int OFF>
+struct HalvingReduce {
+    static __device__ __forceinline__ void run(double* v, int lane, int& base, int& len) {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double lo = v[k];
+            const double hi = (H + k < N) ? v[H + k] : 0.0;
+            const double send = up ? lo : hi;
+            const double keep = up ? hi : lo;
+            v[k] = keep + __shfl_xor(send, OFF, 64);
+        }
+        base += up ? H : 0;
+        len = up ? len - H : (len < H ? len : H);
+        HalvingReduce<H, OFF / 2>::run(v, lane, base, len);
+    }
+};
+template <int N>
+struct HalvingReduce<N, 0> {
+    static __device__ __forceinline__ void run(double*, int, int&, int&) {}
+};
+
 template <typename T>
-__device__ __forceinline__ void load_yrec(const T* Y, int q, T rec[18], int& cam) {
-    const T* src = Y + (size_t)q * YREC;
-    if (sizeof(T) == 4) {
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        float tmp[20];
+__global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int2 wg = ds.pwg_blocks[blockIdx.x];       // {first block, number of blocks (<= 4)}
+    if (w >= wg.y) return;
+    const int b = wg.x + w;
+    const int2 cj = ds.blk_cams[b];
+    const bool diag = cj.x == cj.y;
+    const T* Y = reinterpret_cast<const T*>(db.Y);
+    double acc[36];
 #pragma unroll
-        for (int v = 0; v < 5; ++v) { const float4 x = s4[v]; tmp[4 * v] = x.x; tmp[4 * v + 1] = x.y; tmp[4 * v + 2] = x.z; tmp[4 * v + 3] = x.w; }
+    for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+    const int p1 = ds.blk_ptr[b + 1];
+    for (int p = ds.blk_ptr[b] + lane; p < p1; p += 64) {
+        const int2 pr = ds.pairs[p];
+        T ra[YREC], rb[YREC];
+        load_rec<T>(Y, pr.x, ra);
+        load_rec<T>(Y, pr.y, rb);
+        // M = C_a C_b^T
+        const T m00 = ra[9] * rb[9] + ra[10] * rb[10] + ra[11] * rb[11];
+        const T m01 = ra[9] * rb[12] + ra[10] * rb[13] + ra[11] * rb[14];
+        const T m10 = ra[12] * rb[9] + ra[13] * rb[10] + ra[14] * rb[11];
+        const T m11 = ra[12] * rb[12] + ra[13] * rb[13] + ra[14] * rb[14];
+        T Aa[12], Ab[12], Tm[12];
+        rec_camera_block<T>(ra, Aa);
+        rec_camera_block<T>(rb, Ab);
 #pragma unroll
-        for (int e = 0; e < 18; ++e) rec[e] = (T)tmp[e];
-        cam = __float_as_int(tmp[18]);
-    } else {
-        const double2* s2 = reinterpret_cast<const double2*>(src);
-        double tmp[20];
+        for (int c = 0; c < 6; ++c) { Tm[c] = m00 * Ab[c] + m01 * Ab[6 + c]; Tm[6 + c] = m10 * Ab[c] + m11 * Ab[6 + c]; }
 #pragma unroll
-        for (int v = 0; v < 10; ++v) { const double2 x = s2[v]; tmp[2 * v] = x.x; tmp[2 * v + 1] = x.y; }
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int e = 0; e < 18; ++e) rec[e] = (T)tmp[e];
-        cam = (int)__double_as_longlong(tmp[18]);
+            for (int c = 0; c < 6; ++c) {
+                const T v = Aa[r] * Tm[c] + Aa[6 + r] * Tm[6 + c];
+                acc[6 * r + c] += (double)v;
+                if (diag) acc[6 * c + r] += (double)v;   // same camera twice: Y_a Y_b^T + Y_b Y_a^T
+            }
+    }
+    int base = 0, len = 36;
+    HalvingReduce<36, 32>::run(acc, lane, base, len);
+    if (len >= 1) {
+        const int r = base / 6, c = base - 6 * r;
+        const double* sa = db.cscale + 6 * cj.x;
+        const double* sb = db.cscale + 6 * cj.y;
+        db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = -acc[0] * sa[r] * sb[c];
+    }
+    if (diag && lane < 6) {   // the owner of block (j,j) also clears what k_cam_diag accumulates with atomics
+        const int e = 6 * cj.x + lane;
+        db.udiag[e] = 0.0; db.bc[e] = 0.0; db.rhs[e] = 0.0;
+        db.S[(size_t)e * ds.ld + ds.d - 1] = 0.0;
     }
 }
 
-#define NRED 41   // Ujj(21) Sjf(6) bc(6) rhs(6) uff bf
+// ------------------------------------------------------------------------------------------
+// K2b: camera-diagonal pass, one workgroup per (camera, range of its observations).  A group of 8
+// lanes shares one observation: all lanes read the same packed record (one 64-B request), lane a < 6
+// owns row a of the camera block:
+//   S_jj[a][a..5] += A~^T (I - C C^T) A~   (U_jj minus the self term Y_a Y_a^T)
+//   undamped diagonal, S_jf, b_c, reduced rhs; lane 6 owns the focal-focal sums.
+// ------------------------------------------------------------------------------------------
+#define CD_NV 10     // per-lane accumulators: Sjj row (6) udiag Sjf bc rhs
 
 template <typename T>
-__global__ __launch_bounds__(BLK) void k_cam_schur(DeviceStructure ds, DeviceBuffers db) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    double* acc = reinterpret_cast<double*>(smem_raw);
+__global__ __launch_bounds__(BLK) void k_cam_diag(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double red[(BLK / 64) * 8 * CD_NV];
     const int4 ch = ds.chunks[blockIdx.x];
     const int j = ch.x;
-    const int wlo = ch.w * ds.win_cams;
-    const int whi = min(ds.ncam, wlo + ds.win_cams);
-    const int wcols = 6 * (whi - wlo);
-    double* red = acc + 6 * 6 * ds.win_cams;   // [BLK/64][NRED]
-    for (int e = threadIdx.x; e < 6 * wcols; e += blockDim.x) acc[e] = 0.0;
-    __syncthreads();
-
-    const bool primary = (wlo <= j && j < whi);
     const LMState* st = db.st;
     const int cur = st->cur;
-    const double* ct = db.camtab[cur] + (size_t)j * CT_STRIDE;
     const double focal = st->focal[cur];
-    const double fscale = st->fscale;
+    const T fscale = (T)st->fscale;
     const T* Y = reinterpret_cast<const T*>(db.Y);
-
-    double loc[NRED];
+    const int l = threadIdx.x & 7;                 // role inside the group
+    const int g = threadIdx.x >> 3;                // group inside the workgroup
+    const int a = l < 6 ? l : 0;
+    T sc[6];
 #pragma unroll
-    for (int e = 0; e < NRED; ++e) loc[e] = 0.0;
+    for (int c = 0; c < 6; ++c) sc[c] = (T)db.cscale[6 * j + c];
 
-    for (int e = ch.y + threadIdx.x; e < ch.z; e += blockDim.x) {
+    double loc[CD_NV];
+#pragma unroll
+    for (int e = 0; e < CD_NV; ++e) loc[e] = 0.0;
+
+    for (int e = ch.y + g; e < ch.z; e += BLK / 8) {
         const int q = ds.cam_obs[e];
         const int i = ds.cam_obs_pt[e];
-        T Ya[18];
-        int ca;
-        load_yrec<T>(Y, q, Ya, ca);
-        if (primary) {
-            const double X[3] = { db.pts[cur][3 * i], db.pts[cur][3 * i + 1], db.pts[cur][3 * i + 2] };
-            double ox, oy;
-            load_obs<T>(ds.obs_xy, q, ox, oy);
-            const Proj pr = project_point(ct, CT_R, CT_T, X);
-            const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
-            T B[6], A[12];
-            point_block<T>(ct, pr, focal, B);
-            camera_block<T>(ct, pr, focal, X, B, A);
+        T rec[YREC], A[12];
+        load_rec<T>(Y, q, rec);
+        rec_camera_block<T>(rec, A);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) { const T s = (T)ct[CT_SCALE + a]; A[a] *= s; A[6 + a] *= s; }
-            const T g0 = (T)(pr.xp * fscale), g1 = (T)(pr.yp * fscale);
-            int u = 0;
+        for (int c = 0; c < 6; ++c) { A[c] *= sc[c]; A[6 + c] *= sc[c]; }
+        double ox, oy;
+        load_obs<T>(ds.obs_xy, q, ox, oy);
+        const double r0 = focal * (double)rec[7] - ox, r1 = focal * (double)rec[8] - oy;
+        const T g0 = rec[7] * fscale, g1 = rec[8] * fscale;
+        if (l < 6) {
+            // N = I - C C^T
+            const T n00 = (T)1 - (rec[9] * rec[9] + rec[10] * rec[10] + rec[11] * rec[11]);
+            const T n01 = -(rec[9] * rec[12] + rec[10] * rec[13] + rec[11] * rec[14]);
+            const T n11 = (T)1 - (rec[12] * rec[12] + rec[13] * rec[13] + rec[14] * rec[14]);
+            // dynamic row select without dynamic register indexing
+            T a0 = A[0], a1 = A[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+            for (int c = 1; c < 6; ++c) { a0 = (a == c) ? A[c] : a0; a1 = (a == c) ? A[6 + c] : a1; }
+            const T p0 = n00 * a0 + n01 * a1, p1 = n01 * a0 + n11 * a1;
 #pragma unroll
-                for (int b = a; b < 6; ++b) loc[u++] += (double)(A[a] * A[b] + A[6 + a] * A[6 + b]);
-            const double t0 = db.pt_t[3 * i], t1 = db.pt_t[3 * i + 1], t2 = db.pt_t[3 * i + 2];
-            const double y0 = db.pt_yf[3 * i], y1 = db.pt_yf[3 * i + 1], y2 = db.pt_yf[3 * i + 2];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const double ar = (double)A[a] * r0 + (double)A[6 + a] * r1;
-                const double yt = (double)Ya[3 * a] * t0 + (double)Ya[3 * a + 1] * t1 + (double)Ya[3 * a + 2] * t2;
-                const double yf = (double)Ya[3 * a] * y0 + (double)Ya[3 * a + 1] * y1 + (double)Ya[3 * a + 2] * y2;
-                loc[21 + a] += (double)(A[a] * g0 + A[6 + a] * g1) - yf;   // S[j,f]
-                loc[27 + a] += ar;                                          // b_c (scaled gradient)
-                loc[33 + a] += ar - yt;                                     // reduced rhs
-            }
-            loc[39] += (double)(g0 * g0 + g1 * g1);
-            loc[40] += (double)g0 * r0 + (double)g1 * r1;
-        }
-        // partners: observations of the same point with camera slot >= j (sorted ascending inside a point)
-        const int qend = ds.pt_ptr[i + 1];
-        for (int qb = q; qb < qend; ++qb) {
-            T Yb[18];
-            int cb;
-            if (qb == q) {
-                cb = j;
-#pragma unroll
-                for (int m = 0; m < 18; ++m) Yb[m] = Ya[m];
-            } else {
-                load_yrec<T>(Y, qb, Yb, cb);
-            }
-            if (cb < wlo) continue;
-            if (cb >= whi) break;
-            double* dst = acc + 6 * (cb - wlo);
-            const bool sym = (cb == j) && (qb != q);   // same camera observing the point twice
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    T v = Ya[3 * r] * Yb[3 * c] + Ya[3 * r + 1] * Yb[3 * c + 1] + Ya[3 * r + 2] * Yb[3 * c + 2];
-                    if (sym) v += Ya[3 * c] * Yb[3 * r] + Ya[3 * c + 1] * Yb[3 * r + 1] + Ya[3 * c + 2] * Yb[3 * r + 2];
-                    atomicAdd(&dst[r * wcols + c], -(double)v);
-                }
-            }
+            for (int b = 0; b < 6; ++b) loc[b] += (double)(p0 * A[b] + p1 * A[6 + b]);   // full row; b < a is unused
+            const double t0 = db.pt_t[3 * (size_t)i], t1 = db.pt_t[3 * (size_t)i + 1], t2 = db.pt_t[3 * (size_t)i + 2];
+            const double y0 = db.pt_yf[3 * (size_t)i], y1 = db.pt_yf[3 * (size_t)i + 1], y2 = db.pt_yf[3 * (size_t)i + 2];
+            // Y v = A~^T (C v)
+            const double ct0 = (double)rec[9] * t0 + (double)rec[10] * t1 + (double)rec[11] * t2;
+            const double ct1 = (double)rec[12] * t0 + (double)rec[13] * t1 + (double)rec[14] * t2;
+            const double cy0 = (double)rec[9] * y0 + (double)rec[10] * y1 + (double)rec[11] * y2;
+            const double cy1 = (double)rec[12] * y0 + (double)rec[13] * y1 + (double)rec[14] * y2;
+            const double d0 = (double)a0, d1 = (double)a1;
+            const double ar = d0 * r0 + d1 * r1;
+            loc[6] += d0 * d0 + d1 * d1;                                        // undamped diagonal
+            loc[7] += (double)(a0 * g0 + a1 * g1) - (d0 * cy0 + d1 * cy1);      // S[j,f]
+            loc[8] += ar;                                                       // b_c (scaled gradient)
+            loc[9] += ar - (d0 * ct0 + d1 * ct1);                               // reduced rhs
+        } else if (l == 6) {
+            loc[0] += (double)(g0 * g0 + g1 * g1);
+            loc[1] += (double)g0 * r0 + (double)g1 * r1;
         }
     }
-
-    if (primary) {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // lanes with the same role: xor 8, 16, 32 inside the wave, then across the 4 waves through LDS
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-        for (int e = 0; e < NRED; ++e) {
-            const double s = wave_sum(loc[e]);
-            if (lane == 0) red[w * NRED + e] = s;
-        }
+    for (int e = 0; e < CD_NV; ++e) {
+        double s = loc[e];
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 8) red[(w * 8 + lane) * CD_NV + e] = s;
     }
     __syncthreads();
-    const int row0 = 6 * j;
-    if (primary && threadIdx.x < NRED) {
+    if (threadIdx.x < 8 * CD_NV) {
+        const int role = threadIdx.x / CD_NV, e = threadIdx.x % CD_NV;
         double s = 0.0;
-        for (int w = 0; w < BLK / 64; ++w) s += red[w * NRED + threadIdx.x];
-        const int e = threadIdx.x;
-        const int fo = ds.d - 1;
-        if (e < 21) {
-            int a = 0, rem = e;
-            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-            const int b = a + rem;
-            atomicAdd(&db.S[(size_t)(row0 + a) * ds.ld + row0 + b], s);
-            if (a == b) atomicAdd(&db.udiag[row0 + a], s);
-        } else if (e < 27) {
-            atomicAdd(&db.S[(size_t)(row0 + e - 21) * ds.ld + fo], s);
-        } else if (e < 33) {
-            atomicAdd(&db.bc[row0 + e - 27], s);
-        } else if (e < 39) {
-            atomicAdd(&db.rhs[row0 + e - 33], s);
-        } else if (e == 39) {
-            atomicAdd(&db.S[(size_t)fo * ds.ld + fo], s);
-            atomicAdd(&db.udiag[fo], s);
-        } else {
-            atomicAdd(&db.bc[fo], s);
-            atomicAdd(&db.rhs[fo], s);
+        for (int ww = 0; ww < BLK / 64; ++ww) s += red[(ww * 8 + role) * CD_NV + e];
+        const int row0 = 6 * j, fo = ds.d - 1;
+        if (role < 6) {
+            if (e < 6) { if (e >= role) atomicAdd(&db.S[(size_t)(row0 + role) * ds.ld + row0 + e], s); }
+            else if (e == 6) atomicAdd(&db.udiag[row0 + role], s);
+            else if (e == 7) atomicAdd(&db.S[(size_t)(row0 + role) * ds.ld + fo], s);
+            else if (e == 8) atomicAdd(&db.bc[row0 + role], s);
+            else atomicAdd(&db.rhs[row0 + role], s);
+        } else if (role == 6) {
+            if (e == 0) { atomicAdd(&db.facc[0], s); atomicAdd(&db.facc[2], s); }
+            else if (e == 1) { atomicAdd(&db.facc[1], s); atomicAdd(&db.facc[3], s); }
         }
-    }
-    // flush the LDS row block (upper triangle only: column >= row)
-    for (int e = threadIdx.x; e < 6 * wcols; e += blockDim.x) {
-        const int r = e / wcols, c = e - r * wcols;
-        const int gc = 6 * wlo + c;
-        const double v = acc[e];
-        if (gc >= row0 + r && v != 0.0) atomicAdd(&db.S[(size_t)(row0 + r) * ds.ld + gc], v);
     }
 }
 
-static bool use_lds_table(const DeviceStructure& ds, int stride) { return (size_t)ds.ncam * stride * sizeof(double) <= 56 * 1024; }
+static bool use_lds_table(const DeviceStructure& ds, int stride) { return (size_t)ds.ncam * stride * sizeof(double) <= 96 * 1024; }
 
-size_t build_lds_bytes(const DeviceStructure& ds) {
-    return sizeof(double) * (size_t)(36 * ds.win_cams + (BLK / 64) * NRED);
+// kernels whose dynamic LDS may exceed the 64 KB default (gfx950 has 160 KB per CU)
+static bool allow_big_lds(const void* fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) == hipSuccess;
+}
+
+// persistent point-pass grid: a few workgroups per CU, each staging the camera table once
+static int persistent_grid(const DeviceStructure& ds) {
+    const int need = (ds.npt * GRP + BLK - 1) / BLK;     // one 8-lane group per point
+    return need < 1024 ? need : 1024;
 }
 
 void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    // S | rhs | udiag | bc are contiguous; only the upper triangle of S is ever read, but a flat memset is cheapest
-    (void)hipMemsetAsync(db.S, 0, sizeof(double) * ((size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld), s);
+    // every entry of the upper triangle, rhs, udiag and bc is overwritten each iteration (k_schur_pairs,
+    // k_cam_diag, k_finalize); only the four focal-focal accumulators are summed with atomics
+    (void)ds;
+    (void)hipMemsetAsync(db.facc, 0, sizeof(double) * 4, s);
 }
 
 template <typename T>
 void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    const dim3 grid((ds.npt + BLK - 1) / BLK);
-    if (use_lds_table(ds, CT_STRIDE))
-        hipLaunchKernelGGL((k_point_build<T, true>), grid, dim3(BLK), sizeof(double) * ds.ncam * CT_STRIDE, s, ds, db);
-    else
-        hipLaunchKernelGGL((k_point_build<T, false>), grid, dim3(BLK), 0, s, ds, db);
+    const dim3 grid(persistent_grid(ds));
+    const size_t base = 0;
+    if (use_lds_table(ds, CT_LDS)) {
+        const size_t lds = base + sizeof(double) * ds.ncam * CT_LDS;
+        static bool once = allow_big_lds((const void*)k_point_build<T, true>);
+        (void)once;
+        hipLaunchKernelGGL((k_point_build<T, true>), grid, dim3(BLK), lds, s, ds, db);
+    } else {
+        hipLaunchKernelGGL((k_point_build<T, false>), grid, dim3(BLK), base, s, ds, db);
+    }
 }
 template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 
 template <typename T>
-void launch_cam_schur(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_cam_schur<T>, dim3(ds.nchunk), dim3(BLK), build_lds_bytes(ds), s, ds, db);
+void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+    hipLaunchKernelGGL(k_schur_pairs<T>, dim3(ds.npairwg), dim3(BLK), 0, s, ds, db);
 }
-template void launch_cam_schur<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-template void launch_cam_schur<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_schur_pairs<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+
+template <typename T>
+void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+    hipLaunchKernelGGL(k_cam_diag<T>, dim3(ds.nchunk), dim3(BLK), 0, s, ds, db);
+}
+template void launch_cam_diag<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 
 // ------------------------------------------------------------------------------------------
 // finalize: damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding
@@ -545,6 +638,12 @@ __global__ void k_finalize(DeviceStructure ds, DeviceBuffers db) {
     const LMState* st = db.st;
     double g = 0.0;
     if (e < ds.d) {
+        if (e == ds.d - 1) {   // focal-focal entries were accumulated with atomics
+            db.S[(size_t)e * ds.ld + e] = db.facc[0];
+            db.rhs[e] = db.facc[1];
+            db.udiag[e] = db.facc[2];
+            db.bc[e] = db.facc[3];
+        }
         const double dd = fmin(fmax(db.udiag[e], st->min_diag), st->max_diag) / st->radius;
         db.S[(size_t)e * ds.ld + e] += dd;
         const double sc = e < ds.d - 1 ? db.cscale[e] : st->fscale;
@@ -659,33 +758,58 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     if (threadIdx.x == 0) { atomicAdd(&st->acc[ACC_STEP2], s2); atomicAdd(&st->acc[ACC_XNEW2], x2); }
 }
 
-// One thread per point: y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost
+// Obs-parallel back-substitution: same workgroup/point ownership as k_point_build.
+//   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost
+
+template <typename T>
+struct ObsStep {   // what both sweeps of k_point_update need about one observation
+    Proj pr;
+    double r0, r1;
+    double dp0, dp1, dp2;   // unscaled change of p caused by the camera step: G dw + dt
+};
+
+template <typename CamPtr>
+__device__ __forceinline__ void camera_step_dp(CamPtr stb, const double X[3], double& dp0, double& dp1, double& dp2) {
+    const double kx = stb[ST_KV], ky = stb[ST_KV + 1], kz = stb[ST_KV + 2];
+    const double c0 = ky * X[2] - kz * X[1], c1 = kz * X[0] - kx * X[2], c2 = kx * X[1] - ky * X[0];
+    if (stb[ST_SMALL] != 0.0) { dp0 = c0; dp1 = c1; dp2 = c2; }
+    else {
+        dp0 = stb[ST_R + 0] * c0 + stb[ST_R + 1] * c1 + stb[ST_R + 2] * c2;
+        dp1 = stb[ST_R + 3] * c0 + stb[ST_R + 4] * c1 + stb[ST_R + 5] * c2;
+        dp2 = stb[ST_R + 6] * c0 + stb[ST_R + 7] * c1 + stb[ST_R + 8] * c2;
+    }
+    dp0 += stb[ST_DT]; dp1 += stb[ST_DT + 1]; dp2 += stb[ST_DT + 2];
+}
+
 template <typename T, bool LDS_TAB>
 __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ double scratch[BLK / 64];
+    double* ltab = reinterpret_cast<double*>(smem_raw);
     const LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
     const double* gtab = db.steptab;
-    const double* tab = gtab;
     if (LDS_TAB) {
-        double* ltab = reinterpret_cast<double*>(smem_raw);
         for (int e = threadIdx.x; e < ds.ncam * ST_STRIDE; e += blockDim.x) ltab[e] = gtab[e];
         __syncthreads();
-        tab = ltab;
     }
+    const double* tab = LDS_TAB ? ltab : gtab;
     const double focal = st->focal[cur], focal_n = st->focal[nxt];
     const double dfoc = focal - focal_n;           // unscaled focal step to SUBTRACT (= fscale * y_f)
     const double radius = st->radius;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* pts = db.pts[cur];
+    const int l = threadIdx.x & (GRP - 1);
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / GRP;
+    const int ngroups = gridDim.x * blockDim.x / GRP;
     double trial = 0.0, model = 0.0, step2 = 0.0, xn2 = 0.0, bad = 0.0;
-    if (i < ds.npt) {
-        const double* P = db.pts[cur] + 3 * (size_t)i;
-        const double X[3] = { P[0], P[1], P[2] };
-        const T sp[3] = { (T)db.pscale[3 * i], (T)db.pscale[3 * i + 1], (T)db.pscale[3 * i + 2] };
+
+    for (int i = group; i < ds.npt; i += ngroups) {
+        const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
+        const double spd[3] = { db.pscale[3 * (size_t)i], db.pscale[3 * (size_t)i + 1], db.pscale[3 * (size_t)i + 2] };
+        const T sp[3] = { (T)spd[0], (T)spd[1], (T)spd[2] };
         const int q0 = ds.pt_ptr[i], q1 = ds.pt_ptr[i + 1];
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
-        for (int q = q0; q < q1; ++q) {
+        for (int q = q0 + l; q < q1; q += GRP) {
             const double* stb = tab + (size_t)ds.obs_cam[q] * ST_STRIDE;
             double ox, oy;
             load_obs<T>(ds.obs_xy, q, ox, oy);
@@ -693,20 +817,12 @@ __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, Device
             const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
             T B[6];
             point_block<T>(stb, pr, focal, B);     // ST_R == CT_R == 0
-            // u = A (scale*y_c) + g (fscale*y_f):  A dc = Aproj (G dw + dt), G dw = R_J (kv x X)
-            const T kx = (T)stb[ST_KV], ky = (T)stb[ST_KV + 1], kz = (T)stb[ST_KV + 2];
-            const T c0 = ky * (T)X[2] - kz * (T)X[1], c1 = kz * (T)X[0] - kx * (T)X[2], c2 = kx * (T)X[1] - ky * (T)X[0];
-            T dp0, dp1, dp2;
-            if (stb[ST_SMALL] != 0.0) { dp0 = c0; dp1 = c1; dp2 = c2; }
-            else {
-                dp0 = (T)stb[ST_R + 0] * c0 + (T)stb[ST_R + 1] * c1 + (T)stb[ST_R + 2] * c2;
-                dp1 = (T)stb[ST_R + 3] * c0 + (T)stb[ST_R + 4] * c1 + (T)stb[ST_R + 5] * c2;
-                dp2 = (T)stb[ST_R + 6] * c0 + (T)stb[ST_R + 7] * c1 + (T)stb[ST_R + 8] * c2;
-            }
-            dp0 += (T)stb[ST_DT]; dp1 += (T)stb[ST_DT + 1]; dp2 += (T)stb[ST_DT + 2];
-            const T fz = (T)(focal * pr.iz), xp = (T)pr.xp, yp = (T)pr.yp;
-            const T u0 = fz * (dp0 - xp * dp2) + xp * (T)dfoc;
-            const T u1 = fz * (dp1 - yp * dp2) + yp * (T)dfoc;
+            double dp0, dp1, dp2;
+            camera_step_dp(stb, X, dp0, dp1, dp2);
+            // u = A (scale*y_c) + g (fscale*y_f) = Aproj dp + (xp,yp) dfoc
+            const double fz = focal * pr.iz;
+            const double u0 = fz * (dp0 - pr.xp * dp2) + pr.xp * dfoc;
+            const double u1 = fz * (dp1 - pr.yp * dp2) + pr.yp * dfoc;
 #pragma unroll
             for (int c = 0; c < 3; ++c) { B[c] *= sp[c]; B[3 + c] *= sp[c]; }
             V[0] += (double)(B[0] * B[0] + B[3] * B[3]);
@@ -716,54 +832,53 @@ __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, Device
             V[4] += (double)(B[2] * B[1] + B[5] * B[4]);
             V[5] += (double)(B[2] * B[2] + B[5] * B[5]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) bp[c] += (double)B[c] * (r0 - (double)u0) + (double)B[3 + c] * (r1 - (double)u1);
+            for (int c = 0; c < 3; ++c) bp[c] += (double)B[c] * (r0 - u0) + (double)B[3 + c] * (r1 - u1);
         }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) V[c] = group_sum8(V[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bp[c] = group_sum8(bp[c]);
         V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
         V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
         V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
         double Li[6];
         chol3_inverse(V, Li);
-        // y_p = L^-T L^-1 (b_p - c)
+        // y_p = L^-T L^-1 (b_p - W^T y_c)
         const double t0 = Li[0] * bp[0];
         const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
         const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
         const double y2 = Li[5] * t2;
         const double y1 = Li[2] * t1 + Li[4] * t2;
         const double y0 = Li[0] * t0 + Li[1] * t1 + Li[3] * t2;
-        const double dX[3] = { (double)sp[0] * y0, (double)sp[1] * y1, (double)sp[2] * y2 };
+        const double dX[3] = { spd[0] * y0, spd[1] * y1, spd[2] * y2 };
         double Xn[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            Xn[c] = X[c] - dX[c];
-            const double df = X[c] - Xn[c];
-            step2 += df * df;
-            xn2 += Xn[c] * Xn[c];
-            db.pts[nxt][3 * (size_t)i + c] = Xn[c];
+        for (int c = 0; c < 3; ++c) Xn[c] = X[c] - dX[c];
+        if (l == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double df = X[c] - Xn[c];
+                step2 += df * df;
+                xn2 += Xn[c] * Xn[c];
+                db.pts[nxt][3 * (size_t)i + c] = Xn[c];
+            }
         }
-        for (int q = q0; q < q1; ++q) {
+        for (int q = q0 + l; q < q1; q += GRP) {
             const double* stb = tab + (size_t)ds.obs_cam[q] * ST_STRIDE;
             double ox, oy;
             load_obs<T>(ds.obs_xy, q, ox, oy);
             const Proj pr = project_point(stb, ST_R, ST_T, X);
             const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
-            // model residual m = J step = -(u + B dX), all unscaled quantities; dpt = total unscaled change of p
-            const double kx = stb[ST_KV], ky = stb[ST_KV + 1], kz = stb[ST_KV + 2];
-            const double c0 = ky * X[2] - kz * X[1], c1 = kz * X[0] - kx * X[2], c2 = kx * X[1] - ky * X[0];
             double dp0, dp1, dp2;
-            if (stb[ST_SMALL] != 0.0) { dp0 = c0; dp1 = c1; dp2 = c2; }
-            else {
-                dp0 = stb[ST_R + 0] * c0 + stb[ST_R + 1] * c1 + stb[ST_R + 2] * c2;
-                dp1 = stb[ST_R + 3] * c0 + stb[ST_R + 4] * c1 + stb[ST_R + 5] * c2;
-                dp2 = stb[ST_R + 6] * c0 + stb[ST_R + 7] * c1 + stb[ST_R + 8] * c2;
-            }
-            dp0 += stb[ST_DT] + stb[ST_R + 0] * dX[0] + stb[ST_R + 1] * dX[1] + stb[ST_R + 2] * dX[2];
-            dp1 += stb[ST_DT + 1] + stb[ST_R + 3] * dX[0] + stb[ST_R + 4] * dX[1] + stb[ST_R + 5] * dX[2];
-            dp2 += stb[ST_DT + 2] + stb[ST_R + 6] * dX[0] + stb[ST_R + 7] * dX[1] + stb[ST_R + 8] * dX[2];
+            camera_step_dp(stb, X, dp0, dp1, dp2);
+            // model residual m = J step = -(u + B dX): total unscaled change of p, then Aproj
+            dp0 += stb[ST_R + 0] * dX[0] + stb[ST_R + 1] * dX[1] + stb[ST_R + 2] * dX[2];
+            dp1 += stb[ST_R + 3] * dX[0] + stb[ST_R + 4] * dX[1] + stb[ST_R + 5] * dX[2];
+            dp2 += stb[ST_R + 6] * dX[0] + stb[ST_R + 7] * dX[1] + stb[ST_R + 8] * dX[2];
             const double fz = focal * pr.iz;
             const double m0 = -(fz * (dp0 - pr.xp * dp2) + pr.xp * dfoc);
             const double m1 = -(fz * (dp1 - pr.yp * dp2) + pr.yp * dfoc);
             model -= m0 * (r0 + 0.5 * m0) + m1 * (r1 + 0.5 * m1);
-            // trial residual
             const Proj pn = project_point(stb, ST_RN, ST_TN, Xn);
             const double n0 = focal_n * pn.xp - ox, n1 = focal_n * pn.yp - oy;
             if (!finite_d(n0) || !finite_d(n1)) bad = 1.0;
@@ -790,11 +905,16 @@ void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuf
 
 template <typename T>
 void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    const dim3 grid((ds.npt + BLK - 1) / BLK);
-    if (use_lds_table(ds, ST_STRIDE))
-        hipLaunchKernelGGL((k_point_update<T, true>), grid, dim3(BLK), sizeof(double) * ds.ncam * ST_STRIDE, s, ds, db);
-    else
-        hipLaunchKernelGGL((k_point_update<T, false>), grid, dim3(BLK), 0, s, ds, db);
+    const dim3 grid(persistent_grid(ds));
+    const size_t base = 0;
+    if (use_lds_table(ds, ST_STRIDE)) {
+        const size_t lds = base + sizeof(double) * ds.ncam * ST_STRIDE;
+        static bool once = allow_big_lds((const void*)k_point_update<T, true>);
+        (void)once;
+        hipLaunchKernelGGL((k_point_update<T, true>), grid, dim3(BLK), lds, s, ds, db);
+    } else {
+        hipLaunchKernelGGL((k_point_update<T, false>), grid, dim3(BLK), base, s, ds, db);
+    }
 }
 template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);

@@ -15,7 +15,9 @@ struct DenseSolver {
     double* y = nullptr;      // [ld] work vector of the back substitution
     // PCG
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
-    double* vec = nullptr;    // [6*ld] x r z p q b
+    double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
+    double* part = nullptr;   // [2][256] per-workgroup partial p.q
+    int last_iters = 0;       // CG iterations of the previous solve (sizes the first launch batch)
     double* binv = nullptr;   // [ld*6] inverses of the 6x6 diagonal blocks (+1x1 focal)
     double* scal = nullptr;   // [8] rz, pq, bnorm2, rnorm2, ...
     int* flags = nullptr;     // [4] done, iters

@@ -15,6 +15,7 @@
 #include "dense_solver.h"
 #include <math.h>
 #include <stdio.h>
+#include <algorithm>
 
 namespace sfmba {
 
@@ -201,27 +202,34 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 }
 
 // ------------------------------------------------------------------------------------------
-// Block-Jacobi preconditioned conjugate gradients on the dense reduced system
+// Block-Jacobi preconditioned conjugate gradients on the dense reduced system.
+//
+// The preconditioner is folded into the matrix once per solve: with Lb = blockdiag(chol(S_jj)) (6x6
+// camera blocks + the 1x1 focal), S~ = Lb^-1 S Lb^-T has identity diagonal blocks and plain CG on
+// S~ x~ = Lb^-1 rhs is exactly block-Jacobi PCG on S.  Each CG iteration is then ONE kernel launch:
+// every workgroup redundantly forms alpha, r, beta and the new search direction p (length d, from L2)
+// in LDS, multiplies its own rows of S~ by p and publishes its slice of x, r, p, q = S~ p plus its
+// partial p.q; the next launch (stream order) finishes the dot product.  Vectors are double-buffered
+// by iteration parity so no workgroup overwrites what another one is still reading.  The rows a
+// workgroup owns never change, so its slab of S~ stays in its XCD's L2 across iterations.
 // ------------------------------------------------------------------------------------------
-enum { SC_RZ = 0, SC_PQ = 1, SC_B2 = 2, SC_R2 = 3 };
-enum { VX = 0, VR = 1, VZ = 2, VP = 3, VQ = 4 };
+constexpr int PCG_MAXWG = 256;
+enum { PF_DONE = 0, PF_ITERS = 1, PF_XBUF = 2 };
+enum { PS_RR0 = 0 };
+// vec layout: x[2] r[2] p[2] q[2], each ld doubles; btilde after them
+__device__ __forceinline__ double* pcg_vec(double* vec, int which, int buf, int ld) { return vec + (size_t)(2 * which + buf) * ld; }
 
-__global__ void k_mirror_full(const double* __restrict__ S, int ld, int d, double* __restrict__ F) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= d) return;
-    F[(size_t)r * ld + c] = c >= r ? S[(size_t)r * ld + c] : S[(size_t)c * ld + r];
-}
-
-// inverse of each 6x6 diagonal block (and the trailing 1x1): one thread per block
-__global__ void k_block_inverse(const double* __restrict__ S, int ld, int d, double* __restrict__ binv, int* info) {
+// Linv of each diagonal block: row-major lower 6x6 (zeros above), focal: 1/sqrt(S_ff) at [nb6*36]
+__global__ void k_pcg_blockchol(const double* __restrict__ S, int ld, int d, double* __restrict__ linv, int* info) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb6 = (d - 1) / 6;
-    if (b > nb6) return;
-    if (b == nb6) {   // focal
-        const double v = S[(size_t)(d - 1) * ld + d - 1];
-        if (!(v > 0.0)) atomicCAS(info, 0, d);
-        binv[(size_t)b * 36] = 1.0 / v;
+    const int rem = d - 6 * nb6;     // trailing scalars (1 for a BA system)
+    if (b >= nb6 + rem) return;
+    if (b >= nb6) {
+        const int e = 6 * nb6 + (b - nb6);
+        const double v = S[(size_t)e * ld + e];
+        if (!(v > 0.0)) atomicCAS(info, 0, e + 1);
+        linv[(size_t)nb6 * 36 + (b - nb6)] = 1.0 / sqrt(v > 0.0 ? v : 1.0);
         return;
     }
     double L[6][6], Li[6][6];
@@ -250,125 +258,300 @@ __global__ void k_block_inverse(const double* __restrict__ S, int ld, int d, dou
             Li[r][c] = v / L[r][r];
         }
     for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) linv[(size_t)b * 36 + r * 6 + c] = Li[r][c];
+}
+
+// F = Lb^-1 S Lb^-T (full symmetric, d rows x ld), btilde = Lb^-1 rhs.  One thread per block pair I <= J;
+// trailing 1x1 blocks are padded to 6x6 with zeros so that every loop has compile-time bounds (registers).
+__global__ __launch_bounds__(64) void k_pcg_transform(const double* __restrict__ S, int ld, int d, const double* __restrict__ linv,
+                                                      const double* __restrict__ rhs, double* __restrict__ F, double* __restrict__ bt) {
+    const int nb6 = (d - 1) / 6;
+    const int nB = nb6 + (d - 6 * nb6);
+    const int J = blockIdx.x * blockDim.x + threadIdx.x;
+    const int I = blockIdx.y;
+    if (J >= nB || J < I) return;
+    const int ri = I < nb6 ? 6 * I : 6 * nb6 + (I - nb6), si = I < nb6 ? 6 : 1;
+    const int rj = J < nb6 ? 6 * J : 6 * nb6 + (J - nb6), sj = J < nb6 ? 6 : 1;
+    double A[6][6], Lj[6][6], Li[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double fi = (r == 0 && c == 0) ? linv[(size_t)nb6 * 36 + (I < nb6 ? 0 : I - nb6)] : 0.0;
+            const double fj = (r == 0 && c == 0) ? linv[(size_t)nb6 * 36 + (J < nb6 ? 0 : J - nb6)] : 0.0;
+            Li[r][c] = (I < nb6) ? linv[(size_t)I * 36 + r * 6 + c] : fi;
+            Lj[r][c] = (J < nb6) ? linv[(size_t)J * 36 + r * 6 + c] : fj;
+            const int gr = ri + r, gc = rj + c;
+            const bool in = r < si && c < sj;
+            // upper storage: element (gr, gc) with column >= row, mirrored inside diagonal blocks
+            A[r][c] = in ? (gc >= gr ? S[(size_t)gr * ld + gc] : S[(size_t)gc * ld + gr]) : 0.0;
+        }
+    double U[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
         for (int c = 0; c < 6; ++c) {
             double v = 0.0;
-            for (int t = (r > c ? r : c); t < 6; ++t) v += Li[t][r] * Li[t][c];
-            binv[(size_t)b * 36 + r * 6 + c] = v;
-        }
-}
-
-__device__ __forceinline__ double precond_apply(const double* binv, const double* r, int e, int d) {
-    const int nb6 = (d - 1) / 6;
-    const int b = e / 6;
-    if (b >= nb6) return binv[(size_t)nb6 * 36] * r[e];
-    const double* Bi = binv + (size_t)b * 36 + (e - 6 * b) * 6;
-    const double* rb = r + 6 * b;
-    return Bi[0] * rb[0] + Bi[1] * rb[1] + Bi[2] * rb[2] + Bi[3] * rb[3] + Bi[4] * rb[4] + Bi[5] * rb[5];
-}
-
-__device__ __forceinline__ double block_reduce_1024(double v, double* sm) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double s = 0.0;
-    const int nw = blockDim.x >> 6;
-    for (int i = 0; i < nw; ++i) s += sm[i];
-    return s;
+            for (int t = 0; t < 6; ++t) v += Li[r][t] * A[t][c];      // Li is lower triangular (zeros above)
+            U[r][c] = v;
+        }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) v += U[r][t] * Lj[c][t];
+            if (r < si && c < sj) {
+                F[(size_t)(ri + r) * ld + rj + c] = v;
+                if (I != J) F[(size_t)(rj + c) * ld + ri + r] = v;
+            }
+        }
+    if (I == J) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) v += (t < si) ? Li[r][t] * rhs[ri + t] : 0.0;
+            if (r < si) bt[ri + r] = v;
+        }
+    }
 }
 
-__global__ __launch_bounds__(1024) void k_pcg_init(int d, int ld, const double* __restrict__ b, double* __restrict__ vec,
-                                                   const double* __restrict__ binv, double* scal, int* flags) {
-    __shared__ double sm[16];
-    double* x = vec + VX * ld; double* r = vec + VR * ld; double* z = vec + VZ * ld; double* p = vec + VP * ld;
-    double b2 = 0.0;
-    for (int e = threadIdx.x; e < d; e += blockDim.x) { x[e] = 0.0; r[e] = b[e]; b2 += b[e] * b[e]; }
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    const int w = threadIdx.x >> 6;
     __syncthreads();
-    double rz = 0.0;
-    for (int e = threadIdx.x; e < d; e += blockDim.x) { const double ze = precond_apply(binv, r, e, d); z[e] = ze; p[e] = ze; rz += r[e] * ze; }
-    rz = block_reduce_1024(rz, sm);
-    b2 = block_reduce_1024(b2, sm);
-    if (threadIdx.x == 0) { scal[SC_RZ] = rz; scal[SC_PQ] = 0.0; scal[SC_B2] = b2; scal[SC_R2] = b2; flags[0] = (b2 == 0.0); flags[1] = 0; }
+    if ((threadIdx.x & 63) == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    a = red[0] + red[2] + red[4] + red[6];
+    b = red[1] + red[3] + red[5] + red[7];
 }
 
-// q = S p, one wave per row; pq += p^T q
-__global__ __launch_bounds__(256) void k_pcg_matvec(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
-                                                    double* scal, const int* flags) {
-    if (flags[0]) return;
-    const double* p = vec + VP * ld; double* q = vec + VQ * ld;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + w;
-    double pq = 0.0;
-    if (row < d) {
+template <bool INIT>
+__global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
+                                                  const double* __restrict__ bt, double* __restrict__ part, double* scal,
+                                                  int* flags, int rows_per_wg, double tol2, int in, int* info) {
+    extern __shared__ __align__(16) double sm[];
+    double* pl = sm;            // [ld] new search direction
+    double* red = sm + ld;      // [8]
+    if (!INIT && flags[PF_DONE]) return;
+    const int tid = threadIdx.x, out = in ^ 1;
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int row1 = min(d, row0 + rows_per_wg);
+    double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld);
+    double* p_out = pcg_vec(vec, 2, out, ld); double* q_out = pcg_vec(vec, 3, out, ld);
+    if (INIT) {
+        double rr = 0.0, dummy = 0.0;
+        for (int e = tid; e < d; e += 256) { const double v = bt[e]; pl[e] = v; rr += v * v; }
+        block_sum2(rr, dummy, red);
+        for (int e = row0 + tid; e < row1; e += 256) { x_out[e] = 0.0; r_out[e] = pl[e]; p_out[e] = pl[e]; }
+        if (blockIdx.x == 0 && tid == 0) { scal[PS_RR0] = rr; flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out; }
+    } else {
+        const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = pcg_vec(vec, 1, in, ld);
+        const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
+        double pq = (tid < (int)gridDim.x) ? part[in * PCG_MAXWG + tid] : 0.0;
+        double rr = 0.0;
+        for (int e = tid; e < d; e += 256) { const double v = r_in[e]; rr += v * v; }
+        block_sum2(pq, rr, red);
+        const double alpha = rr / pq;
+        double rrn = 0.0, dummy = 0.0;
+        for (int e = tid; e < d; e += 256) { const double v = r_in[e] - alpha * q_in[e]; pl[e] = v; rrn += v * v; }
+        block_sum2(rrn, dummy, red);
+        for (int e = row0 + tid; e < row1; e += 256) x_out[e] = x_in[e] + alpha * p_in[e];
+        const bool broke = !(pq > 0.0) || !(rrn == rrn);
+        if (rrn <= tol2 * scal[PS_RR0] || broke) {
+            if (blockIdx.x == 0 && tid == 0) {
+                flags[PF_DONE] = 1; flags[PF_XBUF] = out; flags[PF_ITERS] += 1;
+                if (broke) atomicCAS(info, 0, d + 1);
+            }
+            return;
+        }
+        const double beta = rrn / rr;
+        for (int e = row0 + tid; e < row1; e += 256) r_out[e] = pl[e];      // pl holds r_new (synced by block_sum2)
+        __syncthreads();
+        for (int e = tid; e < d; e += 256) pl[e] = pl[e] + beta * p_in[e];
+        __syncthreads();
+        for (int e = row0 + tid; e < row1; e += 256) p_out[e] = pl[e];
+        if (blockIdx.x == 0 && tid == 0) { flags[PF_ITERS] += 1; flags[PF_XBUF] = out; }
+    }
+    __syncthreads();
+    // q = S~ p for the rows this workgroup owns: one wave per row
+    const int lane = tid & 63, w = tid >> 6;
+    double pqp = 0.0;
+    for (int row = row0 + w; row < row1; row += 4) {
         const double* Fr = F + (size_t)row * ld;
         double s = 0.0;
-        for (int c = lane; c < d; c += 64) s += Fr[c] * p[c];
+        for (int c = lane; c < d; c += 64) s += Fr[c] * pl[c];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) { q[row] = s; pq = p[row] * s; }
+        if (lane == 0) { q_out[row] = s; pqp += pl[row] * s; }
     }
-    __shared__ double sm[4];
-    if (lane == 0) sm[w] = pq;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&scal[SC_PQ], sm[0] + sm[1] + sm[2] + sm[3]);
+    if (lane == 0) red[w] = pqp;
+    __syncthreads();
+    if (tid == 0) part[out * PCG_MAXWG + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(1024) void k_pcg_update(int d, int ld, double* __restrict__ vec, const double* __restrict__ binv,
-                                                     double* scal, int* flags, double tol2) {
-    __shared__ double sm[16];
-    if (flags[0]) return;
-    double* x = vec + VX * ld; double* r = vec + VR * ld; double* z = vec + VZ * ld; double* p = vec + VP * ld; double* q = vec + VQ * ld;
-    const double rz = scal[SC_RZ];
-    const double alpha = rz / scal[SC_PQ];
-    double r2 = 0.0;
-    for (int e = threadIdx.x; e < d; e += blockDim.x) { x[e] += alpha * p[e]; const double re = r[e] - alpha * q[e]; r[e] = re; r2 += re * re; }
-    __syncthreads();
-    double rzn = 0.0;
-    for (int e = threadIdx.x; e < d; e += blockDim.x) { const double ze = precond_apply(binv, r, e, d); z[e] = ze; rzn += r[e] * ze; }
-    rzn = block_reduce_1024(rzn, sm);
-    r2 = block_reduce_1024(r2, sm);
-    const double beta = rzn / rz;
-    for (int e = threadIdx.x; e < d; e += blockDim.x) p[e] = z[e] + beta * p[e];
-    if (threadIdx.x == 0) {
-        scal[SC_RZ] = rzn; scal[SC_PQ] = 0.0; scal[SC_R2] = r2;
-        flags[1] += 1;
-        if (r2 <= tol2 * scal[SC_B2] || !(r2 == r2)) flags[0] = 1;
+// Fast path of one CG iteration for d <= 1280 (all BASELINE single-GPU configs): every global load of
+// the iteration -- the three length-d vectors, the partial dot products and this wave's rows of S~ --
+// is issued up front into registers, so the launch pays ONE memory round trip; the rest is LDS + ALU.
+constexpr int PCG_EPT = 5;    // vector elements per thread  (256 * 5 >= d)
+constexpr int PCG_RPW = 2;    // rows of S~ per wave         (rows_per_wg <= 8)
+constexpr int PCG_CPL = 20;   // columns per lane            (64 * 20 >= d)
+
+__global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
+                                                       double* __restrict__ part, const double* __restrict__ scal,
+                                                       int* flags, int rows_per_wg, double tol2, int in, int* info) {
+    extern __shared__ __align__(16) double sm[];
+    double* pl = sm;
+    double* red = sm + ld;
+    if (flags[PF_DONE]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int row1 = min(d, row0 + rows_per_wg);
+    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = pcg_vec(vec, 1, in, ld);
+    const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
+    double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld);
+    double* p_out = pcg_vec(vec, 2, out, ld); double* q_out = pcg_vec(vec, 3, out, ld);
+
+    // ---- all global loads of this iteration ----
+    double rv[PCG_EPT], qv[PCG_EPT], pv[PCG_EPT];
+#pragma unroll
+    for (int m = 0; m < PCG_EPT; ++m) {
+        const int e = tid + 256 * m;
+        const bool ok = e < d;
+        rv[m] = ok ? r_in[e] : 0.0; qv[m] = ok ? q_in[e] : 0.0; pv[m] = ok ? p_in[e] : 0.0;
     }
+    double pq = (tid < (int)gridDim.x) ? part[in * PCG_MAXWG + tid] : 0.0;
+    const double rr0 = scal[PS_RR0];
+    double fv[PCG_RPW][PCG_CPL];
+#pragma unroll
+    for (int k = 0; k < PCG_RPW; ++k) {
+        const int row = row0 + w + 4 * k;
+        const double* Fr = F + (size_t)(row < row1 ? row : row0) * ld;
+#pragma unroll
+        for (int m = 0; m < PCG_CPL; ++m) {
+            const int c = lane + 64 * m;
+            fv[k][m] = (row < row1 && c < d) ? Fr[c] : 0.0;
+        }
+    }
+    const int xrow = row0 + tid;
+    const double x_old = (xrow < row1) ? x_in[xrow] : 0.0;
+
+    // ---- alpha, r_new, beta, p_new ----
+    double rr = 0.0;
+#pragma unroll
+    for (int m = 0; m < PCG_EPT; ++m) rr += rv[m] * rv[m];
+    block_sum2(pq, rr, red);
+    const double alpha = rr / pq;
+    double rrn = 0.0, dummy = 0.0;
+#pragma unroll
+    for (int m = 0; m < PCG_EPT; ++m) { rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
+    block_sum2(rrn, dummy, red);
+    const bool broke = !(pq > 0.0) || !(rrn == rrn);
+    const bool done = rrn <= tol2 * rr0 || broke;
+    const double beta = rrn / rr;
+#pragma unroll
+    for (int m = 0; m < PCG_EPT; ++m) {
+        const int e = tid + 256 * m;
+        if (e < d) {
+            const double pn = rv[m] + beta * pv[m];
+            pl[e] = pn;
+            if (e >= row0 && e < row1) { x_out[e] = x_in[e] + alpha * pv[m]; if (!done) { r_out[e] = rv[m]; p_out[e] = pn; } }
+        }
+    }
+    (void)x_old; (void)xrow;
+    if (done) {
+        if (blockIdx.x == 0 && tid == 0) {
+            flags[PF_DONE] = 1; flags[PF_XBUF] = out; flags[PF_ITERS] += 1;
+            if (broke) atomicCAS(info, 0, d + 1);
+        }
+        return;
+    }
+    if (blockIdx.x == 0 && tid == 0) { flags[PF_ITERS] += 1; flags[PF_XBUF] = out; }
+    __syncthreads();
+    // ---- q = S~ p for the rows of this workgroup ----
+    double pqp = 0.0;
+#pragma unroll
+    for (int k = 0; k < PCG_RPW; ++k) {
+        const int row = row0 + w + 4 * k;
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < PCG_CPL; ++m) {
+            const int c = lane + 64 * m;
+            sacc += fv[k][m] * ((c < d) ? pl[c] : 0.0);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+        if (lane == 0 && row < row1) { q_out[row] = sacc; pqp += pl[row] * sacc; }
+    }
+    __syncthreads();
+    if (lane == 0) red[w] = pqp;
+    __syncthreads();
+    if (tid == 0) part[out * PCG_MAXWG + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void k_copy_vec(int d, const double* __restrict__ src, double* __restrict__ dst) {
+
+// solution of the original system: z = Lb^-T x~
+__global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, const double* __restrict__ linv, const int* flags,
+                             double* __restrict__ z) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < d) dst[e] = src[e];
+    if (e >= d) return;
+    const double* x = vec + (size_t)(flags[PF_XBUF]) * ld;   // x buffers are vec[0], vec[1]
+    const int nb6 = (d - 1) / 6;
+    const int b = e / 6;
+    if (b >= nb6) { z[e] = linv[(size_t)nb6 * 36 + (e - 6 * nb6)] * x[e]; return; }
+    const int c = e - 6 * b;
+    double v = 0.0;
+    for (int t = c; t < 6; ++t) v += linv[(size_t)b * 36 + t * 6 + c] * x[6 * b + t];
+    z[e] = v;
 }
 
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof) {
     const int ld = ws->ld, d = ws->d;
     if (!ws->Sfull) {
-        if (hipMalloc(&ws->Sfull, sizeof(double) * (size_t)ld * ld) != hipSuccess) return -1;
+        if (hipMalloc(&ws->Sfull, sizeof(double) * (size_t)d * ld) != hipSuccess) return -1;
     }
     if (max_iters <= 0) max_iters = 4 * d;
+    const int nb6 = (d - 1) / 6, nB = nb6 + (d - 6 * nb6);
+    const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
+    const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
+    const size_t lds = sizeof(double) * (size_t)(ld + 8);
+    double* bt = ws->vec + (size_t)8 * ld;
     { ProfScope ps(prof, KID_PCG_SETUP, s);
-    hipLaunchKernelGGL(k_mirror_full, dim3((d + 255) / 256, d), dim3(256), 0, s, S, ld, d, ws->Sfull);
-    hipLaunchKernelGGL(k_block_inverse, dim3(((d - 1) / 6 + 1 + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
-    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, s, d, ld, rhs, ws->vec, ws->binv, ws->scal, ws->flags); }
-    int it = 0;
-    const int batch = 8;
+      hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
+      hipLaunchKernelGGL(k_pcg_transform, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
+    { ProfScope ps(prof, KID_PCG_ITER, s);
+      hipLaunchKernelGGL(k_pcg_iter<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                         rows_per_wg, tol * tol, 0, info_dev); }
+    int in = 1, it = 0;
+    int batch = ws->last_iters > 0 ? ws->last_iters + 2 : 32;
     while (it < max_iters) {
-        const int n = (max_iters - it) < batch ? (max_iters - it) : batch;
+        const int n = std::min(max_iters - it, batch);
+        const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
         for (int b = 0; b < n; ++b) {
-            { ProfScope ps(prof, KID_PCG_MATVEC, s);
-            hipLaunchKernelGGL(k_pcg_matvec, dim3((d + 3) / 4), dim3(256), 0, s, d, ld, ws->Sfull, ws->vec, ws->scal, ws->flags); }
-            ProfScope ps2(prof, KID_PCG_UPDATE, s);
-            hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(1024), 0, s, d, ld, ws->vec, ws->binv, ws->scal, ws->flags, tol * tol);
+            ProfScope ps(prof, KID_PCG_ITER, s);
+            if (fast)
+                hipLaunchKernelGGL(k_pcg_iter_fast, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, ws->part, ws->scal, ws->flags,
+                                   rows_per_wg, tol * tol, in, info_dev);
+            else
+                hipLaunchKernelGGL(k_pcg_iter<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                                   rows_per_wg, tol * tol, in, info_dev);
+            in ^= 1;
         }
         it += n;
-        (void)hipMemcpyAsync(ws->h_flags, ws->flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(ws->h_flags, ws->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
-        if (ws->h_flags[0]) { it = ws->h_flags[1]; break; }
+        if (ws->h_flags[PF_DONE]) break;
+        batch = 8;
     }
-    hipLaunchKernelGGL(k_copy_vec, dim3((d + 255) / 256), dim3(256), 0, s, d, ws->vec + VX * ld, rhs);
-    return it;
+    { ProfScope ps(prof, KID_PCG_FINISH, s);
+      hipLaunchKernelGGL(k_pcg_finish, dim3((d + 255) / 256), dim3(256), 0, s, d, ld, ws->vec, ws->binv, ws->flags, rhs); }
+    ws->last_iters = ws->h_flags[PF_ITERS];
+    return ws->h_flags[PF_ITERS];
 }
 
 int dense_solver_create(DenseSolver* ws, int d, int ld) {
@@ -376,7 +559,8 @@ int dense_solver_create(DenseSolver* ws, int d, int ld) {
     const int nblk = ld / NB;
     if (hipMalloc(&ws->minv, sizeof(double) * (size_t)nblk * NB * NB) != hipSuccess) return -1;
     if (hipMalloc(&ws->y, sizeof(double) * ld) != hipSuccess) return -1;
-    if (hipMalloc(&ws->vec, sizeof(double) * 6 * (size_t)ld) != hipSuccess) return -1;
+    if (hipMalloc(&ws->vec, sizeof(double) * 9 * (size_t)ld) != hipSuccess) return -1;
+    if (hipMalloc(&ws->part, sizeof(double) * 2 * 256) != hipSuccess) return -1;
     if (hipMalloc(&ws->binv, sizeof(double) * 36 * (size_t)(ld / 6 + 2)) != hipSuccess) return -1;
     if (hipMalloc(&ws->scal, sizeof(double) * 8) != hipSuccess) return -1;
     if (hipMalloc(&ws->flags, sizeof(int) * 4) != hipSuccess) return -1;
@@ -389,6 +573,7 @@ void dense_solver_destroy(DenseSolver* ws) {
     if (ws->minv) (void)hipFree(ws->minv);
     if (ws->y) (void)hipFree(ws->y);
     if (ws->vec) (void)hipFree(ws->vec);
+    if (ws->part) (void)hipFree(ws->part);
     if (ws->binv) (void)hipFree(ws->binv);
     if (ws->scal) (void)hipFree(ws->scal);
     if (ws->flags) (void)hipFree(ws->flags);

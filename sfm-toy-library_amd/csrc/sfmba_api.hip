@@ -89,6 +89,10 @@ struct sfmba_problem {
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr;
+    int* d_blk_ptr = nullptr;
+    int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr;
+    int* d_pwg_ptr = nullptr;
+    double* d_facc = nullptr;
     double *d_cam0 = nullptr, *d_pts0 = nullptr;  // parameters given at create time
     double focal0 = 0.0;
     double *d_sys = nullptr;                      // S | rhs | udiag | bc (contiguous)
@@ -203,7 +207,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
         { ProfScope ps(prof, KID_ZERO, p->stream); launch_zero_system(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_POINT_BUILD, p->stream); launch_point_build<T>(p->stream, p->ds, p->db); }
-        { ProfScope ps(prof, KID_CAM_SCHUR, p->stream); launch_cam_schur<T>(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_SCHUR_PAIRS, p->stream); launch_schur_pairs<T>(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_POST_LIN, p->stream); launch_post_lin(p->stream, p->ds, p->db); }
         if (o.linear_solver == SFMBA_LINEAR_PCG) {
@@ -301,7 +306,7 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     dense_solver_destroy(&p->solver);
     void* frees[] = { p->d_pt_ptr, p->d_obs_cam, p->d_cam_ptr, p->d_cam_obs, p->d_cam_obs_pt, p->d_obs_pt, p->d_obs_xy, p->d_chunks,
-                      p->d_cam0, p->d_pts0, p->d_sys, p->d_info, p->db.cam[0], p->db.cam[1], p->db.pts[0], p->db.pts[1],
+                      p->d_cam0, p->d_pts0, p->d_sys, p->d_info, p->d_blk_ptr, p->d_pairs, p->d_blk_cams, p->d_facc, p->d_pwg_blocks, p->d_pwg_ptr, p->db.cam[0], p->db.cam[1], p->db.pts[0], p->db.pts[1],
                       p->db.camtab[0], p->db.camtab[1], p->db.steptab, p->db.cscale, p->db.pscale, p->db.Y, p->db.pt_t, p->db.pt_yf,
                       p->db.st, p->db.trace };
     for (void* f : frees) if (f) (void)hipFree(f);
@@ -383,19 +388,73 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
         cam_obs[e] = q;
         cam_obs_pt[e] = pm_pt[q];
     }
-    // chunks of the camera pass: (camera, entry range, column window)
-    const int lds_budget_doubles = 7200;                       // 36*win_cams doubles <= ~56 KB
-    const int win_cams = std::max(1, std::min(ncam, lds_budget_doubles / 36));
-    const int nwin = (ncam + win_cams - 1) / win_cams;
+    // chunks of the camera-major list (used by the column-norm pass): (camera, entry range)
     int chunk_len = (int)std::max<int64_t>(256, ((int64_t)nobs + 1023) / 1024);
     chunk_len = ((chunk_len + 255) / 256) * 256;
     std::vector<int4> chunks;
-    for (int j = 0; j < ncam; ++j) {
-        for (int w = j / win_cams; w < nwin; ++w)
-            for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
-                int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = w;
-                chunks.push_back(c);
+    for (int j = 0; j < ncam; ++j)
+        for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
+            int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = 0;
+            chunks.push_back(c);
+        }
+    // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the
+    // self pairs are folded into the camera-diagonal pass)
+    // goes to block (ja, jb) of the upper triangle of S; counting sort by block.
+    const int64_t nblock64 = (int64_t)ncam * (ncam + 1) / 2;
+    if (nblock64 >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many cameras");
+    const int nblock = (int)nblock64;
+    auto block_of = [ncam](int ja, int jb) { return (int)((int64_t)ja * ncam - (int64_t)ja * (ja - 1) / 2 + (jb - ja)); };
+    std::vector<int> blk_ptr((size_t)nblock + 1, 0);
+    int64_t npair = 0;
+    for (int i = 0; i < npt; ++i)
+        for (int a = pt_ptr[i]; a < pt_ptr[(size_t)i + 1]; ++a)
+            for (int b = a + 1; b < pt_ptr[(size_t)i + 1]; ++b) { blk_ptr[(size_t)block_of(pm_cam[a], pm_cam[b]) + 1]++; ++npair; }
+    if (npair >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
+    for (int b = 0; b < nblock; ++b) blk_ptr[(size_t)b + 1] += blk_ptr[b];
+    std::vector<int2> pairs((size_t)npair);
+    {
+        std::vector<int> bfill(blk_ptr.begin(), blk_ptr.end() - 1);
+        for (int i = 0; i < npt; ++i)
+            for (int a = pt_ptr[i]; a < pt_ptr[(size_t)i + 1]; ++a)
+                for (int b = a + 1; b < pt_ptr[(size_t)i + 1]; ++b) {
+                    int2 pr; pr.x = a; pr.y = b;
+                    pairs[(size_t)bfill[block_of(pm_cam[a], pm_cam[b])]++] = pr;
+                }
+    }
+    std::vector<int2> blk_cams((size_t)nblock);
+    for (int ja = 0; ja < ncam; ++ja)
+        for (int jb = ja; jb < ncam; ++jb) { int2 c; c.x = ja; c.y = jb; blk_cams[(size_t)block_of(ja, jb)] = c; }
+    // workgroups of the pair pass: 4 consecutive blocks of ONE block-row each; rows are dealt to the 8
+    // XCDs (blockIdx % 8, the observed dispatch order) so a row's records stay in one L2.  Performance
+    // only: any placement gives the same result.
+    std::vector<int2> pwg_blocks;
+    {
+        std::vector<std::vector<int2>> per_xcd(8);
+        for (int ja = 0; ja < ncam; ++ja) {
+            const int b0 = block_of(ja, ja), nb = ncam - ja;
+            for (int o = 0; o < nb; o += 4) { int2 w; w.x = b0 + o; w.y = std::min(4, nb - o); per_xcd[ja % 8].push_back(w); }
+        }
+        size_t longest = 0;
+        for (auto& v : per_xcd) longest = std::max(longest, v.size());
+        for (size_t m = 0; m < longest; ++m)
+            for (int x = 0; x < 8; ++x) {
+                int2 w; w.x = 0; w.y = 0;
+                if (m < per_xcd[x].size()) w = per_xcd[x][m];
+                pwg_blocks.push_back(w);
             }
+    }
+    // workgroups of the point passes: contiguous point ranges with at most 256 observations (a point with
+    // more observations than that gets a range of its own and is swept in several rounds)
+    std::vector<int> pwg_ptr;
+    pwg_ptr.push_back(0);
+    {
+        int cnt = 0, npts_in = 0;
+        for (int i = 0; i < npt; ++i) {
+            const int k = pt_ptr[(size_t)i + 1] - pt_ptr[i];
+            if (npts_in > 0 && (cnt + k > 256 || npts_in >= 256)) { pwg_ptr.push_back(i); cnt = 0; npts_in = 0; }
+            cnt += k; ++npts_in;
+        }
+        pwg_ptr.push_back(npt);
     }
 
     // ---- upload ----
@@ -405,6 +464,11 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     HIP_TRY(dev_upload(&p->d_cam_obs, cam_obs));
     HIP_TRY(dev_upload(&p->d_cam_obs_pt, cam_obs_pt));
     HIP_TRY(dev_upload(&p->d_chunks, chunks));
+    HIP_TRY(dev_upload(&p->d_blk_ptr, blk_ptr));
+    HIP_TRY(dev_upload(&p->d_pairs, pairs));
+    HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
+    HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
+    HIP_TRY(dev_upload(&p->d_pwg_ptr, pwg_ptr));
     {
         std::vector<int> both((size_t)2 * nobs);
         std::copy(pm_pt.begin(), pm_pt.end(), both.begin());
@@ -437,7 +501,11 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     ds.ld = dense_padded_dim(ds.d);
     ds.pt_ptr = p->d_pt_ptr; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
     ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt;
-    ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks; ds.win_cams = win_cams;
+    ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
+    ds.obs_pt = p->d_obs_pt;
+    ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
+    ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks;
+    ds.npwg = (int)pwg_ptr.size() - 1; ds.pwg_ptr = p->d_pwg_ptr;
 
     DeviceBuffers& db = p->db;
     for (int b = 0; b < 2; ++b) {
@@ -459,6 +527,10 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     db.udiag = db.rhs + ds.ld;
     db.bc = db.udiag + ds.ld;
     HIP_TRY(dev_alloc(&db.st, 1));
+    HIP_TRY(dev_alloc(&p->d_facc, 4));
+    db.facc = p->d_facc;
+    // padding of the reduced system (rows/columns >= d) is zero apart from the identity diagonal set by k_finalize
+    HIP_TRY(hipMemset(p->d_sys, 0, sizeof(double) * sys_len));
     HIP_TRY(dev_alloc(&p->d_info, 1));
     db.trace = nullptr; db.trace_cap = 0;
     if (dense_solver_create(&p->solver, ds.d, ds.ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
@@ -643,12 +715,14 @@ int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, doub
         launch_linearise_setup<float>(p, o.jacobi_scaling);
         launch_zero_system(p->stream, p->ds, p->db);
         launch_point_build<float>(p->stream, p->ds, p->db);
-        launch_cam_schur<float>(p->stream, p->ds, p->db);
+        launch_schur_pairs<float>(p->stream, p->ds, p->db);
+        launch_cam_diag<float>(p->stream, p->ds, p->db);
     } else {
         launch_linearise_setup<double>(p, o.jacobi_scaling);
         launch_zero_system(p->stream, p->ds, p->db);
         launch_point_build<double>(p->stream, p->ds, p->db);
-        launch_cam_schur<double>(p->stream, p->ds, p->db);
+        launch_schur_pairs<double>(p->stream, p->ds, p->db);
+        launch_cam_diag<double>(p->stream, p->ds, p->db);
     }
     launch_finalize(p->stream, p->ds, p->db);
     launch_post_lin(p->stream, p->ds, p->db);

@@ -36,9 +36,9 @@ constexpr int ST_RN = 19;      // R[9] at the trial point
 constexpr int ST_TN = 28;      // t[3] at the trial point
 constexpr int ST_STRIDE = 32;
 
-// One padded record per observation written by the point pass and read by the camera pass:
-// Y = A~^T B~ L^-T (6x3, row-major) + the camera slot of the observation.
-constexpr int YREC = 20;       // 18 values + cam slot (as int bits) + pad  -> 16-byte aligned in fp32 and fp64
+// One packed record per observation written by the point pass and read by the reduced-system passes
+// (layout in ba_kernels.hip): 16 values = 64 B in fp32 (one sector), 128 B in fp64 (one line).
+constexpr int YREC = 16;
 
 template <typename T> struct ObsXY;
 template <> struct ObsXY<float>  { typedef float2 type; };
