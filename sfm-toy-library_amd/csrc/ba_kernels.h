@@ -15,7 +15,11 @@ enum {
     ACC_GMAX = 5,         // max |g| (bit pattern, atomicMax)
     ACC_BAD_LIN = 6,      // != 0: non-finite value in the linearisation
     ACC_LIN_COST = 7,     // sum r^2 at the linearisation point
-    ACC_COUNT = 8
+    ACC_COUNT = 8,
+    // focal-focal partial sums of the reduced system (same slotted buffer)
+    ACC_SFF = 8, ACC_RHSF = 9, ACC_UDF = 10, ACC_BCF = 11,
+    SLOT_W = 12,
+    NSLOT = 64          // same-address global atomics serialise (~12 ns each): workgroups spread over 64 slots
 };
 
 // Device-resident Levenberg-Marquardt state (TrustRegionMinimizer + LevenbergMarquardtStrategy
@@ -72,8 +76,8 @@ struct DeviceStructure {
     const int2* pairs;        // [npair] {qa, qb} point-major positions of two observations of one point, qa < qb
     int npairwg;
     const int2* pwg_blocks;   // [npairwg] {first block, #blocks <= 4} per workgroup of the pair pass (XCD-grouped rows)
-    int npwg;
-    const int* pwg_ptr;       // [npwg+1] point ranges of the point-pass workgroups (<= 256 observations each)
+    int nwv;
+    const int* wv_ptr;        // [nwv+1] point ranges of the point-pass waves (whole points, <= 64 observations each)
 };
 
 struct DeviceBuffers {
@@ -90,7 +94,7 @@ struct DeviceBuffers {
     double* rhs;              // [ld]  (overwritten by the solution)
     double* udiag;            // [ld]  diag(J~^T J~) of the reduced unknowns, undamped
     double* bc;               // [ld]  scaled gradient of the reduced unknowns
-    double* facc;             // [4]   focal-focal accumulators: S_ff, rhs_f, udiag_f, bc_f (atomics)
+    double* slots;            // [NSLOT][SLOT_W] slotted accumulators (cost, norms, gradient max, focal-focal sums)
     LMState* st;
     TraceRow* trace;
     int trace_cap;

@@ -26,6 +26,26 @@ __device__ __forceinline__ double wave_max(double v) {
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; }
 
+// slotted accumulators: one atomic per value per workgroup, spread over NSLOT addresses
+__device__ __forceinline__ double* slot_ptr(const DeviceBuffers& db, int which) {
+    return db.slots + (size_t)(blockIdx.x % NSLOT) * SLOT_W + which;
+}
+// sum (or max for ACC_GMAX) of one accumulator over the slots, then clear it; single thread
+__device__ double slots_take(const DeviceBuffers& db, int which) {
+    double s = 0.0;
+    for (int k = 0; k < NSLOT; ++k) {
+        double* p = db.slots + (size_t)k * SLOT_W + which;
+        if (which == ACC_GMAX) {
+            const double v = __longlong_as_double((long long)*reinterpret_cast<unsigned long long*>(p));
+            s = (v > s || v != v) ? v : s;
+        } else {
+            s += *p;
+        }
+        *p = 0.0;
+    }
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------
 // camera tables
 // ------------------------------------------------------------------------------------------
@@ -100,7 +120,7 @@ __global__ void k_xnorm(DeviceStructure ds, DeviceBuffers db) {
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { const double f = db.st->focal[cur]; s += f * f; }
     s = block_sum(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(&db.st->acc[ACC_XNEW2], s);
+    if (threadIdx.x == 0) atomicAdd(slot_ptr(db, ACC_XNEW2), s);
 }
 
 void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
@@ -164,14 +184,15 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
     }
     for (int c = 0; c < 7; ++c) {
         const double s = block_sum(n[c], scratch);
-        if (threadIdx.x == 0) atomicAdd(c < 6 ? &db.udiag[6 * j + c] : &db.udiag[ds.d - 1], s);
+        if (threadIdx.x == 0) atomicAdd(c < 6 ? &db.udiag[6 * j + c] : slot_ptr(db, ACC_UDF), s);
     }
 }
 
 __global__ void k_colnorm_finish(DeviceStructure ds, DeviceBuffers db, int jacobi) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= ds.d) return;
-    const double s = jacobi ? 1.0 / (1.0 + sqrt(db.udiag[e])) : 1.0;
+    const double n2 = e < ds.d - 1 ? db.udiag[e] : slots_take(db, ACC_UDF);
+    const double s = jacobi ? 1.0 / (1.0 + sqrt(n2)) : 1.0;
     if (e < ds.d - 1) db.cscale[e] = s; else db.st->fscale = s;
 }
 
@@ -261,121 +282,153 @@ __device__ __forceinline__ void rec_camera_block(const T rec[YREC], T A[12]) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: point pass.  A group of 8 lanes owns one point: the lanes stride over the point's observations
-// (8 consecutive 8/16-byte records per load -> coalesced), the per-point sums are finished with three
-// xor-shuffles, every lane then holds V, b_p, E_f and factors the 3x3 block redundantly.  No
-// __syncthreads inside the loop: waves run independently, the only LDS use is the camera table that
-// each (persistent) workgroup stages once.
+// K1: point pass.  One lane per observation, one wave per contiguous range of whole points with at
+// most 64 observations (host-built wv_ptr).  Every global load of a lane (its observation, its point,
+// its camera-table row) is issued up front: two dependent memory levels per wave, no load-bearing
+// loop (measured loaded latency on MI355X is 1-6 us per dependent access, so depth is what costs).
+// Per-point sums go through wave-private LDS: lane p adds up the <= 64 rows of its point.
 // ------------------------------------------------------------------------------------------
-#define CT_LDS 22    // camera-table columns staged in LDS: R, t, K', small-angle flag
-#define GRP 8        // lanes per point
+#define PB_LD 10     // V(6) E_f(3) + pad, products of T values; B~^T r separately in fp64
+#define WPB (BLK / 64)
 
-__device__ __forceinline__ double group_sum8(double v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    return v;
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS traffic of one wave is processed in order; this only stops the compiler from moving the
+    // accesses and waits for outstanding LDS writes before other lanes of the wave read them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T, bool LDS_TAB>
+template <typename T>
 __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceBuffers db) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ double scratch[BLK / 64];
-    double* ltab = reinterpret_cast<double*>(smem_raw);
+    __shared__ T sv[WPB][64][PB_LD];
+    __shared__ double sb[WPB][64][3];
+    __shared__ T sl[WPB][64][6];
+    __shared__ double scratch[WPB];
     const LMState* st = db.st;
     const int cur = st->cur;
-    const double* gtab = db.camtab[cur];
-    if (LDS_TAB) {
-        for (int e = threadIdx.x; e < ds.ncam * CT_LDS; e += blockDim.x) ltab[e] = gtab[(size_t)(e / CT_LDS) * CT_STRIDE + e % CT_LDS];
-        __syncthreads();
-    }
-    const double* tab = LDS_TAB ? ltab : gtab;
-    const int tstride = LDS_TAB ? CT_LDS : CT_STRIDE;
+    const double* tab = db.camtab[cur];
     const double focal = st->focal[cur];
     const T fscale = (T)st->fscale;
     const double radius = st->radius;
     const double* pts = db.pts[cur];
     T* Yout = reinterpret_cast<T*>(db.Y);
-    const int l = threadIdx.x & (GRP - 1);
-    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / GRP;
-    const int ngroups = gridDim.x * blockDim.x / GRP;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + w;
     double lin_cost = 0.0, sff = 0.0, rhsf = 0.0, gmax = 0.0, bad = 0.0;
 
-    for (int i = group; i < ds.npt; i += ngroups) {
-        const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
-        const double spd[3] = { db.pscale[3 * (size_t)i], db.pscale[3 * (size_t)i + 1], db.pscale[3 * (size_t)i + 2] };
-        const T sp[3] = { (T)spd[0], (T)spd[1], (T)spd[2] };
-        const int q0 = ds.pt_ptr[i], q1 = ds.pt_ptr[i + 1];
+    if (gw < ds.nwv) {
+        const int pt0 = ds.wv_ptr[gw], pt1 = ds.wv_ptr[gw + 1];
+        const int npts = pt1 - pt0;
+        const int o0 = ds.pt_ptr[pt0], o1 = ds.pt_ptr[pt1];
+        const bool single = (o1 - o0) <= 64;           // false only for a point with more than 64 observations
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 }, Ef[3] = { 0, 0, 0 };
-        for (int q = q0 + l; q < q1; q += GRP) {
-            const double* ct = tab + (size_t)ds.obs_cam[q] * tstride;
-            double ox, oy;
-            load_obs<T>(ds.obs_xy, q, ox, oy);
-            const Proj pr = project_point(ct, CT_R, CT_T, X);
-            const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
-            lin_cost += r0 * r0 + r1 * r1;
-            T B[6];
-            point_block<T>(ct, pr, focal, B);
+        const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
+        const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
+        T Bk[6], Ak[12];                                // kept for the record sweep when single
+        Proj prk = { 0.0, 0.0, 0.0 };
+        int ik = 0, jk = 0;
+        T spk[3] = { (T)0, (T)0, (T)0 };
+
+        for (int c0 = o0; c0 < o1; c0 += 64) {
+            const int q = c0 + lane;
+            if (q < o1) {
+                const int i = ds.obs_pt[q], j = ds.obs_cam[q];
+                double ox, oy;
+                load_obs<T>(ds.obs_xy, q, ox, oy);
+                const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
+                const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
+                const double* ct = tab + (size_t)j * CT_STRIDE;
+                const Proj pr = project_point(ct, CT_R, CT_T, X);
+                const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
+                lin_cost += r0 * r0 + r1 * r1;
+                T B[6];
+                point_block<T>(ct, pr, focal, B);
+                camera_block<T>(ct, pr, focal, X, B, Ak);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { B[c] *= sp[c]; B[3 + c] *= sp[c]; }
-            const T g0 = (T)pr.xp * fscale, g1 = (T)pr.yp * fscale;
-            V[0] += (double)(B[0] * B[0] + B[3] * B[3]);
-            V[1] += (double)(B[1] * B[0] + B[4] * B[3]);
-            V[2] += (double)(B[1] * B[1] + B[4] * B[4]);
-            V[3] += (double)(B[2] * B[0] + B[5] * B[3]);
-            V[4] += (double)(B[2] * B[1] + B[5] * B[4]);
-            V[5] += (double)(B[2] * B[2] + B[5] * B[5]);
+                for (int c = 0; c < 3; ++c) { B[c] *= sp[c]; B[3 + c] *= sp[c]; }
+                const T g0 = (T)pr.xp * fscale, g1 = (T)pr.yp * fscale;
+                T* o = sv[w][lane];
+                o[0] = B[0] * B[0] + B[3] * B[3];
+                o[1] = B[1] * B[0] + B[4] * B[3];
+                o[2] = B[1] * B[1] + B[4] * B[4];
+                o[3] = B[2] * B[0] + B[5] * B[3];
+                o[4] = B[2] * B[1] + B[5] * B[4];
+                o[5] = B[2] * B[2] + B[5] * B[5];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                bp[c] += (double)B[c] * r0 + (double)B[3 + c] * r1;
-                Ef[c] += (double)(B[c] * g0 + B[3 + c] * g1);
+                for (int c = 0; c < 3; ++c) {
+                    o[6 + c] = B[c] * g0 + B[3 + c] * g1;
+                    sb[w][lane][c] = (double)B[c] * r0 + (double)B[3 + c] * r1;
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Bk[c] = B[c];
+                prk = pr; ik = i; jk = j; spk[0] = sp[0]; spk[1] = sp[1]; spk[2] = sp[2];
             }
+            wave_lds_fence();
+            if (lane < npts) {
+                const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
+                for (int e = a; e < b; ++e) {
+                    const T* o = sv[w][e];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) V[c] += (double)o[c];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { Ef[c] += (double)o[6 + c]; bp[c] += sb[w][e][c]; }
+                }
+            }
+            wave_lds_fence();
         }
+        if (lane < npts) {
+            const size_t i = (size_t)(pt0 + lane);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) V[c] = group_sum8(V[c]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { bp[c] = group_sum8(bp[c]); Ef[c] = group_sum8(Ef[c]); }
-        // LM damping D^2 = clamp(diag(J~^T J~)) / radius   [LevenbergMarquardtStrategy::ComputeStep]
-        V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
-        V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
-        V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
-        double Li[6];
-        const bool pd = chol3_inverse(V, Li);
-        if (l == 0) {
+            for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c] / db.pscale[3 * i + c]));
+            // LM damping D^2 = clamp(diag(J~^T J~)) / radius   [LevenbergMarquardtStrategy::ComputeStep]
+            V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
+            V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
+            V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
+            double Li[6];
+            const bool pd = chol3_inverse(V, Li);
             const double t0 = Li[0] * bp[0];
             const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
             const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
             const double y0 = Li[0] * Ef[0];
             const double y1 = Li[1] * Ef[0] + Li[2] * Ef[1];
             const double y2 = Li[3] * Ef[0] + Li[4] * Ef[1] + Li[5] * Ef[2];
-            db.pt_t[3 * (size_t)i] = t0; db.pt_t[3 * (size_t)i + 1] = t1; db.pt_t[3 * (size_t)i + 2] = t2;
-            db.pt_yf[3 * (size_t)i] = y0; db.pt_yf[3 * (size_t)i + 1] = y1; db.pt_yf[3 * (size_t)i + 2] = y2;
+            db.pt_t[3 * i] = t0; db.pt_t[3 * i + 1] = t1; db.pt_t[3 * i + 2] = t2;
+            db.pt_yf[3 * i] = y0; db.pt_yf[3 * i + 1] = y1; db.pt_yf[3 * i + 2] = y2;
             sff -= y0 * y0 + y1 * y1 + y2 * y2;
             rhsf -= y0 * t0 + y1 * t1 + y2 * t2;
             if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2)) bad = 1.0;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c] / spd[c]));
+            for (int c = 0; c < 6; ++c) sl[w][lane][c] = (T)Li[c];
         }
-        // second sweep: one packed record per observation
-        const T l00 = (T)Li[0], l10 = (T)Li[1], l11 = (T)Li[2], l20 = (T)Li[3], l21 = (T)Li[4], l22 = (T)Li[5];
-        for (int q = q0 + l; q < q1; q += GRP) {
-            const int j = ds.obs_cam[q];
-            const double* ct = tab + (size_t)j * tstride;
-            const Proj pr = project_point(ct, CT_R, CT_T, X);
-            T B[6], A[12];
-            point_block<T>(ct, pr, focal, B);
-            camera_block<T>(ct, pr, focal, X, B, A);
+        wave_lds_fence();
+        // record sweep: one packed 64-byte (fp32) record per observation
+        for (int c0 = o0; c0 < o1; c0 += 64) {
+            const int q = c0 + lane;
+            if (q >= o1) continue;
+            if (!single) {      // more than 64 observations on one point: recompute this round's blocks
+                ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
+                const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
+                spk[0] = (T)db.pscale[3 * (size_t)ik]; spk[1] = (T)db.pscale[3 * (size_t)ik + 1]; spk[2] = (T)db.pscale[3 * (size_t)ik + 2];
+                const double* ct = tab + (size_t)jk * CT_STRIDE;
+                prk = project_point(ct, CT_R, CT_T, X);
+                point_block<T>(ct, prk, focal, Bk);
+                camera_block<T>(ct, prk, focal, X, Bk, Ak);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { Bk[c] *= spk[c]; Bk[3 + c] *= spk[c]; }
+            }
+            const T* Lp = sl[w][ik - pt0];
+            const T l00 = Lp[0], l10 = Lp[1], l11 = Lp[2], l20 = Lp[3], l21 = Lp[4], l22 = Lp[5];
             T rec[YREC];
-            rec[0] = A[0]; rec[1] = A[1]; rec[2] = A[2]; rec[3] = A[6]; rec[4] = A[7]; rec[5] = A[8];
-            rec[6] = (T)(focal * pr.iz); rec[7] = (T)pr.xp; rec[8] = (T)pr.yp;
+            rec[0] = Ak[0]; rec[1] = Ak[1]; rec[2] = Ak[2]; rec[3] = Ak[6]; rec[4] = Ak[7]; rec[5] = Ak[8];
+            rec[6] = (T)(focal * prk.iz); rec[7] = (T)prk.xp; rec[8] = (T)prk.yp;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {   // C = B~ L^-T
-                const T b0 = B[3 * r] * sp[0], b1 = B[3 * r + 1] * sp[1], b2 = B[3 * r + 2] * sp[2];
+                const T b0 = Bk[3 * r], b1 = Bk[3 * r + 1], b2 = Bk[3 * r + 2];
                 rec[9 + 3 * r + 0] = b0 * l00;
                 rec[9 + 3 * r + 1] = b0 * l10 + b1 * l11;
                 rec[9 + 3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
             }
-            if (sizeof(T) == 4) rec[15] = (T)__int_as_float(j); else rec[15] = (T)__longlong_as_double((long long)j);
+            if (sizeof(T) == 4) rec[15] = (T)__int_as_float(jk); else rec[15] = (T)__longlong_as_double((long long)jk);
             store_rec<T>(Yout, q, rec);
         }
     }
@@ -386,12 +439,12 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
     const double r_sum = block_sum(rhsf, scratch);
     const double b_sum = block_sum(bad, scratch);
     const double gm = wave_max(gmax);
-    if ((threadIdx.x & 63) == 0 && gm > 0.0) atomic_max_nonneg(&db.st->acc[ACC_GMAX], gm);
+    if ((threadIdx.x & 63) == 0 && gm > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), gm);
     if (threadIdx.x == 0) {
-        atomicAdd(&db.st->acc[ACC_LIN_COST], c_sum);
-        atomicAdd(&db.facc[0], f_sum);
-        atomicAdd(&db.facc[1], r_sum);
-        if (b_sum != 0.0) atomicAdd(&db.st->acc[ACC_BAD_LIN], b_sum);
+        atomicAdd(slot_ptr(db, ACC_LIN_COST), c_sum);
+        atomicAdd(slot_ptr(db, ACC_SFF), f_sum);
+        atomicAdd(slot_ptr(db, ACC_RHSF), r_sum);
+        if (b_sum != 0.0) atomicAdd(slot_ptr(db, ACC_BAD_LIN), b_sum);
     }
 }
 
@@ -480,17 +533,18 @@ __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceB
 }
 
 // ------------------------------------------------------------------------------------------
-// K2b: camera-diagonal pass, one workgroup per (camera, range of its observations).  A group of 8
-// lanes shares one observation: all lanes read the same packed record (one 64-B request), lane a < 6
-// owns row a of the camera block:
-//   S_jj[a][a..5] += A~^T (I - C C^T) A~   (U_jj minus the self term Y_a Y_a^T)
-//   undamped diagonal, S_jf, b_c, reduced rhs; lane 6 owns the focal-focal sums.
+// K2b: camera-diagonal pass.  One lane per observation of the camera (no loop, two dependent memory
+// levels), 1024 lanes per workgroup = one chunk of one camera.  Each lane forms its 47 terms in T;
+// the sums over lanes are carried in fp64: halving butterfly inside the wave, LDS across the 16 waves,
+// one atomic per value per workgroup.
+//   S_jj += A~^T (I - C C^T) A~   (U_jj minus the self term Y_a Y_a^T), undamped diagonal, S_jf, b_c, rhs
 // ------------------------------------------------------------------------------------------
-#define CD_NV 10     // per-lane accumulators: Sjj row (6) udiag Sjf bc rhs
+#define CD_N 48      // Sjj(21) udiag(6) Sjf(6) bc(6) rhs(6) uff bf + pad
+#define CD_BLK 1024
 
 template <typename T>
-__global__ __launch_bounds__(BLK) void k_cam_diag(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double red[(BLK / 64) * 8 * CD_NV];
+__global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double red[CD_BLK / 64][CD_N];
     const int4 ch = ds.chunks[blockIdx.x];
     const int j = ch.x;
     const LMState* st = db.st;
@@ -498,120 +552,104 @@ __global__ __launch_bounds__(BLK) void k_cam_diag(DeviceStructure ds, DeviceBuff
     const double focal = st->focal[cur];
     const T fscale = (T)st->fscale;
     const T* Y = reinterpret_cast<const T*>(db.Y);
-    const int l = threadIdx.x & 7;                 // role inside the group
-    const int g = threadIdx.x >> 3;                // group inside the workgroup
-    const int a = l < 6 ? l : 0;
-    T sc[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) sc[c] = (T)db.cscale[6 * j + c];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = ch.y + threadIdx.x;
 
-    double loc[CD_NV];
+    T v[CD_N];
 #pragma unroll
-    for (int e = 0; e < CD_NV; ++e) loc[e] = 0.0;
-
-    for (int e = ch.y + g; e < ch.z; e += BLK / 8) {
+    for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
+    if (e < ch.z) {
         const int q = ds.cam_obs[e];
         const int i = ds.cam_obs_pt[e];
         T rec[YREC], A[12];
         load_rec<T>(Y, q, rec);
-        rec_camera_block<T>(rec, A);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) { A[c] *= sc[c]; A[6 + c] *= sc[c]; }
         double ox, oy;
         load_obs<T>(ds.obs_xy, q, ox, oy);
-        const double r0 = focal * (double)rec[7] - ox, r1 = focal * (double)rec[8] - oy;
+        const T t0 = (T)db.pt_t[3 * (size_t)i], t1 = (T)db.pt_t[3 * (size_t)i + 1], t2 = (T)db.pt_t[3 * (size_t)i + 2];
+        const T y0 = (T)db.pt_yf[3 * (size_t)i], y1 = (T)db.pt_yf[3 * (size_t)i + 1], y2 = (T)db.pt_yf[3 * (size_t)i + 2];
+        rec_camera_block<T>(rec, A);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { const T s = (T)db.cscale[6 * j + c]; A[c] *= s; A[6 + c] *= s; }
+        const T r0 = (T)(focal * (double)rec[7] - ox), r1 = (T)(focal * (double)rec[8] - oy);
         const T g0 = rec[7] * fscale, g1 = rec[8] * fscale;
-        if (l < 6) {
-            // N = I - C C^T
-            const T n00 = (T)1 - (rec[9] * rec[9] + rec[10] * rec[10] + rec[11] * rec[11]);
-            const T n01 = -(rec[9] * rec[12] + rec[10] * rec[13] + rec[11] * rec[14]);
-            const T n11 = (T)1 - (rec[12] * rec[12] + rec[13] * rec[13] + rec[14] * rec[14]);
-            // dynamic row select without dynamic register indexing
-            T a0 = A[0], a1 = A[6];
+        // N = I - C C^T
+        const T n00 = (T)1 - (rec[9] * rec[9] + rec[10] * rec[10] + rec[11] * rec[11]);
+        const T n01 = -(rec[9] * rec[12] + rec[10] * rec[13] + rec[11] * rec[14]);
+        const T n11 = (T)1 - (rec[12] * rec[12] + rec[13] * rec[13] + rec[14] * rec[14]);
+        // Y v = A~^T (C v)
+        const T ct0 = rec[9] * t0 + rec[10] * t1 + rec[11] * t2, ct1 = rec[12] * t0 + rec[13] * t1 + rec[14] * t2;
+        const T cy0 = rec[9] * y0 + rec[10] * y1 + rec[11] * y2, cy1 = rec[12] * y0 + rec[13] * y1 + rec[14] * y2;
+        int u = 0;
 #pragma unroll
-            for (int c = 1; c < 6; ++c) { a0 = (a == c) ? A[c] : a0; a1 = (a == c) ? A[6 + c] : a1; }
-            const T p0 = n00 * a0 + n01 * a1, p1 = n01 * a0 + n11 * a1;
+        for (int a = 0; a < 6; ++a) {
+            const T p0 = n00 * A[a] + n01 * A[6 + a], p1 = n01 * A[a] + n11 * A[6 + a];
 #pragma unroll
-            for (int b = 0; b < 6; ++b) loc[b] += (double)(p0 * A[b] + p1 * A[6 + b]);   // full row; b < a is unused
-            const double t0 = db.pt_t[3 * (size_t)i], t1 = db.pt_t[3 * (size_t)i + 1], t2 = db.pt_t[3 * (size_t)i + 2];
-            const double y0 = db.pt_yf[3 * (size_t)i], y1 = db.pt_yf[3 * (size_t)i + 1], y2 = db.pt_yf[3 * (size_t)i + 2];
-            // Y v = A~^T (C v)
-            const double ct0 = (double)rec[9] * t0 + (double)rec[10] * t1 + (double)rec[11] * t2;
-            const double ct1 = (double)rec[12] * t0 + (double)rec[13] * t1 + (double)rec[14] * t2;
-            const double cy0 = (double)rec[9] * y0 + (double)rec[10] * y1 + (double)rec[11] * y2;
-            const double cy1 = (double)rec[12] * y0 + (double)rec[13] * y1 + (double)rec[14] * y2;
-            const double d0 = (double)a0, d1 = (double)a1;
-            const double ar = d0 * r0 + d1 * r1;
-            loc[6] += d0 * d0 + d1 * d1;                                        // undamped diagonal
-            loc[7] += (double)(a0 * g0 + a1 * g1) - (d0 * cy0 + d1 * cy1);      // S[j,f]
-            loc[8] += ar;                                                       // b_c (scaled gradient)
-            loc[9] += ar - (d0 * ct0 + d1 * ct1);                               // reduced rhs
-        } else if (l == 6) {
-            loc[0] += (double)(g0 * g0 + g1 * g1);
-            loc[1] += (double)g0 * r0 + (double)g1 * r1;
+            for (int b = a; b < 6; ++b) v[u++] = p0 * A[b] + p1 * A[6 + b];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const T ar = A[a] * r0 + A[6 + a] * r1;
+            v[21 + a] = A[a] * A[a] + A[6 + a] * A[6 + a];                               // undamped diagonal
+            v[27 + a] = (A[a] * g0 + A[6 + a] * g1) - (A[a] * cy0 + A[6 + a] * cy1);     // S[j,f]
+            v[33 + a] = ar;                                                              // b_c (scaled gradient)
+            v[39 + a] = ar - (A[a] * ct0 + A[6 + a] * ct1);                              // reduced rhs
+        }
+        v[45] = g0 * g0 + g1 * g1;
+        v[46] = g0 * r0 + g1 * r1;
+    }
+    // first halving step on the T values (one 32-bit shuffle each), the rest in fp64
+    double acc[CD_N / 2];
+    {
+        const bool up = (lane & 32) != 0;
+#pragma unroll
+        for (int k = 0; k < CD_N / 2; ++k) {
+            const T lo = v[k], hi = v[CD_N / 2 + k];
+            const T send = up ? lo : hi, keep = up ? hi : lo;
+            acc[k] = (double)keep + (double)__shfl_xor(send, 32, 64);
         }
     }
-    // lanes with the same role: xor 8, 16, 32 inside the wave, then across the 4 waves through LDS
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int e = 0; e < CD_NV; ++e) {
-        double s = loc[e];
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (lane < 8) red[(w * 8 + lane) * CD_NV + e] = s;
-    }
+    int base = (lane & 32) ? CD_N / 2 : 0, len = CD_N / 2;
+    HalvingReduce<CD_N / 2, 16>::run(acc, lane, base, len);
+    if (len >= 1) red[w][base] = acc[0];
     __syncthreads();
-    if (threadIdx.x < 8 * CD_NV) {
-        const int role = threadIdx.x / CD_NV, e = threadIdx.x % CD_NV;
+    if (threadIdx.x < 47) {
+        const int k = threadIdx.x;
         double s = 0.0;
-        for (int ww = 0; ww < BLK / 64; ++ww) s += red[(ww * 8 + role) * CD_NV + e];
+#pragma unroll
+        for (int ww = 0; ww < CD_BLK / 64; ++ww) s += red[ww][k];
         const int row0 = 6 * j, fo = ds.d - 1;
-        if (role < 6) {
-            if (e < 6) { if (e >= role) atomicAdd(&db.S[(size_t)(row0 + role) * ds.ld + row0 + e], s); }
-            else if (e == 6) atomicAdd(&db.udiag[row0 + role], s);
-            else if (e == 7) atomicAdd(&db.S[(size_t)(row0 + role) * ds.ld + fo], s);
-            else if (e == 8) atomicAdd(&db.bc[row0 + role], s);
-            else atomicAdd(&db.rhs[row0 + role], s);
-        } else if (role == 6) {
-            if (e == 0) { atomicAdd(&db.facc[0], s); atomicAdd(&db.facc[2], s); }
-            else if (e == 1) { atomicAdd(&db.facc[1], s); atomicAdd(&db.facc[3], s); }
+        if (k < 21) {
+            int a = 0, rem = k;
+            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+            atomicAdd(&db.S[(size_t)(row0 + a) * ds.ld + row0 + a + rem], s);
+        } else if (k < 27) {
+            atomicAdd(&db.udiag[row0 + k - 21], s);
+        } else if (k < 33) {
+            atomicAdd(&db.S[(size_t)(row0 + k - 27) * ds.ld + fo], s);
+        } else if (k < 39) {
+            atomicAdd(&db.bc[row0 + k - 33], s);
+        } else if (k < 45) {
+            atomicAdd(&db.rhs[row0 + k - 39], s);
+        } else if (k == 45) {
+            atomicAdd(slot_ptr(db, ACC_SFF), s);
+            atomicAdd(slot_ptr(db, ACC_UDF), s);
+        } else {
+            atomicAdd(slot_ptr(db, ACC_RHSF), s);
+            atomicAdd(slot_ptr(db, ACC_BCF), s);
         }
     }
 }
 
-static bool use_lds_table(const DeviceStructure& ds, int stride) { return (size_t)ds.ncam * stride * sizeof(double) <= 96 * 1024; }
-
-// kernels whose dynamic LDS may exceed the 64 KB default (gfx950 has 160 KB per CU)
-static bool allow_big_lds(const void* fn) {
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) == hipSuccess;
-}
-
-// persistent point-pass grid: a few workgroups per CU, each staging the camera table once
-static int persistent_grid(const DeviceStructure& ds) {
-    const int need = (ds.npt * GRP + BLK - 1) / BLK;     // one 8-lane group per point
-    return need < 1024 ? need : 1024;
-}
 
 void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     // every entry of the upper triangle, rhs, udiag and bc is overwritten each iteration (k_schur_pairs,
     // k_cam_diag, k_finalize); only the four focal-focal accumulators are summed with atomics
-    (void)ds;
-    (void)hipMemsetAsync(db.facc, 0, sizeof(double) * 4, s);
+    (void)ds; (void)db; (void)s;   // the slotted accumulators are cleared by their consumers
 }
 
 template <typename T>
 void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    const dim3 grid(persistent_grid(ds));
-    const size_t base = 0;
-    if (use_lds_table(ds, CT_LDS)) {
-        const size_t lds = base + sizeof(double) * ds.ncam * CT_LDS;
-        static bool once = allow_big_lds((const void*)k_point_build<T, true>);
-        (void)once;
-        hipLaunchKernelGGL((k_point_build<T, true>), grid, dim3(BLK), lds, s, ds, db);
-    } else {
-        hipLaunchKernelGGL((k_point_build<T, false>), grid, dim3(BLK), base, s, ds, db);
-    }
+    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(BLK), 0, s, ds, db);
 }
 template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
@@ -625,7 +663,7 @@ template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, co
 
 template <typename T>
 void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_cam_diag<T>, dim3(ds.nchunk), dim3(BLK), 0, s, ds, db);
+    hipLaunchKernelGGL(k_cam_diag<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
 }
 template void launch_cam_diag<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
@@ -638,31 +676,33 @@ __global__ void k_finalize(DeviceStructure ds, DeviceBuffers db) {
     const LMState* st = db.st;
     double g = 0.0;
     if (e < ds.d) {
-        if (e == ds.d - 1) {   // focal-focal entries were accumulated with atomics
-            db.S[(size_t)e * ds.ld + e] = db.facc[0];
-            db.rhs[e] = db.facc[1];
-            db.udiag[e] = db.facc[2];
-            db.bc[e] = db.facc[3];
+        if (e == ds.d - 1) {   // focal-focal entries were accumulated in the slotted buffer
+            db.S[(size_t)e * ds.ld + e] = slots_take(db, ACC_SFF);
+            db.rhs[e] = slots_take(db, ACC_RHSF);
+            db.udiag[e] = slots_take(db, ACC_UDF);
+            db.bc[e] = slots_take(db, ACC_BCF);
         }
         const double dd = fmin(fmax(db.udiag[e], st->min_diag), st->max_diag) / st->radius;
         db.S[(size_t)e * ds.ld + e] += dd;
         const double sc = e < ds.d - 1 ? db.cscale[e] : st->fscale;
         g = fabs(db.bc[e] / sc);
-        if (!finite_d(db.S[(size_t)e * ds.ld + e]) || !finite_d(db.rhs[e])) atomicAdd(&db.st->acc[ACC_BAD_LIN], 1.0);
+        if (!finite_d(db.S[(size_t)e * ds.ld + e]) || !finite_d(db.rhs[e])) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
     } else if (e < ds.ld) {
         db.S[(size_t)e * ds.ld + e] = 1.0;
         db.rhs[e] = 0.0;
     }
     g = wave_max(g);
-    if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(&db.st->acc[ACC_GMAX], g);
+    if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), g);
 }
 
 // after a linearisation: initial cost (iteration 0), gradient tolerance, evaluation failure
 __global__ void k_post_lin(DeviceStructure ds, DeviceBuffers db) {
     LMState* st = db.st;
+    const double gmax = slots_take(db, ACC_GMAX);
+    const double bad_lin = slots_take(db, ACC_BAD_LIN);
+    const double lin_cost = slots_take(db, ACC_LIN_COST);
     if (st->termination != -1) return;
-    const double gmax = __longlong_as_double((long long)reinterpret_cast<unsigned long long*>(st->acc)[ACC_GMAX]);
-    if (st->acc[ACC_BAD_LIN] != 0.0) {
+    if (bad_lin != 0.0) {
         st->termination = SFMBA_FAILURE;
         st->message = st->iter == 0 ? MSG_INITIAL_EVAL_FAILED : MSG_EVAL_FAILED;
     }
@@ -670,7 +710,7 @@ __global__ void k_post_lin(DeviceStructure ds, DeviceBuffers db) {
         st->jacobian_evals++;
         st->gmax = gmax;
         if (st->iter == 0) {
-            st->cost = 0.5 * st->acc[ACC_LIN_COST];
+            st->cost = 0.5 * lin_cost;
             if (db.trace_cap > 0) {
                 TraceRow row = {};
                 row.iteration = 0; row.cost = st->cost; row.gradient_max_norm = gmax; row.trust_region_radius = st->radius;
@@ -685,9 +725,6 @@ __global__ void k_post_lin(DeviceStructure ds, DeviceBuffers db) {
         }
         st->x_is_new = 0;
     }
-    st->acc[ACC_GMAX] = 0.0;
-    st->acc[ACC_BAD_LIN] = 0.0;
-    st->acc[ACC_LIN_COST] = 0.0;
 }
 
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
@@ -700,8 +737,8 @@ void launch_post_lin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffe
 // iteration 0 bookkeeping: x_norm from the accumulated ||x||^2
 __global__ void k_iter0(DeviceBuffers db) {
     LMState* st = db.st;
-    st->x_norm = sqrt(st->acc[ACC_XNEW2]);
-    for (int e = 0; e < ACC_COUNT; ++e) st->acc[e] = 0.0;
+    st->x_norm = sqrt(slots_take(db, ACC_XNEW2));
+    for (int e = 0; e < SLOT_W; ++e) if (e != ACC_XNEW2) (void)slots_take(db, e);
 }
 void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     (void)ds;
@@ -755,7 +792,7 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     }
     const double s2 = block_sum(step2, scratch);
     const double x2 = block_sum(xn2, scratch);
-    if (threadIdx.x == 0) { atomicAdd(&st->acc[ACC_STEP2], s2); atomicAdd(&st->acc[ACC_XNEW2], x2); }
+    if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), s2); atomicAdd(slot_ptr(db, ACC_XNEW2), x2); }
 }
 
 // Obs-parallel back-substitution: same workgroup/point ownership as k_point_build.
@@ -781,106 +818,137 @@ __device__ __forceinline__ void camera_step_dp(CamPtr stb, const double X[3], do
     dp0 += stb[ST_DT]; dp1 += stb[ST_DT + 1]; dp2 += stb[ST_DT + 2];
 }
 
-template <typename T, bool LDS_TAB>
+template <typename T>
 __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ double scratch[BLK / 64];
-    double* ltab = reinterpret_cast<double*>(smem_raw);
+    __shared__ T sv[WPB][64][6];
+    __shared__ double sb[WPB][64][3];
+    __shared__ double sx[WPB][64][6];      // dX(3), Xn(3) per local point
+    __shared__ double scratch[WPB];
     const LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
-    const double* gtab = db.steptab;
-    if (LDS_TAB) {
-        for (int e = threadIdx.x; e < ds.ncam * ST_STRIDE; e += blockDim.x) ltab[e] = gtab[e];
-        __syncthreads();
-    }
-    const double* tab = LDS_TAB ? ltab : gtab;
+    const double* tab = db.steptab;
     const double focal = st->focal[cur], focal_n = st->focal[nxt];
     const double dfoc = focal - focal_n;           // unscaled focal step to SUBTRACT (= fscale * y_f)
     const double radius = st->radius;
     const double* pts = db.pts[cur];
-    const int l = threadIdx.x & (GRP - 1);
-    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / GRP;
-    const int ngroups = gridDim.x * blockDim.x / GRP;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + w;
     double trial = 0.0, model = 0.0, step2 = 0.0, xn2 = 0.0, bad = 0.0;
 
-    for (int i = group; i < ds.npt; i += ngroups) {
-        const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
-        const double spd[3] = { db.pscale[3 * (size_t)i], db.pscale[3 * (size_t)i + 1], db.pscale[3 * (size_t)i + 2] };
-        const T sp[3] = { (T)spd[0], (T)spd[1], (T)spd[2] };
-        const int q0 = ds.pt_ptr[i], q1 = ds.pt_ptr[i + 1];
+    if (gw < ds.nwv) {
+        const int pt0 = ds.wv_ptr[gw], pt1 = ds.wv_ptr[gw + 1];
+        const int npts = pt1 - pt0;
+        const int o0 = ds.pt_ptr[pt0], o1 = ds.pt_ptr[pt1];
+        const bool single = (o1 - o0) <= 64;
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
-        for (int q = q0 + l; q < q1; q += GRP) {
-            const double* stb = tab + (size_t)ds.obs_cam[q] * ST_STRIDE;
-            double ox, oy;
-            load_obs<T>(ds.obs_xy, q, ox, oy);
-            const Proj pr = project_point(stb, ST_R, ST_T, X);
-            const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
-            T B[6];
-            point_block<T>(stb, pr, focal, B);     // ST_R == CT_R == 0
-            double dp0, dp1, dp2;
-            camera_step_dp(stb, X, dp0, dp1, dp2);
-            // u = A (scale*y_c) + g (fscale*y_f) = Aproj dp + (xp,yp) dfoc
-            const double fz = focal * pr.iz;
-            const double u0 = fz * (dp0 - pr.xp * dp2) + pr.xp * dfoc;
-            const double u1 = fz * (dp1 - pr.yp * dp2) + pr.yp * dfoc;
+        const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
+        const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
+        // kept for the second sweep when single
+        Proj prk = { 0.0, 0.0, 0.0 };
+        double r0k = 0, r1k = 0, dpk[3] = { 0, 0, 0 }, oxk = 0, oyk = 0;
+        int ik = 0, jk = 0;
+
+        for (int c0 = o0; c0 < o1; c0 += 64) {
+            const int q = c0 + lane;
+            if (q < o1) {
+                const int i = ds.obs_pt[q], j = ds.obs_cam[q];
+                double ox, oy;
+                load_obs<T>(ds.obs_xy, q, ox, oy);
+                const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
+                const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
+                const double* stb = tab + (size_t)j * ST_STRIDE;
+                const Proj pr = project_point(stb, ST_R, ST_T, X);
+                const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
+                T B[6];
+                point_block<T>(stb, pr, focal, B);     // ST_R == CT_R == 0
+                double dp0, dp1, dp2;
+                camera_step_dp(stb, X, dp0, dp1, dp2);
+                // u = A (scale*y_c) + g (fscale*y_f) = Aproj dp + (xp,yp) dfoc
+                const double fz = focal * pr.iz;
+                const double u0 = fz * (dp0 - pr.xp * dp2) + pr.xp * dfoc;
+                const double u1 = fz * (dp1 - pr.yp * dp2) + pr.yp * dfoc;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { B[c] *= sp[c]; B[3 + c] *= sp[c]; }
-            V[0] += (double)(B[0] * B[0] + B[3] * B[3]);
-            V[1] += (double)(B[1] * B[0] + B[4] * B[3]);
-            V[2] += (double)(B[1] * B[1] + B[4] * B[4]);
-            V[3] += (double)(B[2] * B[0] + B[5] * B[3]);
-            V[4] += (double)(B[2] * B[1] + B[5] * B[4]);
-            V[5] += (double)(B[2] * B[2] + B[5] * B[5]);
+                for (int c = 0; c < 3; ++c) { B[c] *= sp[c]; B[3 + c] *= sp[c]; }
+                T* o = sv[w][lane];
+                o[0] = B[0] * B[0] + B[3] * B[3];
+                o[1] = B[1] * B[0] + B[4] * B[3];
+                o[2] = B[1] * B[1] + B[4] * B[4];
+                o[3] = B[2] * B[0] + B[5] * B[3];
+                o[4] = B[2] * B[1] + B[5] * B[4];
+                o[5] = B[2] * B[2] + B[5] * B[5];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) bp[c] += (double)B[c] * (r0 - u0) + (double)B[3 + c] * (r1 - u1);
+                for (int c = 0; c < 3; ++c) sb[w][lane][c] = (double)B[c] * (r0 - u0) + (double)B[3 + c] * (r1 - u1);
+                prk = pr; r0k = r0; r1k = r1; dpk[0] = dp0; dpk[1] = dp1; dpk[2] = dp2; oxk = ox; oyk = oy; ik = i; jk = j;
+            }
+            wave_lds_fence();
+            if (lane < npts) {
+                const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
+                for (int e = a; e < b; ++e) {
+                    const T* o = sv[w][e];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) V[c] += (double)o[c];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) bp[c] += sb[w][e][c];
+                }
+            }
+            wave_lds_fence();
         }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) V[c] = group_sum8(V[c]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) bp[c] = group_sum8(bp[c]);
-        V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
-        V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
-        V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
-        double Li[6];
-        chol3_inverse(V, Li);
-        // y_p = L^-T L^-1 (b_p - W^T y_c)
-        const double t0 = Li[0] * bp[0];
-        const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
-        const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
-        const double y2 = Li[5] * t2;
-        const double y1 = Li[2] * t1 + Li[4] * t2;
-        const double y0 = Li[0] * t0 + Li[1] * t1 + Li[3] * t2;
-        const double dX[3] = { spd[0] * y0, spd[1] * y1, spd[2] * y2 };
-        double Xn[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Xn[c] = X[c] - dX[c];
-        if (l == 0) {
+        if (lane < npts) {
+            const size_t i = (size_t)(pt0 + lane);
+            V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
+            V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
+            V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
+            double Li[6];
+            chol3_inverse(V, Li);
+            // y_p = L^-T L^-1 (b_p - W^T y_c)
+            const double t0 = Li[0] * bp[0];
+            const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
+            const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
+            const double y2 = Li[5] * t2;
+            const double y1 = Li[2] * t1 + Li[4] * t2;
+            const double y0 = Li[0] * t0 + Li[1] * t1 + Li[3] * t2;
+            const double dX[3] = { db.pscale[3 * i] * y0, db.pscale[3 * i + 1] * y1, db.pscale[3 * i + 2] * y2 };
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const double df = X[c] - Xn[c];
+                const double x = pts[3 * i + c];
+                const double xn = x - dX[c];
+                const double df = x - xn;
                 step2 += df * df;
-                xn2 += Xn[c] * Xn[c];
-                db.pts[nxt][3 * (size_t)i + c] = Xn[c];
+                xn2 += xn * xn;
+                db.pts[nxt][3 * i + c] = xn;
+                sx[w][lane][c] = dX[c];
+                sx[w][lane][3 + c] = xn;
             }
         }
-        for (int q = q0 + l; q < q1; q += GRP) {
-            const double* stb = tab + (size_t)ds.obs_cam[q] * ST_STRIDE;
-            double ox, oy;
-            load_obs<T>(ds.obs_xy, q, ox, oy);
-            const Proj pr = project_point(stb, ST_R, ST_T, X);
-            const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
-            double dp0, dp1, dp2;
-            camera_step_dp(stb, X, dp0, dp1, dp2);
+        wave_lds_fence();
+        for (int c0 = o0; c0 < o1; c0 += 64) {
+            const int q = c0 + lane;
+            if (q >= o1) continue;
+            const double* stb;
+            if (!single) {
+                ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
+                load_obs<T>(ds.obs_xy, q, oxk, oyk);
+                const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
+                stb = tab + (size_t)jk * ST_STRIDE;
+                prk = project_point(stb, ST_R, ST_T, X);
+                r0k = focal * prk.xp - oxk; r1k = focal * prk.yp - oyk;
+                camera_step_dp(stb, X, dpk[0], dpk[1], dpk[2]);
+            } else {
+                stb = tab + (size_t)jk * ST_STRIDE;
+            }
+            const double* pl = sx[w][ik - pt0];
+            const double dX[3] = { pl[0], pl[1], pl[2] };
+            const double Xn[3] = { pl[3], pl[4], pl[5] };
             // model residual m = J step = -(u + B dX): total unscaled change of p, then Aproj
-            dp0 += stb[ST_R + 0] * dX[0] + stb[ST_R + 1] * dX[1] + stb[ST_R + 2] * dX[2];
-            dp1 += stb[ST_R + 3] * dX[0] + stb[ST_R + 4] * dX[1] + stb[ST_R + 5] * dX[2];
-            dp2 += stb[ST_R + 6] * dX[0] + stb[ST_R + 7] * dX[1] + stb[ST_R + 8] * dX[2];
-            const double fz = focal * pr.iz;
-            const double m0 = -(fz * (dp0 - pr.xp * dp2) + pr.xp * dfoc);
-            const double m1 = -(fz * (dp1 - pr.yp * dp2) + pr.yp * dfoc);
-            model -= m0 * (r0 + 0.5 * m0) + m1 * (r1 + 0.5 * m1);
+            const double dp0 = dpk[0] + stb[ST_R + 0] * dX[0] + stb[ST_R + 1] * dX[1] + stb[ST_R + 2] * dX[2];
+            const double dp1 = dpk[1] + stb[ST_R + 3] * dX[0] + stb[ST_R + 4] * dX[1] + stb[ST_R + 5] * dX[2];
+            const double dp2 = dpk[2] + stb[ST_R + 6] * dX[0] + stb[ST_R + 7] * dX[1] + stb[ST_R + 8] * dX[2];
+            const double fz = focal * prk.iz;
+            const double m0 = -(fz * (dp0 - prk.xp * dp2) + prk.xp * dfoc);
+            const double m1 = -(fz * (dp1 - prk.yp * dp2) + prk.yp * dfoc);
+            model -= m0 * (r0k + 0.5 * m0) + m1 * (r1k + 0.5 * m1);
             const Proj pn = project_point(stb, ST_RN, ST_TN, Xn);
-            const double n0 = focal_n * pn.xp - ox, n1 = focal_n * pn.yp - oy;
+            const double n0 = focal_n * pn.xp - oxk, n1 = focal_n * pn.yp - oyk;
             if (!finite_d(n0) || !finite_d(n1)) bad = 1.0;
             trial += n0 * n0 + n1 * n1;
         }
@@ -891,11 +959,11 @@ __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, Device
     const double d = block_sum(xn2, scratch);
     const double e = block_sum(bad, scratch);
     if (threadIdx.x == 0) {
-        atomicAdd(&db.st->acc[ACC_TRIAL_COST], a);
-        atomicAdd(&db.st->acc[ACC_MODEL], b);
-        atomicAdd(&db.st->acc[ACC_STEP2], c);
-        atomicAdd(&db.st->acc[ACC_XNEW2], d);
-        if (e != 0.0) atomicAdd(&db.st->acc[ACC_BAD_TRIAL], e);
+        atomicAdd(slot_ptr(db, ACC_TRIAL_COST), a);
+        atomicAdd(slot_ptr(db, ACC_MODEL), b);
+        atomicAdd(slot_ptr(db, ACC_STEP2), c);
+        atomicAdd(slot_ptr(db, ACC_XNEW2), d);
+        if (e != 0.0) atomicAdd(slot_ptr(db, ACC_BAD_TRIAL), e);
     }
 }
 
@@ -905,16 +973,7 @@ void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuf
 
 template <typename T>
 void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    const dim3 grid(persistent_grid(ds));
-    const size_t base = 0;
-    if (use_lds_table(ds, ST_STRIDE)) {
-        const size_t lds = base + sizeof(double) * ds.ncam * ST_STRIDE;
-        static bool once = allow_big_lds((const void*)k_point_update<T, true>);
-        (void)once;
-        hipLaunchKernelGGL((k_point_update<T, true>), grid, dim3(BLK), lds, s, ds, db);
-    } else {
-        hipLaunchKernelGGL((k_point_update<T, false>), grid, dim3(BLK), base, s, ds, db);
-    }
+    hipLaunchKernelGGL(k_point_update<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(BLK), 0, s, ds, db);
 }
 template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
@@ -925,12 +984,15 @@ template void launch_point_update<double>(hipStream_t, const DeviceStructure&, c
 // ------------------------------------------------------------------------------------------
 __global__ void k_lm_control(DeviceBuffers db) {
     LMState* st = db.st;
+    const double trial2 = slots_take(db, ACC_TRIAL_COST);
+    const double model = slots_take(db, ACC_MODEL);
+    const double step2 = slots_take(db, ACC_STEP2);
+    const double xnew2 = slots_take(db, ACC_XNEW2);
+    const double bad_trial = slots_take(db, ACC_BAD_TRIAL);
     if (st->termination != -1) return;
     const int it = ++st->iter;
     TraceRow row = {};
     row.iteration = it;
-    const double model = st->acc[ACC_MODEL];
-    const double step2 = st->acc[ACC_STEP2];
     const bool lin_fail = st->lin_info != 0 || !finite_d(step2) || !finite_d(model);
     const bool step_valid = !lin_fail && model > 0.0;
     row.step_is_valid = step_valid;
@@ -947,8 +1009,8 @@ __global__ void k_lm_control(DeviceBuffers db) {
         }
     } else {
         st->consecutive_invalid = 0;
-        double cand = 0.5 * st->acc[ACC_TRIAL_COST];
-        if (st->acc[ACC_BAD_TRIAL] != 0.0 || !finite_d(cand)) cand = DBL_MAX;
+        double cand = 0.5 * trial2;
+        if (bad_trial != 0.0 || !finite_d(cand)) cand = DBL_MAX;
         st->residual_evals++;
         row.step_norm = sqrt(step2);
         const double step_tol = st->parameter_tolerance * (st->x_norm + st->parameter_tolerance);
@@ -967,7 +1029,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
                     st->last_step_successful = 1;
                     st->cur ^= 1;
                     st->cost = cand;
-                    st->x_norm = sqrt(st->acc[ACC_XNEW2]);
+                    st->x_norm = sqrt(xnew2);
                     const double t = 2.0 * row.relative_decrease - 1.0;
                     st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
                     st->radius = fmin(st->max_radius, st->radius);
@@ -991,11 +1053,6 @@ __global__ void k_lm_control(DeviceBuffers db) {
     row.cost = report_cost;
     row.trust_region_radius = st->radius;
     if (it < db.trace_cap) db.trace[it] = row;
-    st->acc[ACC_TRIAL_COST] = 0.0;
-    st->acc[ACC_MODEL] = 0.0;
-    st->acc[ACC_STEP2] = 0.0;
-    st->acc[ACC_XNEW2] = 0.0;
-    st->acc[ACC_BAD_TRIAL] = 0.0;
     st->lin_info = 0;
 }
 

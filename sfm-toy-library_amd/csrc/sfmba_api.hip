@@ -389,8 +389,7 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
         cam_obs_pt[e] = pm_pt[q];
     }
     // chunks of the camera-major list (used by the column-norm pass): (camera, entry range)
-    int chunk_len = (int)std::max<int64_t>(256, ((int64_t)nobs + 1023) / 1024);
-    chunk_len = ((chunk_len + 255) / 256) * 256;
+    const int chunk_len = 1024;   // k_cam_diag: one lane per entry, 1024 lanes per workgroup
     std::vector<int4> chunks;
     for (int j = 0; j < ncam; ++j)
         for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
@@ -443,18 +442,18 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
                 pwg_blocks.push_back(w);
             }
     }
-    // workgroups of the point passes: contiguous point ranges with at most 256 observations (a point with
-    // more observations than that gets a range of its own and is swept in several rounds)
-    std::vector<int> pwg_ptr;
-    pwg_ptr.push_back(0);
+    // waves of the point passes: contiguous ranges of whole points with at most 64 observations (a point
+    // with more observations than that gets a wave of its own and is swept in several rounds)
+    std::vector<int> wv_ptr;
+    wv_ptr.push_back(0);
     {
         int cnt = 0, npts_in = 0;
         for (int i = 0; i < npt; ++i) {
             const int k = pt_ptr[(size_t)i + 1] - pt_ptr[i];
-            if (npts_in > 0 && (cnt + k > 256 || npts_in >= 256)) { pwg_ptr.push_back(i); cnt = 0; npts_in = 0; }
+            if (npts_in > 0 && (cnt + k > 64 || npts_in >= 64)) { wv_ptr.push_back(i); cnt = 0; npts_in = 0; }
             cnt += k; ++npts_in;
         }
-        pwg_ptr.push_back(npt);
+        wv_ptr.push_back(npt);
     }
 
     // ---- upload ----
@@ -468,7 +467,7 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     HIP_TRY(dev_upload(&p->d_pairs, pairs));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
     HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
-    HIP_TRY(dev_upload(&p->d_pwg_ptr, pwg_ptr));
+    HIP_TRY(dev_upload(&p->d_pwg_ptr, wv_ptr));
     {
         std::vector<int> both((size_t)2 * nobs);
         std::copy(pm_pt.begin(), pm_pt.end(), both.begin());
@@ -505,7 +504,7 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     ds.obs_pt = p->d_obs_pt;
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks;
-    ds.npwg = (int)pwg_ptr.size() - 1; ds.pwg_ptr = p->d_pwg_ptr;
+    ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr;
 
     DeviceBuffers& db = p->db;
     for (int b = 0; b < 2; ++b) {
@@ -527,8 +526,9 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     db.udiag = db.rhs + ds.ld;
     db.bc = db.udiag + ds.ld;
     HIP_TRY(dev_alloc(&db.st, 1));
-    HIP_TRY(dev_alloc(&p->d_facc, 4));
-    db.facc = p->d_facc;
+    HIP_TRY(dev_alloc(&p->d_facc, (size_t)NSLOT * SLOT_W));
+    HIP_TRY(hipMemset(p->d_facc, 0, sizeof(double) * NSLOT * SLOT_W));
+    db.slots = p->d_facc;
     // padding of the reduced system (rows/columns >= d) is zero apart from the identity diagonal set by k_finalize
     HIP_TRY(hipMemset(p->d_sys, 0, sizeof(double) * sys_len));
     HIP_TRY(dev_alloc(&p->d_info, 1));
@@ -783,7 +783,7 @@ int64_t sfmba_shard_reduce_len(const sfmba_problem* p) {
     return p && !p->empty ? (int64_t)p->ds.ld * p->ds.ld + 3 * (int64_t)p->ds.ld : 0;
 }
 void* sfmba_shard_reduce_buf(sfmba_problem* p) { return p ? (void*)p->d_sys : nullptr; }
-void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p && p->db.st ? (void*)p->db.st->acc : nullptr; }
+void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p ? (void*)p->db.slots : nullptr; }
 
 int sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt) {
     (void)p; (void)opt;
