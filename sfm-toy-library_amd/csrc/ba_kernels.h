@@ -98,6 +98,12 @@ struct DeviceBuffers {
     LMState* st;
     TraceRow* trace;
     int trace_cap;
+    int* lin_info;            // dense-solver status word (device), consumed and cleared by k_lm_control
+    int* fin_counter;         // arrival counter of k_finalize (last block runs the post-linearisation logic)
+    // block-Jacobi PCG: the solution is x~ with z = Lb^-T x~ (dense_solver.hip); k_cam_update applies Lb^-T itself
+    const double* pcg_vec;    // x~ buffers (two, selected by pcg_flags[2]); nullptr when the Cholesky path wrote z to rhs
+    const double* pcg_linv;
+    const int* pcg_flags;
 };
 
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
@@ -108,7 +114,6 @@ template <typename T> void launch_point_build(hipStream_t s, const DeviceStructu
 template <typename T> void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-void launch_post_lin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);

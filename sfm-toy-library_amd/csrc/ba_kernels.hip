@@ -30,20 +30,19 @@ __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; 
 __device__ __forceinline__ double* slot_ptr(const DeviceBuffers& db, int which) {
     return db.slots + (size_t)(blockIdx.x % NSLOT) * SLOT_W + which;
 }
-// sum (or max for ACC_GMAX) of one accumulator over the slots, then clear it; single thread
+// sum (or max for ACC_GMAX) of one accumulator over the NSLOT (= 64) slots, then clear it.
+// Must be called by all 64 lanes of one wave; every lane returns the result.
 __device__ double slots_take(const DeviceBuffers& db, int which) {
-    double s = 0.0;
-    for (int k = 0; k < NSLOT; ++k) {
-        double* p = db.slots + (size_t)k * SLOT_W + which;
-        if (which == ACC_GMAX) {
-            const double v = __longlong_as_double((long long)*reinterpret_cast<unsigned long long*>(p));
-            s = (v > s || v != v) ? v : s;
-        } else {
-            s += *p;
-        }
-        *p = 0.0;
+    double* p = db.slots + (size_t)(threadIdx.x & 63) * SLOT_W + which;
+    double v = *p;
+    *p = 0.0;
+    if (which == ACC_GMAX) {
+        v = __longlong_as_double((long long)__double_as_longlong(v));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = (o > v || o != o) ? o : v; }
+        return v;
     }
-    return s;
+    return wave_sum(v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -190,10 +189,12 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
 
 __global__ void k_colnorm_finish(DeviceStructure ds, DeviceBuffers db, int jacobi) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ds.d) return;
-    const double n2 = e < ds.d - 1 ? db.udiag[e] : slots_take(db, ACC_UDF);
-    const double s = jacobi ? 1.0 / (1.0 + sqrt(n2)) : 1.0;
-    if (e < ds.d - 1) db.cscale[e] = s; else db.st->fscale = s;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {      // focal column: summed over the slots by one wave
+        const double n2 = slots_take(db, ACC_UDF);
+        if (threadIdx.x == 0) db.st->fscale = jacobi ? 1.0 / (1.0 + sqrt(n2)) : 1.0;
+    }
+    if (e >= ds.d - 1) return;
+    db.cscale[e] = jacobi ? 1.0 / (1.0 + sqrt(db.udiag[e])) : 1.0;
 }
 
 template <typename T>
@@ -493,8 +494,12 @@ __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceB
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = 0.0;
     const int p1 = ds.blk_ptr[b + 1];
-    for (int p = ds.blk_ptr[b] + lane; p < p1; p += 64) {
-        const int2 pr = ds.pairs[p];
+    int p = ds.blk_ptr[b] + lane;
+    int2 pr_next = make_int2(0, 0);
+    if (p < p1) pr_next = ds.pairs[p];
+    for (; p < p1; p += 64) {
+        const int2 pr = pr_next;
+        if (p + 64 < p1) pr_next = ds.pairs[p + 64];   // next round's indices travel with this round's records
         T ra[YREC], rb[YREC];
         load_rec<T>(Y, pr.x, ra);
         load_rec<T>(Y, pr.y, rb);
@@ -671,36 +676,13 @@ template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const
 // ------------------------------------------------------------------------------------------
 // finalize: damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding
 // ------------------------------------------------------------------------------------------
-__global__ void k_finalize(DeviceStructure ds, DeviceBuffers db) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const LMState* st = db.st;
-    double g = 0.0;
-    if (e < ds.d) {
-        if (e == ds.d - 1) {   // focal-focal entries were accumulated in the slotted buffer
-            db.S[(size_t)e * ds.ld + e] = slots_take(db, ACC_SFF);
-            db.rhs[e] = slots_take(db, ACC_RHSF);
-            db.udiag[e] = slots_take(db, ACC_UDF);
-            db.bc[e] = slots_take(db, ACC_BCF);
-        }
-        const double dd = fmin(fmax(db.udiag[e], st->min_diag), st->max_diag) / st->radius;
-        db.S[(size_t)e * ds.ld + e] += dd;
-        const double sc = e < ds.d - 1 ? db.cscale[e] : st->fscale;
-        g = fabs(db.bc[e] / sc);
-        if (!finite_d(db.S[(size_t)e * ds.ld + e]) || !finite_d(db.rhs[e])) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
-    } else if (e < ds.ld) {
-        db.S[(size_t)e * ds.ld + e] = 1.0;
-        db.rhs[e] = 0.0;
-    }
-    g = wave_max(g);
-    if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), g);
-}
-
-// after a linearisation: initial cost (iteration 0), gradient tolerance, evaluation failure
-__global__ void k_post_lin(DeviceStructure ds, DeviceBuffers db) {
+// after a linearisation: initial cost (iteration 0), gradient tolerance, evaluation failure.  One wave.
+__device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db) {
     LMState* st = db.st;
     const double gmax = slots_take(db, ACC_GMAX);
     const double bad_lin = slots_take(db, ACC_BAD_LIN);
     const double lin_cost = slots_take(db, ACC_LIN_COST);
+    if ((threadIdx.x & 63) != 0) return;
     if (st->termination != -1) return;
     if (bad_lin != 0.0) {
         st->termination = SFMBA_FAILURE;
@@ -727,22 +709,69 @@ __global__ void k_post_lin(DeviceStructure ds, DeviceBuffers db) {
     }
 }
 
+// damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding; the last
+// workgroup to arrive (agent-scope release/acquire around an arrival counter) runs post_linearisation
+__global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ int is_last;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const LMState* st = db.st;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
+        // focal-focal entries were accumulated in the slotted buffer: the last wave of the last block owns them
+        const double sff = slots_take(db, ACC_SFF), rhsf = slots_take(db, ACC_RHSF);
+        const double udf = slots_take(db, ACC_UDF), bcf = slots_take(db, ACC_BCF);
+        if (threadIdx.x == 192) {
+            const int fo = ds.d - 1;
+            const double dd = fmin(fmax(udf, st->min_diag), st->max_diag) / st->radius;
+            db.S[(size_t)fo * ds.ld + fo] = sff + dd;
+            db.rhs[fo] = rhsf; db.udiag[fo] = udf; db.bc[fo] = bcf;
+            const double g = fabs(bcf / st->fscale);
+            if (g > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), g);
+            if (!finite_d(sff + dd) || !finite_d(rhsf)) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
+        }
+    }
+    double g = 0.0;
+    if (e < ds.d - 1) {
+        const double dd = fmin(fmax(db.udiag[e], st->min_diag), st->max_diag) / st->radius;
+        db.S[(size_t)e * ds.ld + e] += dd;
+        g = fabs(db.bc[e] / db.cscale[e]);
+        if (!finite_d(db.S[(size_t)e * ds.ld + e]) || !finite_d(db.rhs[e])) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
+    } else if (e >= ds.d && e < ds.ld) {
+        db.S[(size_t)e * ds.ld + e] = 1.0;
+        db.rhs[e] = 0.0;
+    }
+    g = wave_max(g);
+    if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), g);
+    // ---- arrival: every wave drains its stores, one lane releases and takes a ticket ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(db.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (ticket == (int)gridDim.x - 1);
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(db.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (is_last && threadIdx.x < 64) post_linearisation(ds, db);
+}
+
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     hipLaunchKernelGGL(k_finalize, dim3((ds.ld + 255) / 256), dim3(256), 0, s, ds, db);
-}
-void launch_post_lin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_post_lin, dim3(1), dim3(1), 0, s, ds, db);
 }
 
 // iteration 0 bookkeeping: x_norm from the accumulated ||x||^2
 __global__ void k_iter0(DeviceBuffers db) {
     LMState* st = db.st;
-    st->x_norm = sqrt(slots_take(db, ACC_XNEW2));
+    const double x2 = slots_take(db, ACC_XNEW2);
     for (int e = 0; e < SLOT_W; ++e) if (e != ACC_XNEW2) (void)slots_take(db, e);
+    if (threadIdx.x == 0) { st->x_norm = sqrt(x2); *db.fin_counter = 0; }
 }
 void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     (void)ds;
-    hipLaunchKernelGGL(k_iter0, dim3(1), dim3(1), 0, s, db);
+    hipLaunchKernelGGL(k_iter0, dim3(1), dim3(64), 0, s, db);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -757,10 +786,17 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     double step2 = 0.0, xn2 = 0.0;
     if (j < ds.ncam) {
         const double* ct = db.camtab[cur] + (size_t)j * CT_STRIDE;
-        double dlt[6], cn[6];
+        double dlt[6], cn[6], z[6];
+        if (db.pcg_vec) {          // z_j = Linv_j^T x~_j  (block-Jacobi transformed unknowns)
+            const double* x = db.pcg_vec + (size_t)db.pcg_flags[2] * ds.ld + 6 * j;
+            const double* Li = db.pcg_linv + (size_t)j * 36;
+            for (int c = 0; c < 6; ++c) { double v = 0.0; for (int t = c; t < 6; ++t) v += Li[t * 6 + c] * x[t]; z[c] = v; }
+        } else {
+            for (int c = 0; c < 6; ++c) z[c] = db.rhs[6 * j + c];
+        }
         for (int e = 0; e < 6; ++e) {
             const double c0 = db.cam[cur][6 * j + e];
-            dlt[e] = db.cscale[6 * j + e] * db.rhs[6 * j + e];
+            dlt[e] = db.cscale[6 * j + e] * z[e];
             cn[e] = c0 - dlt[e];
             const double df = c0 - cn[e];
             step2 += df * df;
@@ -784,7 +820,9 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double f0 = st->focal[cur];
-        const double fn = f0 - st->fscale * db.rhs[ds.d - 1];
+        double zf = db.rhs[ds.d - 1];
+        if (db.pcg_vec) zf = db.pcg_linv[(size_t)ds.ncam * 36] * db.pcg_vec[(size_t)db.pcg_flags[2] * ds.ld + ds.d - 1];
+        const double fn = f0 - st->fscale * zf;
         st->focal[nxt] = fn;
         const double df = f0 - fn;
         step2 += df * df;
@@ -989,6 +1027,9 @@ __global__ void k_lm_control(DeviceBuffers db) {
     const double step2 = slots_take(db, ACC_STEP2);
     const double xnew2 = slots_take(db, ACC_XNEW2);
     const double bad_trial = slots_take(db, ACC_BAD_TRIAL);
+    if (threadIdx.x != 0) return;
+    st->lin_info = *db.lin_info;
+    *db.lin_info = 0;
     if (st->termination != -1) return;
     const int it = ++st->iter;
     TraceRow row = {};
@@ -1058,7 +1099,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
 
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     (void)ds;
-    hipLaunchKernelGGL(k_lm_control, dim3(1), dim3(1), 0, s, db);
+    hipLaunchKernelGGL(k_lm_control, dim3(1), dim3(64), 0, s, db);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "profiler.h"
+#include <vector>
 
 namespace sfmba {
 
@@ -17,7 +18,8 @@ struct DenseSolver {
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][256] per-workgroup partial p.q
-    int last_iters = 0;       // CG iterations of the previous solve (sizes the first launch batch)
+    int last_iters = 0;       // CG iterations of the previous solve
+    std::vector<int> hist;    // CG iterations of the previous call per caller key (LM iteration index): sizes the first launch batch
     double* binv = nullptr;   // [ld*6] inverses of the 6x6 diagonal blocks (+1x1 focal)
     double* scal = nullptr;   // [8] rz, pq, bnorm2, rnorm2, ...
     int* flags = nullptr;     // [4] done, iters
@@ -36,6 +38,9 @@ inline int dense_padded_dim(int d) { return ((d + 1 + CHOL_NB - 1) / CHOL_NB) * 
 void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof = nullptr);
 
 // Block-Jacobi PCG on the same storage.  Returns the number of iterations (host sync inside).
-int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof = nullptr);
+// finish = false leaves the solution in transformed form (x~, see dense_solver.hip) for k_cam_update;
+// hist_key >= 0 selects the history slot used to size the first batch of launches.
+int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev,
+                    Profiler* prof = nullptr, bool finish = true, int hist_key = -1);
 
 }  // namespace sfmba

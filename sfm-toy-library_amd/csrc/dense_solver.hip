@@ -510,7 +510,8 @@ __global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, cons
     z[e] = v;
 }
 
-int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof) {
+int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof,
+                    bool finish, int hist_key) {
     const int ld = ws->ld, d = ws->d;
     if (!ws->Sfull) {
         if (hipMalloc(&ws->Sfull, sizeof(double) * (size_t)d * ld) != hipSuccess) return -1;
@@ -528,7 +529,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       hipLaunchKernelGGL(k_pcg_iter<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                          rows_per_wg, tol * tol, 0, info_dev); }
     int in = 1, it = 0;
-    int batch = ws->last_iters > 0 ? ws->last_iters + 2 : 32;
+    int batch = 24;
+    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + 1;
     while (it < max_iters) {
         const int n = std::min(max_iters - it, batch);
         const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
@@ -548,9 +550,13 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
         if (ws->h_flags[PF_DONE]) break;
         batch = 8;
     }
-    { ProfScope ps(prof, KID_PCG_FINISH, s);
+    if (finish) { ProfScope ps(prof, KID_PCG_FINISH, s);
       hipLaunchKernelGGL(k_pcg_finish, dim3((d + 255) / 256), dim3(256), 0, s, d, ld, ws->vec, ws->binv, ws->flags, rhs); }
     ws->last_iters = ws->h_flags[PF_ITERS];
+    if (hist_key >= 0) {
+        if (hist_key >= (int)ws->hist.size()) ws->hist.resize((size_t)hist_key + 1, 0);
+        ws->hist[hist_key] = ws->h_flags[PF_ITERS];
+    }
     return ws->h_flags[PF_ITERS];
 }
 

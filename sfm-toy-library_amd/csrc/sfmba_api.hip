@@ -201,6 +201,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
+    std::vector<int> lin_hist;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
@@ -210,18 +211,19 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         { ProfScope ps(prof, KID_SCHUR_PAIRS, p->stream); launch_schur_pairs<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db); }
-        { ProfScope ps(prof, KID_POST_LIN, p->stream); launch_post_lin(p->stream, p->ds, p->db); }
+        DeviceBuffers dbu = p->db;
         if (o.linear_solver == SFMBA_LINEAR_PCG) {
-            const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof);
+            const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
+                                           /*finish=*/false, /*hist_key=*/host_iter);
             if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             sum.linear_iters += it;
+            lin_hist.push_back(it);
+            dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
         } else {
             dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, prof);
+            lin_hist.push_back(0);
         }
-        // hand the dense-solver status to the control kernel
-        HIP_TRY(hipMemcpyAsync(&p->db.st->lin_info, p->d_info, sizeof(int), hipMemcpyDeviceToDevice, p->stream));
-        HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
-        { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
         { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, p->db); }
         rc = download_state(p);
@@ -254,6 +256,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     std::vector<TraceRow> tr((size_t)std::max(rows, 1));
     HIP_TRY(hipMemcpy(tr.data(), p->db.trace, sizeof(TraceRow) * (size_t)rows, hipMemcpyDeviceToHost));
     sum.initial_cost = rows > 0 ? tr[0].cost : hs.cost;
+    for (int r = 1; r < rows && r - 1 < (int)lin_hist.size(); ++r) tr[(size_t)r].linear_iters = lin_hist[(size_t)r - 1];
     if (trace && trace_cap > 0) {
         const int n = std::min(rows, trace_cap);
         static_assert(sizeof(TraceRow) == sizeof(sfmba_iteration), "trace row layout");
@@ -531,7 +534,11 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     db.slots = p->d_facc;
     // padding of the reduced system (rows/columns >= d) is zero apart from the identity diagonal set by k_finalize
     HIP_TRY(hipMemset(p->d_sys, 0, sizeof(double) * sys_len));
-    HIP_TRY(dev_alloc(&p->d_info, 1));
+    HIP_TRY(dev_alloc(&p->d_info, 2));
+    HIP_TRY(hipMemset(p->d_info, 0, 2 * sizeof(int)));
+    db.lin_info = p->d_info;
+    db.fin_counter = p->d_info + 1;
+    db.pcg_vec = nullptr; db.pcg_linv = nullptr; db.pcg_flags = nullptr;
     db.trace = nullptr; db.trace_cap = 0;
     if (dense_solver_create(&p->solver, ds.d, ds.ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
 
@@ -725,7 +732,6 @@ int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, doub
         launch_cam_diag<double>(p->stream, p->ds, p->db);
     }
     launch_finalize(p->stream, p->ds, p->db);
-    launch_post_lin(p->stream, p->ds, p->db);
     const int d = p->ds.d;
     double *d_full = nullptr, *d_scale = nullptr;
     HIP_TRY(dev_alloc(&d_full, (size_t)d * d));

@@ -88,3 +88,16 @@ def test_synthetic_generator_is_deterministic_and_matches_spec(sfm):
     assert np.all(np.diff(a.obs_cam)[same_pt] > 0)                             # ascending view inside a point
     s0, s1 = a.shard_points(0, 2), a.shard_points(1, 2)
     assert s0.n_obs + s1.n_obs == a.n_obs and s0.n_pt + s1.n_pt == a.n_pt
+
+
+def test_cpp_shim_exports_reference_symbol(capi):
+    """The shim library carries sfmtoylib::SfMBundleAdjustmentUtils::adjustBundle with the reference's mangled signature."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build_host()
+    so = os.path.join(ROOT, "sfm-toy-library_amd", "host", "libsfmba_shim.so")
+    assert os.path.exists(so)
+    syms = subprocess.check_output(["nm", "-C", so]).decode()
+    assert "sfmtoylib::SfMBundleAdjustmentUtils::adjustBundle(" in syms
+    assert "std::vector<cv::Matx<float, 3, 4>" in syms
+    C.CDLL(so)   # loads (and resolves libsfmba_hip.so through its rpath)
