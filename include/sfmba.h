@@ -195,18 +195,38 @@ SFMBA_API int sfmba_dense_spd_solve(int device, int n, const double* A, const do
                           int method, double pcg_tol, int pcg_max_iters, int* info, int* iters);
 
 /*
- * Sharded API (multi-GPU): every rank holds the observations of a disjoint set
- * of points and a replica of all cameras + focal.  One LM iteration is
- *     partial_build -> [all-reduce of `reduce_buf` by the caller (RCCL)] -> solve_update
- *     -> [all-reduce of the 8 doubles of `scalars_buf`] -> finish
+ * Sharded API (multi-GPU): every rank holds the observations of a disjoint set of points
+ * and a replica of all cameras + the focal.  Points are independent given the cameras (the Schur
+ * structure), so each rank eliminates its own points and the ONLY exchange per LM iteration is the
+ * sum of the partial reduced camera systems:
+ *
+ *   begin -> [all-reduce SUM of setup_buf] -> setup_finish
+ *   repeat: partial_build -> [all-reduce SUM of reduce_buf] -> solve_update
+ *                         -> [all-reduce SUM of scalars_buf] -> finish(&done)
+ *   end
+ *
  * All buffers are DEVICE pointers owned by the problem (wrap them as torch tensors for
- * torch.distributed); everything is enqueued on sfmba_problem_stream().
+ * torch.distributed / RCCL); every phase is enqueued on sfmba_problem_stream().  Every rank solves the
+ * reduced system redundantly and takes bit-identical accept/reject decisions (no broadcast).
+ *   reduce_buf  = [ S (ld*ld) | rhs (ld) | udiag (ld) | bc (ld) | scalars (SFMBA_SHARD_SCALARS) ]
+ *   setup_buf   = the tail of reduce_buf starting at udiag (column norms for the Jacobi scaling, ||x||^2)
+ *   scalars_buf = the last SFMBA_SHARD_SCALARS doubles (trial cost, model change, step norms; one
+ *                 per-rank slot each for the gradient max-norm, gathered through the SUM)
  */
+#define SFMBA_SHARD_SCALARS 80
+SFMBA_API int     sfmba_problem_create_sharded(int device, int precision,
+                          int n_cam, const double* cam6, const unsigned char* cam_active /* [n_cam] globally observed cameras */,
+                          int n_pt, const double* pt3,
+                          int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                          double focal, int rank, int world, sfmba_problem** out);
 SFMBA_API int     sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt);
+SFMBA_API int     sfmba_shard_setup_finish(sfmba_problem* p);
 SFMBA_API int64_t sfmba_shard_reduce_len(const sfmba_problem* p);       /* doubles in reduce_buf */
-SFMBA_API void*   sfmba_shard_reduce_buf(sfmba_problem* p);             /* packed partial S | rhs | scalars */
-SFMBA_API void*   sfmba_shard_scalars_buf(sfmba_problem* p);            /* 8 doubles: trial cost, model change, norms */
-SFMBA_API int     sfmba_shard_partial_build(sfmba_problem* p);          /* linearise own points, partial S/rhs/scalars */
+SFMBA_API void*   sfmba_shard_reduce_buf(sfmba_problem* p);
+SFMBA_API int64_t sfmba_shard_setup_len(const sfmba_problem* p);
+SFMBA_API void*   sfmba_shard_setup_buf(sfmba_problem* p);
+SFMBA_API void*   sfmba_shard_scalars_buf(sfmba_problem* p);            /* SFMBA_SHARD_SCALARS doubles */
+SFMBA_API int     sfmba_shard_partial_build(sfmba_problem* p);          /* linearise own points: partial S / rhs / scalars */
 SFMBA_API int     sfmba_shard_solve_update(sfmba_problem* p);           /* after all-reduce #1: solve, back-substitute, trial cost */
 SFMBA_API int     sfmba_shard_finish(sfmba_problem* p, int* done);      /* after all-reduce #2: accept/reject, convergence */
 SFMBA_API int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);

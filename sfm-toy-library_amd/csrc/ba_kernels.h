@@ -104,6 +104,7 @@ struct DeviceBuffers {
     const double* pcg_vec;    // x~ buffers (two, selected by pcg_flags[2]); nullptr when the Cholesky path wrote z to rhs
     const double* pcg_linv;
     const int* pcg_flags;
+    double shared_weight;     // 1 normally; 0 on ranks > 0 of a sharded solve (replicated cameras/focal counted once)
 };
 
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
@@ -122,6 +123,14 @@ template <typename T> void launch_eval_residuals(hipStream_t s, const DeviceStru
                                                  const int* perm, double* res_out, double* cost_out);
 template <typename T> void launch_eval_jacobian(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
                                                 const int* obs_pt, const int* perm, double* jc, double* jp, double* jf);
+// sharded mode: move slotted accumulators to / from the all-reduce scalar block
+void launch_shard_pack(hipStream_t s, const DeviceBuffers& db, double* scal, int phase, int rank);
+void launch_shard_unpack(hipStream_t s, const DeviceBuffers& db, const double* scal, int phase, int world);
+void launch_clear_slots(hipStream_t s, const DeviceBuffers& db);
+void launch_shard_xnorm_finish(hipStream_t s, const DeviceBuffers& db);
+void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int precision_f32);
+void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int precision_f32);
+void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi);
 void launch_mirror_scale(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* S_full, double* scale_out);
 
 

@@ -115,9 +115,9 @@ __global__ void k_xnorm(DeviceStructure ds, DeviceBuffers db) {
     double s = 0.0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nc + np; e += gridDim.x * blockDim.x) {
         const double v = e < nc ? cam[e] : pts[e - nc];
-        s += v * v;
+        s += (e < nc ? db.shared_weight : 1.0) * v * v;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { const double f = db.st->focal[cur]; s += f * f; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { const double f = db.st->focal[cur]; s += db.shared_weight * f * f; }
     s = block_sum(s, scratch);
     if (threadIdx.x == 0) atomicAdd(slot_ptr(db, ACC_XNEW2), s);
 }
@@ -195,6 +195,20 @@ __global__ void k_colnorm_finish(DeviceStructure ds, DeviceBuffers db, int jacob
     }
     if (e >= ds.d - 1) return;
     db.cscale[e] = jacobi ? 1.0 / (1.0 + sqrt(db.udiag[e])) : 1.0;
+}
+
+void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int f32) {
+    if (f32) hipLaunchKernelGGL(k_colnorm_points<float>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
+    else hipLaunchKernelGGL(k_colnorm_points<double>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
+}
+void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int f32) {
+    (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
+    if (!jacobi) return;
+    if (f32) hipLaunchKernelGGL(k_colnorm_cams<float>, dim3(ds.nchunk), dim3(BLK), 0, s, ds, db);
+    else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk), dim3(BLK), 0, s, ds, db);
+}
+void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi) {
+    hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi);
 }
 
 template <typename T>
@@ -830,7 +844,7 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     }
     const double s2 = block_sum(step2, scratch);
     const double x2 = block_sum(xn2, scratch);
-    if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), s2); atomicAdd(slot_ptr(db, ACC_XNEW2), x2); }
+    if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), db.shared_weight * s2); atomicAdd(slot_ptr(db, ACC_XNEW2), db.shared_weight * x2); }
 }
 
 // Obs-parallel back-substitution: same workgroup/point ownership as k_point_build.
@@ -1101,6 +1115,67 @@ void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffer
     (void)ds;
     hipLaunchKernelGGL(k_lm_control, dim3(1), dim3(64), 0, s, db);
 }
+
+// ------------------------------------------------------------------------------------------
+// sharded mode: the slotted accumulators travel through one all-reduce(SUM) as a small scalar block.
+//   phase 0 (setup):  [0] ||x||^2  [1] focal column norm^2
+//   phase 1 (build):  [0] sum r^2  [1] bad linearisation  [2..5] focal-focal sums  [16 + rank] gradient max-norm
+//   phase 2 (update): [0] trial sum r^2  [1] model change  [2] step^2  [3] ||x_trial||^2  [4] bad trial
+// ------------------------------------------------------------------------------------------
+__global__ void k_shard_pack(DeviceBuffers db, double* scal, int phase, int rank) {
+    double v[6] = { 0, 0, 0, 0, 0, 0 };
+    double gmax = 0.0;
+    if (phase == 0) { v[0] = slots_take(db, ACC_XNEW2); v[1] = slots_take(db, ACC_UDF); }
+    else if (phase == 1) {
+        v[0] = slots_take(db, ACC_LIN_COST); v[1] = slots_take(db, ACC_BAD_LIN);
+        v[2] = slots_take(db, ACC_SFF); v[3] = slots_take(db, ACC_RHSF); v[4] = slots_take(db, ACC_UDF); v[5] = slots_take(db, ACC_BCF);
+        gmax = slots_take(db, ACC_GMAX);
+    } else {
+        v[0] = slots_take(db, ACC_TRIAL_COST); v[1] = slots_take(db, ACC_MODEL); v[2] = slots_take(db, ACC_STEP2);
+        v[3] = slots_take(db, ACC_XNEW2); v[4] = slots_take(db, ACC_BAD_TRIAL);
+    }
+    const int t = threadIdx.x;
+    for (int e = t; e < SFMBA_SHARD_SCALARS; e += 64) scal[e] = 0.0;
+    __syncthreads();
+    if (t == 0) {
+        for (int k = 0; k < 6; ++k) scal[k] = v[k];
+        if (phase == 1) scal[16 + rank] = gmax;
+    }
+}
+
+__global__ void k_shard_unpack(DeviceBuffers db, const double* scal, int phase, int world) {
+    if (threadIdx.x != 0) return;
+    double* s0 = db.slots;   // slot 0 (all slots are empty after the pack)
+    if (phase == 0) { s0[ACC_XNEW2] = scal[0]; s0[ACC_UDF] = scal[1]; }
+    else if (phase == 1) {
+        s0[ACC_LIN_COST] = scal[0]; s0[ACC_BAD_LIN] = scal[1];
+        s0[ACC_SFF] = scal[2]; s0[ACC_RHSF] = scal[3]; s0[ACC_UDF] = scal[4]; s0[ACC_BCF] = scal[5];
+        double g = 0.0;
+        for (int r = 0; r < world; ++r) { const double v = scal[16 + r]; g = (v > g || v != v) ? v : g; }
+        reinterpret_cast<unsigned long long*>(s0)[ACC_GMAX] = (unsigned long long)__double_as_longlong(g);
+    } else {
+        s0[ACC_TRIAL_COST] = scal[0]; s0[ACC_MODEL] = scal[1]; s0[ACC_STEP2] = scal[2]; s0[ACC_XNEW2] = scal[3]; s0[ACC_BAD_TRIAL] = scal[4];
+    }
+}
+
+__global__ void k_clear_slots(DeviceBuffers db) {
+    for (int e = 0; e < SLOT_W; ++e) (void)slots_take(db, e);
+    if (threadIdx.x == 0) *db.fin_counter = 0;
+}
+
+__global__ void k_shard_xnorm_finish(DeviceBuffers db) {
+    const double x2 = slots_take(db, ACC_XNEW2);
+    if (threadIdx.x == 0) db.st->x_norm = sqrt(x2);
+}
+
+void launch_shard_pack(hipStream_t s, const DeviceBuffers& db, double* scal, int phase, int rank) {
+    hipLaunchKernelGGL(k_shard_pack, dim3(1), dim3(64), 0, s, db, scal, phase, rank);
+}
+void launch_shard_unpack(hipStream_t s, const DeviceBuffers& db, const double* scal, int phase, int world) {
+    hipLaunchKernelGGL(k_shard_unpack, dim3(1), dim3(64), 0, s, db, scal, phase, world);
+}
+void launch_clear_slots(hipStream_t s, const DeviceBuffers& db) { hipLaunchKernelGGL(k_clear_slots, dim3(1), dim3(64), 0, s, db); }
+void launch_shard_xnorm_finish(hipStream_t s, const DeviceBuffers& db) { hipLaunchKernelGGL(k_shard_xnorm_finish, dim3(1), dim3(64), 0, s, db); }
 
 // ------------------------------------------------------------------------------------------
 // kernel-level entry points used by the parity tests (C ABI: sfmba_problem_eval_*)

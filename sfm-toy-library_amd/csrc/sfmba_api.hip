@@ -106,6 +106,10 @@ struct sfmba_problem {
     bool shard_active = false;
     double shard_t0 = 0.0;
     int shard_phase = 0;
+    int shard_rank = 0, shard_world = 1;
+    double* d_scal = nullptr;                     // tail of d_sys: SFMBA_SHARD_SCALARS doubles
+    int shard_host_iter = 0;
+    sfmba_summary shard_sum;
     Profiler prof;
 };
 
@@ -319,9 +323,26 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     delete p;
 }
 
+static int create_impl(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
+                       int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                       double focal, int rank, int world, sfmba_problem** out);
+
 int sfmba_problem_create(int device, int precision, int n_cam, const double* cam6, int n_pt, const double* pt3,
                          int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                          double focal, sfmba_problem** out) {
+    return create_impl(device, precision, n_cam, cam6, nullptr, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal, 0, 1, out);
+}
+
+int sfmba_problem_create_sharded(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active,
+                                 int n_pt, const double* pt3, int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt,
+                                 const double* obs_xy, double focal, int rank, int world, sfmba_problem** out) {
+    if (world < 1 || rank < 0 || rank >= world || world > SFMBA_SHARD_SCALARS - 16) return fail(SFMBA_ERR_INVALID_ARG, "bad rank/world");
+    return create_impl(device, precision, n_cam, cam6, cam_active, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal, rank, world, out);
+}
+
+static int create_impl(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
+                       int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                       double focal, int rank, int world, sfmba_problem** out) {
     if (!out) return fail(SFMBA_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     if (n_cam < 0 || n_pt < 0 || n_obs < 0 || n_obs >= (int64_t)1 << 31) return fail(SFMBA_ERR_INVALID_ARG, "bad sizes");
@@ -337,6 +358,7 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     p->precision = precision;
     p->n_cam_full = n_cam; p->n_pt_full = n_pt; p->n_obs = n_obs;
     p->focal0 = p->focal = focal;
+    p->shard_rank = rank; p->shard_world = world;
     struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
 
     // ---- structure (host) ----
@@ -347,12 +369,14 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
         cam_slot[obs_cam[k]] = 0;
         pt_slot[obs_pt[k]] = 0;
     }
+    if (cam_active)   // sharded: every globally observed camera is part of every rank's reduced system
+        for (int j = 0; j < n_cam; ++j) if (cam_active[j]) cam_slot[j] = 0;
     for (int j = 0; j < n_cam; ++j) if (cam_slot[j] == 0) { cam_slot[j] = (int)p->acam_id.size(); p->acam_id.push_back(j); }
     for (int i = 0; i < n_pt; ++i) if (pt_slot[i] == 0) { pt_slot[i] = (int)p->apt_id.size(); p->apt_id.push_back(i); }
     const int ncam = (int)p->acam_id.size(), npt = (int)p->apt_id.size(), nobs = (int)n_obs;
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LMState), hipHostMallocDefault));
-    if (nobs == 0) {
+    if (nobs == 0 && !cam_active) {
         p->empty = true;
         guard.p = nullptr;
         *out = p;
@@ -522,12 +546,14 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
     HIP_TRY(hipMalloc(&db.Y, ybytes));
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
-    const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld;
+    const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
     HIP_TRY(dev_alloc(&p->d_sys, sys_len));
     db.S = p->d_sys;
     db.rhs = db.S + (size_t)ds.ld * ds.ld;
     db.udiag = db.rhs + ds.ld;
     db.bc = db.udiag + ds.ld;
+    p->d_scal = db.bc + ds.ld;
+    db.shared_weight = 1.0;
     HIP_TRY(dev_alloc(&db.st, 1));
     HIP_TRY(dev_alloc(&p->d_facc, (size_t)NSLOT * SLOT_W));
     HIP_TRY(hipMemset(p->d_facc, 0, sizeof(double) * NSLOT * SLOT_W));
@@ -782,22 +808,142 @@ int sfmba_dense_spd_solve(int device, int n, const double* A, const double* b, d
 }
 
 // ---- sharded (multi-GPU) API --------------------------------------------------------------------
-// reduce_buf = [S (ld*ld) | rhs (ld) | udiag (ld) | bc (ld)] : one all-reduce(SUM) covers the reduced
-// system, its right-hand side, the undamped diagonal and the scaled gradient.  The scalar block is
-// LMState::acc (trial cost, model change, norms) -- see ba_kernels.h.
+// reduce_buf = [S (ld*ld) | rhs (ld) | udiag (ld) | bc (ld) | scalars]: one all-reduce(SUM) per LM iteration
+// carries the partial reduced camera system, its right-hand side, the undamped diagonal, the scaled
+// gradient and the linearisation scalars.  See include/sfmba.h for the protocol.
 int64_t sfmba_shard_reduce_len(const sfmba_problem* p) {
-    return p && !p->empty ? (int64_t)p->ds.ld * p->ds.ld + 3 * (int64_t)p->ds.ld : 0;
+    return p && !p->empty ? (int64_t)p->ds.ld * p->ds.ld + 3 * (int64_t)p->ds.ld + SFMBA_SHARD_SCALARS : 0;
 }
 void* sfmba_shard_reduce_buf(sfmba_problem* p) { return p ? (void*)p->d_sys : nullptr; }
-void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p ? (void*)p->db.slots : nullptr; }
+int64_t sfmba_shard_setup_len(const sfmba_problem* p) { return p && !p->empty ? 2 * (int64_t)p->ds.ld + SFMBA_SHARD_SCALARS : 0; }
+void* sfmba_shard_setup_buf(sfmba_problem* p) { return p ? (void*)p->db.udiag : nullptr; }
+void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p ? (void*)p->d_scal : nullptr; }
 
 int sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt) {
-    (void)p; (void)opt;
-    return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build");
+    if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
+    if (opt) p->shard_opt = *opt; else sfmba_options_default(&p->shard_opt);
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = ensure_trace(p, std::min(std::max(p->shard_opt.max_iters, 0) + 2, 1 << 16));
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->shard_t0 = now_seconds();
+    p->shard_active = true;
+    p->shard_host_iter = 0;
+    std::memset(&p->shard_sum, 0, sizeof(p->shard_sum));
+    p->db.shared_weight = p->shard_rank == 0 ? 1.0 : 0.0;
+    LMState st;
+    init_state(p, st, p->shard_opt);
+    rc = upload_state(p, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
+    const size_t n = 6 * (size_t)p->ds.ncam;
+    const int f32 = p->precision == SFMBA_PRECISION_F32J;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
+    launch_clear_slots(p->stream, p->db);
+    launch_cam_setup<double>(p->stream, p->ds, p->db, p->cur);
+    launch_xnorm(p->stream, p->ds, p->db);
+    launch_colnorm_points_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32);
+    launch_colnorm_cams_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32);
+    HIP_TRY(hipMemsetAsync(p->db.bc, 0, sizeof(double) * p->ds.ld, p->stream));
+    launch_shard_pack(p->stream, p->db, p->d_scal, 0, p->shard_rank);
+    return SFMBA_OK;
 }
-int sfmba_shard_partial_build(sfmba_problem* p) { (void)p; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
-int sfmba_shard_solve_update(sfmba_problem* p) { (void)p; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
-int sfmba_shard_finish(sfmba_problem* p, int* done) { (void)p; (void)done; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
-int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) { (void)p; (void)summary; return fail(SFMBA_ERR_INVALID_ARG, "sharded mode: not implemented in this build"); }
+
+int sfmba_shard_setup_finish(sfmba_problem* p) {
+    if (!p || !p->shard_active) return fail(SFMBA_ERR_INVALID_ARG, "shard_begin was not called");
+    HIP_TRY(hipSetDevice(p->device));
+    launch_shard_unpack(p->stream, p->db, p->d_scal, 0, p->shard_world);
+    launch_shard_xnorm_finish(p->stream, p->db);
+    launch_colnorm_finish(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling);
+    launch_cam_setup<double>(p->stream, p->ds, p->db, p->cur);
+    return SFMBA_OK;
+}
+
+int sfmba_shard_partial_build(sfmba_problem* p) {
+    if (!p || !p->shard_active) return fail(SFMBA_ERR_INVALID_ARG, "shard_begin was not called");
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->precision == SFMBA_PRECISION_F32J) {
+        launch_point_build<float>(p->stream, p->ds, p->db);
+        launch_schur_pairs<float>(p->stream, p->ds, p->db);
+        launch_cam_diag<float>(p->stream, p->ds, p->db);
+    } else {
+        launch_point_build<double>(p->stream, p->ds, p->db);
+        launch_schur_pairs<double>(p->stream, p->ds, p->db);
+        launch_cam_diag<double>(p->stream, p->ds, p->db);
+    }
+    launch_shard_pack(p->stream, p->db, p->d_scal, 1, p->shard_rank);
+    return SFMBA_OK;
+}
+
+int sfmba_shard_solve_update(sfmba_problem* p) {
+    if (!p || !p->shard_active) return fail(SFMBA_ERR_INVALID_ARG, "shard_begin was not called");
+    HIP_TRY(hipSetDevice(p->device));
+    const sfmba_options& o = p->shard_opt;
+    launch_shard_unpack(p->stream, p->db, p->d_scal, 1, p->shard_world);
+    launch_finalize(p->stream, p->ds, p->db);
+    DeviceBuffers dbu = p->db;
+    if (o.linear_solver == SFMBA_LINEAR_PCG) {
+        const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
+                                       false, p->shard_host_iter);
+        if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+        p->shard_sum.linear_iters += it;
+        dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
+    } else {
+        dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, nullptr);
+    }
+    launch_cam_update(p->stream, p->ds, dbu);
+    if (p->precision == SFMBA_PRECISION_F32J) launch_point_update<float>(p->stream, p->ds, p->db);
+    else launch_point_update<double>(p->stream, p->ds, p->db);
+    launch_shard_pack(p->stream, p->db, p->d_scal, 2, p->shard_rank);
+    return SFMBA_OK;
+}
+
+int sfmba_shard_finish(sfmba_problem* p, int* done) {
+    if (!p || !p->shard_active || !done) return fail(SFMBA_ERR_INVALID_ARG, "shard_begin was not called");
+    HIP_TRY(hipSetDevice(p->device));
+    const sfmba_options& o = p->shard_opt;
+    launch_shard_unpack(p->stream, p->db, p->d_scal, 2, p->shard_world);
+    launch_control(p->stream, p->ds, p->db);
+    int rc = download_state(p);
+    if (rc) return rc;
+    p->shard_host_iter = p->h_state->iter;
+    *done = 0;
+    if (p->h_state->termination != -1) {
+        p->shard_sum.termination = p->h_state->termination;
+        std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(p->h_state->message));
+        *done = 1;
+    } else if (p->shard_host_iter >= o.max_iters) {
+        p->shard_sum.termination = SFMBA_NO_CONVERGENCE;
+        std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(MSG_MAX_ITERS));
+        *done = 1;
+    }
+    // the wall-clock limit is deliberately not applied here: ranks would disagree on it
+    return SFMBA_OK;
+}
+
+int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) {
+    if (!p || !p->shard_active) return fail(SFMBA_ERR_INVALID_ARG, "shard_begin was not called");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = download_state(p);
+    if (rc) return rc;
+    const LMState& hs = *p->h_state;
+    p->cur = hs.cur;
+    p->focal = hs.focal[hs.cur];
+    p->db.shared_weight = 1.0;
+    p->shard_active = false;
+    sfmba_summary& sum = p->shard_sum;
+    sum.iterations = hs.iter;
+    sum.successful_steps = hs.successful;
+    sum.unsuccessful_steps = hs.unsuccessful;
+    sum.residual_evals = hs.residual_evals;
+    sum.jacobian_evals = hs.jacobian_evals;
+    sum.final_cost = hs.cost;
+    sum.seconds = now_seconds() - p->shard_t0;
+    TraceRow row0;
+    HIP_TRY(hipMemcpy(&row0, p->db.trace, sizeof(TraceRow), hipMemcpyDeviceToHost));
+    sum.initial_cost = row0.cost;
+    if (summary) *summary = sum;
+    return SFMBA_OK;
+}
 
 }  // extern "C"

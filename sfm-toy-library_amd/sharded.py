@@ -1,0 +1,118 @@
+"""One-process-per-GPU bundle adjustment of ONE problem whose points are sharded across ranks
+(BASELINE.json config 5).
+
+Points are conditionally independent given the cameras, so each rank eliminates its own points and the
+only data-path exchange per LM iteration is the sum of the partial reduced camera systems
+(torch.distributed all_reduce == RCCL over xGMI on the GPU box, gloo in the CPU tests).  Every rank then
+solves the reduced system redundantly and takes the same accept/reject decision -- no broadcast.
+
+The choreography (``solve_sharded``) is backend-agnostic: the product backend is ``HipShardBackend``
+(the C ABI of include/sfmba.h on the rank's GPU); tests drive the same choreography with a CPU backend.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .structs import SfmbaSummary
+
+
+class _DevicePtr:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can wrap it without a copy."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class HipShardBackend:
+    """Rank-local half of the sharded solve on one MI355X."""
+
+    def __init__(self, full_prob, rank, world, device=0, precision=1):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.device = rank, world, device
+        shard = full_prob.shard_points(rank, world)
+        active = np.zeros(full_prob.n_cam, dtype=np.uint8)
+        active[np.unique(full_prob.obs_cam)] = 1
+        self._point_range = shard.meta["point_range"]
+        self._template = (np.ascontiguousarray(shard.cam6, np.float64).copy(), np.ascontiguousarray(shard.pt3, np.float64).copy())
+        cam6, pt3 = self._template
+        oc = np.ascontiguousarray(shard.obs_cam, np.int32)
+        op = np.ascontiguousarray(shard.obs_pt, np.int32)
+        oxy = np.ascontiguousarray(shard.obs_xy, np.float64)
+        self._h = C.c_void_p()
+        L = capi.lib()
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        capi._check(L.sfmba_problem_create_sharded(
+            C.c_int(device), C.c_int(precision), C.c_int(shard.n_cam), cam6.ctypes.data_as(dp),
+            active.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_int(shard.n_pt), pt3.ctypes.data_as(dp), C.c_int64(shard.n_obs),
+            oc.ctypes.data_as(ip), op.ctypes.data_as(ip), oxy.ctypes.data_as(dp), C.c_double(shard.focal),
+            C.c_int(rank), C.c_int(world), C.byref(self._h)))
+        self.L = L
+        self.stream = torch.cuda.ExternalStream(L.sfmba_problem_stream(self._h), device=torch.device("cuda", device))
+        dev = "cuda:%d" % device
+        self.reduce_t = torch.as_tensor(_DevicePtr(L.sfmba_shard_reduce_buf(self._h), L.sfmba_shard_reduce_len(self._h)), device=dev)
+        self.setup_t = torch.as_tensor(_DevicePtr(L.sfmba_shard_setup_buf(self._h), L.sfmba_shard_setup_len(self._h)), device=dev)
+        self.scalars_t = torch.as_tensor(_DevicePtr(L.sfmba_shard_scalars_buf(self._h), 80), device=dev)
+
+    # -- protocol --
+    def begin(self, opt):
+        self._opt = opt
+        capi._check(self.L.sfmba_shard_begin(self._h, C.byref(opt)))
+
+    def setup_finish(self):
+        capi._check(self.L.sfmba_shard_setup_finish(self._h))
+
+    def partial_build(self):
+        capi._check(self.L.sfmba_shard_partial_build(self._h))
+
+    def solve_update(self):
+        capi._check(self.L.sfmba_shard_solve_update(self._h))
+
+    def finish(self):
+        done = C.c_int(0)
+        capi._check(self.L.sfmba_shard_finish(self._h, C.byref(done)))
+        return bool(done.value)
+
+    def end(self):
+        summ = SfmbaSummary()
+        capi._check(self.L.sfmba_shard_end(self._h, C.byref(summ)))
+        return summ.as_dict()
+
+    def all_reduce(self, dist, which, group=None):
+        t = {"setup": self.setup_t, "reduce": self.reduce_t, "scalars": self.scalars_t}[which]
+        with self.torch.cuda.stream(self.stream):           # the collective is ordered on the solver's own stream
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+    def get_params(self):
+        """(cam6 of all cameras, pt3 of this rank's point range, focal)."""
+        cam6, pt3 = self._template[0].copy(), self._template[1].copy()
+        focal = C.c_double(0.0)
+        dp = C.POINTER(C.c_double)
+        capi._check(self.L.sfmba_problem_get_params(self._h, cam6.ctypes.data_as(dp), pt3.ctypes.data_as(dp), C.byref(focal)))
+        return cam6, pt3, focal.value
+
+    def reset(self):
+        capi._check(self.L.sfmba_problem_reset(self._h))
+
+    def close(self):
+        if self._h:
+            self.L.sfmba_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def solve_sharded(backend, dist, opt, group=None):
+    """The LM loop of one rank.  `dist` is torch.distributed (or any object with the same all_reduce API).
+    Exactly three collectives are issued: one before the first iteration (column norms for the Jacobi
+    scaling, ||x||), then two per LM iteration (reduced system + linearisation scalars; trial-step scalars)."""
+    backend.begin(opt)
+    backend.all_reduce(dist, "setup", group)
+    backend.setup_finish()
+    while True:
+        backend.partial_build()
+        backend.all_reduce(dist, "reduce", group)
+        backend.solve_update()
+        backend.all_reduce(dist, "scalars", group)
+        if backend.finish():
+            break
+    return backend.end()
