@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", help="name in synthetic.CONFIGS (default: the BASELINE metric config)")
-    ap.add_argument("--linear", default="cholesky", choices=["cholesky", "pcg"])
+    ap.add_argument("--linear", default="pcg", choices=["cholesky", "pcg"],
+                    help="reduced-system solver: pcg = block-Jacobi PCG on the dense reduced system (north_star), "
+                         "cholesky = DENSE_SCHUR-equivalent exact factorisation (reference configuration)")
     ap.add_argument("--precision", default="f32j", choices=["f32j", "f64"])
     ap.add_argument("--pcg-tol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,6 +247,10 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
                      "note": "reads camera-major index lists, obs, records, per-point t / y_f"},
         "point_update": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_pt * (24 + 24 + 24 + 4),
                          "note": "reads obs, points, scales; writes trial points"},
+        "pcg_iter": {"bound": "hbm", "bytes": 8 * d * d + 9 * 8 * d,
+                     "note": "one CG iteration = one launch: reads its rows of the preconditioned reduced matrix S~ once "
+                             "(8 d^2 bytes) + the x/r/p/q vectors; launch/latency bound (d = %d): the matrix is re-read from "
+                             "L2/MALL every launch because L2 does not survive the kernel boundary" % d},
         "chol_update": {"bound": "mfma", "flops": 2.0 * d * d * d / 3.0 / max(nblk - 1, 1), "peak_tflops": 78.6,
                         "note": "fp64 trailing update; d^3/3 flops of the factorisation spread over its launches; peak = fp64 matrix 78.6 TF"},
         "chol_panel": {"bound": "mfma", "flops": 2.0 * d * nb * nb / 2.0, "peak_tflops": 78.6,

@@ -95,7 +95,7 @@ __global__ void k_cam_setup(int ncam, const double* __restrict__ cam, const doub
     double c6[6], ct[CT_STRIDE];
     for (int e = 0; e < 6; ++e) c6[e] = cam[6 * j + e];
     make_cam_table(c6, cscale + 6 * j, ct);
-    for (int e = 0; e < CT_STRIDE; ++e) camtab[(size_t)j * CT_STRIDE + e] = ct[e];
+    for (int e = 0; e < CT_STRIDE; ++e) camtab[(size_t)e * ncam + j] = ct[e];
 }
 
 template <typename T>
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLK) void k_colnorm_points(DeviceStructure ds, Devi
     double n0 = 0, n1 = 0, n2 = 0;
     if (jacobi) {
         for (int q = ds.pt_ptr[i]; q < ds.pt_ptr[i + 1]; ++q) {
-            const double* ct = tab + (size_t)ds.obs_cam[q] * CT_STRIDE;
+            const CamRow ct = { tab + ds.obs_cam[q], ds.ncam };
             const Proj pr = project_point(ct, CT_R, CT_T, X);
             T B[6];
             point_block<T>(ct, pr, focal, B);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
     const int4 ch = ds.chunks[blockIdx.x];
     const int j = ch.x;
     const int cur = db.st->cur;
-    const double* ct = db.camtab[cur] + (size_t)j * CT_STRIDE;
+    const CamRow ct = { db.camtab[cur] + j, ds.ncam };
     const double focal = db.st->focal[cur];
     const typename ObsXY<T>::type* oxy = reinterpret_cast<const typename ObsXY<T>::type*>(ds.obs_xy);
     (void)oxy;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
                 load_obs<T>(ds.obs_xy, q, ox, oy);
                 const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
                 const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
-                const double* ct = tab + (size_t)j * CT_STRIDE;
+                const CamRow ct = { tab + j, ds.ncam };
                 const Proj pr = project_point(ct, CT_R, CT_T, X);
                 const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
                 lin_cost += r0 * r0 + r1 * r1;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
                 ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
                 const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
                 spk[0] = (T)db.pscale[3 * (size_t)ik]; spk[1] = (T)db.pscale[3 * (size_t)ik + 1]; spk[2] = (T)db.pscale[3 * (size_t)ik + 2];
-                const double* ct = tab + (size_t)jk * CT_STRIDE;
+                const CamRow ct = { tab + jk, ds.ncam };
                 prk = project_point(ct, CT_R, CT_T, X);
                 point_block<T>(ct, prk, focal, Bk);
                 camera_block<T>(ct, prk, focal, X, Bk, Ak);
@@ -495,6 +495,107 @@ struct HalvingReduce<N, 0> {
     static __device__ __forceinline__ void run(double*, int, int&, int&) {}
 };
 
+// one pair of observations: acc += A_a^T (C_a C_b^T) A_b   (unscaled; the camera scales are applied once at the end)
+template <typename T>
+__device__ __forceinline__ void pair_product(const T ra[YREC], const T rb[YREC], bool diag, T acc[36]) {
+    const T m00 = ra[9] * rb[9] + ra[10] * rb[10] + ra[11] * rb[11];
+    const T m01 = ra[9] * rb[12] + ra[10] * rb[13] + ra[11] * rb[14];
+    const T m10 = ra[12] * rb[9] + ra[13] * rb[10] + ra[14] * rb[11];
+    const T m11 = ra[12] * rb[12] + ra[13] * rb[13] + ra[14] * rb[14];
+    T Aa[12], Ab[12], Tm[12];
+    rec_camera_block<T>(ra, Aa);
+    rec_camera_block<T>(rb, Ab);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { Tm[c] = m00 * Ab[c] + m01 * Ab[6 + c]; Tm[6 + c] = m10 * Ab[c] + m11 * Ab[6 + c]; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const T v = Aa[r] * Tm[c] + Aa[6 + r] * Tm[6 + c];
+            acc[6 * r + c] += v;
+            if (diag) acc[6 * c + r] += v;   // same camera twice: Y_a Y_b^T + Y_b Y_a^T
+        }
+}
+
+// quad helpers: the four lanes 4g..4g+3 cooperate on one pair
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// lane s of a quad holds values [4s, 4s+4) of a 16-value record; rebuild the whole record in every lane
+template <typename T>
+__device__ __forceinline__ void quad_assemble(const T q[4], T rec[YREC]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        rec[m] = quad_bcast<0>(q[m]);
+        rec[4 + m] = quad_bcast<1>(q[m]);
+        rec[8 + m] = quad_bcast<2>(q[m]);
+        rec[12 + m] = quad_bcast<3>(q[m]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void load_quarter(const T* Y, int q, int s, T out[4]) {
+    const T* src = Y + (size_t)q * YREC + 4 * s;
+    if (sizeof(T) == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(src);
+        out[0] = (T)x.x; out[1] = (T)x.y; out[2] = (T)x.z; out[3] = (T)x.w;
+    } else {
+        const double2 x = reinterpret_cast<const double2*>(src)[0], y = reinterpret_cast<const double2*>(src)[1];
+        out[0] = (T)x.x; out[1] = (T)x.y; out[2] = (T)y.x; out[3] = (T)y.y;
+    }
+}
+
+// One pair handled by a quad: lane s accumulates rows s and s+4 (the latter only for s < 2) of
+//   A_a^T (C_a C_b^T) A_b   (+ its transpose inside diagonal blocks: same camera observing a point twice)
+template <typename T>
+__device__ __forceinline__ void quad_pair_product(const T ra[YREC], const T rb[YREC], int s, bool diag, T acc[12]) {
+    const T m00 = ra[9] * rb[9] + ra[10] * rb[10] + ra[11] * rb[11];
+    const T m01 = ra[9] * rb[12] + ra[10] * rb[13] + ra[11] * rb[14];
+    const T m10 = ra[12] * rb[9] + ra[13] * rb[10] + ra[14] * rb[11];
+    const T m11 = ra[12] * rb[12] + ra[13] * rb[13] + ra[14] * rb[14];
+    T Aa[12], Ab[12], Tm[12];
+    rec_camera_block<T>(ra, Aa);
+    rec_camera_block<T>(rb, Ab);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { Tm[c] = m00 * Ab[c] + m01 * Ab[6 + c]; Tm[6 + c] = m10 * Ab[c] + m11 * Ab[6 + c]; }
+    // rows owned by this lane, selected with data (no divergent code)
+    const T a0 = s == 0 ? Aa[0] : s == 1 ? Aa[1] : s == 2 ? Aa[2] : Aa[3];
+    const T a1 = s == 0 ? Aa[6] : s == 1 ? Aa[7] : s == 2 ? Aa[8] : Aa[9];
+    const T b0 = s == 0 ? Aa[4] : s == 1 ? Aa[5] : (T)0;
+    const T b1 = s == 0 ? Aa[10] : s == 1 ? Aa[11] : (T)0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        acc[c] += a0 * Tm[c] + a1 * Tm[6 + c];
+        acc[6 + c] += b0 * Tm[c] + b1 * Tm[6 + c];
+    }
+    if (diag) {   // + v^T: out[r][c] += A_a[.][c] . Tm[.][r]
+        const T t0 = s == 0 ? Tm[0] : s == 1 ? Tm[1] : s == 2 ? Tm[2] : Tm[3];
+        const T t1 = s == 0 ? Tm[6] : s == 1 ? Tm[7] : s == 2 ? Tm[8] : Tm[9];
+        const T u0 = s == 0 ? Tm[4] : s == 1 ? Tm[5] : (T)0;
+        const T u1 = s == 0 ? Tm[10] : s == 1 ? Tm[11] : (T)0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            acc[c] += Aa[c] * t0 + Aa[6 + c] * t1;
+            acc[6 + c] += Aa[c] * u0 + Aa[6 + c] * u1;
+        }
+    }
+}
+
+// Four lanes share one pair: each record is ONE 64-byte request of four adjacent lanes instead of four
+// requests per lane -- the kernel was bound by the vector-memory pipe walking 64 different lines for
+// every 16-byte load instruction, not by bytes.  A wave has 4 x 16 pairs in flight per round; the
+// lane-local sums of its few products stay in T, the sum over the wave is carried in fp64.
+#define PAIR_UNROLL 4
+
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -504,45 +605,56 @@ __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceB
     const int2 cj = ds.blk_cams[b];
     const bool diag = cj.x == cj.y;
     const T* Y = reinterpret_cast<const T*>(db.Y);
-    double acc[36];
+    const int s = lane & 3, g = lane >> 2;
+    T acc[12];
 #pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+    for (int e = 0; e < 12; ++e) acc[e] = (T)0;
     const int p1 = ds.blk_ptr[b + 1];
-    int p = ds.blk_ptr[b] + lane;
-    int2 pr_next = make_int2(0, 0);
-    if (p < p1) pr_next = ds.pairs[p];
-    for (; p < p1; p += 64) {
-        const int2 pr = pr_next;
-        if (p + 64 < p1) pr_next = ds.pairs[p + 64];   // next round's indices travel with this round's records
-        T ra[YREC], rb[YREC];
-        load_rec<T>(Y, pr.x, ra);
-        load_rec<T>(Y, pr.y, rb);
-        // M = C_a C_b^T
-        const T m00 = ra[9] * rb[9] + ra[10] * rb[10] + ra[11] * rb[11];
-        const T m01 = ra[9] * rb[12] + ra[10] * rb[13] + ra[11] * rb[14];
-        const T m10 = ra[12] * rb[9] + ra[13] * rb[10] + ra[14] * rb[11];
-        const T m11 = ra[12] * rb[12] + ra[13] * rb[13] + ra[14] * rb[14];
-        T Aa[12], Ab[12], Tm[12];
-        rec_camera_block<T>(ra, Aa);
-        rec_camera_block<T>(rb, Ab);
+    for (int p0 = ds.blk_ptr[b]; p0 < p1; p0 += 16 * PAIR_UNROLL) {
+        T qa[PAIR_UNROLL][4], qb[PAIR_UNROLL][4];
+        bool ok[PAIR_UNROLL];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { Tm[c] = m00 * Ab[c] + m01 * Ab[6 + c]; Tm[6 + c] = m10 * Ab[c] + m11 * Ab[6 + c]; }
+        for (int u = 0; u < PAIR_UNROLL; ++u) {
+            const int p = p0 + 16 * u + g;
+            ok[u] = p < p1;
+            const int2 pr = ds.pairs[ok[u] ? p : p1 - 1];
+            load_quarter<T>(Y, pr.x, s, qa[u]);
+            load_quarter<T>(Y, pr.y, s, qb[u]);
+        }
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int u = 0; u < PAIR_UNROLL; ++u) {
+            T ra[YREC], rb[YREC];
+            quad_assemble<T>(qa[u], ra);
+            quad_assemble<T>(qb[u], rb);
+            if (!ok[u]) {        // keep the lanes in step (DPP needs them), contribute nothing
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const T v = Aa[r] * Tm[c] + Aa[6 + r] * Tm[6 + c];
-                acc[6 * r + c] += (double)v;
-                if (diag) acc[6 * c + r] += (double)v;   // same camera twice: Y_a Y_b^T + Y_b Y_a^T
+                for (int e = 9; e < 15; ++e) ra[e] = (T)0;
             }
+            quad_pair_product<T>(ra, rb, s, diag, acc);
+        }
     }
-    int base = 0, len = 36;
-    HalvingReduce<36, 32>::run(acc, lane, base, len);
-    if (len >= 1) {
-        const int r = base / 6, c = base - 6 * r;
+    // sum over the 16 pair slots of the wave (lane bits 2..5) in fp64
+    double accd[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        double v = (double)acc[e];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        accd[e] = v;
+    }
+    if (lane < 4) {
         const double* sa = db.cscale + 6 * cj.x;
         const double* sb = db.cscale + 6 * cj.y;
-        db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = -acc[0] * sa[r] * sb[c];
+        double* Srow0 = db.S + (size_t)(6 * cj.x + s) * ds.ld + 6 * cj.y;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Srow0[c] = -accd[c] * sa[s] * sb[c];
+        if (s < 2) {
+            double* Srow1 = db.S + (size_t)(6 * cj.x + s + 4) * ds.ld + 6 * cj.y;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Srow1[c] = -accd[6 + c] * sa[s + 4] * sb[c];
+        }
     }
     if (diag && lane < 6) {   // the owner of block (j,j) also clears what k_cam_diag accumulates with atomics
         const int e = 6 * cj.x + lane;
@@ -799,7 +911,7 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double step2 = 0.0, xn2 = 0.0;
     if (j < ds.ncam) {
-        const double* ct = db.camtab[cur] + (size_t)j * CT_STRIDE;
+        const CamRow ct = { db.camtab[cur] + j, ds.ncam };
         double dlt[6], cn[6], z[6];
         if (db.pcg_vec) {          // z_j = Linv_j^T x~_j  (block-Jacobi transformed unknowns)
             const double* x = db.pcg_vec + (size_t)db.pcg_flags[2] * ds.ld + 6 * j;
@@ -819,9 +931,8 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
         }
         double ctn[CT_STRIDE];
         make_cam_table(cn, db.cscale + 6 * j, ctn);
-        double* outc = db.camtab[nxt] + (size_t)j * CT_STRIDE;
-        for (int e = 0; e < CT_STRIDE; ++e) outc[e] = ctn[e];
-        double* stb = db.steptab + (size_t)j * ST_STRIDE;
+        for (int e = 0; e < CT_STRIDE; ++e) db.camtab[nxt][(size_t)e * ds.ncam + j] = ctn[e];
+        double stb[ST_STRIDE] = {};
         for (int e = 0; e < 9; ++e) { stb[ST_R + e] = ct[CT_R + e]; stb[ST_RN + e] = ctn[CT_R + e]; }
         for (int e = 0; e < 3; ++e) { stb[ST_T + e] = ct[CT_T + e]; stb[ST_TN + e] = ctn[CT_T + e]; stb[ST_DT + e] = dlt[3 + e]; }
         if (ct[CT_SMALL] != 0.0) {
@@ -831,6 +942,7 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
                 stb[ST_KV + r] = ct[CT_K + 3 * r] * dlt[0] + ct[CT_K + 3 * r + 1] * dlt[1] + ct[CT_K + 3 * r + 2] * dlt[2];
         }
         stb[ST_SMALL] = ct[CT_SMALL];
+        for (int e = 0; e < ST_STRIDE; ++e) db.steptab[(size_t)e * ds.ncam + j] = stb[e];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double f0 = st->focal[cur];
@@ -908,7 +1020,7 @@ __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, Device
                 load_obs<T>(ds.obs_xy, q, ox, oy);
                 const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
                 const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
-                const double* stb = tab + (size_t)j * ST_STRIDE;
+                const CamRow stb = { tab + j, ds.ncam };
                 const Proj pr = project_point(stb, ST_R, ST_T, X);
                 const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
                 T B[6];
@@ -976,18 +1088,16 @@ __global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, Device
         for (int c0 = o0; c0 < o1; c0 += 64) {
             const int q = c0 + lane;
             if (q >= o1) continue;
-            const double* stb;
             if (!single) {
                 ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
                 load_obs<T>(ds.obs_xy, q, oxk, oyk);
                 const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
-                stb = tab + (size_t)jk * ST_STRIDE;
-                prk = project_point(stb, ST_R, ST_T, X);
+                const CamRow stb2 = { tab + jk, ds.ncam };
+                prk = project_point(stb2, ST_R, ST_T, X);
                 r0k = focal * prk.xp - oxk; r1k = focal * prk.yp - oyk;
-                camera_step_dp(stb, X, dpk[0], dpk[1], dpk[2]);
-            } else {
-                stb = tab + (size_t)jk * ST_STRIDE;
+                camera_step_dp(stb2, X, dpk[0], dpk[1], dpk[2]);
             }
+            const CamRow stb = { tab + jk, ds.ncam };
             const double* pl = sx[w][ik - pt0];
             const double dX[3] = { pl[0], pl[1], pl[2] };
             const double Xn[3] = { pl[3], pl[4], pl[5] };
@@ -1189,7 +1299,7 @@ __global__ __launch_bounds__(BLK) void k_eval_residuals(DeviceStructure ds, Devi
     double c = 0.0;
     if (q < ds.nobs) {
         const int i = obs_pt[q];
-        const double* ct = db.camtab[cur] + (size_t)ds.obs_cam[q] * CT_STRIDE;
+        const CamRow ct = { db.camtab[cur] + ds.obs_cam[q], ds.ncam };
         const double X[3] = { db.pts[cur][3 * i], db.pts[cur][3 * i + 1], db.pts[cur][3 * i + 2] };
         double ox, oy;
         load_obs<T>(ds.obs_xy, q, ox, oy);
@@ -1210,7 +1320,7 @@ __global__ __launch_bounds__(BLK) void k_eval_jacobian(DeviceStructure ds, Devic
     if (q >= ds.nobs) return;
     const int cur = db.st->cur;
     const int i = obs_pt[q];
-    const double* ct = db.camtab[cur] + (size_t)ds.obs_cam[q] * CT_STRIDE;
+    const CamRow ct = { db.camtab[cur] + ds.obs_cam[q], ds.ncam };
     const double X[3] = { db.pts[cur][3 * i], db.pts[cur][3 * i + 1], db.pts[cur][3 * i + 2] };
     const Proj pr = project_point(ct, CT_R, CT_T, X);
     const double f = db.st->focal[cur];

@@ -40,6 +40,14 @@ constexpr int ST_STRIDE = 32;
 // (layout in ba_kernels.hip): 16 values = 64 B in fp32 (one sector), 128 B in fp64 (one line).
 constexpr int YREC = 16;
 
+// Camera tables are stored component-major (SoA): value k of camera j lives at tab[k * ncam + j], so that a
+// wave whose lanes need the same component of 64 different cameras touches ncam*8/128 lines instead of 64.
+struct CamRow {
+    const double* base;   // tab + j
+    int stride;           // ncam
+    __device__ __forceinline__ double operator[](int k) const { return base[(size_t)k * stride]; }
+};
+
 template <typename T> struct ObsXY;
 template <> struct ObsXY<float>  { typedef float2 type; };
 template <> struct ObsXY<double> { typedef double2 type; };
