@@ -195,6 +195,7 @@ def main():
                                        "achieved_GBps": b_iter * (g_iters / world) / g_dt / 1e9,
                                        "frac_of_8TBps": b_iter * (g_iters / world) / g_dt / 8.0e12}
         line["roofline"] = roofline_entry(profile, prob, precision)
+        line["roofline_all_kernels"] = roofline_entry(profile, prob, precision, all_kernels=True)
         line["ms_per_step_with_event_bracketing"] = 1e3 * dt_prof / args.steps
         line["kernel_profile_us"] = {k: round(v["avg_us"], 2) for k, v in profile.items()}
         line["kernel_profile_share"] = {k: round(v["total_us"] / max(1e-9, sum(x["total_us"] for x in profile.values())), 4)
@@ -208,27 +209,70 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_entry(profile, prob, precision):
-    """Roofline of the dominant kernel (largest share of the timed region, HIP-event timing per launch)."""
+PMC_KERNEL_NAMES = {"pcg_iter": "k_pcg_iter_fast", "schur_pairs": "k_schur_pairs", "cam_diag": "k_cam_diag",
+                    "point_build": "k_point_build", "point_update": "k_point_update", "chol_panel": "k_chol_panel",
+                    "chol_update": "k_chol_update"}
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc summary of the same
+    command (profiles/; PMC passes cannot be collected from inside bench.py).  FETCH_SIZE is doubled for the
+    streaming kernels as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")))
+    want = PMC_KERNEL_NAMES.get(kernel)
+    if not files or not want:
+        return None
+    for line in open(files[-1]):
+        if want in line and not line.startswith("#"):
+            parts = line.split()
+            try:
+                fetch_kb, write_kb = float(parts[-2]), float(parts[-1])
+            except ValueError:
+                return None
+            wide = kernel in ("pcg_iter", "point_build", "point_update")     # 16-byte-per-lane coalesced streams
+            return {"bytes": (fetch_kb * (2.0 if wide else 1.0) + write_kb) * 1024.0, "fetch_kb": fetch_kb, "write_kb": write_kb,
+                    "fetch_x2_correction": wide, "source": os.path.basename(files[-1])}
+    return None
+
+
+def roofline_one(name, profile, model, overhead_us):
+    avg_us = profile[name]["avg_us"]
+    net_us = max(avg_us - overhead_us, 1e-3)
+    m = model.get(name)
+    tr = pmc_traffic(name)
+    base = {"kernel": name, "avg_launch_us": avg_us, "event_bracket_overhead_us": overhead_us, "avg_launch_us_net": net_us,
+            "launches": profile[name]["launches"], "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr}
+    if m is None:
+        base.update({"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None})
+        return base
+    if m["bound"] == "hbm":
+        ach = m["bytes"] / (net_us * 1e-6) / 1e9
+        base.update({"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                     "algorithmic_bytes_per_launch": m["bytes"], "note": m["note"]})
+    else:
+        ach = m["flops"] / (net_us * 1e-6) / 1e12
+        base.update({"bound": "mfma", "achieved": ach, "peak": m["peak_tflops"], "unit": "TFLOP/s", "frac": ach / m["peak_tflops"],
+                     "algorithmic_flops_per_launch": m["flops"], "note": m["note"]})
+    return base
+
+
+def roofline_entry(profile, prob, precision, all_kernels=False):
+    """Roofline of the dominant kernel (largest share of the timed region).  Launch durations are measured live with
+    HIP events recorded on the solver's own stream around every launch; `event_bracket_overhead_us` is the same
+    bracket around nothing (the fixed cost of the two event records), subtracted in `avg_launch_us_net`, which is the
+    number to compare with rocprofv3's average kernel duration (profiles/)."""
     if not profile:
         return None
-    name = max(profile, key=lambda k: profile[k]["total_us"])
-    avg_s = profile[name]["avg_us"] * 1e-6
-    n_obs, n_pt, n_cam = prob.n_obs, prob.n_pt, prob.n_cam
-    d = 6 * n_cam + 1
     t = 4 if precision == 1 else 8
-    model = kernel_models(n_obs, n_pt, n_cam, d, t)
-    m = model.get(name)
-    if m is None:
-        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
-                "avg_launch_us": profile[name]["avg_us"]}
-    if m["bound"] == "hbm":
-        ach = m["bytes"] / avg_s / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                "algorithmic_bytes_per_launch": m["bytes"], "avg_launch_us": profile[name]["avg_us"], "note": m["note"]}
-    ach = m["flops"] / avg_s / 1e12
-    return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": m["peak_tflops"], "unit": "TFLOP/s", "frac": ach / m["peak_tflops"],
-            "traffic": None, "algorithmic_flops_per_launch": m["flops"], "avg_launch_us": profile[name]["avg_us"], "note": m["note"]}
+    model = kernel_models(prob.n_obs, prob.n_pt, prob.n_cam, 6 * prob.n_cam + 1, t)
+    overhead = profile.get("empty_bracket", {}).get("avg_us", 0.0)
+    names = [k for k in profile if k != "empty_bracket"]
+    if all_kernels:
+        return [roofline_one(k, profile, model, overhead) for k in sorted(names, key=lambda k: -profile[k]["total_us"])
+                if k in model]
+    name = max(names, key=lambda k: profile[k]["total_us"])
+    return roofline_one(name, profile, model, overhead)
 
 
 def kernel_models(n_obs, n_pt, n_cam, d, t):

@@ -24,71 +24,103 @@ namespace sfmba {
 
 // ------------------------------------------------------------------------------------------
 // panel: factor A_kk, M_k = L_kk^-T, L_ik = A_ik L_kk^-T
+//
+// Wave-level, register-resident: lane r owns row r of a 64x64 tile in 64 VGPR pairs; the only
+// communication is one column of L per step, published in LDS and read back as broadcasts.
+//   factor (wave 0 of every workgroup, redundantly):  for j: l = a_j / sqrt(a_jj);  a_c -= l * L(c,j), c > j
+//   solve  (every wave, one tile each):               for j: x = a_j / L(j,j);      a_c -= x * L(c,j), c > j
+// i.e. the same rank-1 sweep with a different scalar; no __syncthreads inside the 64 steps.
+// Tasks of step k: task 0 = identity tile (gives M_k = L_kk^-T for the back substitution),
+// task t >= 1 = tile row k + t.  Four tasks per workgroup.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int ld, int k, int d,
+__device__ __forceinline__ void chol_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// FACTOR: a[j] /= sqrt(pivot) and the column is published in LDS; otherwise a[j] *= dinv[j].
+// Then a[c] -= s * L(c, j) for c > j with L(c, j) read back from LDS as a broadcast.
+template <bool FACTOR>
+__device__ __forceinline__ void rank_one_sweep(double (&a)[NB], double (*Lc)[NB], const double* dinv, int lane, int kb, int d,
+                                               int* info, bool report) {
+    int badcol = 0;     // first non-positive pivot (1-based), reported ONCE after the sweep: a branch with an atomic inside
+                        // the 64-step unrolled loop made the register allocator spill the whole tile
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double s;
+        if (FACTOR) {
+            double dj = __shfl(a[j], j, 64);        // pivot = a[j] of lane j
+            const bool ok = (dj > 0.0) && (dj <= 1.7e308);
+            badcol = (!ok && badcol == 0 && kb + j < d) ? kb + j + 1 : badcol;
+            dj = ok ? dj : 1.0;     // augmented / padded columns and failed pivots: keep going with a harmless value
+            // 1/sqrt(pivot): hardware estimate + two Newton steps.  The generic 1.0 / sqrt() expansion is a ~40-deep
+            // dependent fp64 chain (measured 32 cycles per dependent DFMA), i.e. most of a 64-step sequential panel.
+            double di = __builtin_amdgcn_rsq(dj);
+            {
+                const double h = 0.5 * di;
+                double e = fma(-dj * di, di, 1.0);
+                di = fma(h, e, di);
+                const double h2 = 0.5 * di;
+                e = fma(-dj * di, di, 1.0);
+                di = fma(h2, e, di);
+            }
+            s = (lane == j) ? dj * di : a[j] * di;
+            a[j] = s;
+            Lc[j][lane] = (lane >= j) ? s : 0.0;
+            chol_wave_fence();
+        } else {
+            s = a[j] * dinv[j];
+            a[j] = s;
+        }
+        // a[c] -= s * L(c, j) in chunks of 24 columns: the scheduler may batch the broadcast LDS reads of one chunk
+        // (48 VGPRs) but not of the whole remaining row, which together with the 128 VGPRs of a[] would spill
+#pragma unroll
+        for (int c0 = j + 1; c0 < NB; c0 += 24) {
+#pragma unroll
+            for (int c = c0; c < c0 + 24 && c < NB; ++c) a[c] -= s * Lc[j][c];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (FACTOR && report && lane == 0 && badcol != 0) atomicCAS(info, 0, badcol);
+}
+
+__global__ __launch_bounds__(256, 1) void k_chol_panel(double* __restrict__ A, int ld, int k, int d, int ntask,
                                                     double* __restrict__ minv, int* __restrict__ info) {
-    __shared__ double Lkk[NB][NB + 1];
-    __shared__ double Aik[NB][NB + 1];
-    const int tid = threadIdx.x;
+    __shared__ double Lc[NB][NB];        // Lc[j][r] = L(r, j): column j contiguous
+    __shared__ double dinv[NB];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int kb = k * NB;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx % NB, c = idx / NB;
-        Lkk[r][c] = (r >= c) ? AT(kb + r, kb + c) : 0.0;
+    double a[NB];
+    if (w == 0) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = (lane >= c) ? AT(kb + lane, kb + c) : 0.0;
+        rank_one_sweep<true>(a, Lc, dinv, lane, kb, d, info, blockIdx.x == 0);
+        dinv[lane] = 1.0 / Lc[lane][lane];
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) if (lane >= c) AT(kb + lane, kb + c) = a[c];
+        }
     }
     __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        double dj = Lkk[j][j];
-        if (!(dj > 0.0) || !(dj <= 1.7e308)) {
-            // not positive definite: flag it for real columns; augmented/padded columns are forced to 1
-            if (kb + j < d && tid == 0 && blockIdx.x == 0) atomicCAS(info, 0, kb + j + 1);
-            dj = 1.0;
-        }
-        const double dinv = 1.0 / sqrt(dj);
-        __syncthreads();
-        if (tid >= j && tid < NB) Lkk[tid][j] = (tid == j) ? dj * dinv : Lkk[tid][j] * dinv;
-        __syncthreads();
-        const int m = NB - j - 1;
-        for (int idx = tid; idx < m * m; idx += 256) {
-            const int r = j + 1 + idx % m, c = j + 1 + idx / m;
-            if (r >= c) Lkk[r][c] -= Lkk[r][j] * Lkk[c][j];
-        }
-        __syncthreads();
-    }
-    const bool diag_block = (blockIdx.x == 0);
-    const int ib = (k + blockIdx.x) * NB;
-    if (diag_block) {
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            const int r = idx % NB, c = idx / NB;
-            if (r >= c) AT(kb + r, kb + c) = Lkk[r][c];
-            Aik[r][c] = (r == c) ? 1.0 : 0.0;          // identity -> becomes L_kk^-T
-        }
+    const int task = blockIdx.x * 4 + w;
+    if (task >= ntask) return;
+    if (task == 0) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = (lane == c) ? 1.0 : 0.0;
     } else {
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            const int r = idx % NB, c = idx / NB;
-            Aik[r][c] = AT(ib + r, kb + c);
-        }
+        const int ib = (k + task) * NB;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a[c] = AT(ib + lane, kb + c);
     }
-    __syncthreads();
-    // X L_kk^T = Aik  (column sweep)
-    for (int j = 0; j < NB; ++j) {
-        const double dinv = 1.0 / Lkk[j][j];
-        if (tid < NB) Aik[tid][j] *= dinv;
-        __syncthreads();
-        const int m = NB - j - 1;
-        for (int idx = tid; idx < NB * m; idx += 256) {
-            const int r = idx % NB, c = j + 1 + idx / NB;
-            Aik[r][c] -= Aik[r][j] * Lkk[c][j];
-        }
-        __syncthreads();
-    }
-    if (diag_block) {
+    rank_one_sweep<false>(a, Lc, dinv, lane, kb, d, info, false);
+    if (task == 0) {
         double* M = minv + (size_t)k * NB * NB;     // M[r + c*NB] = (L_kk^-T)(r,c)
-        for (int idx = tid; idx < NB * NB; idx += 256) M[idx] = Aik[idx % NB][idx / NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) M[lane + c * NB] = a[c];
     } else {
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            const int r = idx % NB, c = idx / NB;
-            AT(ib + r, kb + c) = Aik[r][c];
-        }
+        const int ib = (k + task) * NB;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) AT(ib + lane, kb + c) = a[c];
     }
 }
 
@@ -188,7 +220,8 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
       hipLaunchKernelGGL(k_augment, dim3((d + 255) / 256), dim3(256), 0, s, S, ld, d, rhs); }
     for (int k = 0; k < nblk; ++k) {
         { ProfScope ps(prof, KID_CHOL_PANEL, s);
-          hipLaunchKernelGGL(k_chol_panel, dim3(nblk - k), dim3(256), 0, s, S, ld, k, d, ws->minv, info_dev); }
+          const int ntask = nblk - k;
+          hipLaunchKernelGGL(k_chol_panel, dim3((ntask + 3) / 4), dim3(256), 0, s, S, ld, k, d, ntask, ws->minv, info_dev); }
         const int m = nblk - k - 1;
         if (m > 0) { ProfScope ps(prof, KID_CHOL_UPDATE, s);
           hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k); }

@@ -230,6 +230,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
         { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
         rc = download_state(p);
         if (rc) return rc;
         host_iter = p->h_state->iter;
