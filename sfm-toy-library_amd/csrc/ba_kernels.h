@@ -34,7 +34,7 @@ struct LMState {
     int x_is_new;             // the current linearisation is at a freshly accepted point
     int lin_info;             // dense solver status of this iteration (0 ok)
     int last_step_successful;
-    int pad0;
+    int mail_seq;             // number of k_lm_control launches since the solve started
     double cost, x_norm, radius, decrease_factor, gmax;
     double focal[2];
     double fscale;            // Jacobi scale of the focal column
@@ -104,6 +104,7 @@ struct DeviceBuffers {
     const double* pcg_vec;    // x~ buffers (two, selected by pcg_flags[2]); nullptr when the Cholesky path wrote z to rhs
     const double* pcg_linv;
     const int* pcg_flags;
+    int* lm_mailbox;          // host-mapped {seq, termination, message, iter}: polled by the host instead of a D2H copy + sync
     double shared_weight;     // 1 normally; 0 on ranks > 0 of a sharded solve (replicated cameras/focal counted once)
 };
 

@@ -1144,6 +1144,14 @@ template void launch_point_update<double>(hipStream_t, const DeviceStructure&, c
 // LM control: the accept/reject logic of ceres::internal::TrustRegionMinimizer::Minimize()
 // [Ceres-upstream], one thread.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lm_post(int* mb, int seq, int termination, int message, int iter) {
+    if (!mb) return;
+    __hip_atomic_store(mb + 1, termination, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mb + 2, message, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mb + 3, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mb, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void k_lm_control(DeviceBuffers db) {
     LMState* st = db.st;
     const double trial2 = slots_take(db, ACC_TRIAL_COST);
@@ -1154,7 +1162,8 @@ __global__ void k_lm_control(DeviceBuffers db) {
     if (threadIdx.x != 0) return;
     st->lin_info = *db.lin_info;
     *db.lin_info = 0;
-    if (st->termination != -1) return;
+    const int seq = ++st->mail_seq;
+    if (st->termination != -1) { lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter); return; }
     const int it = ++st->iter;
     TraceRow row = {};
     row.iteration = it;
@@ -1219,6 +1228,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
     row.trust_region_radius = st->radius;
     if (it < db.trace_cap) db.trace[it] = row;
     st->lin_info = 0;
+    lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter);
 }
 
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {

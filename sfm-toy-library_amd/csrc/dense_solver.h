@@ -24,6 +24,8 @@ struct DenseSolver {
     double* scal = nullptr;   // [8] rz, pq, bnorm2, rnorm2, ...
     int* flags = nullptr;     // [4] done, iters
     int* h_flags = nullptr;   // pinned host mirror
+    volatile int* h_mailbox = nullptr;   // host-mapped {iterations, done}: polled instead of copy + synchronise
+    int* d_mailbox = nullptr;
 };
 
 int  dense_solver_create(DenseSolver* ws, int d, int ld);

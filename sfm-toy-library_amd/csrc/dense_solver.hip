@@ -16,8 +16,11 @@
 #include <math.h>
 #include <stdio.h>
 #include <algorithm>
+#include <chrono>
 
 namespace sfmba {
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define NB CHOL_NB
 #define AT(i, j) A[(size_t)(i) + (size_t)(j) * ld]
@@ -428,6 +431,13 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* _
     if (tid == 0) part[out * PCG_MAXWG + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Host mailbox (pinned, host-mapped): {iterations, done}.  The host polls it instead of issuing a D2H copy + stream
+// synchronise per batch; written by one lane with system-scope stores.
+__device__ __forceinline__ void pcg_post(int* mailbox, int iters, int done) {
+    __hip_atomic_store(mailbox + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox, iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Fast path of one CG iteration for d <= 1280 (all BASELINE single-GPU configs): every global load of
 // the iteration -- the three length-d vectors, the partial dot products and this wave's rows of S~ --
 // is issued up front into registers, so the launch pays ONE memory round trip; the rest is LDS + ALU.
@@ -435,17 +445,18 @@ constexpr int PCG_EPT = 5;    // vector elements per thread  (256 * 5 >= d)
 constexpr int PCG_RPW = 2;    // rows of S~ per wave         (rows_per_wg <= 8)
 constexpr int PCG_CPL = 20;   // columns per lane            (64 * 20 >= d)
 
+template <bool INIT>
 __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
-                                                       double* __restrict__ part, const double* __restrict__ scal,
-                                                       int* flags, int rows_per_wg, double tol2, int in, int* info) {
+                                                       const double* __restrict__ bt, double* __restrict__ part, double* __restrict__ scal,
+                                                       int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox) {
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;
     double* red = sm + ld;
-    if (flags[PF_DONE]) return;
+    if (!INIT && flags[PF_DONE]) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
     const int row0 = blockIdx.x * rows_per_wg;
     const int row1 = min(d, row0 + rows_per_wg);
-    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = pcg_vec(vec, 1, in, ld);
+    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = INIT ? bt : pcg_vec(vec, 1, in, ld);
     const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
     double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld);
     double* p_out = pcg_vec(vec, 2, out, ld); double* q_out = pcg_vec(vec, 3, out, ld);
@@ -456,10 +467,10 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
     for (int m = 0; m < PCG_EPT; ++m) {
         const int e = tid + 256 * m;
         const bool ok = e < d;
-        rv[m] = ok ? r_in[e] : 0.0; qv[m] = ok ? q_in[e] : 0.0; pv[m] = ok ? p_in[e] : 0.0;
+        rv[m] = ok ? r_in[e] : 0.0; qv[m] = (ok && !INIT) ? q_in[e] : 0.0; pv[m] = (ok && !INIT) ? p_in[e] : 0.0;
     }
-    double pq = (tid < (int)gridDim.x) ? part[in * PCG_MAXWG + tid] : 0.0;
-    const double rr0 = scal[PS_RR0];
+    double pq = (!INIT && tid < (int)gridDim.x) ? part[in * PCG_MAXWG + tid] : 0.0;
+    const double rr0 = INIT ? 0.0 : scal[PS_RR0];
     double fv[PCG_RPW][PCG_CPL];
 #pragma unroll
     for (int k = 0; k < PCG_RPW; ++k) {
@@ -471,40 +482,53 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             fv[k][m] = (row < row1 && c < d) ? Fr[c] : 0.0;
         }
     }
-    const int xrow = row0 + tid;
-    const double x_old = (xrow < row1) ? x_in[xrow] : 0.0;
-
     // ---- alpha, r_new, beta, p_new ----
     double rr = 0.0;
 #pragma unroll
     for (int m = 0; m < PCG_EPT; ++m) rr += rv[m] * rv[m];
     block_sum2(pq, rr, red);
-    const double alpha = rr / pq;
-    double rrn = 0.0, dummy = 0.0;
+    if (INIT) {
+        // x0 = 0, r0 = p0 = b~
 #pragma unroll
-    for (int m = 0; m < PCG_EPT; ++m) { rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
-    block_sum2(rrn, dummy, red);
-    const bool broke = !(pq > 0.0) || !(rrn == rrn);
-    const bool done = rrn <= tol2 * rr0 || broke;
-    const double beta = rrn / rr;
-#pragma unroll
-    for (int m = 0; m < PCG_EPT; ++m) {
-        const int e = tid + 256 * m;
-        if (e < d) {
-            const double pn = rv[m] + beta * pv[m];
-            pl[e] = pn;
-            if (e >= row0 && e < row1) { x_out[e] = x_in[e] + alpha * pv[m]; if (!done) { r_out[e] = rv[m]; p_out[e] = pn; } }
+        for (int m = 0; m < PCG_EPT; ++m) {
+            const int e = tid + 256 * m;
+            if (e < d) {
+                pl[e] = rv[m];
+                if (e >= row0 && e < row1) { x_out[e] = 0.0; r_out[e] = rv[m]; p_out[e] = rv[m]; }
+            }
         }
-    }
-    (void)x_old; (void)xrow;
-    if (done) {
         if (blockIdx.x == 0 && tid == 0) {
-            flags[PF_DONE] = 1; flags[PF_XBUF] = out; flags[PF_ITERS] += 1;
-            if (broke) atomicCAS(info, 0, d + 1);
+            scal[PS_RR0] = rr; flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
+            if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
         }
-        return;
+    } else {
+        const double alpha = rr / pq;
+        double rrn = 0.0, dummy = 0.0;
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
+        block_sum2(rrn, dummy, red);
+        const bool broke = !(pq > 0.0) || !(rrn == rrn);
+        const bool done = rrn <= tol2 * rr0 || broke;
+        const double beta = rrn / rr;
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) {
+            const int e = tid + 256 * m;
+            if (e < d) {
+                const double pn = rv[m] + beta * pv[m];
+                pl[e] = pn;
+                if (e >= row0 && e < row1) { x_out[e] = x_in[e] + alpha * pv[m]; if (!done) { r_out[e] = rv[m]; p_out[e] = pn; } }
+            }
+        }
+        if (done) {
+            if (blockIdx.x == 0 && tid == 0) {
+                flags[PF_DONE] = 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
+                if (broke) atomicCAS(info, 0, d + 1);
+                if (mailbox) pcg_post(mailbox, it, 1);
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
     }
-    if (blockIdx.x == 0 && tid == 0) { flags[PF_ITERS] += 1; flags[PF_XBUF] = out; }
     __syncthreads();
     // ---- q = S~ p for the rows of this workgroup ----
     double pqp = 0.0;
@@ -558,29 +582,48 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     { ProfScope ps(prof, KID_PCG_SETUP, s);
       hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
       hipLaunchKernelGGL(k_pcg_transform, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
+    const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
+    volatile int* mb = ws->h_mailbox;
+    int* mb_dev = fast ? ws->d_mailbox : nullptr;
+    if (mb) { mb[0] = -1; mb[1] = 0; }
     { ProfScope ps(prof, KID_PCG_ITER, s);
-      hipLaunchKernelGGL(k_pcg_iter<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                         rows_per_wg, tol * tol, 0, info_dev); }
+      if (fast)
+          hipLaunchKernelGGL(k_pcg_iter_fast<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                             rows_per_wg, tol * tol, 0, info_dev, mb_dev);
+      else
+          hipLaunchKernelGGL(k_pcg_iter<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                             rows_per_wg, tol * tol, 0, info_dev); }
     int in = 1, it = 0;
     int batch = 24;
     if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + 1;
-    while (it < max_iters) {
+    bool done = false;
+    while (it < max_iters && !done) {
         const int n = std::min(max_iters - it, batch);
-        const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
         for (int b = 0; b < n; ++b) {
             ProfScope ps(prof, KID_PCG_ITER, s);
             if (fast)
-                hipLaunchKernelGGL(k_pcg_iter_fast, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, ws->part, ws->scal, ws->flags,
-                                   rows_per_wg, tol * tol, in, info_dev);
+                hipLaunchKernelGGL(k_pcg_iter_fast<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                                   rows_per_wg, tol * tol, in, info_dev, mb_dev);
             else
                 hipLaunchKernelGGL(k_pcg_iter<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                                    rows_per_wg, tol * tol, in, info_dev);
             in ^= 1;
         }
         it += n;
-        (void)hipMemcpyAsync(ws->h_flags, ws->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
-        if (ws->h_flags[PF_DONE]) break;
+        if (fast && mb) {
+            // poll the mailbox until the last launch of the batch has reported (or convergence was posted)
+            const double t_end = now_s() + 2.0;
+            while (!(mb[1] != 0 || mb[0] >= it)) {
+                if (now_s() > t_end) { (void)hipStreamSynchronize(s); break; }
+            }
+            __sync_synchronize();
+            done = mb[1] != 0;
+            ws->h_flags[PF_DONE] = done; ws->h_flags[PF_ITERS] = mb[0] >= 0 ? mb[0] : it;
+        } else {
+            (void)hipMemcpyAsync(ws->h_flags, ws->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            done = ws->h_flags[PF_DONE] != 0;
+        }
         batch = 8;
     }
     if (finish) { ProfScope ps(prof, KID_PCG_FINISH, s);
@@ -604,6 +647,8 @@ int dense_solver_create(DenseSolver* ws, int d, int ld) {
     if (hipMalloc(&ws->scal, sizeof(double) * 8) != hipSuccess) return -1;
     if (hipMalloc(&ws->flags, sizeof(int) * 4) != hipSuccess) return -1;
     if (hipHostMalloc(reinterpret_cast<void**>(&ws->h_flags), sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) return -1;
+    { void* hm = nullptr; if (hipHostMalloc(&hm, sizeof(int) * 16, hipHostMallocMapped) != hipSuccess) return -1; ws->h_mailbox = static_cast<volatile int*>(hm); }
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_mailbox), const_cast<int*>(ws->h_mailbox), 0) != hipSuccess) return -1;
     ws->Sfull = nullptr;
     return 0;
 }
@@ -617,6 +662,7 @@ void dense_solver_destroy(DenseSolver* ws) {
     if (ws->scal) (void)hipFree(ws->scal);
     if (ws->flags) (void)hipFree(ws->flags);
     if (ws->h_flags) (void)hipHostFree(ws->h_flags);
+    if (ws->h_mailbox) (void)hipHostFree(const_cast<int*>(ws->h_mailbox));
     if (ws->Sfull) (void)hipFree(ws->Sfull);
     *ws = DenseSolver();
 }

@@ -98,6 +98,7 @@ struct sfmba_problem {
     double *d_sys = nullptr;                      // S | rhs | udiag | bc (contiguous)
     int* d_info = nullptr;
     LMState* h_state = nullptr;                   // pinned
+    volatile int* h_lm_mail = nullptr;            // host-mapped mailbox written by k_lm_control
     int cur = 0;                                  // which buffer holds the current parameters
     double focal = 0.0;
     bool empty = false;                           // no observations
@@ -205,7 +206,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
+    int launched_controls = 0;
     std::vector<int> lin_hist;
+    p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
@@ -231,14 +234,31 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
-        rc = download_state(p);
-        if (rc) return rc;
-        host_iter = p->h_state->iter;
+        ++launched_controls;
+        {   // wait for k_lm_control's mailbox post (system-scope stores to host-mapped memory)
+            volatile int* mb = p->h_lm_mail;
+            const double t_end = now_seconds() + 5.0;
+            bool timed_out = false;
+            while (mb[0] < launched_controls) {
+                if (now_seconds() > t_end) { timed_out = true; break; }
+            }
+            __sync_synchronize();
+            if (timed_out) {
+                rc = download_state(p);
+                if (rc) return rc;
+                host_iter = p->h_state->iter;
+                if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; break; }
+            } else {
+                host_iter = mb[3];
+                if (mb[1] != -1) { term = mb[1]; msg = mb[2]; break; }
+            }
+        }
         if (o.verbose) {
+            rc = download_state(p);
+            if (rc) return rc;
             std::fprintf(stderr, "[sfmba] it %3d cost %.12e |g|inf %.3e radius %.3e term %d\n", p->h_state->iter, p->h_state->cost,
                          p->h_state->gmax, p->h_state->radius, p->h_state->termination);
         }
-        if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; break; }
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
     rc = download_state(p);
@@ -293,7 +313,7 @@ void sfmba_options_default(sfmba_options* o) {
     o->max_consecutive_invalid_steps = 5;
     o->linear_solver = SFMBA_LINEAR_CHOLESKY;
     o->precision = SFMBA_PRECISION_F64;
-    o->pcg_tolerance = 1e-10;
+    o->pcg_tolerance = 1e-8;
     o->pcg_max_iters = 0;
     o->verbose = 0;
 }
@@ -320,6 +340,7 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     for (void* f : frees) if (f) (void)hipFree(f);
     p->prof.destroy();
     if (p->h_state) (void)hipHostFree(p->h_state);
+    if (p->h_lm_mail) (void)hipHostFree(const_cast<int*>(p->h_lm_mail));
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -377,6 +398,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     const int ncam = (int)p->acam_id.size(), npt = (int)p->apt_id.size(), nobs = (int)n_obs;
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LMState), hipHostMallocDefault));
+    { void* hm = nullptr; HIP_TRY(hipHostMalloc(&hm, 64, hipHostMallocMapped)); p->h_lm_mail = static_cast<volatile int*>(hm); }
     if (nobs == 0 && !cam_active) {
         p->empty = true;
         guard.p = nullptr;
@@ -566,6 +588,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     db.lin_info = p->d_info;
     db.fin_counter = p->d_info + 1;
     db.pcg_vec = nullptr; db.pcg_linv = nullptr; db.pcg_flags = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&db.lm_mailbox), const_cast<int*>(p->h_lm_mail), 0));
     db.trace = nullptr; db.trace_cap = 0;
     if (dense_solver_create(&p->solver, ds.d, ds.ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
 
