@@ -57,3 +57,8 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# NOTE: the entries small_rejected / small_rejected_r1e9 / small_rejected_r1 (a far-off start of the `small` scene,
+# seed 43, with LM steps that get REJECTED, and two other initial trust-region radii) were added by the snippet
+# recorded in tests/test_gpu_rejections.py::REGENERATE; they exercise the reject / radius-shrink path.
