@@ -238,11 +238,15 @@ def pmc_traffic(kernel):
 
 def roofline_one(name, profile, model, overhead_us):
     avg_us = profile[name]["avg_us"]
-    net_us = max(avg_us - overhead_us, 1e-3)
+    net_us = avg_us
     m = model.get(name)
     tr = pmc_traffic(name)
-    base = {"kernel": name, "avg_launch_us": avg_us, "event_bracket_overhead_us": overhead_us, "avg_launch_us_net": net_us,
-            "launches": profile[name]["launches"], "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr}
+    base = {"kernel": name, "avg_launch_us": avg_us, "empty_event_bracket_us": overhead_us,
+            "launches": profile[name]["launches"], "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr,
+            "timing": ("HIP events on the solver stream around batches of back-to-back launches (per-launch average includes the "
+                       "~1.5-2.6 us launch boundary)" if name == "pcg_iter" else
+                       "HIP events on the solver stream around every launch; an event pair around nothing reads empty_event_bracket_us, "
+                       "so launches shorter than ~10 us are overstated -- compare with the rocprofv3 average in profiles/")}
     if m is None:
         base.update({"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None})
         return base
@@ -259,9 +263,7 @@ def roofline_one(name, profile, model, overhead_us):
 
 def roofline_entry(profile, prob, precision, all_kernels=False):
     """Roofline of the dominant kernel (largest share of the timed region).  Launch durations are measured live with
-    HIP events recorded on the solver's own stream around every launch; `event_bracket_overhead_us` is the same
-    bracket around nothing (the fixed cost of the two event records), subtracted in `avg_launch_us_net`, which is the
-    number to compare with rocprofv3's average kernel duration (profiles/)."""
+    HIP events recorded on the solver's own stream (the stream the kernels run on)."""
     if not profile:
         return None
     t = 4 if precision == 1 else 8

@@ -599,8 +599,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     bool done = false;
     while (it < max_iters && !done) {
         const int n = std::min(max_iters - it, batch);
+        ProfScope psb(prof, KID_PCG_ITER, s, n);
         for (int b = 0; b < n; ++b) {
-            ProfScope ps(prof, KID_PCG_ITER, s);
             if (fast)
                 hipLaunchKernelGGL(k_pcg_iter_fast<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                                    rows_per_wg, tol * tol, in, info_dev, mb_dev);

@@ -28,7 +28,7 @@ struct Profiler {
     bool on = false;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
-    struct Rec { int id; size_t e0, e1; };
+    struct Rec { int id; size_t e0, e1; int launches; };
     std::vector<Rec> recs;
     double total_ms[KID_COUNT] = {};
     long long count[KID_COUNT] = {};
@@ -39,17 +39,17 @@ struct Profiler {
     }
     void begin(int id, hipStream_t s) {
         if (!on) return;
-        Rec r; r.id = id; r.e0 = used; (void)hipEventRecord(next(), s); r.e1 = 0; recs.push_back(r);
+        Rec r; r.id = id; r.e0 = used; (void)hipEventRecord(next(), s); r.e1 = 0; r.launches = 1; recs.push_back(r);
     }
-    void end(hipStream_t s) {
+    void end(hipStream_t s, int launches = 1) {
         if (!on) return;
-        recs.back().e1 = used; (void)hipEventRecord(next(), s);
+        recs.back().e1 = used; recs.back().launches = launches; (void)hipEventRecord(next(), s);
     }
     // call with the stream idle
     void collect() {
         for (const Rec& r : recs) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pool[r.e0], pool[r.e1]) == hipSuccess) { total_ms[r.id] += ms; count[r.id]++; }
+            if (hipEventElapsedTime(&ms, pool[r.e0], pool[r.e1]) == hipSuccess) { total_ms[r.id] += ms; count[r.id] += r.launches; }
         }
         recs.clear();
         used = 0;
@@ -59,9 +59,11 @@ struct Profiler {
 };
 
 struct ProfScope {
-    Profiler* p; hipStream_t s;
-    ProfScope(Profiler* p_, int id, hipStream_t s_) : p(p_), s(s_) { if (p) p->begin(id, s); }
-    ~ProfScope() { if (p) p->end(s); }
+    Profiler* p; hipStream_t s; int launches;
+    // launches > 1: one event pair around a batch of back-to-back launches of the same kernel (per-launch average
+    // then includes the launch boundary, but not the ~5 us cost of an event pair per few-microsecond kernel)
+    ProfScope(Profiler* p_, int id, hipStream_t s_, int launches_ = 1) : p(p_), s(s_), launches(launches_) { if (p) p->begin(id, s); }
+    ~ProfScope() { if (p) p->end(s, launches); }
 };
 
 }  // namespace sfmba
