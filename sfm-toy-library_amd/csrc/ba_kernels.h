@@ -76,6 +76,8 @@ struct DeviceStructure {
     const int2* pairs;        // [npair] {qa, qb} point-major positions of two observations of one point, qa < qb
     int npairwg;
     const int2* pwg_blocks;   // [npairwg] {first block, #blocks <= 4} per workgroup of the pair pass (XCD-grouped rows)
+    int ndupwg;
+    const int2* dup_blocks;   // [ndupwg] like pwg_blocks, but only diagonal blocks that have pairs (same camera seeing a point twice)
     int nwv;
     const int* wv_ptr;        // [nwv+1] point ranges of the point-pass waves (whole points, <= 64 observations each)
 };
@@ -104,6 +106,9 @@ struct DeviceBuffers {
     const double* pcg_vec;    // x~ buffers (two, selected by pcg_flags[2]); nullptr when the Cholesky path wrote z to rhs
     const double* pcg_linv;
     const int* pcg_flags;
+    double* pcg_F;            // [d][ld] preconditioned reduced matrix S~ written directly by k_schur_pairs (PCG mode)
+    double* pcg_bt;           // [ld]    Lb^-1 rhs
+    double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
     int* lm_mailbox;          // host-mapped {seq, termination, message, iter}: polled by the host instead of a D2H copy + sync
     double shared_weight;     // 1 normally; 0 on ranks > 0 of a sharded solve (replicated cameras/focal counted once)
 };
@@ -113,9 +118,11 @@ void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers&
 template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling);
 void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-template <typename T> void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+// mode 0: off-diagonal blocks of S (upper triangle);  mode 1: the same blocks written straight into S~ = Lb^-1 S Lb^-T
+// (both triangles) + the per-camera glue of the block-Jacobi transform;  mode 2: diagonal blocks with duplicate pairs
+template <typename T> void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode);
 template <typename T> void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int pcg);
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);

@@ -331,6 +331,17 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
     const int gw = blockIdx.x * WPB + w;
     double lin_cost = 0.0, sff = 0.0, rhsf = 0.0, gmax = 0.0, bad = 0.0;
 
+    // clear what k_cam_diag (and the duplicate-pair pass) accumulate with atomics: per camera the 6x6 diagonal block,
+    // its focal column, the undamped diagonal, the scaled gradient and the reduced right-hand side
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ds.ncam * 60; e += gridDim.x * blockDim.x) {
+        const int j = e / 60, k = e - 60 * j, row0 = 6 * j;
+        if (k < 36) db.S[(size_t)(row0 + k / 6) * ds.ld + row0 + k % 6] = 0.0;
+        else if (k < 42) db.udiag[row0 + k - 36] = 0.0;
+        else if (k < 48) db.bc[row0 + k - 42] = 0.0;
+        else if (k < 54) db.rhs[row0 + k - 48] = 0.0;
+        else db.S[(size_t)(row0 + k - 54) * ds.ld + ds.d - 1] = 0.0;
+    }
+
     if (gw < ds.nwv) {
         const int pt0 = ds.wv_ptr[gw], pt1 = ds.wv_ptr[gw + 1];
         const int npts = pt1 - pt0;
@@ -596,14 +607,42 @@ __device__ __forceinline__ void quad_pair_product(const T ra[YREC], const T rb[Y
 // lane-local sums of its few products stay in T, the sum over the wave is carried in fp64.
 #define PAIR_UNROLL 4
 
-template <typename T>
+template <typename T, int MODE>
 __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double tile[BLK / 64][36];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int2 wg = ds.pwg_blocks[blockIdx.x];       // {first block, number of blocks (<= 4)}
+    const int2 wg = (MODE == 2 ? ds.dup_blocks : ds.pwg_blocks)[blockIdx.x];       // {first block, number of blocks (<= 4)}
     if (w >= wg.y) return;
     const int b = wg.x + w;
     const int2 cj = ds.blk_cams[b];
     const bool diag = cj.x == cj.y;
+    const int fo = ds.d - 1;
+    if (MODE != 2 && diag) {
+        if (MODE == 1) {
+            // glue of the block-Jacobi transform for camera j: S~_jj = I, S~_jf = Linv_j S_jf / sqrt(S_ff), b~_j = Linv_j rhs_j
+            const int j = cj.x, row0 = 6 * j;
+            const double* Li = db.pcg_binv + (size_t)j * 36;
+            const double linv_f = 1.0 / sqrt(db.S[(size_t)fo * ds.ld + fo]);
+            if (lane < 36) {
+                const int r = lane / 6, c = lane - 6 * r;
+                db.pcg_F[(size_t)(row0 + r) * ds.ld + row0 + c] = (r == c) ? 1.0 : 0.0;
+            }
+            if (lane < 6) {
+                double vf = 0.0, vb = 0.0;
+                for (int a = 0; a <= lane; ++a) { vf += Li[lane * 6 + a] * db.S[(size_t)(row0 + a) * ds.ld + fo]; vb += Li[lane * 6 + a] * db.rhs[row0 + a]; }
+                vf *= linv_f;
+                db.pcg_F[(size_t)(row0 + lane) * ds.ld + fo] = vf;
+                db.pcg_F[(size_t)fo * ds.ld + row0 + lane] = vf;
+                db.pcg_bt[row0 + lane] = vb;
+            }
+            if (j == 0 && lane == 63) {
+                db.pcg_F[(size_t)fo * ds.ld + fo] = 1.0;
+                db.pcg_bt[fo] = db.rhs[fo] * linv_f;
+                db.pcg_binv[(size_t)ds.ncam * 36] = linv_f;
+            }
+        }
+        return;     // pairs inside diagonal blocks (duplicates) were added by the MODE 2 pass before k_finalize
+    }
     const T* Y = reinterpret_cast<const T*>(db.Y);
     const int s = lane & 3, g = lane >> 2;
     T acc[12];
@@ -630,7 +669,7 @@ __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceB
 #pragma unroll
                 for (int e = 9; e < 15; ++e) ra[e] = (T)0;
             }
-            quad_pair_product<T>(ra, rb, s, diag, acc);
+            quad_pair_product<T>(ra, rb, s, MODE == 2, acc);
         }
     }
     // sum over the 16 pair slots of the wave (lane bits 2..5) in fp64
@@ -644,22 +683,51 @@ __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceB
         v += __shfl_xor(v, 32, 64);
         accd[e] = v;
     }
-    if (lane < 4) {
-        const double* sa = db.cscale + 6 * cj.x;
-        const double* sb = db.cscale + 6 * cj.y;
-        double* Srow0 = db.S + (size_t)(6 * cj.x + s) * ds.ld + 6 * cj.y;
+    const double* sa = db.cscale + 6 * cj.x;
+    const double* sb = db.cscale + 6 * cj.y;
+    if (MODE == 0 || MODE == 2) {
+        if (lane < 4) {
+            double* Srow0 = db.S + (size_t)(6 * cj.x + s) * ds.ld + 6 * cj.y;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) Srow0[c] = -accd[c] * sa[s] * sb[c];
-        if (s < 2) {
-            double* Srow1 = db.S + (size_t)(6 * cj.x + s + 4) * ds.ld + 6 * cj.y;
+            for (int c = 0; c < 6; ++c) {
+                const double v = -accd[c] * sa[s] * sb[c];
+                if (MODE == 0) Srow0[c] = v; else if (c >= s) atomicAdd(&Srow0[c], v);     // MODE 2: upper part of the diagonal block
+            }
+            if (s < 2) {
+                double* Srow1 = db.S + (size_t)(6 * cj.x + s + 4) * ds.ld + 6 * cj.y;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) Srow1[c] = -accd[6 + c] * sa[s + 4] * sb[c];
+                for (int c = 0; c < 6; ++c) {
+                    const double v = -accd[6 + c] * sa[s + 4] * sb[c];
+                    if (MODE == 0) Srow1[c] = v; else if (c >= s + 4) atomicAdd(&Srow1[c], v);
+                }
+            }
         }
-    }
-    if (diag && lane < 6) {   // the owner of block (j,j) also clears what k_cam_diag accumulates with atomics
-        const int e = 6 * cj.x + lane;
-        db.udiag[e] = 0.0; db.bc[e] = 0.0; db.rhs[e] = 0.0;
-        db.S[(size_t)e * ds.ld + ds.d - 1] = 0.0;
+    } else {
+        // S~_IJ = Linv_I S_IJ Linv_J^T written to both triangles of the preconditioned matrix
+        if (lane < 4) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) tile[w][6 * s + c] = -accd[c] * sa[s] * sb[c];
+            if (s < 2) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) tile[w][6 * (s + 4) + c] = -accd[6 + c] * sa[s + 4] * sb[c];
+            }
+        }
+        wave_lds_fence();
+        if (lane < 36) {
+            const int r = lane / 6, c = lane - 6 * r;
+            const double* Li = db.pcg_binv + (size_t)cj.x * 36 + r * 6;     // row r of Linv_I (lower triangular)
+            const double* Lj = db.pcg_binv + (size_t)cj.y * 36 + c * 6;     // row c of Linv_J
+            double v = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double u = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Lj[bb];
+                v += Li[a] * u;
+            }
+            db.pcg_F[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
+            db.pcg_F[(size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r] = v;
+        }
     }
 }
 
@@ -786,11 +854,17 @@ template void launch_point_build<float>(hipStream_t, const DeviceStructure&, con
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 
 template <typename T>
-void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_schur_pairs<T>, dim3(ds.npairwg), dim3(BLK), 0, s, ds, db);
+void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
+    if (mode == 2) {
+        if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2>), dim3(ds.ndupwg), dim3(BLK), 0, s, ds, db);
+    } else if (mode == 1) {
+        hipLaunchKernelGGL((k_schur_pairs<T, 1>), dim3(ds.npairwg), dim3(BLK), 0, s, ds, db);
+    } else {
+        hipLaunchKernelGGL((k_schur_pairs<T, 0>), dim3(ds.npairwg), dim3(BLK), 0, s, ds, db);
+    }
 }
-template void launch_schur_pairs<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_schur_pairs<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
+template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 
 template <typename T>
 void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
@@ -835,11 +909,13 @@ __device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffer
     }
 }
 
-// damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding; the last
-// workgroup to arrive (agent-scope release/acquire around an arrival counter) runs post_linearisation
-__global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuffers db) {
+// damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding; in PCG mode also
+// Linv of every damped 6x6 diagonal block (the block-Jacobi preconditioner).  One thread per camera, then per
+// padding row; the focal entries are owned by the last wave of the last workgroup.  The last workgroup to arrive
+// (agent-scope release/acquire around an arrival counter) runs post_linearisation.
+__global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuffers db, int pcg) {
     __shared__ int is_last;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const LMState* st = db.st;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
         // focal-focal entries were accumulated in the slotted buffer: the last wave of the last block owns them
@@ -850,23 +926,72 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             const double dd = fmin(fmax(udf, st->min_diag), st->max_diag) / st->radius;
             db.S[(size_t)fo * ds.ld + fo] = sff + dd;
             db.rhs[fo] = rhsf; db.udiag[fo] = udf; db.bc[fo] = bcf;
-            const double g = fabs(bcf / st->fscale);
-            if (g > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), g);
+            const double gg = fabs(bcf / st->fscale);
+            if (gg > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), gg);
             if (!finite_d(sff + dd) || !finite_d(rhsf)) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
+            if (pcg && !(sff + dd > 0.0)) atomicCAS(db.lin_info, 0, ds.d);
         }
     }
-    double g = 0.0;
-    if (e < ds.d - 1) {
-        const double dd = fmin(fmax(db.udiag[e], st->min_diag), st->max_diag) / st->radius;
-        db.S[(size_t)e * ds.ld + e] += dd;
-        g = fabs(db.bc[e] / db.cscale[e]);
-        if (!finite_d(db.S[(size_t)e * ds.ld + e]) || !finite_d(db.rhs[e])) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
-    } else if (e >= ds.d && e < ds.ld) {
+    double gm = 0.0;
+    if (g < ds.ncam) {
+        const int row0 = 6 * g;
+        bool bad = false;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const int e = row0 + a;
+            const double dd = fmin(fmax(db.udiag[e], st->min_diag), st->max_diag) / st->radius;
+            const double v = db.S[(size_t)e * ds.ld + e] + dd;
+            db.S[(size_t)e * ds.ld + e] = v;
+            gm = fmax(gm, fabs(db.bc[e] / db.cscale[e]));
+            bad = bad || !finite_d(v) || !finite_d(db.rhs[e]);
+        }
+        if (bad) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
+        if (pcg) {
+            // Linv of the damped block (row-major lower, zeros above), see dense_solver.hip
+            double L[6][6], Li[6][6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) L[r][c] = (c <= r) ? db.S[(size_t)(row0 + c) * ds.ld + row0 + r] : 0.0;
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double dj = L[j][j];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) if (t < j) dj -= L[j][t] * L[j][t];
+                ok = ok && (dj > 0.0);
+                const double lj = sqrt(dj > 0.0 ? dj : 1.0);
+                L[j][j] = lj;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (i > j) {
+                    double v = L[i][j];
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) if (t < j) v -= L[i][t] * L[j][t];
+                    L[i][j] = v / lj;
+                }
+            }
+            if (!ok) atomicCAS(db.lin_info, 0, row0 + 1);
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) if (t >= c && t < r) v -= L[r][t] * Li[t][c];
+                    Li[r][c] = (r < c) ? 0.0 : v / L[r][r];
+                }
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) db.pcg_binv[(size_t)g * 36 + r * 6 + c] = Li[r][c];
+        }
+    } else if (g - ds.ncam < ds.ld - ds.d) {
+        const int e = ds.d + (g - ds.ncam);
         db.S[(size_t)e * ds.ld + e] = 1.0;
         db.rhs[e] = 0.0;
     }
-    g = wave_max(g);
-    if ((threadIdx.x & 63) == 0 && g > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), g);
+    gm = wave_max(gm);
+    if ((threadIdx.x & 63) == 0 && gm > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), gm);
     // ---- arrival: every wave drains its stores, one lane releases and takes a ticket ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -884,8 +1009,9 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
     if (is_last && threadIdx.x < 64) post_linearisation(ds, db);
 }
 
-void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_finalize, dim3((ds.ld + 255) / 256), dim3(256), 0, s, ds, db);
+void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int pcg) {
+    const int work = ds.ncam + (ds.ld - ds.d) + 64;     // cameras, padding rows, room for the focal wave
+    hipLaunchKernelGGL(k_finalize, dim3((work + 255) / 256), dim3(256), 0, s, ds, db, pcg);
 }
 
 // iteration 0 bookkeeping: x_norm from the accumulated ||x||^2

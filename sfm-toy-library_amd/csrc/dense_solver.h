@@ -40,9 +40,12 @@ inline int dense_padded_dim(int d) { return ((d + 1 + CHOL_NB - 1) / CHOL_NB) * 
 void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof = nullptr);
 
 // Block-Jacobi PCG on the same storage.  Returns the number of iterations (host sync inside).
+// pretransformed = true: ws->Sfull, the right-hand side at ws->vec + 8*ld and ws->binv were already written by the
+// linearisation kernels (k_finalize / k_schur_pairs mode 1), so the block-Cholesky + transform launches are skipped.
 // finish = false leaves the solution in transformed form (x~, see dense_solver.hip) for k_cam_update;
 // hist_key >= 0 selects the history slot used to size the first batch of launches.
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev,
-                    Profiler* prof = nullptr, bool finish = true, int hist_key = -1);
+                    Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false);
+int dense_pcg_ensure_workspace(DenseSolver* ws);
 
 }  // namespace sfmba

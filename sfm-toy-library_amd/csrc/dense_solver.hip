@@ -568,18 +568,16 @@ __global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, cons
 }
 
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof,
-                    bool finish, int hist_key) {
+                    bool finish, int hist_key, bool pretransformed) {
     const int ld = ws->ld, d = ws->d;
-    if (!ws->Sfull) {
-        if (hipMalloc(&ws->Sfull, sizeof(double) * (size_t)d * ld) != hipSuccess) return -1;
-    }
+    if (dense_pcg_ensure_workspace(ws)) return -1;
     if (max_iters <= 0) max_iters = 4 * d;
     const int nb6 = (d - 1) / 6, nB = nb6 + (d - 6 * nb6);
     const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
     const size_t lds = sizeof(double) * (size_t)(ld + 8);
     double* bt = ws->vec + (size_t)8 * ld;
-    { ProfScope ps(prof, KID_PCG_SETUP, s);
+    if (!pretransformed) { ProfScope ps(prof, KID_PCG_SETUP, s);
       hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
       hipLaunchKernelGGL(k_pcg_transform, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
     const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
@@ -634,6 +632,13 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
         ws->hist[hist_key] = ws->h_flags[PF_ITERS];
     }
     return ws->h_flags[PF_ITERS];
+}
+
+int dense_pcg_ensure_workspace(DenseSolver* ws) {
+    if (!ws->Sfull) {
+        if (hipMalloc(&ws->Sfull, sizeof(double) * (size_t)ws->d * ws->ld) != hipSuccess) return -1;
+    }
+    return 0;
 }
 
 int dense_solver_create(DenseSolver* ws, int d, int ld) {

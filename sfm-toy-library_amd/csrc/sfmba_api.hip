@@ -90,7 +90,7 @@ struct sfmba_problem {
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr;
     int* d_blk_ptr = nullptr;
-    int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr;
+    int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pwg_ptr = nullptr;
     double* d_facc = nullptr;
     double *d_cam0 = nullptr, *d_pts0 = nullptr;  // parameters given at create time
@@ -214,14 +214,27 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
         { ProfScope ps(prof, KID_ZERO, p->stream); launch_zero_system(p->stream, p->ds, p->db); }
+        const bool pcg = o.linear_solver == SFMBA_LINEAR_PCG;
+        if (pcg) {
+            if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+            p->db.pcg_F = p->solver.Sfull;
+        }
         { ProfScope ps(prof, KID_POINT_BUILD, p->stream); launch_point_build<T>(p->stream, p->ds, p->db); }
-        { ProfScope ps(prof, KID_SCHUR_PAIRS, p->stream); launch_schur_pairs<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
-        { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db); }
+        launch_schur_pairs<T>(p->stream, p->ds, p->db, 2);      // duplicate pairs inside diagonal blocks (usually none)
+        if (pcg) {
+            // the preconditioner (Linv of the damped diagonal blocks) is known before the pair pass, which then writes the
+            // preconditioned matrix directly
+            { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db, 1); }
+            { ProfScope ps(prof, KID_SCHUR_PAIRS, p->stream); launch_schur_pairs<T>(p->stream, p->ds, p->db, 1); }
+        } else {
+            { ProfScope ps(prof, KID_SCHUR_PAIRS, p->stream); launch_schur_pairs<T>(p->stream, p->ds, p->db, 0); }
+            { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db, 0); }
+        }
         DeviceBuffers dbu = p->db;
-        if (o.linear_solver == SFMBA_LINEAR_PCG) {
+        if (pcg) {
             const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
-                                           /*finish=*/false, /*hist_key=*/host_iter);
+                                           /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true);
             if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             sum.linear_iters += it;
             lin_hist.push_back(it);
@@ -334,7 +347,7 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     dense_solver_destroy(&p->solver);
     void* frees[] = { p->d_pt_ptr, p->d_obs_cam, p->d_cam_ptr, p->d_cam_obs, p->d_cam_obs_pt, p->d_obs_pt, p->d_obs_xy, p->d_chunks,
-                      p->d_cam0, p->d_pts0, p->d_sys, p->d_info, p->d_blk_ptr, p->d_pairs, p->d_blk_cams, p->d_facc, p->d_pwg_blocks, p->d_pwg_ptr, p->db.cam[0], p->db.cam[1], p->db.pts[0], p->db.pts[1],
+                      p->d_cam0, p->d_pts0, p->d_sys, p->d_info, p->d_blk_ptr, p->d_pairs, p->d_blk_cams, p->d_facc, p->d_pwg_blocks, p->d_pwg_ptr, p->d_dup_blocks, p->db.cam[0], p->db.cam[1], p->db.pts[0], p->db.pts[1],
                       p->db.camtab[0], p->db.camtab[1], p->db.steptab, p->db.cscale, p->db.pscale, p->db.Y, p->db.pt_t, p->db.pt_yf,
                       p->db.st, p->db.trace };
     for (void* f : frees) if (f) (void)hipFree(f);
@@ -492,6 +505,12 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
                 pwg_blocks.push_back(w);
             }
     }
+    // diagonal blocks that contain pairs (the same camera observing a point twice): handled by a separate pass
+    std::vector<int2> dup_blocks;
+    for (int ja = 0; ja < ncam; ++ja) {
+        const int b = block_of(ja, ja);
+        if (blk_ptr[(size_t)b + 1] > blk_ptr[b]) { int2 w; w.x = b; w.y = 1; dup_blocks.push_back(w); }
+    }
     // waves of the point passes: contiguous ranges of whole points with at most 64 observations (a point
     // with more observations than that gets a wave of its own and is swept in several rounds)
     std::vector<int> wv_ptr;
@@ -517,6 +536,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_upload(&p->d_pairs, pairs));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
     HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
+    HIP_TRY(dev_upload(&p->d_dup_blocks, dup_blocks));
     HIP_TRY(dev_upload(&p->d_pwg_ptr, wv_ptr));
     {
         std::vector<int> both((size_t)2 * nobs);
@@ -554,6 +574,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     ds.obs_pt = p->d_obs_pt;
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks;
+    ds.ndupwg = (int)dup_blocks.size(); ds.dup_blocks = p->d_dup_blocks;
     ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr;
 
     DeviceBuffers& db = p->db;
@@ -588,9 +609,12 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     db.lin_info = p->d_info;
     db.fin_counter = p->d_info + 1;
     db.pcg_vec = nullptr; db.pcg_linv = nullptr; db.pcg_flags = nullptr;
+    db.pcg_F = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&db.lm_mailbox), const_cast<int*>(p->h_lm_mail), 0));
     db.trace = nullptr; db.trace_cap = 0;
     if (dense_solver_create(&p->solver, ds.d, ds.ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
+    db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
+    db.pcg_binv = p->solver.binv;
 
     rc = sfmba_problem_reset(p);
     if (rc) return rc;
@@ -772,16 +796,18 @@ int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, doub
         launch_linearise_setup<float>(p, o.jacobi_scaling);
         launch_zero_system(p->stream, p->ds, p->db);
         launch_point_build<float>(p->stream, p->ds, p->db);
-        launch_schur_pairs<float>(p->stream, p->ds, p->db);
         launch_cam_diag<float>(p->stream, p->ds, p->db);
+        launch_schur_pairs<float>(p->stream, p->ds, p->db, 2);
+        launch_schur_pairs<float>(p->stream, p->ds, p->db, 0);
     } else {
         launch_linearise_setup<double>(p, o.jacobi_scaling);
         launch_zero_system(p->stream, p->ds, p->db);
         launch_point_build<double>(p->stream, p->ds, p->db);
-        launch_schur_pairs<double>(p->stream, p->ds, p->db);
         launch_cam_diag<double>(p->stream, p->ds, p->db);
+        launch_schur_pairs<double>(p->stream, p->ds, p->db, 2);
+        launch_schur_pairs<double>(p->stream, p->ds, p->db, 0);
     }
-    launch_finalize(p->stream, p->ds, p->db);
+    launch_finalize(p->stream, p->ds, p->db, 0);
     const int d = p->ds.d;
     double *d_full = nullptr, *d_scale = nullptr;
     HIP_TRY(dev_alloc(&d_full, (size_t)d * d));
@@ -888,12 +914,14 @@ int sfmba_shard_partial_build(sfmba_problem* p) {
     HIP_TRY(hipSetDevice(p->device));
     if (p->precision == SFMBA_PRECISION_F32J) {
         launch_point_build<float>(p->stream, p->ds, p->db);
-        launch_schur_pairs<float>(p->stream, p->ds, p->db);
         launch_cam_diag<float>(p->stream, p->ds, p->db);
+        launch_schur_pairs<float>(p->stream, p->ds, p->db, 2);
+        launch_schur_pairs<float>(p->stream, p->ds, p->db, 0);
     } else {
         launch_point_build<double>(p->stream, p->ds, p->db);
-        launch_schur_pairs<double>(p->stream, p->ds, p->db);
         launch_cam_diag<double>(p->stream, p->ds, p->db);
+        launch_schur_pairs<double>(p->stream, p->ds, p->db, 2);
+        launch_schur_pairs<double>(p->stream, p->ds, p->db, 0);
     }
     launch_shard_pack(p->stream, p->db, p->d_scal, 1, p->shard_rank);
     return SFMBA_OK;
@@ -904,7 +932,7 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     HIP_TRY(hipSetDevice(p->device));
     const sfmba_options& o = p->shard_opt;
     launch_shard_unpack(p->stream, p->db, p->d_scal, 1, p->shard_world);
-    launch_finalize(p->stream, p->ds, p->db);
+    launch_finalize(p->stream, p->ds, p->db, 0);
     DeviceBuffers dbu = p->db;
     if (o.linear_solver == SFMBA_LINEAR_PCG) {
         const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
