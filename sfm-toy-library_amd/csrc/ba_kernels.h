@@ -90,6 +90,7 @@ struct DeviceBuffers {
     double* cscale;           // [6*ncam] Jacobi scale of the camera columns
     double* pscale;           // [npt][3]
     void* Y;                  // [nobs][YREC] float or double
+    void* Z;                  // [nobs][8] float or double: C t, C y_f, residual (side record for the camera-diagonal pass)
     double* pt_t;             // [npt][3] L^-1 b_p
     double* pt_yf;            // [npt][3] L^-1 E_f
     double* S;                // [ld*ld] reduced system: upper triangle of the row-major matrix

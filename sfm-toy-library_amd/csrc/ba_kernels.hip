@@ -318,6 +318,7 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
     __shared__ T sv[WPB][64][PB_LD];
     __shared__ double sb[WPB][64][3];
     __shared__ T sl[WPB][64][6];
+    __shared__ T st_yf[WPB][64][6];          // per local point: t = L^-1 b_p (3), y_f = L^-1 E_f (3)
     __shared__ double scratch[WPB];
     const LMState* st = db.st;
     const int cur = st->cur;
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
         Proj prk = { 0.0, 0.0, 0.0 };
         int ik = 0, jk = 0;
         T spk[3] = { (T)0, (T)0, (T)0 };
+        T rk0 = (T)0, rk1 = (T)0;
 
         for (int c0 = o0; c0 < o1; c0 += 64) {
             const int q = c0 + lane;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
                 }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) Bk[c] = B[c];
-                prk = pr; ik = i; jk = j; spk[0] = sp[0]; spk[1] = sp[1]; spk[2] = sp[2];
+                prk = pr; ik = i; jk = j; spk[0] = sp[0]; spk[1] = sp[1]; spk[2] = sp[2]; rk0 = (T)r0; rk1 = (T)r1;
             }
             wave_lds_fence();
             if (lane < npts) {
@@ -425,6 +427,8 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
             if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2)) bad = 1.0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) sl[w][lane][c] = (T)Li[c];
+            st_yf[w][lane][0] = (T)t0; st_yf[w][lane][1] = (T)t1; st_yf[w][lane][2] = (T)t2;
+            st_yf[w][lane][3] = (T)y0; st_yf[w][lane][4] = (T)y1; st_yf[w][lane][5] = (T)y2;
         }
         wave_lds_fence();
         // record sweep: one packed 64-byte (fp32) record per observation
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
                 spk[0] = (T)db.pscale[3 * (size_t)ik]; spk[1] = (T)db.pscale[3 * (size_t)ik + 1]; spk[2] = (T)db.pscale[3 * (size_t)ik + 2];
                 const CamRow ct = { tab + jk, ds.ncam };
                 prk = project_point(ct, CT_R, CT_T, X);
+                { double ox, oy; load_obs<T>(ds.obs_xy, q, ox, oy); rk0 = (T)(focal * prk.xp - ox); rk1 = (T)(focal * prk.yp - oy); }
                 point_block<T>(ct, prk, focal, Bk);
                 camera_block<T>(ct, prk, focal, X, Bk, Ak);
 #pragma unroll
@@ -456,6 +461,24 @@ __global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceB
             }
             if (sizeof(T) == 4) rec[15] = (T)__int_as_float(jk); else rec[15] = (T)__longlong_as_double((long long)jk);
             store_rec<T>(Yout, q, rec);
+            // side record for k_cam_diag: C t, C y_f, residual
+            const T* ty = st_yf[w][ik - pt0];
+            T z[8];
+            z[0] = rec[9] * ty[0] + rec[10] * ty[1] + rec[11] * ty[2];
+            z[1] = rec[12] * ty[0] + rec[13] * ty[1] + rec[14] * ty[2];
+            z[2] = rec[9] * ty[3] + rec[10] * ty[4] + rec[11] * ty[5];
+            z[3] = rec[12] * ty[3] + rec[13] * ty[4] + rec[14] * ty[5];
+            z[4] = rk0; z[5] = rk1; z[6] = (T)0; z[7] = (T)0;
+            T* zd = reinterpret_cast<T*>(db.Z) + (size_t)q * 8;
+            if (sizeof(T) == 4) {
+                float4* z4 = reinterpret_cast<float4*>(zd);
+                z4[0] = make_float4((float)z[0], (float)z[1], (float)z[2], (float)z[3]);
+                z4[1] = make_float4((float)z[4], (float)z[5], 0.f, 0.f);
+            } else {
+                double2* z2 = reinterpret_cast<double2*>(zd);
+                z2[0] = make_double2((double)z[0], (double)z[1]); z2[1] = make_double2((double)z[2], (double)z[3]);
+                z2[2] = make_double2((double)z[4], (double)z[5]); z2[3] = make_double2(0.0, 0.0);
+            }
         }
     }
     if (!finite_d(lin_cost)) bad = 1.0;
@@ -747,8 +770,6 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
     const int4 ch = ds.chunks[blockIdx.x];
     const int j = ch.x;
     const LMState* st = db.st;
-    const int cur = st->cur;
-    const double focal = st->focal[cur];
     const T fscale = (T)st->fscale;
     const T* Y = reinterpret_cast<const T*>(db.Y);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -759,25 +780,30 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
     for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
     if (e < ch.z) {
         const int q = ds.cam_obs[e];
-        const int i = ds.cam_obs_pt[e];
         T rec[YREC], A[12];
         load_rec<T>(Y, q, rec);
-        double ox, oy;
-        load_obs<T>(ds.obs_xy, q, ox, oy);
-        const T t0 = (T)db.pt_t[3 * (size_t)i], t1 = (T)db.pt_t[3 * (size_t)i + 1], t2 = (T)db.pt_t[3 * (size_t)i + 2];
-        const T y0 = (T)db.pt_yf[3 * (size_t)i], y1 = (T)db.pt_yf[3 * (size_t)i + 1], y2 = (T)db.pt_yf[3 * (size_t)i + 2];
+        T z[8];
+        {
+            const T* zs = reinterpret_cast<const T*>(db.Z) + (size_t)q * 8;
+            if (sizeof(T) == 4) {
+                const float4 a = reinterpret_cast<const float4*>(zs)[0], b = reinterpret_cast<const float4*>(zs)[1];
+                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)a.z; z[3] = (T)a.w; z[4] = (T)b.x; z[5] = (T)b.y;
+            } else {
+                const double2 a = reinterpret_cast<const double2*>(zs)[0], b = reinterpret_cast<const double2*>(zs)[1], c = reinterpret_cast<const double2*>(zs)[2];
+                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)b.x; z[3] = (T)b.y; z[4] = (T)c.x; z[5] = (T)c.y;
+            }
+        }
         rec_camera_block<T>(rec, A);
 #pragma unroll
         for (int c = 0; c < 6; ++c) { const T s = (T)db.cscale[6 * j + c]; A[c] *= s; A[6 + c] *= s; }
-        const T r0 = (T)(focal * (double)rec[7] - ox), r1 = (T)(focal * (double)rec[8] - oy);
+        const T r0 = z[4], r1 = z[5];
         const T g0 = rec[7] * fscale, g1 = rec[8] * fscale;
         // N = I - C C^T
         const T n00 = (T)1 - (rec[9] * rec[9] + rec[10] * rec[10] + rec[11] * rec[11]);
         const T n01 = -(rec[9] * rec[12] + rec[10] * rec[13] + rec[11] * rec[14]);
         const T n11 = (T)1 - (rec[12] * rec[12] + rec[13] * rec[13] + rec[14] * rec[14]);
-        // Y v = A~^T (C v)
-        const T ct0 = rec[9] * t0 + rec[10] * t1 + rec[11] * t2, ct1 = rec[12] * t0 + rec[13] * t1 + rec[14] * t2;
-        const T cy0 = rec[9] * y0 + rec[10] * y1 + rec[11] * y2, cy1 = rec[12] * y0 + rec[13] * y1 + rec[14] * y2;
+        // Y v = A~^T (C v): C t and C y_f come from the side record
+        const T ct0 = z[0], ct1 = z[1], cy0 = z[2], cy1 = z[3];
         int u = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {

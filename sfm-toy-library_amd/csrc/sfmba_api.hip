@@ -348,7 +348,7 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     dense_solver_destroy(&p->solver);
     void* frees[] = { p->d_pt_ptr, p->d_obs_cam, p->d_cam_ptr, p->d_cam_obs, p->d_cam_obs_pt, p->d_obs_pt, p->d_obs_xy, p->d_chunks,
                       p->d_cam0, p->d_pts0, p->d_sys, p->d_info, p->d_blk_ptr, p->d_pairs, p->d_blk_cams, p->d_facc, p->d_pwg_blocks, p->d_pwg_ptr, p->d_dup_blocks, p->db.cam[0], p->db.cam[1], p->db.pts[0], p->db.pts[1],
-                      p->db.camtab[0], p->db.camtab[1], p->db.steptab, p->db.cscale, p->db.pscale, p->db.Y, p->db.pt_t, p->db.pt_yf,
+                      p->db.camtab[0], p->db.camtab[1], p->db.steptab, p->db.cscale, p->db.pscale, p->db.Y, p->db.Z, p->db.pt_t, p->db.pt_yf,
                       p->db.st, p->db.trace };
     for (void* f : frees) if (f) (void)hipFree(f);
     p->prof.destroy();
@@ -588,6 +588,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_alloc(&db.pscale, (size_t)3 * npt));
     const size_t ybytes = (size_t)nobs * YREC * (precision == SFMBA_PRECISION_F32J ? sizeof(float) : sizeof(double));
     HIP_TRY(hipMalloc(&db.Y, ybytes));
+    HIP_TRY(hipMalloc(&db.Z, ybytes / 2));
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
