@@ -39,7 +39,7 @@ def parse():
                     help="reduced-system solver: pcg = block-Jacobi PCG on the dense reduced system (north_star), "
                          "cholesky = DENSE_SCHUR-equivalent exact factorisation (reference configuration)")
     ap.add_argument("--precision", default="f32j", choices=["f32j", "f64"])
-    ap.add_argument("--pcg-tol", type=float, default=1e-8)
+    ap.add_argument("--pcg-tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="LM iterations of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = min(nproc,16))")

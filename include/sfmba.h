@@ -82,7 +82,7 @@ typedef struct sfmba_options {
     int    max_consecutive_invalid_steps; /* 5 */
     int    linear_solver;             /* SFMBA_LINEAR_* */
     int    precision;                 /* SFMBA_PRECISION_* */
-    double pcg_tolerance;             /* relative residual for SFMBA_LINEAR_PCG (1e-8) */
+    double pcg_tolerance;             /* relative residual for SFMBA_LINEAR_PCG (1e-6: final cost within ~1e-11 of the exact solve on cfg 3) */
     int    pcg_max_iters;             /* 0 = 4*dim */
     int    verbose;                   /* 0 silent (BA.cpp:177), 1 per-iteration lines on stderr */
 } sfmba_options;

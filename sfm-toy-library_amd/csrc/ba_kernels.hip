@@ -225,14 +225,14 @@ template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const 
 // 3x3 SPD: L^-1 (lower, 6 values l00 l10 l11 l20 l21 l22 of the INVERSE factor). Returns false if not PD.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool chol3_inverse(const double V[6] /* v00 v10 v11 v20 v21 v22 */, double Li[6]) {
-    const double l00 = sqrt(V[0]);
-    const double l10 = V[1] / l00, l20 = V[3] / l00;
+    // L^-1 directly from reciprocal square roots of the pivots (no sqrt / divide chains)
+    const double i00 = fast_rsq(V[0]);
+    const double l10 = V[1] * i00, l20 = V[3] * i00;
     const double d1 = V[2] - l10 * l10;
-    const double l11 = sqrt(d1);
-    const double l21 = (V[4] - l20 * l10) / l11;
+    const double i11 = fast_rsq(d1);
+    const double l21 = (V[4] - l20 * l10) * i11;
     const double d2 = V[5] - l20 * l20 - l21 * l21;
-    const double l22 = sqrt(d2);
-    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i22 = fast_rsq(d2);
     Li[0] = i00;
     Li[1] = -l10 * i00 * i11;
     Li[2] = i11;
@@ -986,14 +986,14 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
 #pragma unroll
                 for (int t = 0; t < 6; ++t) if (t < j) dj -= L[j][t] * L[j][t];
                 ok = ok && (dj > 0.0);
-                const double lj = sqrt(dj > 0.0 ? dj : 1.0);
-                L[j][j] = lj;
+                const double lji = fast_rsq(dj > 0.0 ? dj : 1.0);
+                L[j][j] = lji;              // the RECIPROCAL of the pivot is what the inverse needs
 #pragma unroll
                 for (int i = 0; i < 6; ++i) if (i > j) {
                     double v = L[i][j];
 #pragma unroll
                     for (int t = 0; t < 6; ++t) if (t < j) v -= L[i][t] * L[j][t];
-                    L[i][j] = v / lj;
+                    L[i][j] = v * lji;
                 }
             }
             if (!ok) atomicCAS(db.lin_info, 0, row0 + 1);
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
                     double v = (r == c) ? 1.0 : 0.0;
 #pragma unroll
                     for (int t = 0; t < 6; ++t) if (t >= c && t < r) v -= L[r][t] * Li[t][c];
-                    Li[r][c] = (r < c) ? 0.0 : v / L[r][r];
+                    Li[r][c] = (r < c) ? 0.0 : v * L[r][r];
                 }
 #pragma unroll
             for (int r = 0; r < 6; ++r)

@@ -326,7 +326,7 @@ void sfmba_options_default(sfmba_options* o) {
     o->max_consecutive_invalid_steps = 5;
     o->linear_solver = SFMBA_LINEAR_CHOLESKY;
     o->precision = SFMBA_PRECISION_F64;
-    o->pcg_tolerance = 1e-8;
+    o->pcg_tolerance = 1e-6;
     o->pcg_max_iters = 0;
     o->verbose = 0;
 }

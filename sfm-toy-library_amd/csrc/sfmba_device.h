@@ -80,6 +80,24 @@ __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
     atomicMax(reinterpret_cast<unsigned long long*>(addr), bits);
 }
 
+// fp64 reciprocal / reciprocal square root: hardware estimate + two Newton steps (full double accuracy).  The
+// compiler's generic expansions of 1.0/x and sqrt(x) are ~20-deep dependent fp64 chains; a dependent DFMA costs
+// ~32 cycles on gfx950 (tools/micro/microbench.hip), and these chains sit on the critical path of latency-bound waves.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ double fast_rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
 // Projection in fp64: p = R X + t, returns xp, yp, 1/pz.  `cam` points at a camera table row.
 struct Proj {
     double xp, yp, iz;
@@ -91,7 +109,7 @@ __device__ __forceinline__ Proj project_point(CamPtr cam, int roff, int toff, co
     const double py = cam[roff + 3] * X[0] + cam[roff + 4] * X[1] + cam[roff + 5] * X[2] + cam[toff + 1];
     const double pz = cam[roff + 6] * X[0] + cam[roff + 7] * X[1] + cam[roff + 8] * X[2] + cam[toff + 2];
     Proj pr;
-    pr.iz = 1.0 / pz;
+    pr.iz = fast_rcp(pz);      // pz == 0 gives inf/NaN exactly like the division (caught by the finiteness checks)
     pr.xp = px * pr.iz;
     pr.yp = py * pr.iz;
     return pr;

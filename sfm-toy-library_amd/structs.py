@@ -36,7 +36,7 @@ class SfmbaOptions(C.Structure):
                 parameter_tolerance=1e-8, initial_radius=1e4, max_radius=1e16, min_radius=1e-32,
                 min_relative_decrease=1e-3, min_lm_diagonal=1e-6, max_lm_diagonal=1e32,
                 jacobi_scaling=1, max_consecutive_invalid_steps=5, linear_solver=LINEAR_CHOLESKY,
-                precision=PRECISION_F64, pcg_tolerance=1e-8, pcg_max_iters=0, verbose=0)
+                precision=PRECISION_F64, pcg_tolerance=1e-6, pcg_max_iters=0, verbose=0)
         for k, v in overrides.items():
             if not hasattr(o, k):
                 raise AttributeError(k)
