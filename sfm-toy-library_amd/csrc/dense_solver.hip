@@ -249,7 +249,9 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 // by iteration parity so no workgroup overwrites what another one is still reading.  The rows a
 // workgroup owns never change, so its slab of S~ stays in its XCD's L2 across iterations.
 // ------------------------------------------------------------------------------------------
-constexpr int PCG_MAXWG = 256;
+constexpr int PCG_MAXWG = 256;        // workgroups of the fast path (one partial dot product per thread)
+constexpr int PCG_MAXWG_BIG = 1024;   // workgroups of the generic path
+constexpr int PCG_PART = 1024;        // stride of the two partial-dot-product buffers
 enum { PF_DONE = 0, PF_ITERS = 1, PF_XBUF = 2 };
 enum { PS_RR0 = 0 };
 // vec layout: x[2] r[2] p[2] q[2], each ld doubles; btilde after them
@@ -366,10 +368,20 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
     b = red[1] + red[3] + red[5] + red[7];
 }
 
+// Host mailbox (pinned, host-mapped): {iterations, done}.  The host polls it instead of issuing a D2H copy + stream
+// synchronise per batch; written by one lane with system-scope stores.
+__device__ __forceinline__ void pcg_post(int* mailbox, int iters, int done) {
+    __hip_atomic_store(mailbox + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox, iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Generic path of one CG iteration (any d).  Vector phase as in the fast path but looped; the matvec streams two rows
+// of S~ per wave with 16-byte loads, four deep, so that a wave keeps 128 B per lane in flight (the rows are HBM/MALL
+// traffic: d*ld*8 bytes per iteration, 289 MB at d = 6001).  Up to PCG_MAXWG_BIG workgroups.
 template <bool INIT>
 __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
                                                   const double* __restrict__ bt, double* __restrict__ part, double* scal,
-                                                  int* flags, int rows_per_wg, double tol2, int in, int* info) {
+                                                  int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox) {
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;            // [ld] new search direction
     double* red = sm + ld;      // [8]
@@ -384,24 +396,29 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* _
         for (int e = tid; e < d; e += 256) { const double v = bt[e]; pl[e] = v; rr += v * v; }
         block_sum2(rr, dummy, red);
         for (int e = row0 + tid; e < row1; e += 256) { x_out[e] = 0.0; r_out[e] = pl[e]; p_out[e] = pl[e]; }
-        if (blockIdx.x == 0 && tid == 0) { scal[PS_RR0] = rr; flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out; }
+        if (blockIdx.x == 0 && tid == 0) {
+            scal[PS_RR0] = rr; flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
+            if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
+        }
     } else {
         const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = pcg_vec(vec, 1, in, ld);
         const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
-        double pq = (tid < (int)gridDim.x) ? part[in * PCG_MAXWG + tid] : 0.0;
+        double pq = 0.0;
+        for (int i = tid; i < (int)gridDim.x; i += 256) pq += part[in * PCG_PART + i];
         double rr = 0.0;
-        for (int e = tid; e < d; e += 256) { const double v = r_in[e]; rr += v * v; }
+        for (int e = tid; e < d; e += 256) { const double v = r_in[e]; pl[e] = v; rr += v * v; }
         block_sum2(pq, rr, red);
         const double alpha = rr / pq;
         double rrn = 0.0, dummy = 0.0;
-        for (int e = tid; e < d; e += 256) { const double v = r_in[e] - alpha * q_in[e]; pl[e] = v; rrn += v * v; }
+        for (int e = tid; e < d; e += 256) { const double v = pl[e] - alpha * q_in[e]; pl[e] = v; rrn += v * v; }   // own elements only
         block_sum2(rrn, dummy, red);
         for (int e = row0 + tid; e < row1; e += 256) x_out[e] = x_in[e] + alpha * p_in[e];
         const bool broke = !(pq > 0.0) || !(rrn == rrn);
         if (rrn <= tol2 * scal[PS_RR0] || broke) {
             if (blockIdx.x == 0 && tid == 0) {
-                flags[PF_DONE] = 1; flags[PF_XBUF] = out; flags[PF_ITERS] += 1;
+                flags[PF_DONE] = 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
                 if (broke) atomicCAS(info, 0, d + 1);
+                if (mailbox) pcg_post(mailbox, it, 1);
             }
             return;
         }
@@ -411,31 +428,51 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* _
         for (int e = tid; e < d; e += 256) pl[e] = pl[e] + beta * p_in[e];
         __syncthreads();
         for (int e = row0 + tid; e < row1; e += 256) p_out[e] = pl[e];
-        if (blockIdx.x == 0 && tid == 0) { flags[PF_ITERS] += 1; flags[PF_XBUF] = out; }
+        if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
     }
     __syncthreads();
-    // q = S~ p for the rows this workgroup owns: one wave per row
+    // q = S~ p for the rows this workgroup owns: each wave takes rows (row0 + w + 4k), two at a time
     const int lane = tid & 63, w = tid >> 6;
+    const int nd2 = d >> 1;                                     // full double2 columns; an odd last column is added by lane 0
+    const double2* pl2 = reinterpret_cast<const double2*>(pl);
     double pqp = 0.0;
-    for (int row = row0 + w; row < row1; row += 4) {
-        const double* Fr = F + (size_t)row * ld;
-        double s = 0.0;
-        for (int c = lane; c < d; c += 64) s += Fr[c] * pl[c];
+    for (int row = row0 + w; row < row1; row += 8) {
+        const int rowb = (row + 4 < row1) ? row + 4 : row;
+        const double2* Fa = reinterpret_cast<const double2*>(F + (size_t)row * ld);
+        const double2* Fb = reinterpret_cast<const double2*>(F + (size_t)rowb * ld);
+        double sa = 0.0, sb = 0.0;
+        int c = lane;
+        for (; c + 192 < nd2; c += 256) {
+            double2 a[4], b[4];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) { q_out[row] = s; pqp += pl[row] * s; }
+            for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double2 pv = pl2[c + 64 * m];
+                sa += a[m].x * pv.x + a[m].y * pv.y;
+                sb += b[m].x * pv.x + b[m].y * pv.y;
+            }
+        }
+        for (; c < nd2; c += 64) {
+            const double2 a = Fa[c], b = Fb[c], pv = pl2[c];
+            sa += a.x * pv.x + a.y * pv.y;
+            sb += b.x * pv.x + b.y * pv.y;
+        }
+        if ((d & 1) && lane == 0) {
+            sa += F[(size_t)row * ld + d - 1] * pl[d - 1];
+            sb += F[(size_t)rowb * ld + d - 1] * pl[d - 1];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
+        if (lane == 0) {
+            q_out[row] = sa; pqp += pl[row] * sa;
+            if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
+        }
     }
     __syncthreads();
     if (lane == 0) red[w] = pqp;
     __syncthreads();
-    if (tid == 0) part[out * PCG_MAXWG + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// Host mailbox (pinned, host-mapped): {iterations, done}.  The host polls it instead of issuing a D2H copy + stream
-// synchronise per batch; written by one lane with system-scope stores.
-__device__ __forceinline__ void pcg_post(int* mailbox, int iters, int done) {
-    __hip_atomic_store(mailbox + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mailbox, iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) part[out * PCG_PART + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 // Fast path of one CG iteration for d <= 1280 (all BASELINE single-GPU configs): every global load of
@@ -469,7 +506,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         const bool ok = e < d;
         rv[m] = ok ? r_in[e] : 0.0; qv[m] = (ok && !INIT) ? q_in[e] : 0.0; pv[m] = (ok && !INIT) ? p_in[e] : 0.0;
     }
-    double pq = (!INIT && tid < (int)gridDim.x) ? part[in * PCG_MAXWG + tid] : 0.0;
+    double pq = (!INIT && tid < (int)gridDim.x) ? part[in * PCG_PART + tid] : 0.0;
     const double rr0 = INIT ? 0.0 : scal[PS_RR0];
     double fv[PCG_RPW][PCG_CPL];
 #pragma unroll
@@ -548,7 +585,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
     __syncthreads();
     if (lane == 0) red[w] = pqp;
     __syncthreads();
-    if (tid == 0) part[out * PCG_MAXWG + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) part[out * PCG_PART + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 
@@ -573,16 +610,17 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     if (dense_pcg_ensure_workspace(ws)) return -1;
     if (max_iters <= 0) max_iters = 4 * d;
     const int nb6 = (d - 1) / 6, nB = nb6 + (d - 6 * nb6);
-    const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
+    int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
+    const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
+    if (!fast) rows_per_wg = std::max(8, ((d + PCG_MAXWG_BIG - 1) / PCG_MAXWG_BIG + 7) / 8 * 8);   // two rows per wave at a time
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
     const size_t lds = sizeof(double) * (size_t)(ld + 8);
     double* bt = ws->vec + (size_t)8 * ld;
     if (!pretransformed) { ProfScope ps(prof, KID_PCG_SETUP, s);
       hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
       hipLaunchKernelGGL(k_pcg_transform, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
-    const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
     volatile int* mb = ws->h_mailbox;
-    int* mb_dev = fast ? ws->d_mailbox : nullptr;
+    int* mb_dev = ws->d_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }
     { ProfScope ps(prof, KID_PCG_ITER, s);
       if (fast)
@@ -590,7 +628,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
                              rows_per_wg, tol * tol, 0, info_dev, mb_dev);
       else
           hipLaunchKernelGGL(k_pcg_iter<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                             rows_per_wg, tol * tol, 0, info_dev); }
+                             rows_per_wg, tol * tol, 0, info_dev, mb_dev); }
     int in = 1, it = 0;
     int batch = 24;
     if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + 1;
@@ -604,11 +642,11 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
                                    rows_per_wg, tol * tol, in, info_dev, mb_dev);
             else
                 hipLaunchKernelGGL(k_pcg_iter<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                                   rows_per_wg, tol * tol, in, info_dev);
+                                   rows_per_wg, tol * tol, in, info_dev, mb_dev);
             in ^= 1;
         }
         it += n;
-        if (fast && mb) {
+        if (mb) {
             // poll the mailbox until the last launch of the batch has reported (or convergence was posted)
             const double t_end = now_s() + 2.0;
             while (!(mb[1] != 0 || mb[0] >= it)) {
@@ -647,7 +685,7 @@ int dense_solver_create(DenseSolver* ws, int d, int ld) {
     if (hipMalloc(&ws->minv, sizeof(double) * (size_t)nblk * NB * NB) != hipSuccess) return -1;
     if (hipMalloc(&ws->y, sizeof(double) * ld) != hipSuccess) return -1;
     if (hipMalloc(&ws->vec, sizeof(double) * 9 * (size_t)ld) != hipSuccess) return -1;
-    if (hipMalloc(&ws->part, sizeof(double) * 2 * 256) != hipSuccess) return -1;
+    if (hipMalloc(&ws->part, sizeof(double) * 2 * PCG_PART) != hipSuccess) return -1;
     if (hipMalloc(&ws->binv, sizeof(double) * 36 * (size_t)(ld / 6 + 2)) != hipSuccess) return -1;
     if (hipMalloc(&ws->scal, sizeof(double) * 8) != hipSuccess) return -1;
     if (hipMalloc(&ws->flags, sizeof(int) * 4) != hipSuccess) return -1;

@@ -150,7 +150,7 @@ def test_dense_cholesky_flags_indefinite(capi):
     assert info == 38          # leading minor of order 38 is not positive definite
 
 
-@pytest.mark.parametrize("n", [7, 121, 1201])
+@pytest.mark.parametrize("n", [7, 121, 1201, 1501, 3002])     # > 1280: the generic (streaming) CG iteration kernel
 def test_dense_pcg(capi, n):
     rng = np.random.default_rng(100 + n)
     M = rng.normal(size=(n, n)) / np.sqrt(n)
