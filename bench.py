@@ -40,6 +40,10 @@ def parse():
                          "cholesky = DENSE_SCHUR-equivalent exact factorisation (reference configuration)")
     ap.add_argument("--precision", default="f32j", choices=["f32j", "f64"])
     ap.add_argument("--pcg-tol", type=float, default=1e-6)
+    ap.add_argument("--mode", default="independent", choices=["independent", "sharded"],
+                    help="N > 1: 'independent' = one whole problem per GPU (weak scaling, no data-path collective; the default the "
+                         "driver runs); 'sharded' = ONE problem with its points sharded over the ranks and the reduced camera "
+                         "system all-reduced over RCCL every LM iteration (strong scaling; BASELINE config 5 is quoted this way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="LM iterations of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = min(nproc,16))")
@@ -113,6 +117,8 @@ def main():
 
     precision = 1 if args.precision == "f32j" else 0
     linear = 1 if args.linear == "pcg" else 0
+    if args.mode == "sharded":
+        return main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear)
     sub = rank if world > 1 else None
     prob = sfm.make_problem(args.workload, sub=sub)
     P = capi.Problem(prob, precision=precision, device=local_rank)
@@ -207,6 +213,51 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear):
+    """ONE problem, points sharded over the ranks (sfm-toy-library_amd/sharded.py); every rank times the same K solves."""
+    from sfm_toy_library_amd import sharded
+    if dist is None:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 2000), rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
+    prob = sfm.make_problem(args.workload)
+    be = sharded.HipShardBackend(prob, rank, world, device=local_rank, precision=precision)
+    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol)
+
+    def barrier():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        be.reset(); sharded.solve_sharded(be, dist, opt)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    summ = None
+    for _ in range(args.steps):
+        be.reset()
+        summ = sharded.solve_sharded(be, dist, opt)
+        iters += summ["iterations"]
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    g_dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "BA LM iterations/sec", "value": iters / g_dt, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * g_dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64" if precision == 0 else "f32 Jacobian blocks, f64 residual/accumulate/solve",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d ranks, reduced camera system "
+                                   "all-reduced (RCCL) once per LM iteration" % (args.workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
+                       "step": "one full LM solve to ceres CONVERGENCE", "lm_iterations_per_step": iters / args.steps},
+            "final_rms_px": float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)), "final_cost": summ["final_cost"],
+            "termination": summ["termination_name"]}), flush=True)
+    be.close()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 PMC_KERNEL_NAMES = {"pcg_iter": "k_pcg_iter_fast", "schur_pairs": "k_schur_pairs", "cam_diag": "k_cam_diag",
