@@ -1,6 +1,7 @@
 // ba_kernels.h -- host-visible declarations of the bundle-adjustment kernels (ba_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 
 namespace sfmba {
@@ -142,5 +143,9 @@ void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const De
 void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi);
 void launch_mirror_scale(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* S_full, double* scale_out);
 
+
+// structure_build.hip: camera-pair lists of the Schur pass, built on the device (pair_off_host: npt + 1 prefix counts)
+int build_pair_lists(hipStream_t s, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt, const int* d_obs_cam,
+                     const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr);
 
 }  // namespace sfmba

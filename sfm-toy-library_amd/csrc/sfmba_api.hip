@@ -397,6 +397,10 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
 
     // ---- structure (host) ----
+    const bool bt_on = std::getenv("SFMBA_BUILD_TIMING") != nullptr;
+    auto bt_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double bt_t = bt_now();
+    auto bt_mark = [&](const char* what) { if (bt_on) { const double t = bt_now(); std::fprintf(stderr, "[sfmba build] %-18s %.2f ms\n", what, 1e3 * (t - bt_t)); bt_t = t; } };
     std::vector<int> cam_slot((size_t)n_cam, -1), pt_slot((size_t)n_pt, -1);
     for (int64_t k = 0; k < n_obs; ++k) {
         if (obs_cam[k] < 0 || obs_cam[k] >= n_cam || obs_pt[k] < 0 || obs_pt[k] >= n_pt)
@@ -419,6 +423,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         return SFMBA_OK;
     }
 
+    bt_mark("compaction+stream");
     std::vector<int> pt_ptr((size_t)npt + 1, 0);
     for (int k = 0; k < nobs; ++k) pt_ptr[(size_t)pt_slot[obs_pt[k]] + 1]++;
     for (int i = 0; i < npt; ++i) pt_ptr[(size_t)i + 1] += pt_ptr[i];
@@ -441,6 +446,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
             pm_cam[b + 1] = c; p->perm[b + 1] = pk;
         }
     }
+    bt_mark("point-major sort");
     std::vector<int> cam_ptr((size_t)ncam + 1, 0);
     for (int q = 0; q < nobs; ++q) cam_ptr[(size_t)pm_cam[q] + 1]++;
     for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] += cam_ptr[j];
@@ -459,6 +465,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
             int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = 0;
             chunks.push_back(c);
         }
+    bt_mark("camera-major");
     // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the
     // self pairs are folded into the camera-diagonal pass)
     // goes to block (ja, jb) of the upper triangle of S; counting sort by block.
@@ -466,23 +473,29 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     if (nblock64 >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many cameras");
     const int nblock = (int)nblock64;
     auto block_of = [ncam](int ja, int jb) { return (int)((int64_t)ja * ncam - (int64_t)ja * (ja - 1) / 2 + (jb - ja)); };
-    std::vector<int> blk_ptr((size_t)nblock + 1, 0);
-    int64_t npair = 0;
-    for (int i = 0; i < npt; ++i)
-        for (int a = pt_ptr[i]; a < pt_ptr[(size_t)i + 1]; ++a)
-            for (int b = a + 1; b < pt_ptr[(size_t)i + 1]; ++b) { blk_ptr[(size_t)block_of(pm_cam[a], pm_cam[b]) + 1]++; ++npair; }
-    if (npair >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
-    for (int b = 0; b < nblock; ++b) blk_ptr[(size_t)b + 1] += blk_ptr[b];
-    std::vector<int2> pairs((size_t)npair);
-    {
-        std::vector<int> bfill(blk_ptr.begin(), blk_ptr.end() - 1);
-        for (int i = 0; i < npt; ++i)
-            for (int a = pt_ptr[i]; a < pt_ptr[(size_t)i + 1]; ++a)
-                for (int b = a + 1; b < pt_ptr[(size_t)i + 1]; ++b) {
-                    int2 pr; pr.x = a; pr.y = b;
-                    pairs[(size_t)bfill[block_of(pm_cam[a], pm_cam[b])]++] = pr;
-                }
+    // The lists themselves are built on the device (structure_build.hip); the host only supplies the per-point offsets.
+    std::vector<long long> pair_off((size_t)npt + 1, 0);
+    for (int i = 0; i < npt; ++i) {
+        const long long n = pt_ptr[(size_t)i + 1] - pt_ptr[i];
+        pair_off[(size_t)i + 1] = pair_off[i] + n * (n - 1) / 2;
     }
+    if (pair_off[npt] >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
+    HIP_TRY(dev_upload(&p->d_pt_ptr, pt_ptr));
+    HIP_TRY(dev_upload(&p->d_obs_cam, pm_cam));
+    {
+        std::vector<int> both((size_t)2 * nobs);
+        std::copy(pm_pt.begin(), pm_pt.end(), both.begin());
+        std::copy(p->perm.begin(), p->perm.end(), both.begin() + nobs);
+        HIP_TRY(dev_upload(&p->d_obs_pt, both));
+        p->d_perm = p->d_obs_pt + nobs;
+    }
+    {
+        const int brc = build_pair_lists(p->stream, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pair_off, &p->d_pairs, &p->d_blk_ptr);
+        if (brc) return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc));
+    }
+    std::vector<int> blk_ptr((size_t)nblock + 1, 0);
+    HIP_TRY(hipMemcpy(blk_ptr.data(), p->d_blk_ptr, sizeof(int) * blk_ptr.size(), hipMemcpyDeviceToHost));
+    bt_mark("pair lists");
     std::vector<int2> blk_cams((size_t)nblock);
     for (int ja = 0; ja < ncam; ++ja)
         for (int jb = ja; jb < ncam; ++jb) { int2 c; c.x = ja; c.y = jb; blk_cams[(size_t)block_of(ja, jb)] = c; }
@@ -525,26 +538,16 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         wv_ptr.push_back(npt);
     }
 
+    bt_mark("maps");
     // ---- upload ----
-    HIP_TRY(dev_upload(&p->d_pt_ptr, pt_ptr));
-    HIP_TRY(dev_upload(&p->d_obs_cam, pm_cam));
     HIP_TRY(dev_upload(&p->d_cam_ptr, cam_ptr));
     HIP_TRY(dev_upload(&p->d_cam_obs, cam_obs));
     HIP_TRY(dev_upload(&p->d_cam_obs_pt, cam_obs_pt));
     HIP_TRY(dev_upload(&p->d_chunks, chunks));
-    HIP_TRY(dev_upload(&p->d_blk_ptr, blk_ptr));
-    HIP_TRY(dev_upload(&p->d_pairs, pairs));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
     HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
     HIP_TRY(dev_upload(&p->d_dup_blocks, dup_blocks));
     HIP_TRY(dev_upload(&p->d_pwg_ptr, wv_ptr));
-    {
-        std::vector<int> both((size_t)2 * nobs);
-        std::copy(pm_pt.begin(), pm_pt.end(), both.begin());
-        std::copy(p->perm.begin(), p->perm.end(), both.begin() + nobs);
-        HIP_TRY(dev_upload(&p->d_obs_pt, both));
-        p->d_perm = p->d_obs_pt + nobs;
-    }
     if (precision == SFMBA_PRECISION_F32J) {
         std::vector<float> xy((size_t)2 * nobs);
         for (int q = 0; q < nobs; ++q) { xy[2 * (size_t)q] = (float)obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = (float)obs_xy[2 * (size_t)p->perm[q] + 1]; }
@@ -558,6 +561,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         HIP_TRY(dev_upload(&d, xy));
         p->d_obs_xy = d;
     }
+    bt_mark("upload structure");
     std::vector<double> cam0((size_t)6 * ncam), pts0((size_t)3 * npt);
     for (int j = 0; j < ncam; ++j) std::memcpy(&cam0[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
     for (int i = 0; i < npt; ++i) std::memcpy(&pts0[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
@@ -577,6 +581,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     ds.ndupwg = (int)dup_blocks.size(); ds.dup_blocks = p->d_dup_blocks;
     ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr;
 
+    bt_mark("upload params");
     DeviceBuffers& db = p->db;
     for (int b = 0; b < 2; ++b) {
         HIP_TRY(dev_alloc(&db.cam[b], (size_t)6 * ncam));
@@ -617,8 +622,10 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
 
+    bt_mark("alloc buffers");
     rc = sfmba_problem_reset(p);
     if (rc) return rc;
+    bt_mark("reset");
     guard.p = nullptr;
     *out = p;
     return SFMBA_OK;

@@ -1,0 +1,107 @@
+// structure_build.hip -- device-side construction of the camera-pair lists of the Schur pass (gfx950).
+//
+// Counterpart of the reference's AddResidualBlock loop (SfMToyLib/SfMBundleAdjustmentUtils.cpp:142-166): the
+// reference hands every observation to ceres::Problem, whose SchurEliminator then walks the (camera, camera)
+// cross terms of each point.  Here those cross terms are enumerated ONCE per problem: every pair (qa < qb) of
+// observations of one point goes to block (cam(qa), cam(qb)) of the upper triangle of the reduced camera matrix.
+//
+// The list has N_pt * m(m-1)/2 entries (4.5 M at BASELINE config 3, 22.5 M at config 5); building it on the host
+// was 2/3 of the one-shot sfmba_solve() call.  On the device: one lane per observation writes its pairs in point order
+// with the block index as key, a stable LSD radix sort (hipCUB / rocPRIM) groups them by block, and a binary search
+// per block gives the CSR pointers.  Stability keeps the pairs of a block in ascending point order, so the summation
+// order of every S block -- and therefore every bit of the result -- is the same from run to run.
+#include "ba_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+namespace sfmba {
+
+namespace {
+
+__device__ __forceinline__ unsigned block_of(int ja, int jb, int ncam) {
+    return (unsigned)((long long)ja * ncam - (long long)ja * (ja - 1) / 2 + (jb - ja));
+}
+
+// One lane per observation a (point-major position): writes the pairs (a, b), b = a+1 .. end of the point.
+__global__ __launch_bounds__(256) void k_pair_gen(int nobs, int ncam, const int* __restrict__ pt_ptr, const int* __restrict__ obs_pt,
+                                                  const int* __restrict__ obs_cam, const long long* __restrict__ pair_off,
+                                                  unsigned* __restrict__ keys, unsigned long long* __restrict__ vals) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nobs) return;
+    const int i = obs_pt[a];
+    const int beg = pt_ptr[i], end = pt_ptr[i + 1];
+    const long long la = a - beg, n = end - beg;
+    long long o = pair_off[i] + la * (n - 1) - la * (la - 1) / 2;
+    const int ca = obs_cam[a];
+    for (int b = a + 1; b < end; ++b, ++o) {
+        keys[o] = block_of(ca, obs_cam[b], ncam);        // cameras ascend inside a point: ca <= cam(b)
+        vals[o] = (unsigned long long)(unsigned)a | ((unsigned long long)(unsigned)b << 32);   // == int2{a, b}
+    }
+}
+
+// blk_ptr[b] = first position whose key is >= b  (b = 0 .. nblock)
+__global__ void k_block_ptr(int nblock, int npair, const unsigned* __restrict__ keys, int* __restrict__ blk_ptr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nblock) return;
+    int lo = 0, hi = npair;
+    while (lo < hi) {
+        const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (keys[mid] < (unsigned)b) lo = mid + 1; else hi = mid;
+    }
+    blk_ptr[b] = lo;
+}
+
+}  // namespace
+
+// pair_off_host[i] = number of pairs of the points before i (npt + 1 entries).  On success *d_pairs (npair int2) and
+// *d_blk_ptr (nblock + 1 ints) are device allocations owned by the caller.  Returns 0, or a hipError_t value.
+int build_pair_lists(hipStream_t s, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt, const int* d_obs_cam,
+                     const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr) {
+    const long long npair = pair_off_host.empty() ? 0 : pair_off_host.back();
+    *d_pairs = nullptr; *d_blk_ptr = nullptr;
+    hipError_t e;
+    long long* d_off = nullptr;
+    unsigned *d_k0 = nullptr, *d_k1 = nullptr;
+    unsigned long long *d_v0 = nullptr, *d_v1 = nullptr;
+    void* d_tmp = nullptr;
+    auto cleanup = [&]() {
+        if (d_off) (void)hipFree(d_off);
+        if (d_k0) (void)hipFree(d_k0);
+        if (d_k1) (void)hipFree(d_k1);
+        if (d_v0) (void)hipFree(d_v0);
+        if (d_tmp) (void)hipFree(d_tmp);
+    };
+#define SB_TRY(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); if (d_v1) (void)hipFree(d_v1); if (*d_blk_ptr) (void)hipFree(*d_blk_ptr); *d_blk_ptr = nullptr; return (int)e; } } while (0)
+    const size_t np = (size_t)(npair > 0 ? npair : 1);
+    SB_TRY(hipMalloc(reinterpret_cast<void**>(d_blk_ptr), sizeof(int) * ((size_t)nblock + 1)));
+    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_v1), sizeof(unsigned long long) * np));
+    if (npair == 0) {
+        SB_TRY(hipMemsetAsync(*d_blk_ptr, 0, sizeof(int) * ((size_t)nblock + 1), s));
+        SB_TRY(hipStreamSynchronize(s));
+        *d_pairs = reinterpret_cast<int2*>(d_v1);
+        return 0;
+    }
+    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_off), sizeof(long long) * pair_off_host.size()));
+    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_k0), sizeof(unsigned) * np));
+    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_k1), sizeof(unsigned) * np));
+    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_v0), sizeof(unsigned long long) * np));
+    SB_TRY(hipMemcpyAsync(d_off, pair_off_host.data(), sizeof(long long) * pair_off_host.size(), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pair_gen, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, ncam, d_pt_ptr, d_obs_pt, d_obs_cam, d_off, d_k0, d_v0);
+    int end_bit = 1;
+    while (end_bit < 32 && ((unsigned long long)1 << end_bit) < (unsigned long long)nblock) ++end_bit;
+    size_t tmp_bytes = 0;
+    SB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
+    SB_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    SB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
+    hipLaunchKernelGGL(k_block_ptr, dim3((nblock + 1 + 255) / 256), dim3(256), 0, s, nblock, (int)npair, d_k1, *d_blk_ptr);
+    SB_TRY(hipGetLastError());
+    SB_TRY(hipStreamSynchronize(s));
+#undef SB_TRY
+    cleanup();
+    *d_pairs = reinterpret_cast<int2*>(d_v1);
+    return 0;
+}
+
+}  // namespace sfmba
