@@ -35,6 +35,9 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.sfmba_oracle_eval_residuals.restype = C.c_double
         _lib.sfmba_oracle_num_threads.restype = C.c_int
+        # The checker keeps one d x d accumulator per OpenMP thread; on a 256-thread host the default team makes small
+        # problems slower by orders of magnitude.  Cap it (bench.py's cpu_baseline sets its own count explicitly).
+        _lib.sfmba_oracle_set_num_threads(C.c_int(max(1, min(os.cpu_count() or 1, 16))))
     return _lib
 
 
