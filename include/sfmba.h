@@ -123,6 +123,10 @@ SFMBA_API int         sfmba_abi_version(void);
 SFMBA_API const char* sfmba_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime missing). */
 SFMBA_API int         sfmba_device_count(void);
+/* Device memory of destroyed problems is kept in a bounded cache (<= 8 GB) and handed to the next problem, so that the
+ * reference's call pattern -- adjustBundle() re-creating the problem after every added view, SfM.cpp:464-466 -- performs
+ * no hipMalloc/hipFree in steady state.  This returns the cached memory to HIP; the number of bytes released. */
+SFMBA_API long long   sfmba_release_cache(void);
 
 /*
  * One-shot solve == the ceres::Problem build + ceres::Solve of BA.cpp:109-179.

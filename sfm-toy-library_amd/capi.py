@@ -26,8 +26,13 @@ SYMBOLS = [
     "sfmba_dense_spd_solve", "sfmba_shard_begin", "sfmba_shard_reduce_len", "sfmba_shard_reduce_buf",
     "sfmba_shard_scalars_buf", "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish",
     "sfmba_shard_end", "sfmba_problem_set_profiling", "sfmba_problem_get_profile",
-    "sfmba_problem_create_sharded", "sfmba_shard_setup_finish", "sfmba_shard_setup_len", "sfmba_shard_setup_buf",
+    "sfmba_problem_create_sharded", "sfmba_shard_setup_finish", "sfmba_shard_setup_len", "sfmba_shard_setup_buf", "sfmba_release_cache",
 ]
+
+
+def release_cache():
+    """Return the device memory cached from destroyed problems to HIP; bytes released."""
+    return int(lib().sfmba_release_cache())
 
 
 class _KernelTime(C.Structure):
@@ -52,6 +57,7 @@ def lib():
         L.sfmba_shard_reduce_len.restype = C.c_int64
         L.sfmba_shard_setup_len.restype = C.c_int64
         L.sfmba_shard_setup_buf.restype = C.c_void_p
+        L.sfmba_release_cache.restype = C.c_longlong
         for name in ("sfmba_problem_reset", "sfmba_problem_set_params", "sfmba_problem_solve", "sfmba_problem_get_params",
                      "sfmba_problem_destroy", "sfmba_problem_stream", "sfmba_problem_reduced_dim",
                      "sfmba_problem_eval_residuals", "sfmba_problem_eval_jacobian", "sfmba_problem_build_reduced",

@@ -145,7 +145,8 @@ void launch_mirror_scale(hipStream_t s, const DeviceStructure& ds, const DeviceB
 
 
 // structure_build.hip: camera-pair lists of the Schur pass, built on the device (pair_off_host: npt + 1 prefix counts)
-int build_pair_lists(hipStream_t s, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt, const int* d_obs_cam,
-                     const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr);
+class DeviceArena;
+int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
+                     const int* d_obs_cam, const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr);
 
 }  // namespace sfmba

@@ -1,6 +1,7 @@
 // dense_solver.h -- dense SPD solve of the reduced camera system on the device.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "device_arena.h"
 #include "profiler.h"
 #include <vector>
 
@@ -26,9 +27,12 @@ struct DenseSolver {
     int* h_flags = nullptr;   // pinned host mirror
     volatile int* h_mailbox = nullptr;   // host-mapped {iterations, done}: polled instead of copy + synchronise
     int* d_mailbox = nullptr;
+    DeviceArena* arena = nullptr;   // when set, the device arrays above live in (and are released with) this arena
+    bool pinned_external = false;   // h_flags / h_mailbox are slices of the caller's pinned block
 };
 
-int  dense_solver_create(DenseSolver* ws, int d, int ld);
+// pinned: optional 128 bytes of pinned, host-mapped memory for {h_flags[4], pad, h_mailbox[16]} (else allocated here)
+int  dense_solver_create(DenseSolver* ws, int d, int ld, DeviceArena* arena = nullptr, char* pinned = nullptr);
 void dense_solver_destroy(DenseSolver* ws);
 
 // Padded leading dimension for a reduced system of dimension d (room for the augmented rhs row).

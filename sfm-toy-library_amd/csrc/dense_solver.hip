@@ -672,41 +672,58 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     return ws->h_flags[PF_ITERS];
 }
 
+template <typename T> static int ws_alloc(DenseSolver* ws, T** p, size_t bytes) {
+    if (ws->arena) { *p = static_cast<T*>(ws->arena->alloc(bytes)); return *p ? 0 : -1; }
+    return hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess ? 0 : -1;
+}
+
 int dense_pcg_ensure_workspace(DenseSolver* ws) {
     if (!ws->Sfull) {
-        if (hipMalloc(&ws->Sfull, sizeof(double) * (size_t)ws->d * ws->ld) != hipSuccess) return -1;
+        if (ws_alloc(ws, &ws->Sfull, sizeof(double) * (size_t)ws->d * ws->ld)) return -1;
     }
     return 0;
 }
 
-int dense_solver_create(DenseSolver* ws, int d, int ld) {
-    ws->d = d; ws->ld = ld;
+int dense_solver_create(DenseSolver* ws, int d, int ld, DeviceArena* arena, char* pinned) {
+    ws->d = d; ws->ld = ld; ws->arena = arena;
     const int nblk = ld / NB;
-    if (hipMalloc(&ws->minv, sizeof(double) * (size_t)nblk * NB * NB) != hipSuccess) return -1;
-    if (hipMalloc(&ws->y, sizeof(double) * ld) != hipSuccess) return -1;
-    if (hipMalloc(&ws->vec, sizeof(double) * 9 * (size_t)ld) != hipSuccess) return -1;
-    if (hipMalloc(&ws->part, sizeof(double) * 2 * PCG_PART) != hipSuccess) return -1;
-    if (hipMalloc(&ws->binv, sizeof(double) * 36 * (size_t)(ld / 6 + 2)) != hipSuccess) return -1;
-    if (hipMalloc(&ws->scal, sizeof(double) * 8) != hipSuccess) return -1;
-    if (hipMalloc(&ws->flags, sizeof(int) * 4) != hipSuccess) return -1;
-    if (hipHostMalloc(reinterpret_cast<void**>(&ws->h_flags), sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) return -1;
-    { void* hm = nullptr; if (hipHostMalloc(&hm, sizeof(int) * 16, hipHostMallocMapped) != hipSuccess) return -1; ws->h_mailbox = static_cast<volatile int*>(hm); }
+    if (ws_alloc(ws, &ws->minv, sizeof(double) * (size_t)nblk * NB * NB)) return -1;
+    if (ws_alloc(ws, &ws->y, sizeof(double) * ld)) return -1;
+    if (ws_alloc(ws, &ws->vec, sizeof(double) * 9 * (size_t)ld)) return -1;
+    if (ws_alloc(ws, &ws->part, sizeof(double) * 2 * PCG_PART)) return -1;
+    if (ws_alloc(ws, &ws->binv, sizeof(double) * 36 * (size_t)(ld / 6 + 2))) return -1;
+    if (ws_alloc(ws, &ws->scal, sizeof(double) * 8)) return -1;
+    if (ws_alloc(ws, &ws->flags, sizeof(int) * 4)) return -1;
+    if (pinned) {
+        ws->pinned_external = true;
+        ws->h_flags = reinterpret_cast<int*>(pinned);
+        ws->h_mailbox = reinterpret_cast<volatile int*>(pinned + 64);
+    } else {
+        if (hipHostMalloc(reinterpret_cast<void**>(&ws->h_flags), sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) return -1;
+        void* hm = nullptr;
+        if (hipHostMalloc(&hm, sizeof(int) * 16, hipHostMallocMapped) != hipSuccess) return -1;
+        ws->h_mailbox = static_cast<volatile int*>(hm);
+    }
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ws->d_mailbox), const_cast<int*>(ws->h_mailbox), 0) != hipSuccess) return -1;
     ws->Sfull = nullptr;
     return 0;
 }
 
 void dense_solver_destroy(DenseSolver* ws) {
-    if (ws->minv) (void)hipFree(ws->minv);
-    if (ws->y) (void)hipFree(ws->y);
-    if (ws->vec) (void)hipFree(ws->vec);
-    if (ws->part) (void)hipFree(ws->part);
-    if (ws->binv) (void)hipFree(ws->binv);
-    if (ws->scal) (void)hipFree(ws->scal);
-    if (ws->flags) (void)hipFree(ws->flags);
-    if (ws->h_flags) (void)hipHostFree(ws->h_flags);
-    if (ws->h_mailbox) (void)hipHostFree(const_cast<int*>(ws->h_mailbox));
-    if (ws->Sfull) (void)hipFree(ws->Sfull);
+    if (!ws->arena) {
+        if (ws->minv) (void)hipFree(ws->minv);
+        if (ws->y) (void)hipFree(ws->y);
+        if (ws->vec) (void)hipFree(ws->vec);
+        if (ws->part) (void)hipFree(ws->part);
+        if (ws->binv) (void)hipFree(ws->binv);
+        if (ws->scal) (void)hipFree(ws->scal);
+        if (ws->flags) (void)hipFree(ws->flags);
+        if (ws->Sfull) (void)hipFree(ws->Sfull);
+    }
+    if (!ws->pinned_external) {
+        if (ws->h_flags) (void)hipHostFree(ws->h_flags);
+        if (ws->h_mailbox) (void)hipHostFree(const_cast<int*>(ws->h_mailbox));
+    }
     *ws = DenseSolver();
 }
 

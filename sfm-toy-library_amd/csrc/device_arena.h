@@ -1,0 +1,56 @@
+// device_arena.h -- per-problem device memory arena with a process-wide chunk cache.
+//
+// A problem needs ~45 device arrays; hipMalloc/hipFree of each cost ~0.1-0.2 ms, which is 2/3 of a resident solve at
+// BASELINE config 3 and matters for the one-shot boundary (adjustBundle() re-creates the problem on every call,
+// SfMToyLib/SfM.cpp:464-466).  The arena carves the arrays out of a few large chunks; chunks of destroyed problems go
+// to a cache (bounded) and are handed to the next problem on the same device, so a steady stream of one-shot calls
+// performs no hipMalloc/hipFree at all.  sfmba_release_cache() (include/sfmba.h) returns the cached memory to HIP.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <vector>
+
+namespace sfmba {
+
+struct ArenaChunk {
+    char* base = nullptr;
+    size_t cap = 0;
+    int device = 0;
+};
+
+class DeviceArena {
+public:
+    explicit DeviceArena(int device = 0) : device_(device) {}
+    DeviceArena(const DeviceArena&) = delete;
+    DeviceArena& operator=(const DeviceArena&) = delete;
+    ~DeviceArena() { release(); }
+    void set_device(int device) { device_ = device; }
+    // 256-byte aligned block of `bytes` (>= 1); nullptr when the device allocation fails.
+    void* alloc(size_t bytes);
+    template <typename T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(sizeof(T) * (n ? n : 1))); }
+    // Returns every chunk to the cache (or to HIP when the cache is full).  All pointers handed out become invalid.
+    void release();
+    size_t bytes_reserved() const;
+
+private:
+    int device_;
+    std::vector<ArenaChunk> chunks_;
+    size_t off_ = 0;   // fill of chunks_.back()
+};
+
+// Host-side resources of a problem that are slow to create and destroy (a private non-blocking stream and one 4 KB
+// block of pinned, host-mapped memory for the LM state mirror and the mailboxes); recycled through the same cache.
+struct HostKit {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char* pinned = nullptr;            // HOSTKIT_PINNED_BYTES, hipHostMallocMapped
+};
+constexpr size_t HOSTKIT_PINNED_BYTES = 4096;
+bool hostkit_acquire(int device, HostKit* kit);     // false on HIP failure
+void hostkit_release(const HostKit& kit);           // the stream must be idle
+
+// Frees every cached chunk and host kit (all devices).  Returns the number of device bytes released.
+size_t arena_cache_release();
+
+}  // namespace sfmba

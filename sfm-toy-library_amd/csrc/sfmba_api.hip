@@ -12,6 +12,7 @@
 #include "../../include/sfmba.h"
 #include "ba_kernels.h"
 #include "dense_solver.h"
+#include "device_arena.h"
 #include "profiler.h"
 #include "sfmba_device.h"
 
@@ -57,7 +58,14 @@ const char* message_text(int id) {
     }
 }
 
-template <typename T> hipError_t dev_alloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1)); }
+// Device arrays of a problem come from its arena (set for the duration of create_impl); API-call temporaries from HIP.
+thread_local DeviceArena* t_arena = nullptr;
+struct ArenaScope { explicit ArenaScope(DeviceArena* a) { t_arena = a; } ~ArenaScope() { t_arena = nullptr; } };
+
+template <typename T> hipError_t dev_alloc(T** p, size_t n) {
+    if (t_arena) { *p = t_arena->alloc_n<T>(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+    return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1));
+}
 
 template <typename T> hipError_t dev_upload(T** p, const std::vector<T>& v) {
     hipError_t e = dev_alloc(p, v.size());
@@ -84,6 +92,8 @@ struct sfmba_problem {
     DeviceStructure ds = {};
     DeviceBuffers db = {};
     DenseSolver solver;
+    DeviceArena arena;                    // every device array below except db.trace
+    HostKit kit;                          // stream + pinned block (recycled)
     // owned device arrays behind ds
     int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
@@ -335,6 +345,8 @@ int sfmba_abi_version(void) { return SFMBA_ABI_VERSION; }
 
 const char* sfmba_last_error(void) { return g_last_error.c_str(); }
 
+long long sfmba_release_cache(void) { return (long long)arena_cache_release(); }
+
 int sfmba_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -346,15 +358,10 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     dense_solver_destroy(&p->solver);
-    void* frees[] = { p->d_pt_ptr, p->d_obs_cam, p->d_cam_ptr, p->d_cam_obs, p->d_cam_obs_pt, p->d_obs_pt, p->d_obs_xy, p->d_chunks,
-                      p->d_cam0, p->d_pts0, p->d_sys, p->d_info, p->d_blk_ptr, p->d_pairs, p->d_blk_cams, p->d_facc, p->d_pwg_blocks, p->d_pwg_ptr, p->d_dup_blocks, p->db.cam[0], p->db.cam[1], p->db.pts[0], p->db.pts[1],
-                      p->db.camtab[0], p->db.camtab[1], p->db.steptab, p->db.cscale, p->db.pscale, p->db.Y, p->db.Z, p->db.pt_t, p->db.pt_yf,
-                      p->db.st, p->db.trace };
-    for (void* f : frees) if (f) (void)hipFree(f);
+    if (p->db.trace) (void)hipFree(p->db.trace);
+    p->arena.release();
     p->prof.destroy();
-    if (p->h_state) (void)hipHostFree(p->h_state);
-    if (p->h_lm_mail) (void)hipHostFree(const_cast<int*>(p->h_lm_mail));
-    if (p->stream) (void)hipStreamDestroy(p->stream);
+    hostkit_release(p->kit);
     delete p;
 }
 
@@ -390,6 +397,8 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
 
     sfmba_problem* p = new sfmba_problem();
     p->device = device;
+    p->arena.set_device(device);
+    ArenaScope arena_scope(&p->arena);
     p->precision = precision;
     p->n_cam_full = n_cam; p->n_pt_full = n_pt; p->n_obs = n_obs;
     p->focal0 = p->focal = focal;
@@ -413,9 +422,11 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     for (int j = 0; j < n_cam; ++j) if (cam_slot[j] == 0) { cam_slot[j] = (int)p->acam_id.size(); p->acam_id.push_back(j); }
     for (int i = 0; i < n_pt; ++i) if (pt_slot[i] == 0) { pt_slot[i] = (int)p->apt_id.size(); p->apt_id.push_back(i); }
     const int ncam = (int)p->acam_id.size(), npt = (int)p->apt_id.size(), nobs = (int)n_obs;
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(LMState), hipHostMallocDefault));
-    { void* hm = nullptr; HIP_TRY(hipHostMalloc(&hm, 64, hipHostMallocMapped)); p->h_lm_mail = static_cast<volatile int*>(hm); }
+    static_assert(sizeof(LMState) <= 1024, "LMState must fit its slice of the pinned block");
+    if (!hostkit_acquire(device, &p->kit)) return fail(SFMBA_ERR_HIP, "stream / pinned memory creation failed");
+    p->stream = p->kit.stream;
+    p->h_state = reinterpret_cast<LMState*>(p->kit.pinned);                        // [0, 1024)
+    p->h_lm_mail = reinterpret_cast<volatile int*>(p->kit.pinned + 1024);          // [1024, 1088)
     if (nobs == 0 && !cam_active) {
         p->empty = true;
         guard.p = nullptr;
@@ -425,25 +436,43 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
 
     bt_mark("compaction+stream");
     std::vector<int> pt_ptr((size_t)npt + 1, 0);
-    for (int k = 0; k < nobs; ++k) pt_ptr[(size_t)pt_slot[obs_pt[k]] + 1]++;
-    for (int i = 0; i < npt; ++i) pt_ptr[(size_t)i + 1] += pt_ptr[i];
-    std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1);
     std::vector<int> pm_cam((size_t)nobs), pm_pt((size_t)nobs);
     p->perm.resize((size_t)nobs);
-    for (int k = 0; k < nobs; ++k) {
-        const int i = pt_slot[obs_pt[k]];
-        const int q = fill[i]++;
-        pm_cam[q] = cam_slot[obs_cam[k]];
-        pm_pt[q] = i;
-        p->perm[q] = k;
+    // adjustBundle() adds its residual blocks point-major with ascending view index (BA.cpp:142-166, std::map order):
+    // that input needs no sort, only the slot mapping.  Anything else goes through a counting sort.
+    bool presorted = true;
+    {
+        int prev_i = -1, prev_c = -1;
+        for (int k = 0; k < nobs; ++k) {
+            const int i = pt_slot[obs_pt[k]], c = cam_slot[obs_cam[k]];
+            if (i < prev_i || (i == prev_i && c < prev_c)) { presorted = false; break; }
+            pm_pt[k] = i; pm_cam[k] = c; p->perm[k] = k;
+            pt_ptr[(size_t)i + 1]++;
+            prev_i = i; prev_c = c;
+        }
     }
-    // ascending camera slot inside each point (stable insertion sort: segments are short)
-    for (int i = 0; i < npt; ++i) {
-        for (int a = pt_ptr[i] + 1; a < pt_ptr[(size_t)i + 1]; ++a) {
-            const int c = pm_cam[a], pk = p->perm[a];
-            int b = a - 1;
-            while (b >= pt_ptr[i] && pm_cam[b] > c) { pm_cam[b + 1] = pm_cam[b]; p->perm[b + 1] = p->perm[b]; --b; }
-            pm_cam[b + 1] = c; p->perm[b + 1] = pk;
+    if (presorted) {
+        for (int i = 0; i < npt; ++i) pt_ptr[(size_t)i + 1] += pt_ptr[i];
+    } else {
+        std::fill(pt_ptr.begin(), pt_ptr.end(), 0);
+        for (int k = 0; k < nobs; ++k) pt_ptr[(size_t)pt_slot[obs_pt[k]] + 1]++;
+        for (int i = 0; i < npt; ++i) pt_ptr[(size_t)i + 1] += pt_ptr[i];
+        std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1);
+        for (int k = 0; k < nobs; ++k) {
+            const int i = pt_slot[obs_pt[k]];
+            const int q = fill[i]++;
+            pm_cam[q] = cam_slot[obs_cam[k]];
+            pm_pt[q] = i;
+            p->perm[q] = k;
+        }
+        // ascending camera slot inside each point (stable insertion sort: segments are short)
+        for (int i = 0; i < npt; ++i) {
+            for (int a = pt_ptr[i] + 1; a < pt_ptr[(size_t)i + 1]; ++a) {
+                const int c = pm_cam[a], pk = p->perm[a];
+                int b = a - 1;
+                while (b >= pt_ptr[i] && pm_cam[b] > c) { pm_cam[b + 1] = pm_cam[b]; p->perm[b + 1] = p->perm[b]; --b; }
+                pm_cam[b + 1] = c; p->perm[b + 1] = pk;
+            }
         }
     }
     bt_mark("point-major sort");
@@ -490,7 +519,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         p->d_perm = p->d_obs_pt + nobs;
     }
     {
-        const int brc = build_pair_lists(p->stream, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pair_off, &p->d_pairs, &p->d_blk_ptr);
+        const int brc = build_pair_lists(p->stream, &p->arena, device, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pair_off, &p->d_pairs, &p->d_blk_ptr);
         if (brc) return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc));
     }
     std::vector<int> blk_ptr((size_t)nblock + 1, 0);
@@ -592,8 +621,9 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_alloc(&db.cscale, (size_t)6 * ncam));
     HIP_TRY(dev_alloc(&db.pscale, (size_t)3 * npt));
     const size_t ybytes = (size_t)nobs * YREC * (precision == SFMBA_PRECISION_F32J ? sizeof(float) : sizeof(double));
-    HIP_TRY(hipMalloc(&db.Y, ybytes));
-    HIP_TRY(hipMalloc(&db.Z, ybytes / 2));
+    db.Y = p->arena.alloc(ybytes);
+    db.Z = p->arena.alloc(ybytes / 2);
+    if (!db.Y || !db.Z) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
@@ -618,7 +648,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     db.pcg_F = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&db.lm_mailbox), const_cast<int*>(p->h_lm_mail), 0));
     db.trace = nullptr; db.trace_cap = 0;
-    if (dense_solver_create(&p->solver, ds.d, ds.ld)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
+    if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
 

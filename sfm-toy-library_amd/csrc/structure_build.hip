@@ -11,6 +11,7 @@
 // per block gives the CSR pointers.  Stability keeps the pairs of a block in ascending point order, so the summation
 // order of every S block -- and therefore every bit of the result -- is the same from run to run.
 #include "ba_kernels.h"
+#include "device_arena.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -56,51 +57,47 @@ __global__ void k_block_ptr(int nblock, int npair, const unsigned* __restrict__ 
 }  // namespace
 
 // pair_off_host[i] = number of pairs of the points before i (npt + 1 entries).  On success *d_pairs (npair int2) and
-// *d_blk_ptr (nblock + 1 ints) are device allocations owned by the caller.  Returns 0, or a hipError_t value.
-int build_pair_lists(hipStream_t s, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt, const int* d_obs_cam,
-                     const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr) {
+// *d_blk_ptr (nblock + 1 ints) live in `arena`; the sort's temporaries come from a scratch arena whose chunks go back to
+// the cache on return (the caller's next allocations pick them up).  Returns 0, or a hipError_t value.
+int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
+                     const int* d_obs_cam, const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr) {
     const long long npair = pair_off_host.empty() ? 0 : pair_off_host.back();
     *d_pairs = nullptr; *d_blk_ptr = nullptr;
     hipError_t e;
-    long long* d_off = nullptr;
-    unsigned *d_k0 = nullptr, *d_k1 = nullptr;
-    unsigned long long *d_v0 = nullptr, *d_v1 = nullptr;
-    void* d_tmp = nullptr;
-    auto cleanup = [&]() {
-        if (d_off) (void)hipFree(d_off);
-        if (d_k0) (void)hipFree(d_k0);
-        if (d_k1) (void)hipFree(d_k1);
-        if (d_v0) (void)hipFree(d_v0);
-        if (d_tmp) (void)hipFree(d_tmp);
-    };
-#define SB_TRY(expr) do { e = (expr); if (e != hipSuccess) { cleanup(); if (d_v1) (void)hipFree(d_v1); if (*d_blk_ptr) (void)hipFree(*d_blk_ptr); *d_blk_ptr = nullptr; return (int)e; } } while (0)
+    DeviceArena scratch(device);
+#define SB_TRY(expr) do { e = (expr); if (e != hipSuccess) return (int)e; } while (0)
+#define SB_ALLOC(ptr, ar, T, n) do { ptr = (ar)->alloc_n<T>(n); if (!ptr) return (int)hipErrorOutOfMemory; } while (0)
     const size_t np = (size_t)(npair > 0 ? npair : 1);
-    SB_TRY(hipMalloc(reinterpret_cast<void**>(d_blk_ptr), sizeof(int) * ((size_t)nblock + 1)));
-    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_v1), sizeof(unsigned long long) * np));
+    unsigned long long* d_v1 = nullptr;
+    SB_ALLOC(*d_blk_ptr, arena, int, (size_t)nblock + 1);
+    SB_ALLOC(d_v1, arena, unsigned long long, np);
+    *d_pairs = reinterpret_cast<int2*>(d_v1);
     if (npair == 0) {
         SB_TRY(hipMemsetAsync(*d_blk_ptr, 0, sizeof(int) * ((size_t)nblock + 1), s));
         SB_TRY(hipStreamSynchronize(s));
-        *d_pairs = reinterpret_cast<int2*>(d_v1);
         return 0;
     }
-    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_off), sizeof(long long) * pair_off_host.size()));
-    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_k0), sizeof(unsigned) * np));
-    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_k1), sizeof(unsigned) * np));
-    SB_TRY(hipMalloc(reinterpret_cast<void**>(&d_v0), sizeof(unsigned long long) * np));
+    long long* d_off = nullptr;
+    unsigned *d_k0 = nullptr, *d_k1 = nullptr;
+    unsigned long long* d_v0 = nullptr;
+    SB_ALLOC(d_off, &scratch, long long, pair_off_host.size());
+    SB_ALLOC(d_k0, &scratch, unsigned, np);
+    SB_ALLOC(d_k1, &scratch, unsigned, np);
+    SB_ALLOC(d_v0, &scratch, unsigned long long, np);
     SB_TRY(hipMemcpyAsync(d_off, pair_off_host.data(), sizeof(long long) * pair_off_host.size(), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pair_gen, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, ncam, d_pt_ptr, d_obs_pt, d_obs_cam, d_off, d_k0, d_v0);
     int end_bit = 1;
     while (end_bit < 32 && ((unsigned long long)1 << end_bit) < (unsigned long long)nblock) ++end_bit;
     size_t tmp_bytes = 0;
     SB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
-    SB_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    void* d_tmp = scratch.alloc(tmp_bytes ? tmp_bytes : 1);
+    if (!d_tmp) return (int)hipErrorOutOfMemory;
     SB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
     hipLaunchKernelGGL(k_block_ptr, dim3((nblock + 1 + 255) / 256), dim3(256), 0, s, nblock, (int)npair, d_k1, *d_blk_ptr);
     SB_TRY(hipGetLastError());
-    SB_TRY(hipStreamSynchronize(s));
+    SB_TRY(hipStreamSynchronize(s));      // the scratch arena must not be recycled before the sort has finished
 #undef SB_TRY
-    cleanup();
-    *d_pairs = reinterpret_cast<int2*>(d_v1);
+#undef SB_ALLOC
     return 0;
 }
 

@@ -134,3 +134,19 @@ def test_cfg3_reduced_system_blocks_against_bruteforce(capi, sfm, cfg3):
         blk = -np.einsum("nij,njk,nlk->il", Wa, Vinv[common], Wb)
         got = S[6 * ja:6 * ja + 6, 6 * jb:6 * jb + 6]
         assert np.abs(got - blk).max() <= 1e-9 * max(1.0, np.abs(blk).max())
+
+
+def test_one_shot_calls_recycle_device_memory(capi, sfm):
+    """adjustBundle() re-creates the problem on every call (SfM.cpp:464-466): repeated one-shot solves must give
+    identical results when their device arrays are carved out of recycled (dirty) arena chunks."""
+    prob = sfm.make_problem("cfg2")
+    capi.release_cache()
+    ref = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1))
+    other = sfm.make_problem("crazyhorse_like")
+    for _ in range(3):
+        capi.solve(other, capi.default_options(max_seconds=0.0))          # dirties the cached chunks with another problem
+        again = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1))
+        assert again[3]["final_cost"] == ref[3]["final_cost"] and again[3]["iterations"] == ref[3]["iterations"]
+        assert np.array_equal(again[0], ref[0]) and np.array_equal(again[1], ref[1])
+    assert capi.release_cache() > 0
+    assert capi.release_cache() == 0
