@@ -508,15 +508,18 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
     }
     double pq = (!INIT && tid < (int)gridDim.x) ? part[in * PCG_PART + tid] : 0.0;
     const double rr0 = INIT ? 0.0 : scal[PS_RR0];
-    double fv[PCG_RPW][PCG_CPL];
+    double2 fv[PCG_RPW][PCG_CPL / 2];          // 16-byte loads: lane takes columns 2*(lane + 64 m), +1
 #pragma unroll
     for (int k = 0; k < PCG_RPW; ++k) {
         const int row = row0 + w + 4 * k;
-        const double* Fr = F + (size_t)(row < row1 ? row : row0) * ld;
+        const double2* Fr = reinterpret_cast<const double2*>(F + (size_t)(row < row1 ? row : row0) * ld);
 #pragma unroll
-        for (int m = 0; m < PCG_CPL; ++m) {
-            const int c = lane + 64 * m;
-            fv[k][m] = (row < row1 && c < d) ? Fr[c] : 0.0;
+        for (int m = 0; m < PCG_CPL / 2; ++m) {
+            const int c2 = lane + 64 * m;
+            double2 v = make_double2(0.0, 0.0);
+            if (row < row1 && 2 * c2 < d) v = Fr[c2];
+            if (2 * c2 + 1 >= d) v.y = 0.0;                 // padding column: never multiply garbage
+            fv[k][m] = v;
         }
     }
     // ---- alpha, r_new, beta, p_new ----
@@ -574,9 +577,11 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         const int row = row0 + w + 4 * k;
         double sacc = 0.0;
 #pragma unroll
-        for (int m = 0; m < PCG_CPL; ++m) {
-            const int c = lane + 64 * m;
-            sacc += fv[k][m] * ((c < d) ? pl[c] : 0.0);
+        for (int m = 0; m < PCG_CPL / 2; ++m) {
+            const int c2 = lane + 64 * m;
+            double2 pv2 = (2 * c2 < d) ? reinterpret_cast<const double2*>(pl)[c2] : make_double2(0.0, 0.0);
+            if (2 * c2 + 1 >= d) pv2.y = 0.0;              // pl[d] is not written
+            sacc += fv[k][m].x * pv2.x + fv[k][m].y * pv2.y;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
