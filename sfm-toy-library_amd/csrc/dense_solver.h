@@ -27,6 +27,11 @@ struct DenseSolver {
     int* h_flags = nullptr;   // pinned host mirror
     volatile int* h_mailbox = nullptr;   // host-mapped {iterations, done}: polled instead of copy + synchronise
     int* d_mailbox = nullptr;
+    // persistent CG (one launch per solve): granule exchange buffers [2][2*ld], running epoch, timeout word
+    unsigned long long* gran = nullptr;
+    unsigned* tmo = nullptr;
+    unsigned epoch = 0;
+    int n_cu = 0;             // compute units of the device (persistent kernel needs one resident workgroup per row slab)
     DeviceArena* arena = nullptr;   // when set, the device arrays above live in (and are released with) this arena
     bool pinned_external = false;   // h_flags / h_mailbox are slices of the caller's pinned block
 };
@@ -51,5 +56,10 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev,
                     Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false);
 int dense_pcg_ensure_workspace(DenseSolver* ws);
+// Whole CG solve in ONE launch (k_pcg_persistent), asynchronous: nothing is waited for.  Requires the pretransformed
+// system (see above) and d <= 1280 with one workgroup per CU; returns false (nothing launched) when that does not
+// hold.  The iteration count is posted to ws->h_mailbox[0] (with h_mailbox[1] = 1) when the kernel ends; the solution
+// stays in transformed form for k_cam_update.
+bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof = nullptr);
 
 }  // namespace sfmba

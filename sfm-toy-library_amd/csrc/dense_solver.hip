@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 
 namespace sfmba {
 
@@ -594,6 +595,169 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent CG (d <= 1280, one workgroup per CU): the WHOLE solve in one launch.
+//
+// The launch-per-iteration kernel above costs one dependent-launch boundary (~1.4 us) plus one full re-read of S~ from
+// MALL (L2 does not survive the boundary) per iteration.  Here every workgroup keeps its 5 rows of S~ in registers for
+// the whole solve and the only per-iteration exchange is the vector q = S~ p (d doubles): published as 8-byte
+// {tag, half} granules with write-through (sc1) stores and gathered by every workgroup with relaxed agent-scope loads
+// until all tags carry the iteration's epoch (MI355X_MICROARCH.md "allgather" row, cdna_hip_programming.md Guideline
+// 16 form R2: the data is the flag, no fences).  alpha, beta, r, p and x are rebuilt redundantly by every workgroup
+// from the same q in the same summation order, so all workgroups take bit-identical convergence decisions and leave
+// the loop together.  Two granule buffers (iteration parity) make reuse safe: a workgroup can only overwrite its
+// iteration-k granules after it has gathered iteration k+1, which every other workgroup publishes only after it has
+// finished reading iteration k.  Spins are bounded; a timeout is reported through *info like a failed factorisation.
+//
+// MEASURED (MI355X, cfg 3, d = 1201): 6.7 us per CG iteration inside this kernel vs 5.7 us kernel + 1.4 us boundary for
+// the launch-per-iteration path -- the gather costs two to three sc1 round trips of ~1.5 us each; end to end the solve
+// is 2.7 % SLOWER than with per-iteration launches (2405 vs 2475 LM iterations/s).  A single polling wave per
+// workgroup is 2.5x slower still.  The path is therefore OFF by default (SFMBA_PCG_PERSISTENT=1 selects it); it is
+// kept, with a parity test, as the measured alternative.
+constexpr int PCG_GPT = 10;                    // granules per thread per sweep (256 * 10 >= 2 d)
+constexpr unsigned PCG_SPIN_LIMIT = 1u << 22;
+
+__global__ __launch_bounds__(256) void k_pcg_persistent(int d, int ld, const double* __restrict__ F, const double* __restrict__ bt,
+                                                        double* __restrict__ vec, unsigned long long* gran, unsigned epoch0,
+                                                        int max_iters, double tol2, int rows_per_wg, int* flags, int* info,
+                                                        int* mailbox, unsigned* tmo) {
+    extern __shared__ __align__(16) double sm[];
+    double* pl = sm;                 // [ld] search direction
+    double* ql = sm + ld;            // [ld] q = S~ p of the current iteration
+    double* red = sm + 2 * ld;       // [8]
+    int* bail = reinterpret_cast<int*>(sm + 2 * ld + 8);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = blockIdx.x * rows_per_wg;
+    const int row1 = min(d, row0 + rows_per_wg);
+    if (tid == 0) *bail = 0;
+
+    // rows of S~ owned by this wave: registers for the whole solve
+    double2 fv[PCG_RPW][PCG_CPL / 2];
+#pragma unroll
+    for (int k = 0; k < PCG_RPW; ++k) {
+        const int row = row0 + w + 4 * k;
+        const double2* Fr = reinterpret_cast<const double2*>(F + (size_t)(row < row1 ? row : row0) * ld);
+#pragma unroll
+        for (int m = 0; m < PCG_CPL / 2; ++m) {
+            const int c2 = lane + 64 * m;
+            double2 v = make_double2(0.0, 0.0);
+            if (row < row1 && 2 * c2 < d) v = Fr[c2];
+            if (2 * c2 + 1 >= d) v.y = 0.0;
+            fv[k][m] = v;
+        }
+    }
+    // x0 = 0, r0 = p0 = b~
+    double rv[PCG_EPT], pv[PCG_EPT], xv[PCG_EPT];
+    double rr = 0.0, dummy = 0.0;
+#pragma unroll
+    for (int m = 0; m < PCG_EPT; ++m) {
+        const int e = tid + 256 * m;
+        rv[m] = (e < d) ? bt[e] : 0.0;
+        pv[m] = rv[m]; xv[m] = 0.0;
+        rr += rv[m] * rv[m];
+        if (e < ld) pl[e] = rv[m];
+    }
+    block_sum2(rr, dummy, red);
+    const double rr0 = rr;
+    double* x_out = pcg_vec(vec, 0, 0, ld);
+    int it = 0;
+    bool broke = false, timed_out = false;
+    if (rr0 > 0.0) {
+        for (it = 1;; ++it) {
+            __syncthreads();                                   // pl complete
+            const unsigned tag = epoch0 + (unsigned)it;
+            unsigned long long* gb = gran + (size_t)(it & 1) * 2 * ld;
+            // ---- q = S~ p for the rows of this workgroup; publish ----
+#pragma unroll
+            for (int k = 0; k < PCG_RPW; ++k) {
+                const int row = row0 + w + 4 * k;
+                double sacc = 0.0;
+#pragma unroll
+                for (int m = 0; m < PCG_CPL / 2; ++m) {
+                    const int c2 = lane + 64 * m;
+                    double2 pv2 = (2 * c2 < d) ? reinterpret_cast<const double2*>(pl)[c2] : make_double2(0.0, 0.0);
+                    if (2 * c2 + 1 >= d) pv2.y = 0.0;
+                    sacc += fv[k][m].x * pv2.x + fv[k][m].y * pv2.y;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+                if (lane < 2 && row < row1) {                  // lane 0: low half, lane 1: high half -- one aligned 8-byte store each
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
+                    const unsigned half = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+                    __hip_atomic_store(gb + 2 * row + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            // ---- gather all of q ----
+            unsigned gv[PCG_GPT];
+            unsigned spins = 0;
+            bool failed = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < PCG_GPT; ++k) {
+                    const int g = tid + 256 * k;
+                    if (g < 2 * d) {
+                        const unsigned long long x = __hip_atomic_load(gb + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gv[k] = (unsigned)x;
+                        ok &= (unsigned)(x >> 32) == tag;
+                    } else gv[k] = 0u;
+                }
+                if (__all(ok)) break;
+                ++spins;
+                if (spins > PCG_SPIN_LIMIT || ((spins & 255u) == 0u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch0)) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (failed) {
+                if (lane == 0) { __hip_atomic_store(tmo, epoch0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *bail = 1; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PCG_GPT; ++k) {
+                    const unsigned hi = __shfl_xor(gv[k], 1, 64);            // odd lane holds the high half of the even lane's element
+                    const int e = (tid + 256 * k) >> 1;
+                    if ((lane & 1) == 0 && e < d) ql[e] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | gv[k]));
+                }
+            }
+            __syncthreads();
+            if (*bail) { timed_out = true; break; }
+            // ---- alpha, x, r, beta, p (identical in every workgroup) ----
+            double qv[PCG_EPT];
+            double pq = 0.0;
+#pragma unroll
+            for (int m = 0; m < PCG_EPT; ++m) {
+                const int e = tid + 256 * m;
+                qv[m] = (e < d) ? ql[e] : 0.0;
+                pq += pv[m] * qv[m];
+            }
+            block_sum2(pq, dummy, red);
+            const double alpha = rr / pq;
+            double rrn = 0.0;
+#pragma unroll
+            for (int m = 0; m < PCG_EPT; ++m) { xv[m] += alpha * pv[m]; rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
+            block_sum2(rrn, dummy, red);
+            broke = !(pq > 0.0) || !(rrn == rrn);
+            if (rrn <= tol2 * rr0 || broke || it >= max_iters) break;
+            const double beta = rrn / rr;
+            rr = rrn;
+#pragma unroll
+            for (int m = 0; m < PCG_EPT; ++m) {
+                const int e = tid + 256 * m;
+                pv[m] = rv[m] + beta * pv[m];
+                if (e < d) pl[e] = pv[m];
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; if (e < d) x_out[e] = xv[m]; }
+        if (tid == 0) {
+            flags[PF_DONE] = 1; flags[PF_ITERS] = it; flags[PF_XBUF] = 0;
+            if (broke) atomicCAS(info, 0, d + 1);
+            if (timed_out) atomicCAS(info, 0, d + 2);
+            if (mailbox) pcg_post(mailbox, it, 1);
+        }
+    }
+}
+
 // solution of the original system: z = Lb^-T x~
 __global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, const double* __restrict__ linv, const int* flags,
                              double* __restrict__ z) {
@@ -682,7 +846,44 @@ template <typename T> static int ws_alloc(DenseSolver* ws, T** p, size_t bytes) 
     return hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess ? 0 : -1;
 }
 
+bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof) {
+    const int ld = ws->ld, d = ws->d;
+    if (dense_pcg_ensure_workspace(ws)) return false;
+    const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
+    const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
+    const bool fits = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && 2 * d <= 256 * PCG_GPT && rows_per_wg <= 4 * PCG_RPW;
+    if (!fits || !ws->gran) return false;
+    if (ws->n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); ws->n_cu = -1; }
+        else ws->n_cu = prop.multiProcessorCount;
+    }
+    if (nwg > ws->n_cu) return false;            // every workgroup must be resident for the in-kernel exchange
+    if (max_iters <= 0) max_iters = 4 * d;
+    if (ws->epoch > 0xE0000000u) {               // tag space nearly used up: start over with clean buffers
+        (void)hipMemsetAsync(ws->gran, 0, sizeof(unsigned long long) * 4 * (size_t)ld, s);
+        (void)hipMemsetAsync(ws->tmo, 0, sizeof(unsigned), s);
+        ws->epoch = 0;
+    }
+    const unsigned epoch0 = ws->epoch + 1;       // tags epoch0 + 1 .. epoch0 + max_iters; tmo marker = epoch0
+    ws->epoch = epoch0 + (unsigned)max_iters + 1;
+    if (ws->h_mailbox) { ws->h_mailbox[0] = -1; ws->h_mailbox[1] = 0; }
+    const size_t lds = sizeof(double) * (size_t)(2 * ld + 16);
+    double* bt = ws->vec + (size_t)8 * ld;
+    ProfScope ps(prof, KID_PCG_ITER, s);
+    hipLaunchKernelGGL(k_pcg_persistent, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, bt, ws->vec, ws->gran, epoch0, max_iters, tol * tol,
+                       rows_per_wg, ws->flags, info_dev, ws->d_mailbox, ws->tmo);
+    return true;
+}
+
 int dense_pcg_ensure_workspace(DenseSolver* ws) {
+    if (!ws->gran) {
+        if (ws_alloc(ws, &ws->gran, sizeof(unsigned long long) * 4 * (size_t)ws->ld)) return -1;
+        if (ws_alloc(ws, &ws->tmo, 256)) return -1;
+        if (hipMemset(ws->gran, 0, sizeof(unsigned long long) * 4 * (size_t)ws->ld) != hipSuccess) return -1;
+        if (hipMemset(ws->tmo, 0, 256) != hipSuccess) return -1;
+        ws->epoch = 0;
+    }
     if (!ws->Sfull) {
         if (ws_alloc(ws, &ws->Sfull, sizeof(double) * (size_t)ws->d * ws->ld)) return -1;
     }
@@ -724,6 +925,8 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->scal) (void)hipFree(ws->scal);
         if (ws->flags) (void)hipFree(ws->flags);
         if (ws->Sfull) (void)hipFree(ws->Sfull);
+        if (ws->gran) (void)hipFree(ws->gran);
+        if (ws->tmo) (void)hipFree(ws->tmo);
     }
     if (!ws->pinned_external) {
         if (ws->h_flags) (void)hipHostFree(ws->h_flags);

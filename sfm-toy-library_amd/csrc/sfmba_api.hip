@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -216,6 +217,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
+    const char* pcg_env = std::getenv("SFMBA_PCG_PERSISTENT");
+    const bool persistent_cg = pcg_env && pcg_env[0] == '1';     // measured slower than per-iteration launches: opt-in
     int launched_controls = 0;
     std::vector<int> lin_hist;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
@@ -242,12 +245,18 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db, 0); }
         }
         DeviceBuffers dbu = p->db;
+        bool pcg_async = false;
         if (pcg) {
-            const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
-                                           /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true);
-            if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
-            sum.linear_iters += it;
-            lin_hist.push_back(it);
+            // opt-in: one persistent launch for the whole CG solve when the reduced system fits (d <= 1280); its iteration
+            // count is read from the solver's mailbox after this LM iteration's control post
+            pcg_async = persistent_cg && dense_pcg_solve_persistent(p->stream, &p->solver, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof);
+            if (!pcg_async) {
+                const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
+                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true);
+                if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+                sum.linear_iters += it;
+                lin_hist.push_back(it);
+            }
             dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
         } else {
             dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, prof);
@@ -270,11 +279,17 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 rc = download_state(p);
                 if (rc) return rc;
                 host_iter = p->h_state->iter;
-                if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; break; }
+                if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; }
             } else {
                 host_iter = mb[3];
-                if (mb[1] != -1) { term = mb[1]; msg = mb[2]; break; }
+                if (mb[1] != -1) { term = mb[1]; msg = mb[2]; }
             }
+            if (pcg_async) {      // posted before k_lm_control ran (same stream)
+                const int it = p->solver.h_mailbox[1] != 0 ? p->solver.h_mailbox[0] : 0;
+                sum.linear_iters += it;
+                lin_hist.push_back(it);
+            }
+            if (term != -1) break;
         }
         if (o.verbose) {
             rc = download_state(p);

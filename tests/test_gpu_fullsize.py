@@ -152,3 +152,21 @@ def test_one_shot_calls_recycle_device_memory(capi, sfm):
         assert np.allclose(again[0], ref[0], rtol=0, atol=1e-9) and np.allclose(again[1], ref[1], rtol=0, atol=1e-9)
     assert capi.release_cache() > 0
     assert capi.release_cache() == 0
+
+
+def test_persistent_cg_kernel_matches_launch_per_iteration(capi, sfm, cfg3, monkeypatch):
+    """SFMBA_PCG_PERSISTENT=1: the whole CG solve in one launch (in-kernel granule exchange between workgroups)."""
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SFMBA_PCG_PERSISTENT", mode)
+        for prob, prec in ((cfg3, 1), (sfm.make_problem("cfg2"), 0)):
+            with capi.Problem(prob, precision=prec) as P:
+                s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=prec, linear_solver=1, pcg_tolerance=1e-10))
+                out[(mode, prob.n_cam)] = (s, tr)
+    for n_cam in (cfg3.n_cam, 20):
+        a, b = out[("0", n_cam)], out[("1", n_cam)]
+        assert a[0]["termination_name"] == b[0]["termination_name"] == "CONVERGENCE"
+        assert a[0]["iterations"] == b[0]["iterations"]
+        assert abs(a[0]["final_cost"] - b[0]["final_cost"]) <= 1e-10 * a[0]["final_cost"]
+        # same CG iteration counts per LM iteration (identical arithmetic up to summation order)
+        assert [abs(x["linear_iters"] - y["linear_iters"]) <= 1 for x, y in zip(a[1], b[1])] == [True] * len(a[1])
