@@ -335,13 +335,15 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
     nb = 64
     nblk = (d + 1 + nb - 1) // nb
     return {
-        "point_build": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_obs * yrec + n_pt * (24 + 24 + 48 + 4),
-                        "note": "reads obs (cam idx + xy), points, scales; writes one packed record per obs + per-point t, y_f"},
-        "schur_pairs": {"bound": "hbm", "bytes": n_obs * yrec + 8 * npair + 8 * d * d // 2,
-                        "note": "reads every record once and the pair list once, writes the upper triangle of S once "
-                                "(each record is in fact gathered ~k-1 times from L2/MALL: non-algorithmic re-reads)"},
-        "cam_diag": {"bound": "hbm", "bytes": n_obs * (8 + 2 * t + yrec) + n_pt * 48,
-                     "note": "reads camera-major index lists, obs, records, per-point t / y_f"},
+        "point_build": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_obs * (yrec + yrec // 2) + n_pt * (24 + 24 + 48 + 4),
+                        "note": "reads obs (cam idx + xy), points, scales; writes one packed record (16 values) and one side "
+                                "record (8 values) per obs + per-point t, y_f"},
+        "schur_pairs": {"bound": "hbm", "bytes": n_obs * yrec + 8 * npair + 8 * d * d,
+                        "note": "reads every record once and the pair list once, writes the preconditioned reduced matrix S~ "
+                                "(both triangles) once (each record is in fact gathered ~k-1 times from L2/MALL: non-algorithmic "
+                                "re-reads; the measured ceiling for random 64-B lines is ~80 G lines/s)"},
+        "cam_diag": {"bound": "hbm", "bytes": n_obs * (4 + yrec + yrec // 2),
+                     "note": "reads the camera-major index list and, per observation, its packed record and side record"},
         "point_update": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_pt * (24 + 24 + 24 + 4),
                          "note": "reads obs, points, scales; writes trial points"},
         "pcg_iter": {"bound": "hbm", "bytes": 8 * d * d + 9 * 8 * d,

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the evidence set of a round -> gpurun_out/evidence/ ; copy what is to be judged into profiles/.
+#   tools/collect_evidence.sh <tag>       e.g. r01_c
+set -u
+TAG=${1:-rXX}
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out/evidence
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py"
+# 1. the bench line itself (with cpu_baseline), PCG (default) and the exact Cholesky path
+$BENCH > $OUT/${TAG}_cfg3_pcg_bench.json 2> $OUT/bench_pcg.err
+$BENCH --linear cholesky --no-cpu-baseline > $OUT/${TAG}_cfg3_cholesky_bench.json 2> $OUT/bench_chol.err
+# 2. rocprofv3 kernel statistics of the same command
+for lin in pcg cholesky; do
+  rm -rf $OUT/stats_$lin
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$lin -- $BENCH --linear $lin --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/stats_$lin.err
+  python $REPO/tools/rocprof_summary.py $OUT/stats_$lin $OUT/${TAG}_cfg3_${lin}_kernel_stats.txt "$TAG: bench.py --linear $lin --steps 10 --warmup 2 (cfg3, f32j) under rocprofv3 --kernel-trace --stats" > /dev/null
+done
+# 3. HBM-side traffic: separate PMC passes, no trace domains besides --kernel-trace
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/pmc_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$c.err
+done
+python $REPO/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_pmc_traffic.txt "python bench.py --steps 2 --warmup 1 --no-cpu-baseline   (cfg3, f32j, PCG)" > /dev/null
+# keep the merge-back small
+rm -rf $OUT/stats_pcg $OUT/stats_cholesky $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+ls -la $OUT
