@@ -10,7 +10,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(path)):
             if r.get("Counter_Name") != counter:
                 continue
-            name = r["Kernel_Name"].split("(")[0]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             acc[name] += float(r["Counter_Value"]); cnt[name] += 1
     return {k: acc[k] / cnt[k] for k in acc}
 
