@@ -358,7 +358,8 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
                              "(8 d^2 bytes) + the x/r/p/q vectors; launch/latency bound (d = %d): the matrix is re-read from "
                              "L2/MALL every launch because L2 does not survive the kernel boundary" % d},
         "chol_update": {"bound": "mfma", "flops": 2.0 * d * d * d / 3.0 / max(nblk - 1, 1), "peak_tflops": 78.6,
-                        "note": "fp64 trailing update; d^3/3 flops of the factorisation spread over its launches; peak = fp64 matrix 78.6 TF"},
+                        "note": "fp64 trailing update on v_mfma_f64_16x16x4_f64; d^3/3 flops of the factorisation spread over its launches; "
+                                "peak = fp64 matrix 78.6 TF (171 tiles of 64^3 at most: latency bound, not MFMA bound)"},
         "chol_panel": {"bound": "mfma", "flops": 2.0 * d * nb * nb / 2.0, "peak_tflops": 78.6,
                        "note": "64-wide panel: diagonal factor + triangular solves (latency bound, not MFMA bound)"},
     }

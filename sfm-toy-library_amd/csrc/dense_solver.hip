@@ -131,6 +131,13 @@ __global__ __launch_bounds__(256, 1) void k_chol_panel(double* __restrict__ A, i
 // ------------------------------------------------------------------------------------------
 // trailing update: A_ij -= L_ik L_jk^T  for k < j <= i
 // ------------------------------------------------------------------------------------------
+// One 64x64 tile per workgroup, one 32x32 quadrant per wave on the fp64 matrix cores:
+// v_mfma_f64_16x16x4_f64, D[m][n] += sum_k Aop[m][k] Bop[k][n] with Aop[m = lane&15][k = lane>>4], Bop[k = lane>>4][n = lane&15]
+// and D held as 4 doubles per lane at (m = (lane>>4) + 4*reg, n = lane&15)  (cdna_hip_programming.md, fragment layout).
+// The product is formed transposed -- m runs over the tile's COLUMNS (rows of L_jk), n over its ROWS (rows of L_ik) --
+// so that the 16 lanes sharing a register index write 16 consecutive rows of the column-major matrix (128 B).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, int k) {
     __shared__ double Li[NB][NB + 1];
     __shared__ double Lj[NB][NB + 1];
@@ -147,28 +154,34 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
         Lj[r][c] = AT(jb + r, kb + c);
     }
     __syncthreads();
-    const int tr = tid % 16, tc = tid / 16;
-    double acc[4][4];
+    const int lane = tid & 63, w = tid >> 6;
+    const int rbase = 32 * (w & 1), cbase = 32 * (w >> 1);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    mfma_d4 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int kk = 0; kk < NB; ++kk) {
-        double li[4], lj[4];
+        for (int b = 0; b < 2; ++b) acc[a][b] = (mfma_d4){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll 4
+    for (int kk = 0; kk < NB; kk += 4) {
+        double av[2], bv[2];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { li[a] = Li[tr + 16 * a][kk]; lj[a] = Lj[tc + 16 * a][kk]; }
+        for (int a = 0; a < 2; ++a) { av[a] = Lj[cbase + 16 * a + l15][kk + l4]; bv[a] = Li[rbase + 16 * a + l15][kk + l4]; }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += li[a] * lj[b];
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int r = tr + 16 * a, c = tc + 16 * b;
-            if (ib + r >= jb + c) AT(ib + r, jb + c) -= acc[a][b];
-        }
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = cbase + 16 * a + l4 + 4 * v;      // m: column of the tile
+                const int r = rbase + 16 * b + l15;             // n: row of the tile
+                if (ib + r >= jb + c) AT(ib + r, jb + c) -= acc[a][b][v];
+            }
 }
 
 // rhs -> augmented row d (row-major column d); padded diagonal is already 1
