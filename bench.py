@@ -39,7 +39,7 @@ def parse():
                     help="reduced-system solver: pcg = block-Jacobi PCG on the dense reduced system (north_star), "
                          "cholesky = DENSE_SCHUR-equivalent exact factorisation (reference configuration)")
     ap.add_argument("--precision", default="f32j", choices=["f32j", "f64"])
-    ap.add_argument("--pcg-tol", type=float, default=1e-6)
+    ap.add_argument("--pcg-tol", type=float, default=1e-8, help="CG tolerance (library default 1e-8, anchored to the first LM iteration)")
     ap.add_argument("--mode", default="independent", choices=["independent", "sharded"],
                     help="N > 1: 'independent' = one whole problem per GPU (weak scaling, no data-path collective; the default the "
                          "driver runs); 'sharded' = ONE problem with its points sharded over the ranks and the reduced camera "

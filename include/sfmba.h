@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SFMBA_ABI_VERSION 1
+#define SFMBA_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define SFMBA_API __attribute__((visibility("default")))
@@ -52,7 +52,9 @@ enum {
 };
 
 enum { SFMBA_LINEAR_CHOLESKY = 0,   /* exact Schur + dense LLT == DENSE_SCHUR (BA.cpp:172) */
-       SFMBA_LINEAR_PCG      = 1 }; /* exact Schur + block-Jacobi PCG on the dense reduced system */
+       SFMBA_LINEAR_PCG      = 1,   /* exact Schur + block-Jacobi PCG on the dense reduced system */
+       SFMBA_LINEAR_AUTO     = 2 }; /* the shim's choice: CHOLESKY while the reduced system is small (<= 256 unknowns: a handful of
+                                       panels, exact), PCG above (parameters agree with the exact solve to ~2e-7, cost to 1e-12) */
 
 enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
        SFMBA_PRECISION_F32J = 1 };  /* fp32 Jacobian blocks, fp64 residual/cost and accumulation */
@@ -82,9 +84,12 @@ typedef struct sfmba_options {
     int    max_consecutive_invalid_steps; /* 5 */
     int    linear_solver;             /* SFMBA_LINEAR_* */
     int    precision;                 /* SFMBA_PRECISION_* */
-    double pcg_tolerance;             /* relative residual for SFMBA_LINEAR_PCG (1e-6: final cost within ~1e-11 of the exact solve on cfg 3) */
+    double pcg_tolerance;             /* CG residual tolerance (1e-8) */
     int    pcg_max_iters;             /* 0 = 4*dim */
     int    verbose;                   /* 0 silent (BA.cpp:177), 1 per-iteration lines on stderr */
+    int    pcg_anchored;              /* 1: inside an LM solve the CG tolerance is anchored to the FIRST iteration's right-hand side,
+                                         |r| <= tol * max(|b_k|, |b_first|), never looser than 1e-4 |b_k| -- every LM step is then solved
+                                         to the same ABSOLUTE accuracy (dense_solver.hip).  0: plain relative residual. */
 } sfmba_options;
 
 typedef struct sfmba_summary {

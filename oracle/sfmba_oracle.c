@@ -1063,9 +1063,10 @@ ORACLE_API void sfmba_oracle_options_default(sfmba_options* o) {
     o->max_consecutive_invalid_steps = 5;
     o->linear_solver = SFMBA_LINEAR_CHOLESKY;
     o->precision = SFMBA_PRECISION_F64;
-    o->pcg_tolerance = 1e-6;
+    o->pcg_tolerance = 1e-8;
     o->pcg_max_iters = 0;
     o->verbose = 0;
+    o->pcg_anchored = 1;
 }
 
 /* OMP_NUM_THREADS is read once when libgomp initialises (torch may have done that already), so the

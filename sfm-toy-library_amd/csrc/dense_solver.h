@@ -54,12 +54,14 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 // finish = false leaves the solution in transformed form (x~, see dense_solver.hip) for k_cam_update;
 // hist_key >= 0 selects the history slot used to size the first batch of launches.
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev,
-                    Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false);
+                    Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false, int anchor = 0);
+// anchor: 0 = relative residual |r| <= tol |b~|; 1 = first solve of an LM run (remembers |b~|); 2 = later solve of the
+// same run: |r| <= tol * max(|b~|, |b~_first|), but never looser than max(tol, 1e-4) relative (see dense_solver.hip)
 int dense_pcg_ensure_workspace(DenseSolver* ws);
 // Whole CG solve in ONE launch (k_pcg_persistent), asynchronous: nothing is waited for.  Requires the pretransformed
 // system (see above) and d <= 1280 with one workgroup per CU; returns false (nothing launched) when that does not
 // hold.  The iteration count is posted to ws->h_mailbox[0] (with h_mailbox[1] = 1) when the kernel ends; the solution
 // stays in transformed form for k_cam_update.
-bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof = nullptr);
+bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof = nullptr, int anchor = 0);
 
 }  // namespace sfmba

@@ -267,7 +267,20 @@ constexpr int PCG_MAXWG = 256;        // workgroups of the fast path (one partia
 constexpr int PCG_MAXWG_BIG = 1024;   // workgroups of the generic path
 constexpr int PCG_PART = 1024;        // stride of the two partial-dot-product buffers
 enum { PF_DONE = 0, PF_ITERS = 1, PF_XBUF = 2 };
-enum { PS_RR0 = 0 };
+enum { PS_RR0 = 0, PS_RRF = 1 };     // threshold base of the running solve; |b~|^2 of the FIRST solve of an anchored sequence
+
+// Stopping rule: |r|^2 <= tol^2 * base.  Plain CG: base = |b~|^2 (relative residual).  Inside one LM solve the
+// tolerance is ANCHORED to the first iteration's right-hand side: base = min(max(|b~_k|^2, |b~_first|^2), cap * |b~_k|^2).
+// Why: the error a truncated solve leaves in the PARAMETERS is ~ cond * |r|, absolute -- the first LM step is orders of
+// magnitude larger than the later ones, so a relative tolerance spends its iterations on the small steps and leaves
+// the big step's error (drift along the gauge directions, 1e-4 at tol 1e-6) in the result.  Anchored, every step is
+// solved to the same absolute accuracy; cap keeps every solve at least 1e-4 relative (the accept/reject and
+// function-tolerance decisions of the LM loop are insensitive well beyond that).
+__device__ __forceinline__ double pcg_threshold_base(double rr, double* scal, int anchor, double cap) {
+    if (anchor == 1) { scal[PS_RRF] = rr; return rr; }
+    if (anchor == 2) return fmin(fmax(rr, scal[PS_RRF]), cap * rr);
+    return rr;
+}
 // vec layout: x[2] r[2] p[2] q[2], each ld doubles; btilde after them
 __device__ __forceinline__ double* pcg_vec(double* vec, int which, int buf, int ld) { return vec + (size_t)(2 * which + buf) * ld; }
 
@@ -395,7 +408,7 @@ __device__ __forceinline__ void pcg_post(int* mailbox, int iters, int done) {
 template <bool INIT>
 __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
                                                   const double* __restrict__ bt, double* __restrict__ part, double* scal,
-                                                  int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox) {
+                                                  int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap) {
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;            // [ld] new search direction
     double* red = sm + ld;      // [8]
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* _
         block_sum2(rr, dummy, red);
         for (int e = row0 + tid; e < row1; e += 256) { x_out[e] = 0.0; r_out[e] = pl[e]; p_out[e] = pl[e]; }
         if (blockIdx.x == 0 && tid == 0) {
-            scal[PS_RR0] = rr; flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
+            scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
             if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
         }
     } else {
@@ -499,7 +512,7 @@ constexpr int PCG_CPL = 20;   // columns per lane            (64 * 20 >= d)
 template <bool INIT>
 __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
                                                        const double* __restrict__ bt, double* __restrict__ part, double* __restrict__ scal,
-                                                       int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox) {
+                                                       int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap) {
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;
     double* red = sm + ld;
@@ -552,7 +565,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             }
         }
         if (blockIdx.x == 0 && tid == 0) {
-            scal[PS_RR0] = rr; flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
+            scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
             if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
         }
     } else {
@@ -625,15 +638,16 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
 // MEASURED (MI355X, cfg 3, d = 1201): 6.7 us per CG iteration inside this kernel vs 5.7 us kernel + 1.4 us boundary for
 // the launch-per-iteration path -- the gather costs two to three sc1 round trips of ~1.5 us each; end to end the solve
 // is 2.7 % SLOWER than with per-iteration launches (2405 vs 2475 LM iterations/s).  A single polling wave per
-// workgroup is 2.5x slower still.  The path is therefore OFF by default (SFMBA_PCG_PERSISTENT=1 selects it); it is
-// kept, with a parity test, as the measured alternative.
+// workgroup is 2.5x slower still.  For SMALL reduced systems the balance flips: the per-iteration launch floor dominates
+// and the exchange is a few hundred granules (20 cameras, d = 121: 0.67 -> 0.50 ms per solve; 7 cameras: 0.73 -> 0.56).
+// run_solve therefore uses this kernel for d <= 640 and per-iteration launches above (SFMBA_PCG_PERSISTENT=0|1 forces).
 constexpr int PCG_GPT = 10;                    // granules per thread per sweep (256 * 10 >= 2 d)
 constexpr unsigned PCG_SPIN_LIMIT = 1u << 22;
 
 __global__ __launch_bounds__(256) void k_pcg_persistent(int d, int ld, const double* __restrict__ F, const double* __restrict__ bt,
                                                         double* __restrict__ vec, unsigned long long* gran, unsigned epoch0,
                                                         int max_iters, double tol2, int rows_per_wg, int* flags, int* info,
-                                                        int* mailbox, unsigned* tmo) {
+                                                        int* mailbox, unsigned* tmo, double* scal, int anchor, double cap) {
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;                 // [ld] search direction
     double* ql = sm + ld;            // [ld] q = S~ p of the current iteration
@@ -671,11 +685,14 @@ __global__ __launch_bounds__(256) void k_pcg_persistent(int d, int ld, const dou
         if (e < ld) pl[e] = rv[m];
     }
     block_sum2(rr, dummy, red);
-    const double rr0 = rr;
+    // every workgroup derives the same threshold base (scal[PS_RRF] was written by an earlier launch; with anchor == 1
+    // only workgroup 0 stores it and nobody reads it in this launch)
+    const double rr0 = (anchor == 2) ? fmin(fmax(rr, scal[PS_RRF]), cap * rr) : rr;
+    if (anchor == 1 && blockIdx.x == 0 && tid == 0) scal[PS_RRF] = rr;
     double* x_out = pcg_vec(vec, 0, 0, ld);
     int it = 0;
     bool broke = false, timed_out = false;
-    if (rr0 > 0.0) {
+    if (rr > 0.0) {
         for (it = 1;; ++it) {
             __syncthreads();                                   // pl complete
             const unsigned tag = epoch0 + (unsigned)it;
@@ -786,8 +803,12 @@ __global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, cons
     z[e] = v;
 }
 
+// cap of the anchored stopping rule: every solve at least max(tol, 1e-4) relative
+static double pcg_cap(double tol) { const double t2 = tol * tol; return t2 > 0.0 ? fmax(t2, 1e-8) / t2 : 1.0; }
+
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof,
-                    bool finish, int hist_key, bool pretransformed) {
+                    bool finish, int hist_key, bool pretransformed, int anchor) {
+    const double cap = pcg_cap(tol);
     const int ld = ws->ld, d = ws->d;
     if (dense_pcg_ensure_workspace(ws)) return -1;
     if (max_iters <= 0) max_iters = 4 * d;
@@ -807,10 +828,10 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     { ProfScope ps(prof, KID_PCG_ITER, s);
       if (fast)
           hipLaunchKernelGGL(k_pcg_iter_fast<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                             rows_per_wg, tol * tol, 0, info_dev, mb_dev);
+                             rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap);
       else
           hipLaunchKernelGGL(k_pcg_iter<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                             rows_per_wg, tol * tol, 0, info_dev, mb_dev); }
+                             rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap); }
     int in = 1, it = 0;
     int batch = 24;
     if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + 1;
@@ -821,10 +842,10 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
         for (int b = 0; b < n; ++b) {
             if (fast)
                 hipLaunchKernelGGL(k_pcg_iter_fast<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                                   rows_per_wg, tol * tol, in, info_dev, mb_dev);
+                                   rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
             else
                 hipLaunchKernelGGL(k_pcg_iter<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                                   rows_per_wg, tol * tol, in, info_dev, mb_dev);
+                                   rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
             in ^= 1;
         }
         it += n;
@@ -859,7 +880,7 @@ template <typename T> static int ws_alloc(DenseSolver* ws, T** p, size_t bytes) 
     return hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess ? 0 : -1;
 }
 
-bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof) {
+bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof, int anchor) {
     const int ld = ws->ld, d = ws->d;
     if (dense_pcg_ensure_workspace(ws)) return false;
     const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
@@ -885,7 +906,7 @@ bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int 
     double* bt = ws->vec + (size_t)8 * ld;
     ProfScope ps(prof, KID_PCG_ITER, s);
     hipLaunchKernelGGL(k_pcg_persistent, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, bt, ws->vec, ws->gran, epoch0, max_iters, tol * tol,
-                       rows_per_wg, ws->flags, info_dev, ws->d_mailbox, ws->tmo);
+                       rows_per_wg, ws->flags, info_dev, ws->d_mailbox, ws->tmo, ws->scal, anchor, pcg_cap(tol));
     return true;
 }
 

@@ -217,8 +217,13 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
+    bool first_linear_solve = true;
+    const char* anchor_env = std::getenv("SFMBA_PCG_ANCHOR");
+    const bool anchored_cg = o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
     const char* pcg_env = std::getenv("SFMBA_PCG_PERSISTENT");
-    const bool persistent_cg = pcg_env && pcg_env[0] == '1';     // measured slower than per-iteration launches: opt-in
+    // One persistent launch per CG solve wins where the solve is launch-bound (small reduced systems: 0.67 -> 0.50 ms per
+    // solve at 20 cameras) and loses 2.7 % at d = 1201: automatic below d = 640, SFMBA_PCG_PERSISTENT=0|1 forces it.
+    const bool persistent_cg = pcg_env ? pcg_env[0] == '1' : p->ds.d <= 640;
     int launched_controls = 0;
     std::vector<int> lin_hist;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
@@ -227,7 +232,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
         { ProfScope ps(prof, KID_ZERO, p->stream); launch_zero_system(p->stream, p->ds, p->db); }
-        const bool pcg = o.linear_solver == SFMBA_LINEAR_PCG;
+        const bool pcg = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
         if (pcg) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
@@ -249,10 +254,12 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (pcg) {
             // opt-in: one persistent launch for the whole CG solve when the reduced system fits (d <= 1280); its iteration
             // count is read from the solver's mailbox after this LM iteration's control post
-            pcg_async = persistent_cg && dense_pcg_solve_persistent(p->stream, &p->solver, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof);
+            const int anchor = anchored_cg ? (first_linear_solve ? 1 : 2) : 0;
+            first_linear_solve = false;
+            pcg_async = persistent_cg && dense_pcg_solve_persistent(p->stream, &p->solver, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof, anchor);
             if (!pcg_async) {
                 const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
-                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true);
+                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor);
                 if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
@@ -351,9 +358,10 @@ void sfmba_options_default(sfmba_options* o) {
     o->max_consecutive_invalid_steps = 5;
     o->linear_solver = SFMBA_LINEAR_CHOLESKY;
     o->precision = SFMBA_PRECISION_F64;
-    o->pcg_tolerance = 1e-6;
+    o->pcg_tolerance = 1e-8;
     o->pcg_max_iters = 0;
     o->verbose = 0;
+    o->pcg_anchored = 1;
 }
 
 int sfmba_abi_version(void) { return SFMBA_ABI_VERSION; }
@@ -987,9 +995,9 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     launch_shard_unpack(p->stream, p->db, p->d_scal, 1, p->shard_world);
     launch_finalize(p->stream, p->ds, p->db, 0);
     DeviceBuffers dbu = p->db;
-    if (o.linear_solver == SFMBA_LINEAR_PCG) {
+    if (o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) {
         const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
-                                       false, p->shard_host_iter);
+                                       false, p->shard_host_iter, /*pretransformed=*/false, /*anchor=*/!o.pcg_anchored ? 0 : p->shard_host_iter == 0 ? 1 : 2);
         if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
         p->shard_sum.linear_iters += it;
         dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;

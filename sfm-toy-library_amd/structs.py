@@ -3,7 +3,7 @@ import ctypes as C
 
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 TERMINATION_NAMES = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
-LINEAR_CHOLESKY, LINEAR_PCG = 0, 1
+LINEAR_CHOLESKY, LINEAR_PCG, LINEAR_AUTO = 0, 1, 2
 PRECISION_F64, PRECISION_F32J = 0, 1
 
 
@@ -27,6 +27,7 @@ class SfmbaOptions(C.Structure):
         ("pcg_tolerance", C.c_double),
         ("pcg_max_iters", C.c_int),
         ("verbose", C.c_int),
+        ("pcg_anchored", C.c_int),
     ]
 
     @classmethod
@@ -36,7 +37,7 @@ class SfmbaOptions(C.Structure):
                 parameter_tolerance=1e-8, initial_radius=1e4, max_radius=1e16, min_radius=1e-32,
                 min_relative_decrease=1e-3, min_lm_diagonal=1e-6, max_lm_diagonal=1e32,
                 jacobi_scaling=1, max_consecutive_invalid_steps=5, linear_solver=LINEAR_CHOLESKY,
-                precision=PRECISION_F64, pcg_tolerance=1e-6, pcg_max_iters=0, verbose=0)
+                precision=PRECISION_F64, pcg_tolerance=1e-8, pcg_max_iters=0, verbose=0, pcg_anchored=1)
         for k, v in overrides.items():
             if not hasattr(o, k):
                 raise AttributeError(k)

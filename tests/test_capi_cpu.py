@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sfmba_abi_version() == 1
+    assert L.sfmba_abi_version() == 2
 
 
 def test_default_options_match_reference_values(capi, sfm, oracle):
@@ -43,7 +43,7 @@ def test_struct_sizes_match_header(capi, sfm):
     # natural C layout of the header structs on x86-64
     assert C.sizeof(sfm.SfmbaIteration) == 4 * 4 + 6 * 8
     assert C.sizeof(sfm.SfmbaSummary) == 7 * 4 + 4 + 4 * 8 + 128
-    assert C.sizeof(sfm.SfmbaOptions) == 8 + 10 * 8 + 4 * 4 + 8 + 2 * 4
+    assert C.sizeof(sfm.SfmbaOptions) == 8 + 10 * 8 + 4 * 4 + 8 + 3 * 4 + 4     # ... pcg_max_iters, verbose, pcg_anchored + tail padding
 
 
 def test_no_cpu_fallback_without_device(capi, sfm):

@@ -24,7 +24,7 @@ def _worker(rank, world, port, name, linear, out):
     from sfm_toy_library_amd.sharded import HipShardBackend, solve_sharded
     prob = sfm.make_problem(name)
     backend = HipShardBackend(prob, rank, world, device=0, precision=0)
-    opt = capi.default_options(max_seconds=0.0, linear_solver=linear, pcg_tolerance=1e-12)
+    opt = capi.default_options(max_seconds=0.0, linear_solver=linear, pcg_tolerance=1e-12, pcg_anchored=0)
     summ = solve_sharded(backend, dist, opt)
     cam, pt, f = backend.get_params()
     out.put((rank, summ, cam, pt, f, backend._point_range))
@@ -47,7 +47,7 @@ def test_two_rank_sharded_hip_solve(sfm, name, linear):
         p.join(timeout=60)
         assert p.exitcode == 0
     prob = sfm.make_problem(name)
-    cam_s, pt_s, f_s, s_s, _ = capi.solve(prob, capi.default_options(max_seconds=0.0, linear_solver=linear, pcg_tolerance=1e-12))
+    cam_s, pt_s, f_s, s_s, _ = capi.solve(prob, capi.default_options(max_seconds=0.0, linear_solver=linear, pcg_tolerance=1e-12, pcg_anchored=0))
     (r0, s0, cam0, pt0, f0, rng0), (r1, s1, cam1, pt1, f1, rng1) = results
     assert s0["termination_name"] == s1["termination_name"] == s_s["termination_name"] == "CONVERGENCE"
     assert s0["iterations"] == s1["iterations"] == s_s["iterations"]
