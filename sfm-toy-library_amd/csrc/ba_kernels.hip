@@ -576,6 +576,47 @@ __device__ __forceinline__ void quad_assemble(const T q[4], T rec[YREC]) {
     }
 }
 
+// exchange with the lane whose quad position differs in one bit (quad_perm [1,0,3,2] / [2,3,0,1])
+template <int CTRL>
+__device__ __forceinline__ float quad_xchg(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_xchg(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// In-place 4x4 transpose across the four lanes of a quad: on entry r[u] (lane s) = element (u, s); on exit r[j] (lane s)
+// = element (s, j).  Two butterfly stages, 8 selects + 4 DPP moves; b0/b1 = bits of the lane's quad position.
+template <typename T>
+__device__ __forceinline__ void quad_transpose(T r[4], bool b0, bool b1) {
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        const T got = quad_xchg<0xB1>(b0 ? r[k] : r[k + 1]);
+        r[k] = b0 ? got : r[k];
+        r[k + 1] = b0 ? r[k + 1] : got;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const T got = quad_xchg<0x4E>(b1 ? r[k] : r[k + 2]);
+        r[k] = b1 ? got : r[k];
+        r[k + 2] = b1 ? r[k + 2] : got;
+    }
+}
+// The quad loaded four pairs cooperatively (lane s holds quarter s of each record); afterwards lane s owns pair s whole.
+template <typename T>
+__device__ __forceinline__ void quad_distribute(T q[4][4], T rec[YREC], bool b0, bool b1) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        T r[4] = { q[0][m], q[1][m], q[2][m], q[3][m] };
+        quad_transpose<T>(r, b0, b1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rec[4 * j + m] = r[j];
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void load_quarter(const T* Y, int q, int s, T out[4]) {
     const T* src = Y + (size_t)q * YREC + 4 * s;
@@ -631,7 +672,7 @@ __device__ __forceinline__ void quad_pair_product(const T ra[YREC], const T rb[Y
 #define PAIR_UNROLL 4
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+__global__ __launch_bounds__(BLK, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[BLK / 64][36];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int2 wg = (MODE == 2 ? ds.dup_blocks : ds.pwg_blocks)[blockIdx.x];       // {first block, number of blocks (<= 4)}
@@ -668,43 +709,52 @@ __global__ __launch_bounds__(BLK) void k_schur_pairs(DeviceStructure ds, DeviceB
     }
     const T* Y = reinterpret_cast<const T*>(db.Y);
     const int s = lane & 3, g = lane >> 2;
-    T acc[12];
+    const bool b0 = (s & 1) != 0, b1 = (s & 2) != 0;
+    // A quad LOADS four pairs cooperatively (each 64-byte record is one request of four adjacent lanes: the vector-memory
+    // pipe walks lines, not bytes) and then transposes them with DPP so that every lane COMPUTES one pair on its own:
+    // the first version had all four lanes form the same 2x2 core and the same T block (75 % VALU-busy, 7.1 wave
+    // instructions per pair); this one needs 3.8.
+    T acc[36];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) acc[e] = (T)0;
+    for (int e = 0; e < 36; ++e) acc[e] = (T)0;
     const int p1 = ds.blk_ptr[b + 1];
-    for (int p0 = ds.blk_ptr[b]; p0 < p1; p0 += 16 * PAIR_UNROLL) {
-        T qa[PAIR_UNROLL][4], qb[PAIR_UNROLL][4];
-        bool ok[PAIR_UNROLL];
+    for (int p0 = ds.blk_ptr[b]; p0 < p1; p0 += 64) {
+        T qa[4][4], qb[4][4];
 #pragma unroll
-        for (int u = 0; u < PAIR_UNROLL; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int p = p0 + 16 * u + g;
-            ok[u] = p < p1;
-            const int2 pr = ds.pairs[ok[u] ? p : p1 - 1];
+            const int2 pr = ds.pairs[p < p1 ? p : p1 - 1];
             load_quarter<T>(Y, pr.x, s, qa[u]);
             load_quarter<T>(Y, pr.y, s, qb[u]);
         }
+        T ra[YREC], rb[YREC];
+        quad_distribute<T>(qa, ra, b0, b1);
+        quad_distribute<T>(qb, rb, b0, b1);
+        if (p0 + 16 * s + g >= p1) {        // this lane's pair lies beyond the block: contribute nothing
 #pragma unroll
-        for (int u = 0; u < PAIR_UNROLL; ++u) {
-            T ra[YREC], rb[YREC];
-            quad_assemble<T>(qa[u], ra);
-            quad_assemble<T>(qb[u], rb);
-            if (!ok[u]) {        // keep the lanes in step (DPP needs them), contribute nothing
-#pragma unroll
-                for (int e = 9; e < 15; ++e) ra[e] = (T)0;
-            }
-            quad_pair_product<T>(ra, rb, s, MODE == 2, acc);
+            for (int e = 9; e < 15; ++e) ra[e] = (T)0;
         }
+        pair_product<T>(ra, rb, MODE == 2, acc);
     }
-    // sum over the 16 pair slots of the wave (lane bits 2..5) in fp64
+    // sum over the quad in T, then lane s keeps rows s and s+4 (as before) and the 16 quads are summed in fp64
+#pragma unroll
+    for (int e = 0; e < 36; ++e) {
+        T v = acc[e];
+        v += quad_xchg<0xB1>(v);
+        v += quad_xchg<0x4E>(v);
+        acc[e] = v;
+    }
     double accd[12];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) {
-        double v = (double)acc[e];
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        accd[e] = v;
+    for (int c = 0; c < 6; ++c) {
+        const T r0 = s == 0 ? acc[c] : s == 1 ? acc[6 + c] : s == 2 ? acc[12 + c] : acc[18 + c];
+        const T r1 = s == 0 ? acc[24 + c] : s == 1 ? acc[30 + c] : (T)0;
+        double v = (double)r0, w2 = (double)r1;
+        v += __shfl_xor(v, 4, 64);   w2 += __shfl_xor(w2, 4, 64);
+        v += __shfl_xor(v, 8, 64);   w2 += __shfl_xor(w2, 8, 64);
+        v += __shfl_xor(v, 16, 64);  w2 += __shfl_xor(w2, 16, 64);
+        v += __shfl_xor(v, 32, 64);  w2 += __shfl_xor(w2, 32, 64);
+        accd[c] = v; accd[6 + c] = w2;
     }
     const double* sa = db.cscale + 6 * cj.x;
     const double* sb = db.cscale + 6 * cj.y;
