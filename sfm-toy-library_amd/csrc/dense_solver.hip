@@ -13,6 +13,7 @@
 // factors the 64x64 diagonal tile redundantly in LDS, then solves its own tile of the panel) and
 // one trailing-update kernel; back substitution is one launch per block column (eager updates).
 #include "dense_solver.h"
+#include "sfmba_device.h"
 #include <math.h>
 #include <stdio.h>
 #include <algorithm>
@@ -569,14 +570,14 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
         }
     } else {
-        const double alpha = rr / pq;
+        const double alpha = rr * fast_rcp(pq);          // rcp + 2 Newton steps: the generic fp64 division is a ~15-deep dependent chain on the critical path
         double rrn = 0.0, dummy = 0.0;
 #pragma unroll
         for (int m = 0; m < PCG_EPT; ++m) { rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
         block_sum2(rrn, dummy, red);
         const bool broke = !(pq > 0.0) || !(rrn == rrn);
         const bool done = rrn <= tol2 * rr0 || broke;
-        const double beta = rrn / rr;
+        const double beta = rrn * fast_rcp(rr);
 #pragma unroll
         for (int m = 0; m < PCG_EPT; ++m) {
             const int e = tid + 256 * m;
@@ -602,14 +603,16 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
 #pragma unroll
     for (int k = 0; k < PCG_RPW; ++k) {
         const int row = row0 + w + 4 * k;
-        double sacc = 0.0;
+        double sacc = 0.0, sacc2 = 0.0;                    // two chains: a dependent DFMA is ~32 cycles
 #pragma unroll
         for (int m = 0; m < PCG_CPL / 2; ++m) {
             const int c2 = lane + 64 * m;
             double2 pv2 = (2 * c2 < d) ? reinterpret_cast<const double2*>(pl)[c2] : make_double2(0.0, 0.0);
             if (2 * c2 + 1 >= d) pv2.y = 0.0;              // pl[d] is not written
-            sacc += fv[k][m].x * pv2.x + fv[k][m].y * pv2.y;
+            sacc = fma(fv[k][m].x, pv2.x, sacc);
+            sacc2 = fma(fv[k][m].y, pv2.y, sacc2);
         }
+        sacc += sacc2;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
         if (lane == 0 && row < row1) { q_out[row] = sacc; pqp += pl[row] * sacc; }
@@ -701,14 +704,16 @@ __global__ __launch_bounds__(256) void k_pcg_persistent(int d, int ld, const dou
 #pragma unroll
             for (int k = 0; k < PCG_RPW; ++k) {
                 const int row = row0 + w + 4 * k;
-                double sacc = 0.0;
+                double sacc = 0.0, sacc2 = 0.0;
 #pragma unroll
                 for (int m = 0; m < PCG_CPL / 2; ++m) {
                     const int c2 = lane + 64 * m;
                     double2 pv2 = (2 * c2 < d) ? reinterpret_cast<const double2*>(pl)[c2] : make_double2(0.0, 0.0);
                     if (2 * c2 + 1 >= d) pv2.y = 0.0;
-                    sacc += fv[k][m].x * pv2.x + fv[k][m].y * pv2.y;
+                    sacc = fma(fv[k][m].x, pv2.x, sacc);
+                    sacc2 = fma(fv[k][m].y, pv2.y, sacc2);
                 }
+                sacc += sacc2;
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
                 if (lane < 2 && row < row1) {                  // lane 0: low half, lane 1: high half -- one aligned 8-byte store each
@@ -759,14 +764,14 @@ __global__ __launch_bounds__(256) void k_pcg_persistent(int d, int ld, const dou
                 pq += pv[m] * qv[m];
             }
             block_sum2(pq, dummy, red);
-            const double alpha = rr / pq;
+            const double alpha = rr * fast_rcp(pq);          // rcp + 2 Newton steps: the generic fp64 division is a ~15-deep dependent chain on the critical path
             double rrn = 0.0;
 #pragma unroll
             for (int m = 0; m < PCG_EPT; ++m) { xv[m] += alpha * pv[m]; rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
             block_sum2(rrn, dummy, red);
             broke = !(pq > 0.0) || !(rrn == rrn);
             if (rrn <= tol2 * rr0 || broke || it >= max_iters) break;
-            const double beta = rrn / rr;
+            const double beta = rrn * fast_rcp(rr);
             rr = rrn;
 #pragma unroll
             for (int m = 0; m < PCG_EPT; ++m) {
