@@ -4,6 +4,11 @@
 #include <vector>
 #include <stdint.h>
 
+// observations of one camera handled by one workgroup of k_cam_diag (one lane each); the host cuts the camera-major list accordingly
+#ifndef SFMBA_CAM_CHUNK
+#define SFMBA_CAM_CHUNK 256
+#endif
+
 namespace sfmba {
 
 // Accumulator slots inside LMState::acc (zeroed by k_lm_control / hipMemsetAsync).

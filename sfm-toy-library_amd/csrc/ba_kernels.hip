@@ -812,7 +812,7 @@ __global__ __launch_bounds__(BLK, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(D
 //   S_jj += A~^T (I - C C^T) A~   (U_jj minus the self term Y_a Y_a^T), undamped diagonal, S_jf, b_c, rhs
 // ------------------------------------------------------------------------------------------
 #define CD_N 48      // Sjj(21) udiag(6) Sjf(6) bc(6) rhs(6) uff bf + pad
-#define CD_BLK 1024
+#define CD_BLK SFMBA_CAM_CHUNK
 
 template <typename T>
 __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceBuffers db) {

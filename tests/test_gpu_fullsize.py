@@ -146,10 +146,11 @@ def test_one_shot_calls_recycle_device_memory(capi, sfm):
     for _ in range(3):
         capi.solve(other, capi.default_options(max_seconds=0.0))          # dirties the cached chunks with another problem
         again = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1))
-        # (fp64 atomics make the summation order, hence the last bits, run-dependent: compare to 1e-11)
+        # (fp64 atomics make the summation order, hence the last bits, run-dependent; the truncated CG solve carries such a
+        # perturbation into the parameters at the level of its own accuracy, ~1e-7: see DESIGN.md, CG stopping rule)
         assert again[3]["iterations"] == ref[3]["iterations"]
         assert abs(again[3]["final_cost"] - ref[3]["final_cost"]) <= 1e-11 * ref[3]["final_cost"]
-        assert np.allclose(again[0], ref[0], rtol=0, atol=1e-9) and np.allclose(again[1], ref[1], rtol=0, atol=1e-9)
+        assert np.allclose(again[0], ref[0], rtol=0, atol=2e-7) and np.allclose(again[1], ref[1], rtol=0, atol=2e-7)
     assert capi.release_cache() > 0
     assert capi.release_cache() == 0
 
