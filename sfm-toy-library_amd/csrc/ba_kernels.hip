@@ -304,7 +304,11 @@ __device__ __forceinline__ void rec_camera_block(const T rec[YREC], T A[12]) {
 // Per-point sums go through wave-private LDS: lane p adds up the <= 64 rows of its point.
 // ------------------------------------------------------------------------------------------
 #define PB_LD 10     // V(6) E_f(3) + pad, products of T values; B~^T r separately in fp64
-#define WPB (BLK / 64)
+// workgroup of the two point passes: PBK / 64 waves that share nothing but the final block reduction
+#ifndef PBK
+#define PBK 128
+#endif
+#define WPB (PBK / 64)
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS traffic of one wave is processed in order; this only stops the compiler from moving the
@@ -314,7 +318,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <typename T>
-__global__ __launch_bounds__(BLK) void k_point_build(DeviceStructure ds, DeviceBuffers db) {
+__global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceBuffers db) {
     __shared__ T sv[WPB][64][PB_LD];
     __shared__ double sb[WPB][64][3];
     __shared__ T sl[WPB][64][6];
@@ -924,7 +928,7 @@ void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBu
 
 template <typename T>
 void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(BLK), 0, s, ds, db);
+    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, db);
 }
 template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
@@ -1185,7 +1189,7 @@ __device__ __forceinline__ void camera_step_dp(CamPtr stb, const double X[3], do
 }
 
 template <typename T>
-__global__ __launch_bounds__(BLK) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
+__global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
     __shared__ T sv[WPB][64][6];
     __shared__ double sb[WPB][64][3];
     __shared__ double sx[WPB][64][6];      // dX(3), Xn(3) per local point
@@ -1337,7 +1341,7 @@ void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuf
 
 template <typename T>
 void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_point_update<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(BLK), 0, s, ds, db);
+    hipLaunchKernelGGL(k_point_update<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, db);
 }
 template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
