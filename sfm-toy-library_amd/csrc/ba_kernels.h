@@ -74,7 +74,9 @@ struct DeviceStructure {
     const int* cam_obs_pt;    // [nobs] point slot of that entry
     const int* obs_pt;        // [nobs] point slot, point-major order
     int nchunk;
-    const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), 0}
+    const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), 0}: SFMBA_CAM_CHUNK entries each (k_cam_diag)
+    int nchunk_coarse;
+    const int4* chunks_coarse; // the same list cut every 1024 entries (column-norm pass: a block loops over its chunk)
     // camera-pair lists of the reduced-system pass: block b = (ja <= jb); pairs sorted by block
     int nblock;
     const int2* blk_cams;     // [nblock] {ja, jb}

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(BLK) void k_colnorm_points(DeviceStructure ds, Devi
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[BLK / 64];
-    const int4 ch = ds.chunks[blockIdx.x];
+    const int4 ch = ds.chunks_coarse[blockIdx.x];
     const int j = ch.x;
     const int cur = db.st->cur;
     const CamRow ct = { db.camtab[cur] + j, ds.ncam };
@@ -204,8 +204,8 @@ void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const 
 void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int f32) {
     (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
     if (!jacobi) return;
-    if (f32) hipLaunchKernelGGL(k_colnorm_cams<float>, dim3(ds.nchunk), dim3(BLK), 0, s, ds, db);
-    else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk), dim3(BLK), 0, s, ds, db);
+    if (f32) hipLaunchKernelGGL(k_colnorm_cams<float>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
+    else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
 }
 void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi) {
     hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi);
@@ -215,7 +215,7 @@ template <typename T>
 void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi) {
     (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
     hipLaunchKernelGGL(k_colnorm_points<T>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
-    if (jacobi) hipLaunchKernelGGL(k_colnorm_cams<T>, dim3(ds.nchunk), dim3(BLK), 0, s, ds, db);
+    if (jacobi) hipLaunchKernelGGL(k_colnorm_cams<T>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
     hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi);
 }
 template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);

@@ -99,7 +99,7 @@ struct sfmba_problem {
     int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
-    int4* d_chunks = nullptr;
+    int4* d_chunks = nullptr, *d_chunks_coarse = nullptr;
     int* d_blk_ptr = nullptr;
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pwg_ptr = nullptr;
@@ -511,13 +511,17 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     }
     // chunks of the camera-major list (used by the column-norm pass): (camera, entry range)
     const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, 1024 lanes per workgroup
-    std::vector<int4> chunks;
-    for (int j = 0; j < ncam; ++j)
+    std::vector<int4> chunks, chunks_coarse;
+    for (int j = 0; j < ncam; ++j) {
         for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
             int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = 0;
             chunks.push_back(c);
         }
-    bt_mark("camera-major");
+        for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += 1024) {
+            int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + 1024, cam_ptr[(size_t)j + 1]); c.w = 0;
+            chunks_coarse.push_back(c);
+        }
+    }
     // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the
     // self pairs are folded into the camera-diagonal pass)
     // goes to block (ja, jb) of the upper triangle of S; counting sort by block.
@@ -596,6 +600,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_upload(&p->d_cam_obs, cam_obs));
     HIP_TRY(dev_upload(&p->d_cam_obs_pt, cam_obs_pt));
     HIP_TRY(dev_upload(&p->d_chunks, chunks));
+    HIP_TRY(dev_upload(&p->d_chunks_coarse, chunks_coarse));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
     HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
     HIP_TRY(dev_upload(&p->d_dup_blocks, dup_blocks));
@@ -627,6 +632,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     ds.pt_ptr = p->d_pt_ptr; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
     ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt;
     ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
+    ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse;
     ds.obs_pt = p->d_obs_pt;
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks;
