@@ -9,6 +9,11 @@
 #define SFMBA_CAM_CHUNK 256
 #endif
 
+// 6x6 blocks (one wave each) handled by one workgroup of k_schur_pairs; the host groups consecutive blocks of a block row
+#ifndef SFMBA_PAIR_WAVES
+#define SFMBA_PAIR_WAVES 1
+#endif
+
 namespace sfmba {
 
 // Accumulator slots inside LMState::acc (zeroed by k_lm_control / hipMemsetAsync).

@@ -676,8 +676,8 @@ __device__ __forceinline__ void quad_pair_product(const T ra[YREC], const T rb[Y
 #define PAIR_UNROLL 4
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(BLK, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double tile[BLK / 64][36];
+__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double tile[SFMBA_PAIR_WAVES][36];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int2 wg = (MODE == 2 ? ds.dup_blocks : ds.pwg_blocks)[blockIdx.x];       // {first block, number of blocks (<= 4)}
     if (w >= wg.y) return;
@@ -936,11 +936,11 @@ template void launch_point_build<double>(hipStream_t, const DeviceStructure&, co
 template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
     if (mode == 2) {
-        if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2>), dim3(ds.ndupwg), dim3(BLK), 0, s, ds, db);
+        if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2>), dim3(ds.ndupwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
     } else if (mode == 1) {
-        hipLaunchKernelGGL((k_schur_pairs<T, 1>), dim3(ds.npairwg), dim3(BLK), 0, s, ds, db);
+        hipLaunchKernelGGL((k_schur_pairs<T, 1>), dim3(ds.npairwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
     } else {
-        hipLaunchKernelGGL((k_schur_pairs<T, 0>), dim3(ds.npairwg), dim3(BLK), 0, s, ds, db);
+        hipLaunchKernelGGL((k_schur_pairs<T, 0>), dim3(ds.npairwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
     }
 }
 template void launch_schur_pairs<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);

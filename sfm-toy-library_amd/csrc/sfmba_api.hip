@@ -563,7 +563,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         std::vector<std::vector<int2>> per_xcd(8);
         for (int ja = 0; ja < ncam; ++ja) {
             const int b0 = block_of(ja, ja), nb = ncam - ja;
-            for (int o = 0; o < nb; o += 4) { int2 w; w.x = b0 + o; w.y = std::min(4, nb - o); per_xcd[ja % 8].push_back(w); }
+            for (int o = 0; o < nb; o += SFMBA_PAIR_WAVES) { int2 w; w.x = b0 + o; w.y = std::min(SFMBA_PAIR_WAVES, nb - o); per_xcd[ja % 8].push_back(w); }
         }
         size_t longest = 0;
         for (auto& v : per_xcd) longest = std::max(longest, v.size());
