@@ -675,6 +675,8 @@ __device__ __forceinline__ void quad_pair_product(const T ra[YREC], const T rb[Y
 // lane-local sums of its few products stay in T, the sum over the wave is carried in fp64.
 #define PAIR_UNROLL 4
 
+__device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db);
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
@@ -687,6 +689,9 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
     const int fo = ds.d - 1;
     if (MODE != 2 && diag) {
         if (MODE == 1) {
+            // k_finalize(pcg = 1) left the post-linearisation bookkeeping (gradient tolerance, cost of iteration 0, failed
+            // evaluation) to this launch, which starts after it in stream order: no arrival counter, no fences there
+            if (cj.x == 0) post_linearisation(ds, db);
             // glue of the block-Jacobi transform for camera j: S~_jj = I, S~_jf = Linv_j S_jf / sqrt(S_ff), b~_j = Linv_j rhs_j
             const int j = cj.x, row0 = 6 * j;
             const double* Li = db.pcg_binv + (size_t)j * 36;
@@ -1072,6 +1077,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
     }
     gm = wave_max(gm);
     if ((threadIdx.x & 63) == 0 && gm > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), gm);
+    if (pcg == 1) return;        // post_linearisation runs in the pair pass that follows (see k_schur_pairs, MODE 1)
     // ---- arrival: every wave drains its stores, one lane releases and takes a ticket ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

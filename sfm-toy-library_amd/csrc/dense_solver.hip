@@ -264,7 +264,10 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 // by iteration parity so no workgroup overwrites what another one is still reading.  The rows a
 // workgroup owns never change, so its slab of S~ stays in its XCD's L2 across iterations.
 // ------------------------------------------------------------------------------------------
-constexpr int PCG_MAXWG = 256;        // workgroups of the fast path (one partial dot product per thread)
+#ifndef SFMBA_PCG_MAXWG
+#define SFMBA_PCG_MAXWG 256
+#endif
+constexpr int PCG_MAXWG = SFMBA_PCG_MAXWG;        // workgroups of the fast path (one partial dot product per thread)
 constexpr int PCG_MAXWG_BIG = 1024;   // workgroups of the generic path
 constexpr int PCG_PART = 1024;        // stride of the two partial-dot-product buffers
 enum { PF_DONE = 0, PF_ITERS = 1, PF_XBUF = 2 };
