@@ -52,3 +52,36 @@ def test_random_problem_matches_oracle(capi, sfm, oracle, n_cam, n_pt, views, se
             assert [r["step_is_successful"] for r in tr] == [r["step_is_successful"] for r in tr_o]
         else:
             assert abs(rms - rms_o) < 1e-4, (precision, linear)     # BASELINE bar for fp32 Jacobian blocks
+
+
+def test_concurrent_resident_problems_are_independent(capi, sfm):
+    """BASELINE config 4 on one GPU: independent problems solved from concurrent host threads, each on its own stream
+    (tools/concurrent_solves.py measures the throughput).  Results must equal the one-at-a-time results."""
+    import threading
+    probs = [sfm.make_problem("cfg4", n_pt=2000, sub=g) for g in range(6)]
+    opt = capi.default_options(max_seconds=0.0, precision=1, linear_solver=1)
+    handles = [capi.Problem(p, precision=1) for p in probs]
+    try:
+        ref = []
+        for h in handles:
+            s, _ = h.solve(opt)
+            ref.append((s["iterations"], s["final_cost"]))
+        out = [None] * len(handles)
+
+        def work(k):
+            got = []
+            for _ in range(5):
+                handles[k].reset()
+                s, _ = handles[k].solve(opt)
+                got.append((s["iterations"], s["final_cost"]))
+            out[k] = got
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(handles))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        for k, got in enumerate(out):
+            for it, cost in got:
+                assert it == ref[k][0]
+                assert abs(cost - ref[k][1]) <= 1e-9 * ref[k][1]
+    finally:
+        for h in handles:
+            h.close()
