@@ -555,31 +555,7 @@ __device__ __forceinline__ void pair_product(const T ra[YREC], const T rb[YREC],
         }
 }
 
-// quad helpers: the four lanes 4g..4g+3 cooperate on one pair
-template <int K>
-__device__ __forceinline__ float quad_bcast(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
-}
-template <int K>
-__device__ __forceinline__ double quad_bcast(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// lane s of a quad holds values [4s, 4s+4) of a 16-value record; rebuild the whole record in every lane
-template <typename T>
-__device__ __forceinline__ void quad_assemble(const T q[4], T rec[YREC]) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        rec[m] = quad_bcast<0>(q[m]);
-        rec[4 + m] = quad_bcast<1>(q[m]);
-        rec[8 + m] = quad_bcast<2>(q[m]);
-        rec[12 + m] = quad_bcast<3>(q[m]);
-    }
-}
-
+// quad helpers: the four lanes 4g..4g+3 cooperate on loading four pairs
 // exchange with the lane whose quad position differs in one bit (quad_perm [1,0,3,2] / [2,3,0,1])
 template <int CTRL>
 __device__ __forceinline__ float quad_xchg(float v) {
@@ -633,47 +609,10 @@ __device__ __forceinline__ void load_quarter(const T* Y, int q, int s, T out[4])
     }
 }
 
-// One pair handled by a quad: lane s accumulates rows s and s+4 (the latter only for s < 2) of
-//   A_a^T (C_a C_b^T) A_b   (+ its transpose inside diagonal blocks: same camera observing a point twice)
-template <typename T>
-__device__ __forceinline__ void quad_pair_product(const T ra[YREC], const T rb[YREC], int s, bool diag, T acc[12]) {
-    const T m00 = ra[9] * rb[9] + ra[10] * rb[10] + ra[11] * rb[11];
-    const T m01 = ra[9] * rb[12] + ra[10] * rb[13] + ra[11] * rb[14];
-    const T m10 = ra[12] * rb[9] + ra[13] * rb[10] + ra[14] * rb[11];
-    const T m11 = ra[12] * rb[12] + ra[13] * rb[13] + ra[14] * rb[14];
-    T Aa[12], Ab[12], Tm[12];
-    rec_camera_block<T>(ra, Aa);
-    rec_camera_block<T>(rb, Ab);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) { Tm[c] = m00 * Ab[c] + m01 * Ab[6 + c]; Tm[6 + c] = m10 * Ab[c] + m11 * Ab[6 + c]; }
-    // rows owned by this lane, selected with data (no divergent code)
-    const T a0 = s == 0 ? Aa[0] : s == 1 ? Aa[1] : s == 2 ? Aa[2] : Aa[3];
-    const T a1 = s == 0 ? Aa[6] : s == 1 ? Aa[7] : s == 2 ? Aa[8] : Aa[9];
-    const T b0 = s == 0 ? Aa[4] : s == 1 ? Aa[5] : (T)0;
-    const T b1 = s == 0 ? Aa[10] : s == 1 ? Aa[11] : (T)0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        acc[c] += a0 * Tm[c] + a1 * Tm[6 + c];
-        acc[6 + c] += b0 * Tm[c] + b1 * Tm[6 + c];
-    }
-    if (diag) {   // + v^T: out[r][c] += A_a[.][c] . Tm[.][r]
-        const T t0 = s == 0 ? Tm[0] : s == 1 ? Tm[1] : s == 2 ? Tm[2] : Tm[3];
-        const T t1 = s == 0 ? Tm[6] : s == 1 ? Tm[7] : s == 2 ? Tm[8] : Tm[9];
-        const T u0 = s == 0 ? Tm[4] : s == 1 ? Tm[5] : (T)0;
-        const T u1 = s == 0 ? Tm[10] : s == 1 ? Tm[11] : (T)0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            acc[c] += Aa[c] * t0 + Aa[6 + c] * t1;
-            acc[6 + c] += Aa[c] * u0 + Aa[6 + c] * u1;
-        }
-    }
-}
-
-// Four lanes share one pair: each record is ONE 64-byte request of four adjacent lanes instead of four
-// requests per lane -- the kernel was bound by the vector-memory pipe walking 64 different lines for
-// every 16-byte load instruction, not by bytes.  A wave has 4 x 16 pairs in flight per round; the
-// lane-local sums of its few products stay in T, the sum over the wave is carried in fp64.
-#define PAIR_UNROLL 4
+// Pair pass.  One wave per 6x6 block of the reduced matrix; 64 pairs per round.  Loads are quad-cooperative (each
+// 64-byte record is ONE request of four adjacent lanes instead of four requests of one lane: the vector-memory pipe
+// walks lines, not bytes), compute is lane-per-pair after a DPP transpose; lane-local sums stay in T, the sum over the
+// wave is carried in fp64.
 
 __device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db);
 
@@ -925,11 +864,6 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
 }
 
 
-void launch_zero_system(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    // every entry of the upper triangle, rhs, udiag and bc is overwritten each iteration (k_schur_pairs,
-    // k_cam_diag, k_finalize); only the four focal-focal accumulators are summed with atomics
-    (void)ds; (void)db; (void)s;   // the slotted accumulators are cleared by their consumers
-}
 
 template <typename T>
 void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {

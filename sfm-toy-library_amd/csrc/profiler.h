@@ -9,7 +9,7 @@
 namespace sfmba {
 
 enum KernelId {
-    KID_SETUP = 0, KID_ZERO, KID_POINT_BUILD, KID_SCHUR_PAIRS, KID_CAM_DIAG, KID_FINALIZE,
+    KID_SETUP = 0, KID_POINT_BUILD, KID_SCHUR_PAIRS, KID_CAM_DIAG, KID_FINALIZE,
     KID_CHOL_AUGMENT, KID_CHOL_PANEL, KID_CHOL_UPDATE, KID_CHOL_EXTRACT, KID_CHOL_BACKSTEP,
     KID_PCG_SETUP, KID_PCG_ITER, KID_PCG_FINISH,
     KID_CAM_UPDATE, KID_POINT_UPDATE, KID_CONTROL, KID_EMPTY, KID_COUNT
@@ -17,7 +17,7 @@ enum KernelId {
 
 inline const char* kernel_name(int id) {
     static const char* names[KID_COUNT] = {
-        "setup", "zero_system", "point_build", "schur_pairs", "cam_diag", "finalize",
+        "setup", "point_build", "schur_pairs", "cam_diag", "finalize",
         "chol_augment", "chol_panel", "chol_update", "chol_extract", "chol_backstep",
         "pcg_setup", "pcg_iter", "pcg_finish",
         "cam_update", "point_update", "lm_control", "empty_bracket" };

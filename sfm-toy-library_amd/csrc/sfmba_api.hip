@@ -231,7 +231,6 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
-        { ProfScope ps(prof, KID_ZERO, p->stream); launch_zero_system(p->stream, p->ds, p->db); }
         const bool pcg = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
         if (pcg) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
@@ -858,17 +857,14 @@ int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, doub
     if (rc) return rc;
     rc = ensure_trace(p, 4);
     if (rc) return rc;
-    launch_zero_system(p->stream, p->ds, p->db);
     if (p->precision == SFMBA_PRECISION_F32J) {
         launch_linearise_setup<float>(p, o.jacobi_scaling);
-        launch_zero_system(p->stream, p->ds, p->db);
         launch_point_build<float>(p->stream, p->ds, p->db);
         launch_cam_diag<float>(p->stream, p->ds, p->db);
         launch_schur_pairs<float>(p->stream, p->ds, p->db, 2);
         launch_schur_pairs<float>(p->stream, p->ds, p->db, 0);
     } else {
         launch_linearise_setup<double>(p, o.jacobi_scaling);
-        launch_zero_system(p->stream, p->ds, p->db);
         launch_point_build<double>(p->stream, p->ds, p->db);
         launch_cam_diag<double>(p->stream, p->ds, p->db);
         launch_schur_pairs<double>(p->stream, p->ds, p->db, 2);
