@@ -95,7 +95,7 @@ __global__ void k_cam_setup(int ncam, const double* __restrict__ cam, const doub
     double c6[6], ct[CT_STRIDE];
     for (int e = 0; e < 6; ++e) c6[e] = cam[6 * j + e];
     make_cam_table(c6, cscale + 6 * j, ct);
-    for (int e = 0; e < CT_STRIDE; ++e) camtab[(size_t)e * ncam + j] = ct[e];
+    for (int e = 0; e < CT_STRIDE; ++e) camtab[cam_tab_index(e, j, ncam)] = ct[e];
 }
 
 template <typename T>
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLK) void k_colnorm_points(DeviceStructure ds, Devi
     double n0 = 0, n1 = 0, n2 = 0;
     if (jacobi) {
         for (int q = ds.pt_ptr[i]; q < ds.pt_ptr[i + 1]; ++q) {
-            const CamRow ct = { tab + ds.obs_cam[q], ds.ncam };
+            const CamRow ct = { tab + 4 * (size_t)(ds.obs_cam[q]), ds.ncam };
             const Proj pr = project_point(ct, CT_R, CT_T, X);
             T B[6];
             point_block<T>(ct, pr, focal, B);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
     const int4 ch = ds.chunks_coarse[blockIdx.x];
     const int j = ch.x;
     const int cur = db.st->cur;
-    const CamRow ct = { db.camtab[cur] + j, ds.ncam };
+    const CamRow ct = { db.camtab[cur] + 4 * (size_t)(j), ds.ncam };
     const double focal = db.st->focal[cur];
     const typename ObsXY<T>::type* oxy = reinterpret_cast<const typename ObsXY<T>::type*>(ds.obs_xy);
     (void)oxy;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
                 load_obs<T>(ds.obs_xy, q, ox, oy);
                 const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
                 const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
-                const CamRow ct = { tab + j, ds.ncam };
+                const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
                 const Proj pr = project_point(ct, CT_R, CT_T, X);
                 const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
                 lin_cost += r0 * r0 + r1 * r1;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
                 ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
                 const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
                 spk[0] = (T)db.pscale[3 * (size_t)ik]; spk[1] = (T)db.pscale[3 * (size_t)ik + 1]; spk[2] = (T)db.pscale[3 * (size_t)ik + 2];
-                const CamRow ct = { tab + jk, ds.ncam };
+                const CamRow ct = { tab + 4 * (size_t)(jk), ds.ncam };
                 prk = project_point(ct, CT_R, CT_T, X);
                 { double ox, oy; load_obs<T>(ds.obs_xy, q, ox, oy); rk0 = (T)(focal * prk.xp - ox); rk1 = (T)(focal * prk.yp - oy); }
                 point_block<T>(ct, prk, focal, Bk);
@@ -1057,7 +1057,7 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double step2 = 0.0, xn2 = 0.0;
     if (j < ds.ncam) {
-        const CamRow ct = { db.camtab[cur] + j, ds.ncam };
+        const CamRow ct = { db.camtab[cur] + 4 * (size_t)(j), ds.ncam };
         double dlt[6], cn[6], z[6];
         if (db.pcg_vec) {          // z_j = Linv_j^T x~_j  (block-Jacobi transformed unknowns)
             const double* x = db.pcg_vec + (size_t)db.pcg_flags[2] * ds.ld + 6 * j;
@@ -1077,7 +1077,7 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
         }
         double ctn[CT_STRIDE];
         make_cam_table(cn, db.cscale + 6 * j, ctn);
-        for (int e = 0; e < CT_STRIDE; ++e) db.camtab[nxt][(size_t)e * ds.ncam + j] = ctn[e];
+        for (int e = 0; e < CT_STRIDE; ++e) db.camtab[nxt][cam_tab_index(e, j, ds.ncam)] = ctn[e];
         double stb[ST_STRIDE] = {};
         for (int e = 0; e < 9; ++e) { stb[ST_R + e] = ct[CT_R + e]; stb[ST_RN + e] = ctn[CT_R + e]; }
         for (int e = 0; e < 3; ++e) { stb[ST_T + e] = ct[CT_T + e]; stb[ST_TN + e] = ctn[CT_T + e]; stb[ST_DT + e] = dlt[3 + e]; }
@@ -1088,7 +1088,7 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
                 stb[ST_KV + r] = ct[CT_K + 3 * r] * dlt[0] + ct[CT_K + 3 * r + 1] * dlt[1] + ct[CT_K + 3 * r + 2] * dlt[2];
         }
         stb[ST_SMALL] = ct[CT_SMALL];
-        for (int e = 0; e < ST_STRIDE; ++e) db.steptab[(size_t)e * ds.ncam + j] = stb[e];
+        for (int e = 0; e < ST_STRIDE; ++e) db.steptab[cam_tab_index(e, j, ds.ncam)] = stb[e];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double f0 = st->focal[cur];
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
                 load_obs<T>(ds.obs_xy, q, ox, oy);
                 const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
                 const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
-                const CamRow stb = { tab + j, ds.ncam };
+                const CamRow stb = { tab + 4 * (size_t)(j), ds.ncam };
                 const Proj pr = project_point(stb, ST_R, ST_T, X);
                 const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
                 T B[6];
@@ -1238,12 +1238,12 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
                 ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
                 load_obs<T>(ds.obs_xy, q, oxk, oyk);
                 const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
-                const CamRow stb2 = { tab + jk, ds.ncam };
+                const CamRow stb2 = { tab + 4 * (size_t)(jk), ds.ncam };
                 prk = project_point(stb2, ST_R, ST_T, X);
                 r0k = focal * prk.xp - oxk; r1k = focal * prk.yp - oyk;
                 camera_step_dp(stb2, X, dpk[0], dpk[1], dpk[2]);
             }
-            const CamRow stb = { tab + jk, ds.ncam };
+            const CamRow stb = { tab + 4 * (size_t)(jk), ds.ncam };
             const double* pl = sx[w][ik - pt0];
             const double dX[3] = { pl[0], pl[1], pl[2] };
             const double Xn[3] = { pl[3], pl[4], pl[5] };
@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(BLK) void k_eval_residuals(DeviceStructure ds, Devi
     double c = 0.0;
     if (q < ds.nobs) {
         const int i = obs_pt[q];
-        const CamRow ct = { db.camtab[cur] + ds.obs_cam[q], ds.ncam };
+        const CamRow ct = { db.camtab[cur] + 4 * (size_t)(ds.obs_cam[q]), ds.ncam };
         const double X[3] = { db.pts[cur][3 * i], db.pts[cur][3 * i + 1], db.pts[cur][3 * i + 2] };
         double ox, oy;
         load_obs<T>(ds.obs_xy, q, ox, oy);
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(BLK) void k_eval_jacobian(DeviceStructure ds, Devic
     if (q >= ds.nobs) return;
     const int cur = db.st->cur;
     const int i = obs_pt[q];
-    const CamRow ct = { db.camtab[cur] + ds.obs_cam[q], ds.ncam };
+    const CamRow ct = { db.camtab[cur] + 4 * (size_t)(ds.obs_cam[q]), ds.ncam };
     const double X[3] = { db.pts[cur][3 * i], db.pts[cur][3 * i + 1], db.pts[cur][3 * i + 2] };
     const Proj pr = project_point(ct, CT_R, CT_T, X);
     const double f = db.st->focal[cur];

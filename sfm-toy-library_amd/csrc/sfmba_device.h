@@ -40,12 +40,17 @@ constexpr int ST_STRIDE = 32;
 // (layout in ba_kernels.hip): 16 values = 64 B in fp32 (one sector), 128 B in fp64 (one line).
 constexpr int YREC = 16;
 
-// Camera tables are stored component-major (SoA): value k of camera j lives at tab[k * ncam + j], so that a
-// wave whose lanes need the same component of 64 different cameras touches ncam*8/128 lines instead of 64.
+// Camera tables are stored in component quads (AoSoA): values 4c .. 4c+3 of camera j are the 32 contiguous bytes at
+// tab[(c * ncam + j) * 4].  A wave whose lanes need the same components of 64 different cameras then issues ONE 32-byte
+// load per lane and quad instead of four 8-byte loads (the vector-memory pipe counts lines per 16-lane group per
+// instruction), while keeping the cameras of one component quad next to each other.
+__host__ __device__ __forceinline__ size_t cam_tab_index(int k, int j, int ncam) {
+    return ((size_t)(k >> 2) * ncam + j) * 4 + (k & 3);
+}
 struct CamRow {
-    const double* base;   // tab + j
+    const double* base;   // tab + 4 * j
     int stride;           // ncam
-    __device__ __forceinline__ double operator[](int k) const { return base[(size_t)k * stride]; }
+    __device__ __forceinline__ double operator[](int k) const { return base[(size_t)(k >> 2) * stride * 4 + (k & 3)]; }
 };
 
 template <typename T> struct ObsXY;
