@@ -121,6 +121,7 @@ struct DeviceBuffers {
     const double* pcg_linv;
     const int* pcg_flags;
     double* pcg_F;            // [d][ld] preconditioned reduced matrix S~ written directly by k_schur_pairs (PCG mode)
+    float* pcg_F32;           // the same in fp32 instead (streaming CG path, d > 1280: the matvec is HBM-bound); else null
     double* pcg_bt;           // [ld]    Lb^-1 rhs
     double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
     int* lm_mailbox;          // host-mapped {seq, termination, message, iter}: polled by the host instead of a D2H copy + sync

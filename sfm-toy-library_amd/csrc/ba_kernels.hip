@@ -616,6 +616,11 @@ __device__ __forceinline__ void load_quarter(const T* Y, int q, int s, T out[4])
 
 __device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db);
 
+// one entry of the preconditioned reduced matrix (fp64, or fp32 when the streaming CG path asked for it)
+__device__ __forceinline__ void store_F(const DeviceBuffers& db, size_t idx, double v) {
+    if (db.pcg_F32) db.pcg_F32[idx] = (float)v; else db.pcg_F[idx] = v;
+}
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
@@ -637,18 +642,18 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
             const double linv_f = 1.0 / sqrt(db.S[(size_t)fo * ds.ld + fo]);
             if (lane < 36) {
                 const int r = lane / 6, c = lane - 6 * r;
-                db.pcg_F[(size_t)(row0 + r) * ds.ld + row0 + c] = (r == c) ? 1.0 : 0.0;
+                store_F(db, (size_t)(row0 + r) * ds.ld + row0 + c, (r == c) ? 1.0 : 0.0);
             }
             if (lane < 6) {
                 double vf = 0.0, vb = 0.0;
                 for (int a = 0; a <= lane; ++a) { vf += Li[lane * 6 + a] * db.S[(size_t)(row0 + a) * ds.ld + fo]; vb += Li[lane * 6 + a] * db.rhs[row0 + a]; }
                 vf *= linv_f;
-                db.pcg_F[(size_t)(row0 + lane) * ds.ld + fo] = vf;
-                db.pcg_F[(size_t)fo * ds.ld + row0 + lane] = vf;
+                store_F(db, (size_t)(row0 + lane) * ds.ld + fo, vf);
+                store_F(db, (size_t)fo * ds.ld + row0 + lane, vf);
                 db.pcg_bt[row0 + lane] = vb;
             }
             if (j == 0 && lane == 63) {
-                db.pcg_F[(size_t)fo * ds.ld + fo] = 1.0;
+                store_F(db, (size_t)fo * ds.ld + fo, 1.0);
                 db.pcg_bt[fo] = db.rhs[fo] * linv_f;
                 db.pcg_binv[(size_t)ds.ncam * 36] = linv_f;
             }
@@ -746,8 +751,8 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
                 for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Lj[bb];
                 v += Li[a] * u;
             }
-            db.pcg_F[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
-            db.pcg_F[(size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r] = v;
+            store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
+            store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
         }
     }
 }

@@ -17,6 +17,7 @@ struct DenseSolver {
     double* y = nullptr;      // [ld] work vector of the back substitution
     // PCG
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
+    float* Sfull32 = nullptr; // fp32 copy for the streaming path (allocated by dense_pcg_want_f32)
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][256] per-workgroup partial p.q
     int last_iters = 0;       // CG iterations of the previous solve
@@ -58,6 +59,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
 // anchor: 0 = relative residual |r| <= tol |b~|; 1 = first solve of an LM run (remembers |b~|); 2 = later solve of the
 // same run: |r| <= tol * max(|b~|, |b~_first|), but never looser than max(tol, 1e-4) relative (see dense_solver.hip)
 int dense_pcg_ensure_workspace(DenseSolver* ws);
+// fp32 storage of the preconditioned matrix for the streaming (d > 1280) path; returns the buffer or null if not applicable
+float* dense_pcg_want_f32(DenseSolver* ws);
 // Whole CG solve in ONE launch (k_pcg_persistent), asynchronous: nothing is waited for.  Requires the pretransformed
 // system (see above) and d <= 1280 with one workgroup per CU; returns false (nothing launched) when that does not
 // hold.  The iteration count is posted to ws->h_mailbox[0] (with h_mailbox[1] = 1) when the kernel ends; the solution

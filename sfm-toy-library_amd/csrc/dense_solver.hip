@@ -409,8 +409,8 @@ __device__ __forceinline__ void pcg_post(int* mailbox, int iters, int done) {
 // Generic path of one CG iteration (any d).  Vector phase as in the fast path but looped; the matvec streams two rows
 // of S~ per wave with 16-byte loads, four deep, so that a wave keeps 128 B per lane in flight (the rows are HBM/MALL
 // traffic: d*ld*8 bytes per iteration, 289 MB at d = 6001).  Up to PCG_MAXWG_BIG workgroups.
-template <bool INIT>
-__global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
+template <bool INIT, typename FT>
+__global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __restrict__ F, double* __restrict__ vec,
                                                   const double* __restrict__ bt, double* __restrict__ part, double* scal,
                                                   int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap) {
     extern __shared__ __align__(16) double sm[];
@@ -464,40 +464,82 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const double* _
     __syncthreads();
     // q = S~ p for the rows this workgroup owns: each wave takes rows (row0 + w + 4k), two at a time
     const int lane = tid & 63, w = tid >> 6;
-    const int nd2 = d >> 1;                                     // full double2 columns; an odd last column is added by lane 0
-    const double2* pl2 = reinterpret_cast<const double2*>(pl);
     double pqp = 0.0;
-    for (int row = row0 + w; row < row1; row += 8) {
-        const int rowb = (row + 4 < row1) ? row + 4 : row;
-        const double2* Fa = reinterpret_cast<const double2*>(F + (size_t)row * ld);
-        const double2* Fb = reinterpret_cast<const double2*>(F + (size_t)rowb * ld);
-        double sa = 0.0, sb = 0.0;
-        int c = lane;
-        for (; c + 192 < nd2; c += 256) {
-            double2 a[4], b[4];
+    if (sizeof(FT) == 8) {
+        const int nd2 = d >> 1;                                     // full double2 columns; an odd last column is added by lane 0
+        const double2* pl2 = reinterpret_cast<const double2*>(pl);
+        for (int row = row0 + w; row < row1; row += 8) {
+            const int rowb = (row + 4 < row1) ? row + 4 : row;
+            const double2* Fa = reinterpret_cast<const double2*>(F + (size_t)row * ld);
+            const double2* Fb = reinterpret_cast<const double2*>(F + (size_t)rowb * ld);
+            double sa = 0.0, sb = 0.0;
+            int c = lane;
+            for (; c + 192 < nd2; c += 256) {
+                double2 a[4], b[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
+                for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const double2 pv = pl2[c + 64 * m];
-                sa += a[m].x * pv.x + a[m].y * pv.y;
-                sb += b[m].x * pv.x + b[m].y * pv.y;
+                for (int m = 0; m < 4; ++m) {
+                    const double2 pv = pl2[c + 64 * m];
+                    sa += a[m].x * pv.x + a[m].y * pv.y;
+                    sb += b[m].x * pv.x + b[m].y * pv.y;
+                }
+            }
+            for (; c < nd2; c += 64) {
+                const double2 a = Fa[c], b = Fb[c], pv = pl2[c];
+                sa += a.x * pv.x + a.y * pv.y;
+                sb += b.x * pv.x + b.y * pv.y;
+            }
+            if ((d & 1) && lane == 0) {
+                sa += (double)F[(size_t)row * ld + d - 1] * pl[d - 1];
+                sb += (double)F[(size_t)rowb * ld + d - 1] * pl[d - 1];
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
+            if (lane == 0) {
+                q_out[row] = sa; pqp += pl[row] * sa;
+                if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
             }
         }
-        for (; c < nd2; c += 64) {
-            const double2 a = Fa[c], b = Fb[c], pv = pl2[c];
-            sa += a.x * pv.x + a.y * pv.y;
-            sb += b.x * pv.x + b.y * pv.y;
-        }
-        if ((d & 1) && lane == 0) {
-            sa += F[(size_t)row * ld + d - 1] * pl[d - 1];
-            sb += F[(size_t)rowb * ld + d - 1] * pl[d - 1];
-        }
+    } else {
+        // fp32 matrix: 16-byte loads of four columns, products and sums in fp64
+        const int nd4 = d >> 2;
+        const float4* dummy4 = nullptr; (void)dummy4;
+        for (int row = row0 + w; row < row1; row += 8) {
+            const int rowb = (row + 4 < row1) ? row + 4 : row;
+            const float4* Fa = reinterpret_cast<const float4*>(F + (size_t)row * ld);
+            const float4* Fb = reinterpret_cast<const float4*>(F + (size_t)rowb * ld);
+            double sa = 0.0, sb = 0.0;
+            int c = lane;
+            for (; c + 192 < nd4; c += 256) {
+                float4 a[4], b[4];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
-        if (lane == 0) {
-            q_out[row] = sa; pqp += pl[row] * sa;
-            if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
+                for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double2 p0 = reinterpret_cast<const double2*>(pl)[2 * (c + 64 * m)], p1 = reinterpret_cast<const double2*>(pl)[2 * (c + 64 * m) + 1];
+                    sa += (double)a[m].x * p0.x + (double)a[m].y * p0.y + (double)a[m].z * p1.x + (double)a[m].w * p1.y;
+                    sb += (double)b[m].x * p0.x + (double)b[m].y * p0.y + (double)b[m].z * p1.x + (double)b[m].w * p1.y;
+                }
+            }
+            for (; c < nd4; c += 64) {
+                const float4 a = Fa[c], b = Fb[c];
+                const double2 p0 = reinterpret_cast<const double2*>(pl)[2 * c], p1 = reinterpret_cast<const double2*>(pl)[2 * c + 1];
+                sa += (double)a.x * p0.x + (double)a.y * p0.y + (double)a.z * p1.x + (double)a.w * p1.y;
+                sb += (double)b.x * p0.x + (double)b.y * p0.y + (double)b.z * p1.x + (double)b.w * p1.y;
+            }
+            if (lane == 0) {
+                for (int cc = 4 * nd4; cc < d; ++cc) {
+                    sa += (double)F[(size_t)row * ld + cc] * pl[cc];
+                    sb += (double)F[(size_t)rowb * ld + cc] * pl[cc];
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
+            if (lane == 0) {
+                q_out[row] = sa; pqp += pl[row] * sa;
+                if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
+            }
         }
     }
     __syncthreads();
@@ -830,6 +872,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     if (!pretransformed) { ProfScope ps(prof, KID_PCG_SETUP, s);
       hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
       hipLaunchKernelGGL(k_pcg_transform, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
+    const bool f32 = !fast && pretransformed && ws->Sfull32 != nullptr;     // the linearisation wrote the fp32 copy
     volatile int* mb = ws->h_mailbox;
     int* mb_dev = ws->d_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }
@@ -837,8 +880,11 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       if (fast)
           hipLaunchKernelGGL(k_pcg_iter_fast<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                              rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap);
+      else if (f32)
+          hipLaunchKernelGGL((k_pcg_iter<true, float>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull32, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                             rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap);
       else
-          hipLaunchKernelGGL(k_pcg_iter<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+          hipLaunchKernelGGL((k_pcg_iter<true, double>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                              rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap); }
     int in = 1, it = 0;
     int batch = 24;
@@ -851,8 +897,11 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
             if (fast)
                 hipLaunchKernelGGL(k_pcg_iter_fast<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                                    rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
+            else if (f32)
+                hipLaunchKernelGGL((k_pcg_iter<false, float>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull32, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                                   rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
             else
-                hipLaunchKernelGGL(k_pcg_iter<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                hipLaunchKernelGGL((k_pcg_iter<false, double>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                                    rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
             in ^= 1;
         }
@@ -918,6 +967,15 @@ bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int 
     return true;
 }
 
+float* dense_pcg_want_f32(DenseSolver* ws) {
+    const int d = ws->d;
+    const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
+    const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
+    if (fast) return nullptr;                    // the fast path is latency-bound: fp64 there
+    if (!ws->Sfull32 && ws_alloc(ws, &ws->Sfull32, sizeof(float) * (size_t)ws->d * ws->ld)) return nullptr;
+    return ws->Sfull32;
+}
+
 int dense_pcg_ensure_workspace(DenseSolver* ws) {
     if (!ws->gran) {
         if (ws_alloc(ws, &ws->gran, sizeof(unsigned long long) * 4 * (size_t)ws->ld)) return -1;
@@ -967,6 +1025,7 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->scal) (void)hipFree(ws->scal);
         if (ws->flags) (void)hipFree(ws->flags);
         if (ws->Sfull) (void)hipFree(ws->Sfull);
+        if (ws->Sfull32) (void)hipFree(ws->Sfull32);
         if (ws->gran) (void)hipFree(ws->gran);
         if (ws->tmo) (void)hipFree(ws->tmo);
     }

@@ -218,6 +218,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
     bool first_linear_solve = true;
+    const char* f32m_env = std::getenv("SFMBA_PCG_F32_MATRIX");
+    const bool f32_matrix = !(f32m_env && f32m_env[0] == '0');
     const char* anchor_env = std::getenv("SFMBA_PCG_ANCHOR");
     const bool anchored_cg = o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
     const char* pcg_env = std::getenv("SFMBA_PCG_PERSISTENT");
@@ -235,6 +237,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (pcg) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
+            // fp32 Jacobian mode + streaming CG path: the preconditioned matrix is stored in fp32 (halves the HBM-bound matvec)
+            p->db.pcg_F32 = (p->precision == SFMBA_PRECISION_F32J && f32_matrix) ? dense_pcg_want_f32(&p->solver) : nullptr;
         }
         { ProfScope ps(prof, KID_POINT_BUILD, p->stream); launch_point_build<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
@@ -673,7 +677,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     db.lin_info = p->d_info;
     db.fin_counter = p->d_info + 1;
     db.pcg_vec = nullptr; db.pcg_linv = nullptr; db.pcg_flags = nullptr;
-    db.pcg_F = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr;
+    db.pcg_F = nullptr; db.pcg_F32 = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&db.lm_mailbox), const_cast<int*>(p->h_lm_mail), 0));
     db.trace = nullptr; db.trace_cap = 0;
     if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");

@@ -171,3 +171,21 @@ def test_persistent_cg_kernel_matches_launch_per_iteration(capi, sfm, cfg3, monk
         assert abs(a[0]["final_cost"] - b[0]["final_cost"]) <= 1e-10 * a[0]["final_cost"]
         # nearly the same CG iteration counts per LM iteration (identical arithmetic up to summation order; the stopping test is a threshold)
         assert all(abs(x["linear_iters"] - y["linear_iters"]) <= 3 for x, y in zip(a[1], b[1]))
+
+
+def test_streaming_cg_path_with_fp32_matrix(capi, sfm, monkeypatch):
+    """d > 1280 (here 230 cameras, d = 1381): the CG matvec streams the preconditioned matrix from HBM; in fp32-Jacobian
+    mode that matrix is stored in fp32.  Against the exact Cholesky solve and against fp64 storage."""
+    prob = sfm.make_problem("cfg3", n_cam=230, n_pt=6000, seed=77)
+    ref = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=0))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SFMBA_PCG_F32_MATRIX", mode)
+        out[mode] = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1))
+    for mode in ("0", "1"):
+        r = out[mode]
+        assert r[3]["termination_name"] == ref[3]["termination_name"] == "CONVERGENCE"
+        assert r[3]["iterations"] == ref[3]["iterations"]
+        assert abs(r[3]["final_cost"] - ref[3]["final_cost"]) <= 1e-9 * ref[3]["final_cost"]
+        assert np.abs(r[0] - ref[0]).max() < 2e-6 and np.abs(r[1] - ref[1]).max() < 2e-6
+    assert abs(out["0"][3]["linear_iters"] - out["1"][3]["linear_iters"]) <= 3
