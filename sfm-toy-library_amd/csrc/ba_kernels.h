@@ -87,6 +87,7 @@ struct DeviceStructure {
     const int2* blk_cams;     // [nblock] {ja, jb}
     const int* blk_ptr;       // [nblock+1]
     const int2* pairs;        // [npair] {qa, qb} point-major positions of two observations of one point, qa < qb
+    int pair_lpb;             // lanes per 6x6 block in the pair pass: 64 (k_schur_pairs) or 16 (k_schur_pairs_sub), from the mean pairs per block
     int npairwg;
     const int2* pwg_blocks;   // [npairwg] {first block, #blocks <= 4} per workgroup of the pair pass (XCD-grouped rows)
     int ndupwg;

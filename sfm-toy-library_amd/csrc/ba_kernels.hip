@@ -757,6 +757,142 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
     }
 }
 
+// Pair pass for SMALL blocks: LPB = 16 lanes per 6x6 block, 64 / LPB consecutive blocks of one block row per wave
+// (a quad per block was measured too: slower than 16 lanes at every density, 346 vs 280 us at 5.6 pairs per block).
+// With a whole wave per block the per-block epilogue (reductions, scaling, Linv transform, stores: ~400 instructions)
+// dominates once a block has only a few dozen pairs -- 1000 cameras: 500k blocks of ~45 pairs; a rank of the sharded
+// mode owns every block with 1/N of its pairs -- here the epilogues of the blocks of a wave run side by side in its
+// lane groups and the reductions are two (or zero) shuffle stages shorter.  Same arithmetic per pair as k_schur_pairs.
+template <typename T, int MODE, int LPB>
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_sub(DeviceStructure ds, DeviceBuffers db) {
+    constexpr int NG = 64 / LPB;
+    __shared__ double tile[NG][36];
+    const int lane = threadIdx.x & 63;
+    if (MODE == 1 && blockIdx.x == 0) post_linearisation(ds, db);        // block (0,0) is in the first workgroup; all 64 lanes here
+    const int2 wg = ds.pwg_blocks[blockIdx.x];                           // {first block, number of blocks (<= NG)}
+    const int sub = lane / LPB, li = lane % LPB;
+    const bool have = sub < wg.y;
+    const int b = wg.x + (have ? sub : 0);
+    const int2 cj = ds.blk_cams[b];
+    const bool diag = cj.x == cj.y;
+    const int fo = ds.d - 1;
+    if (MODE == 1 && have && diag) {
+        // glue of the block-Jacobi transform for camera j (see k_schur_pairs)
+        const int j = cj.x, row0 = 6 * j;
+        const double* Li = db.pcg_binv + (size_t)j * 36;
+        const double linv_f = 1.0 / sqrt(db.S[(size_t)fo * ds.ld + fo]);
+        for (int e = li; e < 36; e += LPB) {
+            const int r = e / 6, c = e - 6 * r;
+            store_F(db, (size_t)(row0 + r) * ds.ld + row0 + c, (r == c) ? 1.0 : 0.0);
+        }
+        for (int l = li; l < 6; l += LPB) {
+            double vf = 0.0, vb = 0.0;
+            for (int a = 0; a <= l; ++a) { vf += Li[l * 6 + a] * db.S[(size_t)(row0 + a) * ds.ld + fo]; vb += Li[l * 6 + a] * db.rhs[row0 + a]; }
+            vf *= linv_f;
+            store_F(db, (size_t)(row0 + l) * ds.ld + fo, vf);
+            store_F(db, (size_t)fo * ds.ld + row0 + l, vf);
+            db.pcg_bt[row0 + l] = vb;
+        }
+        if (j == 0 && li == LPB - 1) {
+            store_F(db, (size_t)fo * ds.ld + fo, 1.0);
+            db.pcg_bt[fo] = db.rhs[fo] * linv_f;
+            db.pcg_binv[(size_t)ds.ncam * 36] = linv_f;
+        }
+    }
+    const bool work = have && !diag;
+    const T* Y = reinterpret_cast<const T*>(db.Y);
+    const int s = lane & 3, g = li >> 2;
+    const bool b0 = (s & 1) != 0, b1 = (s & 2) != 0;
+    T acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+    int p0 = work ? ds.blk_ptr[b] : 0;
+    const int p1 = work ? ds.blk_ptr[b + 1] : 0;
+    while (__any(p0 < p1)) {
+        const bool act = p0 < p1;                      // uniform inside a lane group (hence inside every quad)
+        T qa[4][4], qb[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (act) {
+                const int p = p0 + (LPB / 4) * u + g;
+                const int2 pr = ds.pairs[p < p1 ? p : p1 - 1];
+                load_quarter<T>(Y, pr.x, s, qa[u]);
+                load_quarter<T>(Y, pr.y, s, qb[u]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { qa[u][m] = (T)0; qb[u][m] = (T)0; }
+            }
+        }
+        T ra[YREC], rb[YREC];
+        quad_distribute<T>(qa, ra, b0, b1);
+        quad_distribute<T>(qb, rb, b0, b1);
+        if (!act || p0 + (LPB / 4) * s + g >= p1) {
+#pragma unroll
+            for (int e = 9; e < 15; ++e) ra[e] = (T)0;
+        }
+        pair_product<T>(ra, rb, false, acc);
+        p0 += LPB;
+    }
+#pragma unroll
+    for (int e = 0; e < 36; ++e) {
+        T v = acc[e];
+        v += quad_xchg<0xB1>(v);
+        v += quad_xchg<0x4E>(v);
+        acc[e] = v;
+    }
+    double accd[12];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const T r0 = s == 0 ? acc[c] : s == 1 ? acc[6 + c] : s == 2 ? acc[12 + c] : acc[18 + c];
+        const T r1 = s == 0 ? acc[24 + c] : s == 1 ? acc[30 + c] : (T)0;
+        double v = (double)r0, w2 = (double)r1;
+#pragma unroll
+        for (int off = 4; off < LPB; off <<= 1) { v += __shfl_xor(v, off, 64); w2 += __shfl_xor(w2, off, 64); }
+        accd[c] = v; accd[6 + c] = w2;
+    }
+    const double* sa = db.cscale + 6 * cj.x;
+    const double* sb = db.cscale + 6 * cj.y;
+    if (MODE == 0) {
+        if (work && li < 4) {
+            double* Srow0 = db.S + (size_t)(6 * cj.x + s) * ds.ld + 6 * cj.y;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Srow0[c] = -accd[c] * sa[s] * sb[c];
+            if (s < 2) {
+                double* Srow1 = db.S + (size_t)(6 * cj.x + s + 4) * ds.ld + 6 * cj.y;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Srow1[c] = -accd[6 + c] * sa[s + 4] * sb[c];
+            }
+        }
+    } else {
+        if (work && li < 4) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) tile[sub][6 * s + c] = -accd[c] * sa[s] * sb[c];
+            if (s < 2) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) tile[sub][6 * (s + 4) + c] = -accd[6 + c] * sa[s + 4] * sb[c];
+            }
+        }
+        wave_lds_fence();
+        if (work) {
+            for (int e = li; e < 36; e += LPB) {
+                const int r = e / 6, c = e - 6 * r;
+                const double* Li = db.pcg_binv + (size_t)cj.x * 36 + r * 6;
+                const double* Lj = db.pcg_binv + (size_t)cj.y * 36 + c * 6;
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    double u = 0.0;
+#pragma unroll
+                    for (int bb = 0; bb < 6; ++bb) u += tile[sub][6 * a + bb] * Lj[bb];
+                    v += Li[a] * u;
+                }
+                store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
+                store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K2b: camera-diagonal pass.  One lane per observation of the camera (no loop, two dependent memory
 // levels), 1024 lanes per workgroup = one chunk of one camera.  Each lane forms its 47 terms in T;
@@ -881,6 +1017,9 @@ template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
     if (mode == 2) {
         if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2>), dim3(ds.ndupwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
+    } else if (ds.pair_lpb == 16) {
+        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), dim3(ds.npairwg), dim3(64), 0, s, ds, db);
+        else hipLaunchKernelGGL((k_schur_pairs_sub<T, 0, 16>), dim3(ds.npairwg), dim3(64), 0, s, ds, db);
     } else if (mode == 1) {
         hipLaunchKernelGGL((k_schur_pairs<T, 1>), dim3(ds.npairwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
     } else {

@@ -561,12 +561,20 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     // workgroups of the pair pass: 4 consecutive blocks of ONE block-row each; rows are dealt to the 8
     // XCDs (blockIdx % 8, the observed dispatch order) so a row's records stay in one L2.  Performance
     // only: any placement gives the same result.
+    // Lanes per block of the pair pass, from the mean number of pairs of an off-diagonal block: a whole wave (64 pairs per
+    // round) or 16 lanes (4 blocks per wave).  Measured on MI355X: 16 lanes win at 56 pairs per block (110 vs 139 us) and
+    // below (280 vs 738 us at 5.6), the whole wave wins at 226 (77 vs 105 us).  SFMBA_PAIR_LPB overrides.
+    const long long npair_total = pair_off[npt];
+    const double mean_pairs = (double)npair_total / (double)std::max(1, nblock - ncam);
+    int pair_lpb = mean_pairs >= 128.0 ? 64 : 16;
+    if (const char* e = std::getenv("SFMBA_PAIR_LPB")) { const int v = std::atoi(e); if (v == 64 || v == 16) pair_lpb = v; }
+    const int blocks_per_wg = pair_lpb == 64 ? SFMBA_PAIR_WAVES : 64 / pair_lpb;
     std::vector<int2> pwg_blocks;
     {
         std::vector<std::vector<int2>> per_xcd(8);
         for (int ja = 0; ja < ncam; ++ja) {
             const int b0 = block_of(ja, ja), nb = ncam - ja;
-            for (int o = 0; o < nb; o += SFMBA_PAIR_WAVES) { int2 w; w.x = b0 + o; w.y = std::min(SFMBA_PAIR_WAVES, nb - o); per_xcd[ja % 8].push_back(w); }
+            for (int o = 0; o < nb; o += blocks_per_wg) { int2 w; w.x = b0 + o; w.y = std::min(blocks_per_wg, nb - o); per_xcd[ja % 8].push_back(w); }
         }
         size_t longest = 0;
         for (auto& v : per_xcd) longest = std::max(longest, v.size());
@@ -638,7 +646,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse;
     ds.obs_pt = p->d_obs_pt;
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
-    ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks;
+    ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
     ds.ndupwg = (int)dup_blocks.size(); ds.dup_blocks = p->d_dup_blocks;
     ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr;
 
