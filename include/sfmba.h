@@ -240,6 +240,18 @@ SFMBA_API int     sfmba_shard_solve_update(sfmba_problem* p);           /* after
 SFMBA_API int     sfmba_shard_finish(sfmba_problem* p, int* done);      /* after all-reduce #2: accept/reject, convergence */
 SFMBA_API int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);
 
+/*
+ * The step in front of bundle adjustment: SfMStereoUtilities::triangulateViews
+ * (SfMToyLib/SfMStereoUtilities.cpp:120-206) for n ALIGNED matches -- normalise with K (no distortion), DLT
+ * triangulation (cv::triangulatePoints), de-homogenise, re-project into both views, keep[i] = both reprojection errors
+ * <= max_reproj_px (the reference's MIN_REPROJECTION_ERROR = 10, :42).  left_xy / right_xy [n][2] pixels, K [9]
+ * row-major, P_left / P_right [12] row-major [R|t]; outputs points3d [n][3], keep [n] and (optional) reproj_err [n][2].
+ * Host pointers; the computation runs on `device`.
+ */
+SFMBA_API int sfmba_triangulate(int device, int64_t n, const float* left_xy, const float* right_xy, const float* K,
+                                const float* P_left, const float* P_right, float max_reproj_px,
+                                float* points3d, unsigned char* keep, float* reproj_err);
+
 #ifdef __cplusplus
 }
 #endif

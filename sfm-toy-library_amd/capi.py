@@ -26,8 +26,24 @@ SYMBOLS = [
     "sfmba_dense_spd_solve", "sfmba_shard_begin", "sfmba_shard_reduce_len", "sfmba_shard_reduce_buf",
     "sfmba_shard_scalars_buf", "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish",
     "sfmba_shard_end", "sfmba_problem_set_profiling", "sfmba_problem_get_profile",
-    "sfmba_problem_create_sharded", "sfmba_shard_setup_finish", "sfmba_shard_setup_len", "sfmba_shard_setup_buf", "sfmba_release_cache",
+    "sfmba_problem_create_sharded", "sfmba_shard_setup_finish", "sfmba_shard_setup_len", "sfmba_shard_setup_buf", "sfmba_release_cache", "sfmba_triangulate",
 ]
+
+
+def triangulate(K, P_left, P_right, left_xy, right_xy, max_reproj_px=10.0, device=0):
+    """SfMStereoUtilities::triangulateViews for aligned matches on the GPU: (points3d [n,3] float32, keep [n] bool, err [n,2])."""
+    K = np.ascontiguousarray(K, dtype=np.float32).reshape(9)
+    Pl = np.ascontiguousarray(P_left, dtype=np.float32).reshape(12)
+    Pr = np.ascontiguousarray(P_right, dtype=np.float32).reshape(12)
+    l = np.ascontiguousarray(left_xy, dtype=np.float32).reshape(-1, 2)
+    r = np.ascontiguousarray(right_xy, dtype=np.float32).reshape(-1, 2)
+    n = l.shape[0]
+    X = np.zeros((n, 3), dtype=np.float32); keep = np.zeros(n, dtype=np.uint8); err = np.zeros((n, 2), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    _check(lib().sfmba_triangulate(C.c_int(device), C.c_int64(n), l.ctypes.data_as(fp), r.ctypes.data_as(fp), K.ctypes.data_as(fp),
+                                   Pl.ctypes.data_as(fp), Pr.ctypes.data_as(fp), C.c_float(max_reproj_px), X.ctypes.data_as(fp),
+                                   keep.ctypes.data_as(C.POINTER(C.c_ubyte)), err.ctypes.data_as(fp)))
+    return X, keep.astype(bool), err
 
 
 def release_cache():

@@ -1073,4 +1073,33 @@ int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) {
     return SFMBA_OK;
 }
 
+int sfmba_triangulate(int device, int64_t n, const float* left_xy, const float* right_xy, const float* K, const float* P_left,
+                      const float* P_right, float max_reproj_px, float* points3d, unsigned char* keep, float* reproj_err) {
+    if (n < 0 || !K || !P_left || !P_right || (n > 0 && (!left_xy || !right_xy || !points3d || !keep)))
+        return fail(SFMBA_ERR_INVALID_ARG, "bad argument");
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n == 0) return SFMBA_OK;
+    HIP_TRY(hipSetDevice(device));
+    DeviceArena arena(device);
+    HostKit kit;
+    if (!hostkit_acquire(device, &kit)) return fail(SFMBA_ERR_HIP, "stream creation failed");
+    struct KitGuard { HostKit k; ~KitGuard() { if (k.stream) (void)hipStreamSynchronize(k.stream); hostkit_release(k); } } kg{ kit };
+    float* d_l = arena.alloc_n<float>((size_t)2 * n);
+    float* d_r = arena.alloc_n<float>((size_t)2 * n);
+    float* d_x = arena.alloc_n<float>((size_t)3 * n);
+    float* d_e = reproj_err ? arena.alloc_n<float>((size_t)2 * n) : nullptr;
+    unsigned char* d_k = arena.alloc_n<unsigned char>((size_t)n);
+    if (!d_l || !d_r || !d_x || !d_k || (reproj_err && !d_e)) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(d_l, left_xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, kit.stream));
+    HIP_TRY(hipMemcpyAsync(d_r, right_xy, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, kit.stream));
+    launch_triangulate(kit.stream, (long long)n, d_l, d_r, K, P_left, P_right, max_reproj_px, d_x, d_k, d_e);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(points3d, d_x, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, kit.stream));
+    HIP_TRY(hipMemcpyAsync(keep, d_k, (size_t)n, hipMemcpyDeviceToHost, kit.stream));
+    if (reproj_err) HIP_TRY(hipMemcpyAsync(reproj_err, d_e, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, kit.stream));
+    HIP_TRY(hipStreamSynchronize(kit.stream));
+    return SFMBA_OK;
+}
+
 }  // extern "C"

@@ -32,6 +32,11 @@ struct Point3DInMap {
 };
 
 typedef std::vector<Point3DInMap> PointCloud;
+typedef std::vector<cv::DMatch>   Matching;      // SfMCommon.h:95
+
+struct ImagePair {                                // SfMCommon.h:61-63
+    size_t left, right;
+};
 typedef cv::Matx34f Pose;
 
 }  // namespace sfmtoylib

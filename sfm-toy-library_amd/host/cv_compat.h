@@ -42,6 +42,7 @@ typedef Point_<float> Point2f;
 typedef Point3_<float> Point3f;
 
 struct KeyPoint { Point2f pt; float size = 0, angle = -1, response = 0; int octave = 0, class_id = -1; };
+struct DMatch { int queryIdx = -1, trainIdx = -1, imgIdx = -1; float distance = 0; DMatch() {} DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), distance(d) {} };
 
 // Dense row-major float matrix: only what Intrinsics::K needs (K.at<float>(r, c), BA.cpp:138,151-153,188-189).
 class Mat {
