@@ -94,6 +94,8 @@ struct DeviceStructure {
     const int2* dup_blocks;   // [ndupwg] like pwg_blocks, but only diagonal blocks that have pairs (same camera seeing a point twice)
     int nwv;
     const int* wv_ptr;        // [nwv+1] point ranges of the point-pass waves (whole points, <= 64 observations each)
+    const int4* wv_desc;      // [nwv] {first point, last point + 1, first observation, last observation + 1}: ONE load instead of the
+                              //       dependent wv_ptr -> pt_ptr chain in front of the observation loads
 };
 
 struct DeviceBuffers {

@@ -348,9 +348,10 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
     }
 
     if (gw < ds.nwv) {
-        const int pt0 = ds.wv_ptr[gw], pt1 = ds.wv_ptr[gw + 1];
+        const int4 wd = ds.wv_desc[gw];
+        const int pt0 = wd.x, pt1 = wd.y;
         const int npts = pt1 - pt0;
-        const int o0 = ds.pt_ptr[pt0], o1 = ds.pt_ptr[pt1];
+        const int o0 = wd.z, o1 = wd.w;
         const bool single = (o1 - o0) <= 64;           // false only for a point with more than 64 observations
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 }, Ef[3] = { 0, 0, 0 };
         const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
@@ -1290,9 +1291,10 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
     double trial = 0.0, model = 0.0, step2 = 0.0, xn2 = 0.0, bad = 0.0;
 
     if (gw < ds.nwv) {
-        const int pt0 = ds.wv_ptr[gw], pt1 = ds.wv_ptr[gw + 1];
+        const int4 wd = ds.wv_desc[gw];
+        const int pt0 = wd.x, pt1 = wd.y;
         const int npts = pt1 - pt0;
-        const int o0 = ds.pt_ptr[pt0], o1 = ds.pt_ptr[pt1];
+        const int o0 = wd.z, o1 = wd.w;
         const bool single = (o1 - o0) <= 64;
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
         const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;

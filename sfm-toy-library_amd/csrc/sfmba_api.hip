@@ -99,7 +99,7 @@ struct sfmba_problem {
     int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
-    int4* d_chunks = nullptr, *d_chunks_coarse = nullptr;
+    int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_wv_desc = nullptr;
     int* d_blk_ptr = nullptr;
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pwg_ptr = nullptr;
@@ -616,6 +616,14 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
     HIP_TRY(dev_upload(&p->d_dup_blocks, dup_blocks));
     HIP_TRY(dev_upload(&p->d_pwg_ptr, wv_ptr));
+    {
+        std::vector<int4> wv_desc(wv_ptr.size() - 1);
+        for (size_t g = 0; g + 1 < wv_ptr.size(); ++g) {
+            int4 wd; wd.x = wv_ptr[g]; wd.y = wv_ptr[g + 1]; wd.z = pt_ptr[(size_t)wv_ptr[g]]; wd.w = pt_ptr[(size_t)wv_ptr[g + 1]];
+            wv_desc[g] = wd;
+        }
+        HIP_TRY(dev_upload(&p->d_wv_desc, wv_desc));
+    }
     if (precision == SFMBA_PRECISION_F32J) {
         std::vector<float> xy((size_t)2 * nobs);
         for (int q = 0; q < nobs; ++q) { xy[2 * (size_t)q] = (float)obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = (float)obs_xy[2 * (size_t)p->perm[q] + 1]; }
@@ -648,7 +656,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
     ds.ndupwg = (int)dup_blocks.size(); ds.dup_blocks = p->d_dup_blocks;
-    ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr;
+    ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr; ds.wv_desc = p->d_wv_desc;
 
     bt_mark("upload params");
     DeviceBuffers& db = p->db;
