@@ -90,6 +90,9 @@ struct DeviceStructure {
     int pair_lpb;             // lanes per 6x6 block in the pair pass: 64 (k_schur_pairs) or 16 (k_schur_pairs_sub), from the mean pairs per block
     int npairwg;
     const int2* pwg_blocks;   // [npairwg] {first block, #blocks <= 4} per workgroup of the pair pass (XCD-grouped rows)
+    int pwg_group;            // blocks per workgroup entry (SFMBA_PAIR_WAVES, or 64 / pair_lpb)
+    const int4* pwg_desc;     // [npairwg * pwg_group] {block or -1, row camera ja, first pair, last pair + 1}: everything a wave (or lane
+                              //       group) needs about its block in ONE load; jb follows from the block index
     int ndupwg;
     const int2* dup_blocks;   // [ndupwg] like pwg_blocks, but only diagonal blocks that have pairs (same camera seeing a point twice)
     int nwv;

@@ -626,10 +626,21 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int2 wg = (MODE == 2 ? ds.dup_blocks : ds.pwg_blocks)[blockIdx.x];       // {first block, number of blocks (<= 4)}
-    if (w >= wg.y) return;
-    const int b = wg.x + w;
-    const int2 cj = ds.blk_cams[b];
+    int b, pbeg, pend;
+    int2 cj;
+    if (MODE == 2) {
+        const int2 wg = ds.dup_blocks[blockIdx.x];       // {first block, number of blocks (<= 4)}
+        if (w >= wg.y) return;
+        b = wg.x + w;
+        cj = ds.blk_cams[b];
+        pbeg = ds.blk_ptr[b]; pend = ds.blk_ptr[b + 1];
+    } else {
+        const int4 dsc = ds.pwg_desc[(size_t)blockIdx.x * SFMBA_PAIR_WAVES + w];      // one load: block, row camera, pair range
+        if (dsc.x < 0) return;
+        b = dsc.x; pbeg = dsc.z; pend = dsc.w;
+        cj.x = dsc.y;
+        cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
+    }
     const bool diag = cj.x == cj.y;
     const int fo = ds.d - 1;
     if (MODE != 2 && diag) {
@@ -671,8 +682,8 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
     T acc[36];
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-    const int p1 = ds.blk_ptr[b + 1];
-    for (int p0 = ds.blk_ptr[b]; p0 < p1; p0 += 64) {
+    const int p1 = pend;
+    for (int p0 = pbeg; p0 < p1; p0 += 64) {
         T qa[4][4], qb[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -770,11 +781,13 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
     __shared__ double tile[NG][36];
     const int lane = threadIdx.x & 63;
     if (MODE == 1 && blockIdx.x == 0) post_linearisation(ds, db);        // block (0,0) is in the first workgroup; all 64 lanes here
-    const int2 wg = ds.pwg_blocks[blockIdx.x];                           // {first block, number of blocks (<= NG)}
     const int sub = lane / LPB, li = lane % LPB;
-    const bool have = sub < wg.y;
-    const int b = wg.x + (have ? sub : 0);
-    const int2 cj = ds.blk_cams[b];
+    const int4 dsc = ds.pwg_desc[(size_t)blockIdx.x * NG + sub];         // one load: block, row camera, pair range
+    const bool have = dsc.x >= 0;
+    const int b = have ? dsc.x : 0;
+    int2 cj;
+    cj.x = dsc.y;
+    cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
     const bool diag = cj.x == cj.y;
     const int fo = ds.d - 1;
     if (MODE == 1 && have && diag) {
@@ -807,8 +820,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
     T acc[36];
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-    int p0 = work ? ds.blk_ptr[b] : 0;
-    const int p1 = work ? ds.blk_ptr[b + 1] : 0;
+    int p0 = work ? dsc.z : 0;
+    const int p1 = work ? dsc.w : 0;
     while (__any(p0 < p1)) {
         const bool act = p0 < p1;                      // uniform inside a lane group (hence inside every quad)
         T qa[4][4], qb[4][4];

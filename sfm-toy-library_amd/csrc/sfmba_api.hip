@@ -99,7 +99,7 @@ struct sfmba_problem {
     int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
-    int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_wv_desc = nullptr;
+    int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_wv_desc = nullptr, *d_pwg_desc = nullptr;
     int* d_blk_ptr = nullptr;
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pwg_ptr = nullptr;
@@ -585,6 +585,16 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
                 pwg_blocks.push_back(w);
             }
     }
+    std::vector<int4> pwg_desc(pwg_blocks.size() * (size_t)blocks_per_wg);
+    for (size_t wgi = 0; wgi < pwg_blocks.size(); ++wgi)
+        for (int k = 0; k < blocks_per_wg; ++k) {
+            int4 dsc; dsc.x = -1; dsc.y = 0; dsc.z = 0; dsc.w = 0;
+            if (k < pwg_blocks[wgi].y) {
+                const int b = pwg_blocks[wgi].x + k;
+                dsc.x = b; dsc.y = blk_cams[(size_t)b].x; dsc.z = blk_ptr[(size_t)b]; dsc.w = blk_ptr[(size_t)b + 1];
+            }
+            pwg_desc[wgi * (size_t)blocks_per_wg + k] = dsc;
+        }
     // diagonal blocks that contain pairs (the same camera observing a point twice): handled by a separate pass
     std::vector<int2> dup_blocks;
     for (int ja = 0; ja < ncam; ++ja) {
@@ -614,6 +624,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_upload(&p->d_chunks_coarse, chunks_coarse));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
     HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
+    HIP_TRY(dev_upload(&p->d_pwg_desc, pwg_desc));
     HIP_TRY(dev_upload(&p->d_dup_blocks, dup_blocks));
     HIP_TRY(dev_upload(&p->d_pwg_ptr, wv_ptr));
     {
@@ -655,6 +666,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     ds.obs_pt = p->d_obs_pt;
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
+    ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
     ds.ndupwg = (int)dup_blocks.size(); ds.dup_blocks = p->d_dup_blocks;
     ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr; ds.wv_desc = p->d_wv_desc;
 
