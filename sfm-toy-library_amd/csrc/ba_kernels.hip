@@ -5,9 +5,11 @@
 // elimination of the points, back-substitution, trial-point cost) -- see DESIGN.md for the
 // kernel-by-kernel map and SURVEY.md Appendix A for the math.
 //
-//   k_point_build  (point-major)  per point: V, b, E_f, LDL of V+D^2, whitened blocks Y = A~^T B~ L^-T
-//   k_cam_schur    (camera-major) per camera row block of S: U_jj, -sum Y_a Y_b^T accumulated in LDS
-//   k_finalize     damping of the reduced diagonal, gradient max-norm
+//   k_point_build     (point-major)  per point: V, b, E_f, Cholesky inverse of V + D^2; per observation the packed record
+//                     {A_w, f/p_z, x_p, y_p, C = B~ L^-T, camera} and the side record {C t, C y_f, r}
+//   k_cam_diag        (camera-major) U_jj minus the self terms, S_jf, b_c, rhs, undamped diagonal of one camera
+//   k_schur_pairs     one wave (k_schur_pairs_sub: one 16-lane group) per off-diagonal 6x6 block over a precomputed pair list
+//   k_finalize        damping of the reduced diagonal, gradient max-norm, block-Jacobi factors (PCG)
 //   k_cam_update / k_point_update  back-substitution, trial point, trial cost, model cost change
 //   k_lm_control   accept/reject + trust-region update on the device (no host round trip needed)
 #include "ba_kernels.h"
@@ -909,8 +911,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
 
 // ------------------------------------------------------------------------------------------
 // K2b: camera-diagonal pass.  One lane per observation of the camera (no loop, two dependent memory
-// levels), 1024 lanes per workgroup = one chunk of one camera.  Each lane forms its 47 terms in T;
-// the sums over lanes are carried in fp64: halving butterfly inside the wave, LDS across the 16 waves,
+// levels), SFMBA_CAM_CHUNK (256) lanes per workgroup = one chunk of one camera.  Each lane forms its 47 terms in T;
+// the sums over lanes are carried in fp64: halving butterfly inside the wave, LDS across the waves,
 // one atomic per value per workgroup.
 //   S_jj += A~^T (I - C C^T) A~   (U_jj minus the self term Y_a Y_a^T), undamped diagonal, S_jf, b_c, rhs
 // ------------------------------------------------------------------------------------------

@@ -513,7 +513,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         cam_obs_pt[e] = pm_pt[q];
     }
     // chunks of the camera-major list (used by the column-norm pass): (camera, entry range)
-    const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, 1024 lanes per workgroup
+    const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
     std::vector<int4> chunks, chunks_coarse;
     for (int j = 0; j < ncam; ++j) {
         for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
