@@ -202,7 +202,12 @@ class Problem:
     def solve(self, opt=None, trace_cap=1024):
         opt = opt or default_options()
         summ = SfmbaSummary()
-        trace = (SfmbaIteration * trace_cap)()
+        # the trace buffer is kept with the handle: allocating (and zeroing) 64 KB of ctypes array per call is measurable
+        # next to a ~1 ms solve
+        if getattr(self, "_trace_cap", 0) != trace_cap:
+            self._trace = (SfmbaIteration * trace_cap)()
+            self._trace_cap = trace_cap
+        trace = self._trace
         tl = C.c_int(0)
         _check(lib().sfmba_problem_solve(self._h, C.byref(opt), C.byref(summ), trace, C.c_int(trace_cap), C.byref(tl)))
         return summ.as_dict(), _trace_rows(trace, tl.value, trace_cap)
