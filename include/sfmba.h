@@ -217,8 +217,8 @@ SFMBA_API int sfmba_dense_spd_solve(int device, int n, const double* A, const do
  * All buffers are DEVICE pointers owned by the problem (wrap them as torch tensors for
  * torch.distributed / RCCL); every phase is enqueued on sfmba_problem_stream().  Every rank solves the
  * reduced system redundantly and takes bit-identical accept/reject decisions (no broadcast).
- *   reduce_buf  = [ S (ld*ld) | rhs (ld) | udiag (ld) | bc (ld) | scalars (SFMBA_SHARD_SCALARS) ]
- *   setup_buf   = the tail of reduce_buf starting at udiag (column norms for the Jacobi scaling, ||x||^2)
+ *   reduce_buf  = [ upper triangle of S, packed row after row (ld (ld + 1) / 2) | rhs (ld) | udiag (ld) | bc (ld) | scalars (SFMBA_SHARD_SCALARS) ]
+ *   setup_buf   = [ udiag (ld) | bc (ld) | scalars ] of the problem's own system buffer (column norms for the Jacobi scaling, ||x||^2)
  *   scalars_buf = the last SFMBA_SHARD_SCALARS doubles (trial cost, model change, step norms; one
  *                 per-rank slot each for the gradient max-norm, gathered through the SUM)
  */

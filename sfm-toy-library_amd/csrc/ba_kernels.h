@@ -153,6 +153,7 @@ template <typename T> void launch_eval_jacobian(hipStream_t s, const DeviceStruc
                                                 const int* obs_pt, const int* perm, double* jc, double* jp, double* jf);
 // sharded mode: move slotted accumulators to / from the all-reduce scalar block
 void launch_shard_pack(hipStream_t s, const DeviceBuffers& db, double* scal, int phase, int rank);
+void launch_shard_tri(hipStream_t s, double* sys, double* packed, int ld, long long tail, bool unpack);
 void launch_shard_unpack(hipStream_t s, const DeviceBuffers& db, const double* scal, int phase, int world);
 void launch_clear_slots(hipStream_t s, const DeviceBuffers& db);
 void launch_shard_xnorm_finish(hipStream_t s, const DeviceBuffers& db);

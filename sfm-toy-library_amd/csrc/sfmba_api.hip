@@ -107,6 +107,7 @@ struct sfmba_problem {
     double *d_cam0 = nullptr, *d_pts0 = nullptr;  // parameters given at create time
     double focal0 = 0.0;
     double *d_sys = nullptr;                      // S | rhs | udiag | bc (contiguous)
+    double *d_red = nullptr;                      // sharded mode: packed upper triangle of S + the same tail (the all-reduce buffer)
     int* d_info = nullptr;
     LMState* h_state = nullptr;                   // pinned
     volatile int* h_lm_mail = nullptr;            // host-mapped mailbox written by k_lm_control
@@ -688,6 +689,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
     HIP_TRY(dev_alloc(&p->d_sys, sys_len));
+    if (cam_active) HIP_TRY(dev_alloc(&p->d_red, (size_t)ds.ld * (ds.ld + 1) / 2 + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS));
     db.S = p->d_sys;
     db.rhs = db.S + (size_t)ds.ld * ds.ld;
     db.udiag = db.rhs + ds.ld;
@@ -957,9 +959,9 @@ int sfmba_dense_spd_solve(int device, int n, const double* A, const double* b, d
 // carries the partial reduced camera system, its right-hand side, the undamped diagonal, the scaled
 // gradient and the linearisation scalars.  See include/sfmba.h for the protocol.
 int64_t sfmba_shard_reduce_len(const sfmba_problem* p) {
-    return p && !p->empty ? (int64_t)p->ds.ld * p->ds.ld + 3 * (int64_t)p->ds.ld + SFMBA_SHARD_SCALARS : 0;
+    return p && !p->empty ? (int64_t)p->ds.ld * (p->ds.ld + 1) / 2 + 3 * (int64_t)p->ds.ld + SFMBA_SHARD_SCALARS : 0;
 }
-void* sfmba_shard_reduce_buf(sfmba_problem* p) { return p ? (void*)p->d_sys : nullptr; }
+void* sfmba_shard_reduce_buf(sfmba_problem* p) { return p ? (void*)p->d_red : nullptr; }
 int64_t sfmba_shard_setup_len(const sfmba_problem* p) { return p && !p->empty ? 2 * (int64_t)p->ds.ld + SFMBA_SHARD_SCALARS : 0; }
 void* sfmba_shard_setup_buf(sfmba_problem* p) { return p ? (void*)p->db.udiag : nullptr; }
 void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p ? (void*)p->d_scal : nullptr; }
@@ -1019,6 +1021,7 @@ int sfmba_shard_partial_build(sfmba_problem* p) {
         launch_schur_pairs<double>(p->stream, p->ds, p->db, 0);
     }
     launch_shard_pack(p->stream, p->db, p->d_scal, 1, p->shard_rank);
+    launch_shard_tri(p->stream, p->d_sys, p->d_red, p->ds.ld, 3 * (long long)p->ds.ld + SFMBA_SHARD_SCALARS, /*unpack=*/false);
     return SFMBA_OK;
 }
 
@@ -1026,6 +1029,7 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     if (!p || !p->shard_active) return fail(SFMBA_ERR_INVALID_ARG, "shard_begin was not called");
     HIP_TRY(hipSetDevice(p->device));
     const sfmba_options& o = p->shard_opt;
+    launch_shard_tri(p->stream, p->d_sys, p->d_red, p->ds.ld, 3 * (long long)p->ds.ld + SFMBA_SHARD_SCALARS, /*unpack=*/true);
     launch_shard_unpack(p->stream, p->db, p->d_scal, 1, p->shard_world);
     launch_finalize(p->stream, p->ds, p->db, 0);
     DeviceBuffers dbu = p->db;
