@@ -18,6 +18,7 @@ struct DenseSolver {
     // PCG
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
     float* Sfull32 = nullptr; // fp32 copy for the streaming path (allocated by dense_pcg_want_f32)
+    bool use_f32 = false;     // set by the caller per solve: the preconditioned matrix of THIS solve lives in Sfull32
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][256] per-workgroup partial p.q
     int last_iters = 0;       // CG iterations of the previous solve

@@ -332,8 +332,9 @@ __global__ void k_pcg_blockchol(const double* __restrict__ S, int ld, int d, dou
 
 // F = Lb^-1 S Lb^-T (full symmetric, d rows x ld), btilde = Lb^-1 rhs.  One thread per block pair I <= J;
 // trailing 1x1 blocks are padded to 6x6 with zeros so that every loop has compile-time bounds (registers).
+template <typename FT>
 __global__ __launch_bounds__(64) void k_pcg_transform(const double* __restrict__ S, int ld, int d, const double* __restrict__ linv,
-                                                      const double* __restrict__ rhs, double* __restrict__ F, double* __restrict__ bt) {
+                                                      const double* __restrict__ rhs, FT* __restrict__ F, double* __restrict__ bt) {
     const int nb6 = (d - 1) / 6;
     const int nB = nb6 + (d - 6 * nb6);
     const int J = blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,8 +374,8 @@ __global__ __launch_bounds__(64) void k_pcg_transform(const double* __restrict__
 #pragma unroll
             for (int t = 0; t < 6; ++t) v += U[r][t] * Lj[c][t];
             if (r < si && c < sj) {
-                F[(size_t)(ri + r) * ld + rj + c] = v;
-                if (I != J) F[(size_t)(rj + c) * ld + ri + r] = v;
+                F[(size_t)(ri + r) * ld + rj + c] = (FT)v;
+                if (I != J) F[(size_t)(rj + c) * ld + ri + r] = (FT)v;
             }
         }
     if (I == J) {
@@ -869,10 +870,12 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
     const size_t lds = sizeof(double) * (size_t)(ld + 8);
     double* bt = ws->vec + (size_t)8 * ld;
+    // fp32 storage of S~ on the streaming path whenever the caller asked for it (dense_pcg_want_f32 allocated the buffer)
+    const bool f32 = !fast && ws->use_f32 && ws->Sfull32 != nullptr;
     if (!pretransformed) { ProfScope ps(prof, KID_PCG_SETUP, s);
       hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
-      hipLaunchKernelGGL(k_pcg_transform, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
-    const bool f32 = !fast && pretransformed && ws->Sfull32 != nullptr;     // the linearisation wrote the fp32 copy
+      if (f32) hipLaunchKernelGGL(k_pcg_transform<float>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull32, bt);
+      else hipLaunchKernelGGL(k_pcg_transform<double>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
     volatile int* mb = ws->h_mailbox;
     int* mb_dev = ws->d_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }

@@ -240,6 +240,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             p->db.pcg_F = p->solver.Sfull;
             // fp32 Jacobian mode + streaming CG path: the preconditioned matrix is stored in fp32 (halves the HBM-bound matvec)
             p->db.pcg_F32 = (p->precision == SFMBA_PRECISION_F32J && f32_matrix) ? dense_pcg_want_f32(&p->solver) : nullptr;
+            p->solver.use_f32 = p->db.pcg_F32 != nullptr;
         }
         { ProfScope ps(prof, KID_POINT_BUILD, p->stream); launch_point_build<T>(p->stream, p->ds, p->db); }
         { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
@@ -1034,6 +1035,8 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     launch_finalize(p->stream, p->ds, p->db, 0);
     DeviceBuffers dbu = p->db;
     if (o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) {
+        // fp32 Jacobian mode: the streaming CG path keeps the preconditioned matrix in fp32 (k_pcg_transform writes it)
+        p->solver.use_f32 = p->precision == SFMBA_PRECISION_F32J && dense_pcg_want_f32(&p->solver) != nullptr;
         const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
                                        false, p->shard_host_iter, /*pretransformed=*/false, /*anchor=*/!o.pcg_anchored ? 0 : p->shard_host_iter == 0 ? 1 : 2);
         if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
