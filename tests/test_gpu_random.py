@@ -85,3 +85,29 @@ def test_concurrent_resident_problems_are_independent(capi, sfm):
     finally:
         for h in handles:
             h.close()
+
+
+def test_invalid_arguments_are_reported_not_crashed(capi, sfm):
+    """Error model of the C ABI: integer return code + sfmba_last_error(), nothing is touched, nothing crashes."""
+    import ctypes as C
+    prob = sfm.make_problem("tiny")
+    bad = sfm.BAProblem(prob.cam6, prob.pt3, prob.focal, prob.obs_cam.copy(), prob.obs_pt.copy(), prob.obs_xy)
+    bad.obs_cam[3] = prob.n_cam                        # camera index out of range
+    with pytest.raises(capi.SfmbaError) as e:
+        capi.solve(bad)
+    assert "out of range" in str(e.value)
+    bad.obs_cam[3] = 0
+    bad.obs_pt[0] = -1                                  # negative point index
+    with pytest.raises(capi.SfmbaError):
+        capi.solve(bad)
+    L = capi.lib()
+    # NULL outputs / handles
+    assert L.sfmba_problem_solve(None, None, None, None, C.c_int(0), None) != 0
+    assert L.sfmba_problem_reset(None) != 0
+    assert L.sfmba_triangulate(C.c_int(0), C.c_int64(-1), None, None, None, None, None, C.c_float(10.0), None, None, None) != 0
+    # a device index that does not exist
+    with pytest.raises(capi.SfmbaError):
+        capi.Problem(prob, device=63)
+    # the library is still usable afterwards
+    s = capi.solve(prob)[3]
+    assert s["termination_name"] == "CONVERGENCE"
