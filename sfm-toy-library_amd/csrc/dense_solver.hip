@@ -891,7 +891,9 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
                              rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap); }
     int in = 1, it = 0;
     int batch = 24;
-    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + 1;
+    static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 2; }();      // +2: a CG solve that needs one more iteration than last time
+                                                                                 // costs a host round trip, a surplus (early-exit) launch ~2 us
+    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra;
     bool done = false;
     while (it < max_iters && !done) {
         const int n = std::min(max_iters - it, batch);
