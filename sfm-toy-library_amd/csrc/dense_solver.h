@@ -18,6 +18,8 @@ struct DenseSolver {
     // PCG
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
     float* Sfull32 = nullptr; // fp32 copy for the streaming path (allocated by dense_pcg_want_f32)
+    // launch parameters of the running CG solve (dense_pcg_solve ... dense_pcg_more)
+    struct CgRun { int nwg = 0, rows_per_wg = 0; size_t lds = 0; bool fast = false, f32 = false; double tol2 = 0.0; int in = 1, launched = 0, max_iters = 0; int* info = nullptr; } run;
     bool use_f32 = false;     // set by the caller per solve: the preconditioned matrix of THIS solve lives in Sfull32
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][256] per-workgroup partial p.q
@@ -56,9 +58,15 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 // finish = false leaves the solution in transformed form (x~, see dense_solver.hip) for k_cam_update;
 // hist_key >= 0 selects the history slot used to size the first batch of launches.
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev,
-                    Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false, int anchor = 0);
+                    Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false, int anchor = 0,
+                    bool no_wait = false);
 // anchor: 0 = relative residual |r| <= tol |b~|; 1 = first solve of an LM run (remembers |b~|); 2 = later solve of the
 // same run: |r| <= tol * max(|b~|, |b~_first|), but never looser than max(tol, 1e-4) relative (see dense_solver.hip)
+// no_wait variant: dense_pcg_solve(..., no_wait = true) enqueues the first batch of iterations and returns at once (the
+// iteration count is then unknown to the host: consumers gate on ws->flags[0] on the device); dense_pcg_more enqueues up to
+// n further iterations of the same solve (returns how many; 0 = max_iters reached); dense_pcg_note records the final count.
+int dense_pcg_more(hipStream_t s, DenseSolver* ws, int n, Profiler* prof = nullptr);
+void dense_pcg_note(DenseSolver* ws, int hist_key, int iters);
 int dense_pcg_ensure_workspace(DenseSolver* ws);
 // fp32 storage of the preconditioned matrix for the streaming (d > 1280) path; returns the buffer or null if not applicable
 float* dense_pcg_want_f32(DenseSolver* ws);

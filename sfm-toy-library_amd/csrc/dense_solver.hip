@@ -854,11 +854,43 @@ __global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, cons
     z[e] = v;
 }
 
+int dense_pcg_more(hipStream_t s, DenseSolver* ws, int n, Profiler* prof) {
+    DenseSolver::CgRun& r = ws->run;
+    n = std::min(n, r.max_iters - r.launched);
+    if (n <= 0) return 0;
+    const int d = ws->d, ld = ws->ld;
+    double* bt = ws->vec + (size_t)8 * ld;
+    int* mb_dev = ws->d_mailbox;
+    ProfScope psb(prof, KID_PCG_ITER, s, n);
+    for (int b = 0; b < n; ++b) {
+        if (r.fast)
+            hipLaunchKernelGGL(k_pcg_iter_fast<false>, dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                               r.rows_per_wg, r.tol2, r.in, r.info, mb_dev, 0, 1.0);
+        else if (r.f32)
+            hipLaunchKernelGGL((k_pcg_iter<false, float>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull32, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                               r.rows_per_wg, r.tol2, r.in, r.info, mb_dev, 0, 1.0);
+        else
+            hipLaunchKernelGGL((k_pcg_iter<false, double>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
+                               r.rows_per_wg, r.tol2, r.in, r.info, mb_dev, 0, 1.0);
+        r.in ^= 1;
+    }
+    r.launched += n;
+    return n;
+}
+
+void dense_pcg_note(DenseSolver* ws, int hist_key, int iters) {
+    ws->last_iters = iters;
+    if (hist_key >= 0) {
+        if (hist_key >= (int)ws->hist.size()) ws->hist.resize((size_t)hist_key + 1, 0);
+        ws->hist[hist_key] = iters;
+    }
+}
+
 // cap of the anchored stopping rule: every solve at least max(tol, 1e-4) relative
 static double pcg_cap(double tol) { const double t2 = tol * tol; return t2 > 0.0 ? fmax(t2, 1e-8) / t2 : 1.0; }
 
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof,
-                    bool finish, int hist_key, bool pretransformed, int anchor) {
+                    bool finish, int hist_key, bool pretransformed, int anchor, bool no_wait) {
     const double cap = pcg_cap(tol);
     const int ld = ws->ld, d = ws->d;
     if (dense_pcg_ensure_workspace(ws)) return -1;
@@ -889,28 +921,17 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       else
           hipLaunchKernelGGL((k_pcg_iter<true, double>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
                              rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap); }
-    int in = 1, it = 0;
+    ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32;
+    ws->run.tol2 = tol * tol; ws->run.in = 1; ws->run.launched = 0; ws->run.max_iters = max_iters; ws->run.info = info_dev;
     int batch = 24;
-    static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 2; }();      // +2: a CG solve that needs one more iteration than last time
-                                                                                 // costs a host round trip, a surplus (early-exit) launch ~2 us
+    static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 2; }();
+    // history + 2: a solve that needs one more iteration than last time costs a host round trip, a surplus (early-exit) launch ~2 us
     if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra;
+    if (no_wait) return dense_pcg_more(s, ws, batch, prof);
     bool done = false;
-    while (it < max_iters && !done) {
-        const int n = std::min(max_iters - it, batch);
-        ProfScope psb(prof, KID_PCG_ITER, s, n);
-        for (int b = 0; b < n; ++b) {
-            if (fast)
-                hipLaunchKernelGGL(k_pcg_iter_fast<false>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                                   rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
-            else if (f32)
-                hipLaunchKernelGGL((k_pcg_iter<false, float>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull32, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                                   rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
-            else
-                hipLaunchKernelGGL((k_pcg_iter<false, double>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                                   rows_per_wg, tol * tol, in, info_dev, mb_dev, 0, 1.0);
-            in ^= 1;
-        }
-        it += n;
+    while (!done) {
+        if (dense_pcg_more(s, ws, batch, prof) == 0) break;
+        const int it = ws->run.launched;
         if (mb) {
             // poll the mailbox until the last launch of the batch has reported (or convergence was posted)
             const double t_end = now_s() + 2.0;
