@@ -1212,6 +1212,7 @@ void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers&
 // One thread per camera: delta = scale * y ; trial camera = camera - delta ; step table; table of the trial camera
 __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[BLK / 64];
+    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // the CG batch in front of this launch was too short
     LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1294,6 +1295,7 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
     __shared__ double sb[WPB][64][3];
     __shared__ double sx[WPB][64][6];      // dX(3), Xn(3) per local point
     __shared__ double scratch[WPB];
+    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // see k_cam_update
     const LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
     const double* tab = db.steptab;
@@ -1451,8 +1453,9 @@ template void launch_point_update<double>(hipStream_t, const DeviceStructure&, c
 // LM control: the accept/reject logic of ceres::internal::TrustRegionMinimizer::Minimize()
 // [Ceres-upstream], one thread.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lm_post(int* mb, int seq, int termination, int message, int iter) {
+__device__ __forceinline__ void lm_post(int* mb, int seq, int termination, int message, int iter, int cg_iters = 0) {
     if (!mb) return;
+    __hip_atomic_store(mb + 4, cg_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(mb + 1, termination, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(mb + 2, message, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(mb + 3, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1461,6 +1464,12 @@ __device__ __forceinline__ void lm_post(int* mb, int seq, int termination, int m
 
 __global__ void k_lm_control(DeviceBuffers db) {
     LMState* st = db.st;
+    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) {
+        // the linear solve has not converged within the launches enqueued so far: tell the host (termination code -2),
+        // touch nothing -- it will enqueue more CG iterations followed by the same three kernels
+        if (threadIdx.x == 0) { const int seq = ++st->mail_seq; lm_post(db.lm_mailbox, seq, -2, 0, st->iter); }
+        return;
+    }
     const double trial2 = slots_take(db, ACC_TRIAL_COST);
     const double model = slots_take(db, ACC_MODEL);
     const double step2 = slots_take(db, ACC_STEP2);
@@ -1470,7 +1479,8 @@ __global__ void k_lm_control(DeviceBuffers db) {
     st->lin_info = *db.lin_info;
     *db.lin_info = 0;
     const int seq = ++st->mail_seq;
-    if (st->termination != -1) { lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter); return; }
+    const int cg_iters = db.cg_gate ? db.cg_gate[1] : 0;          // CG iterations of this LM iteration (device-side count)
+    if (st->termination != -1) { lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters); return; }
     const int it = ++st->iter;
     TraceRow row = {};
     row.iteration = it;
@@ -1535,7 +1545,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
     row.trust_region_radius = st->radius;
     if (it < db.trace_cap) db.trace[it] = row;
     st->lin_info = 0;
-    lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter);
+    lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters);
 }
 
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {

@@ -219,6 +219,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
     bool first_linear_solve = true;
+    const char* gate_env = std::getenv("SFMBA_PCG_GATED");
+    const bool gated_cg = !(gate_env && gate_env[0] == '0');
     const char* f32m_env = std::getenv("SFMBA_PCG_F32_MATRIX");
     const bool f32_matrix = !(f32m_env && f32m_env[0] == '0');
     const char* anchor_env = std::getenv("SFMBA_PCG_ANCHOR");
@@ -255,7 +257,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db, 0); }
         }
         DeviceBuffers dbu = p->db;
-        bool pcg_async = false;
+        bool pcg_async = false, pcg_gated = false;
         if (pcg) {
             // opt-in: one persistent launch for the whole CG solve when the reduced system fits (d <= 1280); its iteration
             // count is read from the solver's mailbox after this LM iteration's control post
@@ -263,23 +265,30 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             first_linear_solve = false;
             pcg_async = persistent_cg && dense_pcg_solve_persistent(p->stream, &p->solver, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof, anchor);
             if (!pcg_async) {
+                // Launch-per-iteration CG: a batch of the length the previous solve needed (+2) goes into the queue together
+                // with the three kernels that consume the solution; those are GATED on the CG's done flag, so the host does
+                // not wait for the linear solve.  If the batch was too short k_lm_control says so and more is enqueued.
+                pcg_gated = gated_cg;
                 const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
-                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor);
+                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/pcg_gated);
                 if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
-                sum.linear_iters += it;
-                lin_hist.push_back(it);
+                if (!pcg_gated) { sum.linear_iters += it; lin_hist.push_back(it); }
             }
             dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
+            dbu.cg_gate = pcg_gated ? p->solver.flags : nullptr;
+            dbu.cg_force = 0;
         } else {
             dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, prof);
             lin_hist.push_back(0);
         }
-        { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
-        { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, p->db); }
-        { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, p->db); }
-        { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
-        ++launched_controls;
-        {   // wait for k_lm_control's mailbox post (system-scope stores to host-mapped memory)
+        bool lm_done = false;
+        while (!lm_done) {
+            { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
+            { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, dbu); }
+            { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, dbu); }
+            { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
+            ++launched_controls;
+            // wait for k_lm_control's mailbox post (system-scope stores to host-mapped memory)
             volatile int* mb = p->h_lm_mail;
             const double t_end = now_seconds() + 5.0;
             bool timed_out = false;
@@ -287,6 +296,12 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 if (now_seconds() > t_end) { timed_out = true; break; }
             }
             __sync_synchronize();
+            if (!timed_out && mb[1] == -2) {
+                // the CG batch was too short: enqueue more iterations (or force the step once max_iters are spent), then the trio again
+                if (dense_pcg_more(p->stream, &p->solver, 8, prof) == 0) dbu.cg_force = 1;
+                continue;
+            }
+            lm_done = true;
             if (timed_out) {
                 rc = download_state(p);
                 if (rc) return rc;
@@ -300,9 +315,14 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 const int it = p->solver.h_mailbox[1] != 0 ? p->solver.h_mailbox[0] : 0;
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
+            } else if (pcg_gated) {
+                const int it = timed_out ? p->solver.run.launched : mb[4];
+                dense_pcg_note(&p->solver, (int)lin_hist.size(), it);
+                sum.linear_iters += it;
+                lin_hist.push_back(it);
             }
-            if (term != -1) break;
         }
+        if (term != -1) break;
         if (o.verbose) {
             rc = download_state(p);
             if (rc) return rc;
