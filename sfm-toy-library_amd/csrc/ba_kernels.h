@@ -126,6 +126,8 @@ struct DeviceBuffers {
     const double* pcg_vec;    // x~ buffers (two, selected by pcg_flags[2]); nullptr when the Cholesky path wrote z to rhs
     const double* pcg_linv;
     const int* pcg_flags;
+    LMState* st_mirror;       // host-mapped copy of the LM state, refreshed by k_lm_control before every mailbox post (the host then needs no
+                              // blocking copy at the end of a solve); the trace rows may live in host-mapped memory too
     const int* cg_gate;       // non-null: k_cam_update / k_point_update / k_lm_control do nothing unless cg_gate[0] (CG done) is set or cg_force
     int cg_force;             //           (the host enqueues them behind a CG batch of guessed length without waiting for it)
     double* pcg_F;            // [d][ld] preconditioned reduced matrix S~ written directly by k_schur_pairs (PCG mode)

@@ -1480,7 +1480,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
     *db.lin_info = 0;
     const int seq = ++st->mail_seq;
     const int cg_iters = db.cg_gate ? db.cg_gate[1] : 0;          // CG iterations of this LM iteration (device-side count)
-    if (st->termination != -1) { lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters); return; }
+    if (st->termination != -1) { if (db.st_mirror) *db.st_mirror = *st; lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters); return; }
     const int it = ++st->iter;
     TraceRow row = {};
     row.iteration = it;
@@ -1545,6 +1545,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
     row.trust_region_radius = st->radius;
     if (it < db.trace_cap) db.trace[it] = row;
     st->lin_info = 0;
+    if (db.st_mirror) *db.st_mirror = *st;      // plain stores; the release store of the sequence number in lm_post orders them
     lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters);
 }
 

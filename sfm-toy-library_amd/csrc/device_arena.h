@@ -39,14 +39,14 @@ private:
     size_t off_ = 0;   // fill of chunks_.back()
 };
 
-// Host-side resources of a problem that are slow to create and destroy (a private non-blocking stream and one 4 KB
+// Host-side resources of a problem that are slow to create and destroy (a private non-blocking stream and one 64 KB
 // block of pinned, host-mapped memory for the LM state mirror and the mailboxes); recycled through the same cache.
 struct HostKit {
     int device = 0;
     hipStream_t stream = nullptr;
     char* pinned = nullptr;            // HOSTKIT_PINNED_BYTES, hipHostMallocMapped
 };
-constexpr size_t HOSTKIT_PINNED_BYTES = 4096;
+constexpr size_t HOSTKIT_PINNED_BYTES = 65536;    // [0,1024) LM state mirror, [1024,2048) LM mailbox, [2048,4096) solver, [4096,..) trace rows
 bool hostkit_acquire(int device, HostKit* kit);     // false on HIP failure
 void hostkit_release(const HostKit& kit);           // the stream must be idle
 

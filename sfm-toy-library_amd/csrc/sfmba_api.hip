@@ -111,6 +111,8 @@ struct sfmba_problem {
     int* d_info = nullptr;
     LMState* h_state = nullptr;                   // pinned
     volatile int* h_lm_mail = nullptr;            // host-mapped mailbox written by k_lm_control
+    char* d_pinned = nullptr;                     // device address of kit.pinned
+    bool trace_mapped = false;                    // db.trace points into the pinned block
     int cur = 0;                                  // which buffer holds the current parameters
     double focal = 0.0;
     bool empty = false;                           // no observations
@@ -172,10 +174,17 @@ int download_state(sfmba_problem* p) {
 
 int ensure_trace(sfmba_problem* p, int rows) {
     if (rows <= p->db.trace_cap) return SFMBA_OK;
-    if (p->db.trace) (void)hipFree(p->db.trace);
+    if (p->db.trace && !p->trace_mapped) (void)hipFree(p->db.trace);
     p->db.trace = nullptr;
     p->db.trace_cap = 0;
-    HIP_TRY(dev_alloc(&p->db.trace, (size_t)rows));
+    p->trace_mapped = false;
+    if (p->d_pinned && sizeof(TraceRow) * (size_t)rows <= HOSTKIT_PINNED_BYTES - 4096) {
+        // the rows live in the handle's host-mapped block: k_lm_control writes them over PCIe, nothing is copied back
+        p->db.trace = reinterpret_cast<TraceRow*>(p->d_pinned + 4096);
+        p->trace_mapped = true;
+    } else {
+        HIP_TRY(dev_alloc(&p->db.trace, (size_t)rows));
+    }
     p->db.trace_cap = rows;
     return SFMBA_OK;
 }
@@ -218,6 +227,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
+    bool state_mirrored = false;
     bool first_linear_solve = true;
     const char* gate_env = std::getenv("SFMBA_PCG_GATED");
     const bool gated_cg = !(gate_env && gate_env[0] == '0');
@@ -302,6 +312,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 continue;
             }
             lm_done = true;
+            state_mirrored = !timed_out;
             if (timed_out) {
                 rc = download_state(p);
                 if (rc) return rc;
@@ -330,9 +341,13 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                          p->h_state->gmax, p->h_state->radius, p->h_state->termination);
         }
     }
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    rc = download_state(p);
-    if (rc) return rc;
+    // k_lm_control mirrored the LM state into the pinned block before its last mailbox post, and it is the last kernel of
+    // an iteration: unless that post was missed (or events have to be collected) there is nothing to wait for or to copy
+    if (!state_mirrored || p->prof.on) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        rc = download_state(p);
+        if (rc) return rc;
+    }
     if (p->prof.on) p->prof.collect();
     const LMState& hs = *p->h_state;
     p->cur = hs.cur;
@@ -349,7 +364,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // trace rows
     const int rows = std::min(hs.iter + 1, p->db.trace_cap);
     std::vector<TraceRow> tr((size_t)std::max(rows, 1));
-    HIP_TRY(hipMemcpy(tr.data(), p->db.trace, sizeof(TraceRow) * (size_t)rows, hipMemcpyDeviceToHost));
+    if (p->trace_mapped) std::memcpy(tr.data(), p->kit.pinned + 4096, sizeof(TraceRow) * (size_t)rows);
+    else HIP_TRY(hipMemcpy(tr.data(), p->db.trace, sizeof(TraceRow) * (size_t)rows, hipMemcpyDeviceToHost));
     sum.initial_cost = rows > 0 ? tr[0].cost : hs.cost;
     for (int r = 1; r < rows && r - 1 < (int)lin_hist.size(); ++r) tr[(size_t)r].linear_iters = lin_hist[(size_t)r - 1];
     if (trace && trace_cap > 0) {
@@ -406,7 +422,7 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     dense_solver_destroy(&p->solver);
-    if (p->db.trace) (void)hipFree(p->db.trace);
+    if (p->db.trace && !p->trace_mapped) (void)hipFree(p->db.trace);
     p->arena.release();
     p->prof.destroy();
     hostkit_release(p->kit);
@@ -729,7 +745,9 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     db.fin_counter = p->d_info + 1;
     db.pcg_vec = nullptr; db.pcg_linv = nullptr; db.pcg_flags = nullptr;
     db.pcg_F = nullptr; db.pcg_F32 = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&db.lm_mailbox), const_cast<int*>(p->h_lm_mail), 0));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
+    db.lm_mailbox = reinterpret_cast<int*>(p->d_pinned + 1024);
+    db.st_mirror = reinterpret_cast<LMState*>(p->d_pinned);
     db.trace = nullptr; db.trace_cap = 0;
     if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
@@ -1114,7 +1132,8 @@ int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) {
     sum.final_cost = hs.cost;
     sum.seconds = now_seconds() - p->shard_t0;
     TraceRow row0;
-    HIP_TRY(hipMemcpy(&row0, p->db.trace, sizeof(TraceRow), hipMemcpyDeviceToHost));
+    if (p->trace_mapped) std::memcpy(&row0, p->kit.pinned + 4096, sizeof(TraceRow));
+    else HIP_TRY(hipMemcpy(&row0, p->db.trace, sizeof(TraceRow), hipMemcpyDeviceToHost));
     sum.initial_cost = row0.cost;
     if (summary) *summary = sum;
     return SFMBA_OK;
