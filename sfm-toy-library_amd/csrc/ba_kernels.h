@@ -140,7 +140,7 @@ struct DeviceBuffers {
 
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
 void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling);
+template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling, bool clear_udiag = true);
 template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 // mode 0: off-diagonal blocks of S (upper triangle);  mode 1: the same blocks written straight into S~ = Lb^-1 S Lb^-T
 // (both triangles) + the per-camera glue of the block-Jacobi transform;  mode 2: diagonal blocks with duplicate pairs

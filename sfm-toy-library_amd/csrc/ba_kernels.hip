@@ -214,14 +214,14 @@ void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const Devic
 }
 
 template <typename T>
-void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi) {
-    (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
+void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, bool clear_udiag) {
+    if (clear_udiag) (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
     hipLaunchKernelGGL(k_colnorm_points<T>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
     if (jacobi) hipLaunchKernelGGL(k_colnorm_cams<T>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
     hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi);
 }
-template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
-template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
+template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool);
+template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool);
 
 // ------------------------------------------------------------------------------------------
 // 3x3 SPD: L^-1 (lower, 6 values l00 l10 l11 l20 l21 l22 of the INVERSE factor). Returns false if not PD.

@@ -75,6 +75,15 @@ template <typename T> hipError_t dev_upload(T** p, const std::vector<T>& v) {
     return e;
 }
 
+// First launch of a solve: the LM state arrives as a kernel argument (no H2D copy), the linear-solver status word, the Jacobi
+// scales and the column-norm accumulators are cleared in the same launch (instead of a copy, two memsets and a fill kernel).
+__global__ void k_begin(LMState st, DeviceBuffers db, int n_cscale, int ld) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) { *db.st = st; *db.lin_info = 0; }
+    if (e < n_cscale) db.cscale[e] = 1.0;
+    if (e < ld) db.udiag[e] = 0.0;
+}
+
 __global__ void k_fill(double* p, size_t n, double v) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) p[e] = v;
@@ -190,13 +199,13 @@ int ensure_trace(sfmba_problem* p, int rows) {
 }
 
 template <typename T>
-void launch_linearise_setup(sfmba_problem* p, int jacobi) {
+void launch_linearise_setup(sfmba_problem* p, int jacobi, bool begun = false) {
     const size_t n = 6 * (size_t)p->ds.ncam;
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
+    if (!begun) hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
     launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
     launch_xnorm(p->stream, p->ds, p->db);
     launch_iter0(p->stream, p->ds, p->db);
-    launch_colnorm<T>(p->stream, p->ds, p->db, jacobi);
+    launch_colnorm<T>(p->stream, p->ds, p->db, jacobi, /*clear_udiag=*/!begun);
     launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
 }
 
@@ -220,10 +229,11 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
 
     LMState st;
     init_state(p, st, o);
-    rc = upload_state(p, st);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
-    { ProfScope ps(p->prof.on ? &p->prof : nullptr, KID_SETUP, p->stream); launch_linearise_setup<T>(p, o.jacobi_scaling); }
+    *p->h_state = st;
+    { ProfScope ps(p->prof.on ? &p->prof : nullptr, KID_SETUP, p->stream);
+      const int nb = std::max(6 * p->ds.ncam, p->ds.ld);
+      hipLaunchKernelGGL(k_begin, dim3((nb + 255) / 256), dim3(256), 0, p->stream, st, p->db, 6 * p->ds.ncam, p->ds.ld);
+      launch_linearise_setup<T>(p, o.jacobi_scaling, /*begun=*/true); }
 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
