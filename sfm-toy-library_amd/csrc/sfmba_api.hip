@@ -224,7 +224,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     const int want_rows = std::min(std::max(o.max_iters, 0) + 2, 1 << 16);
     int rc = ensure_trace(p, want_rows);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    // no stream synchronisation here: whatever the caller enqueued before (reset, set_params) is ordered by the stream
     const double t0 = now_seconds();
 
     LMState st;
