@@ -172,6 +172,9 @@ class DeviceArena;
 int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
                      const int* d_obs_cam, const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr);
 
+int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
+                       int** d_cam_obs, int** d_cam_obs_pt);
+
 // triangulate.hip: two-view DLT triangulation + reprojection filter (SfMStereoUtilities::triangulateViews), device pointers
 void launch_triangulate(hipStream_t s, long long n, const float* d_left, const float* d_right, const float K[9], const float Pl[12],
                         const float Pr[12], float max_err, float* d_points3d, unsigned char* d_keep, float* d_err);

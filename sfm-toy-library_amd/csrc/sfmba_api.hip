@@ -553,13 +553,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     std::vector<int> cam_ptr((size_t)ncam + 1, 0);
     for (int q = 0; q < nobs; ++q) cam_ptr[(size_t)pm_cam[q] + 1]++;
     for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] += cam_ptr[j];
-    std::vector<int> cfill(cam_ptr.begin(), cam_ptr.end() - 1);
-    std::vector<int> cam_obs((size_t)nobs), cam_obs_pt((size_t)nobs);
-    for (int q = 0; q < nobs; ++q) {
-        const int e = cfill[pm_cam[q]]++;
-        cam_obs[e] = q;
-        cam_obs_pt[e] = pm_pt[q];
-    }
+    // (the camera-major lists themselves are built on the device from the uploaded point-major arrays, structure_build.hip)
     // chunks of the camera-major list (used by the column-norm pass): (camera, entry range)
     const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
     std::vector<int4> chunks, chunks_coarse;
@@ -666,8 +660,10 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     bt_mark("maps");
     // ---- upload ----
     HIP_TRY(dev_upload(&p->d_cam_ptr, cam_ptr));
-    HIP_TRY(dev_upload(&p->d_cam_obs, cam_obs));
-    HIP_TRY(dev_upload(&p->d_cam_obs_pt, cam_obs_pt));
+    {
+        const int crc = build_camera_major(p->stream, &p->arena, device, nobs, ncam, p->d_obs_cam, p->d_obs_pt, &p->d_cam_obs, &p->d_cam_obs_pt);
+        if (crc) return fail(SFMBA_ERR_HIP, std::string("camera-major build: ") + hipGetErrorString((hipError_t)crc));
+    }
     HIP_TRY(dev_upload(&p->d_chunks, chunks));
     HIP_TRY(dev_upload(&p->d_chunks_coarse, chunks_coarse));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));

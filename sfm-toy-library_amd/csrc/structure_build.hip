@@ -101,4 +101,45 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int
     return 0;
 }
 
+namespace {
+__global__ void k_iota_cam(int n, const int* __restrict__ obs_cam, unsigned* __restrict__ keys, int* __restrict__ vals) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) { keys[q] = (unsigned)obs_cam[q]; vals[q] = q; }
+}
+__global__ void k_gather_pt(int n, const int* __restrict__ cam_obs, const int* __restrict__ obs_pt, int* __restrict__ cam_obs_pt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) cam_obs_pt[e] = obs_pt[cam_obs[e]];
+}
+}  // namespace
+
+// Camera-major index of the observations on the device: cam_obs[e] = point-major position q, grouped by camera with a stable
+// radix sort (ascending q, i.e. ascending point, inside a camera -- the order the host loop produced), cam_obs_pt[e] = its point.
+int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
+                       int** d_cam_obs, int** d_cam_obs_pt) {
+    *d_cam_obs = arena->alloc_n<int>((size_t)nobs);
+    *d_cam_obs_pt = arena->alloc_n<int>((size_t)nobs);
+    if (!*d_cam_obs || !*d_cam_obs_pt) return (int)hipErrorOutOfMemory;
+    if (nobs == 0) return 0;
+    DeviceArena scratch(device);
+    unsigned* k0 = scratch.alloc_n<unsigned>((size_t)nobs);
+    unsigned* k1 = scratch.alloc_n<unsigned>((size_t)nobs);
+    int* v0 = scratch.alloc_n<int>((size_t)nobs);
+    if (!k0 || !k1 || !v0) return (int)hipErrorOutOfMemory;
+    hipLaunchKernelGGL(k_iota_cam, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, d_obs_cam, k0, v0);
+    int end_bit = 1;
+    while (end_bit < 32 && ((unsigned long long)1 << end_bit) < (unsigned long long)ncam) ++end_bit;
+    size_t tmp_bytes = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, *d_cam_obs, nobs, 0, end_bit, s);
+    if (e != hipSuccess) return (int)e;
+    void* tmp = scratch.alloc(tmp_bytes ? tmp_bytes : 1);
+    if (!tmp) return (int)hipErrorOutOfMemory;
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, *d_cam_obs, nobs, 0, end_bit, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_gather_pt, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, *d_cam_obs, d_obs_pt, *d_cam_obs_pt);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamSynchronize(s);          // the scratch arena is recycled on return
+    return (int)e;
+}
+
 }  // namespace sfmba
