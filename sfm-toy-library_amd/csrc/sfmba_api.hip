@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 using namespace sfmba;
@@ -82,6 +84,16 @@ __global__ void k_begin(LMState st, DeviceBuffers db, int n_cscale, int ld) {
     if (e == 0) { *db.st = st; *db.lin_info = 0; }
     if (e < n_cscale) db.cscale[e] = 1.0;
     if (e < ld) db.udiag[e] = 0.0;
+}
+
+// Host loops over the observation list of a large problem, split over a few threads (structure build of the one-shot call).
+template <typename F>
+void parallel_for(int n, F fn) {
+    unsigned nt = n >= 200000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (nt <= 1) { fn(0, n); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fn, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
+    for (auto& th : pool) th.join();
 }
 
 __global__ void k_fill(double* p, size_t n, double v) {
@@ -516,6 +528,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     // that input needs no sort, only the slot mapping.  Anything else goes through a counting sort.
     bool presorted = true;
     {
+        // (measured: splitting these two passes over threads does not pay -- spawn cost and shared counters eat the gain)
         int prev_i = -1, prev_c = -1;
         for (int k = 0; k < nobs; ++k) {
             const int i = pt_slot[obs_pt[k]], c = cam_slot[obs_cam[k]];
@@ -681,13 +694,17 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     }
     if (precision == SFMBA_PRECISION_F32J) {
         std::vector<float> xy((size_t)2 * nobs);
-        for (int q = 0; q < nobs; ++q) { xy[2 * (size_t)q] = (float)obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = (float)obs_xy[2 * (size_t)p->perm[q] + 1]; }
+        parallel_for(nobs, [&](int q0, int q1) {
+            for (int q = q0; q < q1; ++q) { xy[2 * (size_t)q] = (float)obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = (float)obs_xy[2 * (size_t)p->perm[q] + 1]; }
+        });
         float* d = nullptr;
         HIP_TRY(dev_upload(&d, xy));
         p->d_obs_xy = d;
     } else {
         std::vector<double> xy((size_t)2 * nobs);
-        for (int q = 0; q < nobs; ++q) { xy[2 * (size_t)q] = obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = obs_xy[2 * (size_t)p->perm[q] + 1]; }
+        parallel_for(nobs, [&](int q0, int q1) {
+            for (int q = q0; q < q1; ++q) { xy[2 * (size_t)q] = obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = obs_xy[2 * (size_t)p->perm[q] + 1]; }
+        });
         double* d = nullptr;
         HIP_TRY(dev_upload(&d, xy));
         p->d_obs_xy = d;
