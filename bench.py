@@ -194,7 +194,9 @@ def main():
             "config": {"workload": "%s: %d cams / %d pts / %d obs, shared focal, %s, one independent problem per GPU"
                                    % (args.workload, n_cam, n_pt, n_obs, "DENSE_SCHUR-equivalent Cholesky" if linear == 0 else "block-Jacobi PCG"),
                        "step": "one full LM solve to ceres CONVERGENCE from the resident initial point",
-                       "lm_iterations_per_step": g_iters / (args.steps * world)},
+                       "lm_iterations_per_step": g_iters / (args.steps * world),
+                       "linear_solver": ("block-Jacobi PCG, tolerance %.0e anchored to the first LM iteration (library default)" % args.pcg_tol)
+                                        if linear == 1 else "exact Cholesky (DENSE_SCHUR equivalent)"},
             "residuals_per_sec": 2.0 * n_obs * g_evals / g_dt,
             "ms_per_lm_iteration": 1e3 * g_dt * world / g_iters,
             "final_rms_px": rms,
