@@ -140,8 +140,10 @@ struct DeviceBuffers {
 
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
 void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling, bool clear_udiag = true);
-template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling, bool clear_udiag = true,
+                                         bool points = true);
+template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
+                                             int ps_mode = 0 /* 0: point scales from db.pscale; 1 / 2: form them here (Jacobi / unit) */);
 // mode 0: off-diagonal blocks of S (upper triangle);  mode 1: the same blocks written straight into S~ = Lb^-1 S Lb^-T
 // (both triangles) + the per-camera glue of the block-Jacobi transform;  mode 2: diagonal blocks with duplicate pairs
 template <typename T> void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode);

@@ -214,14 +214,14 @@ void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const Devic
 }
 
 template <typename T>
-void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, bool clear_udiag) {
+void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, bool clear_udiag, bool points) {
     if (clear_udiag) (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
-    hipLaunchKernelGGL(k_colnorm_points<T>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
+    if (points) hipLaunchKernelGGL(k_colnorm_points<T>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
     if (jacobi) hipLaunchKernelGGL(k_colnorm_cams<T>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
     hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi);
 }
-template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool);
-template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool);
+template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool);
+template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool);
 
 // ------------------------------------------------------------------------------------------
 // 3x3 SPD: L^-1 (lower, 6 values l00 l10 l11 l20 l21 l22 of the INVERSE factor). Returns false if not PD.
@@ -320,7 +320,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <typename T>
-__global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceBuffers db) {
+__global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode) {
     __shared__ T sv[WPB][64][PB_LD];
     __shared__ double sb[WPB][64][3];
     __shared__ T sl[WPB][64][6];
@@ -358,10 +358,14 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 }, Ef[3] = { 0, 0, 0 };
         const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
         const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
+        // the Jacobi scales of this lane's point, issued with the first loads (used after the reduction)
+        double sp[3] = { 1.0, 1.0, 1.0 };
+        if (ps_mode == 0 && lane < npts) {
+            sp[0] = db.pscale[3 * (size_t)(pt0 + lane)]; sp[1] = db.pscale[3 * (size_t)(pt0 + lane) + 1]; sp[2] = db.pscale[3 * (size_t)(pt0 + lane) + 2];
+        }
         T Bk[6], Ak[12];                                // kept for the record sweep when single
         Proj prk = { 0.0, 0.0, 0.0 };
         int ik = 0, jk = 0;
-        T spk[3] = { (T)0, (T)0, (T)0 };
         T rk0 = (T)0, rk1 = (T)0;
 
         for (int c0 = o0; c0 < o1; c0 += 64) {
@@ -371,7 +375,6 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
                 double ox, oy;
                 load_obs<T>(ds.obs_xy, q, ox, oy);
                 const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
-                const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
                 const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
                 const Proj pr = project_point(ct, CT_R, CT_T, X);
                 const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
@@ -379,8 +382,7 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
                 T B[6];
                 point_block<T>(ct, pr, focal, B);
                 camera_block<T>(ct, pr, focal, X, B, Ak);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { B[c] *= sp[c]; B[3 + c] *= sp[c]; }
+                // (the point's Jacobi scales are applied to the per-point sums below, not to every observation)
                 const T g0 = (T)pr.xp * fscale, g1 = (T)pr.yp * fscale;
                 T* o = sv[w][lane];
                 o[0] = B[0] * B[0] + B[3] * B[3];
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
                 }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) Bk[c] = B[c];
-                prk = pr; ik = i; jk = j; spk[0] = sp[0]; spk[1] = sp[1]; spk[2] = sp[2]; rk0 = (T)r0; rk1 = (T)r1;
+                prk = pr; ik = i; jk = j; rk0 = (T)r0; rk1 = (T)r1;
             }
             wave_lds_fence();
             if (lane < npts) {
@@ -413,8 +415,20 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
         }
         if (lane < npts) {
             const size_t i = (size_t)(pt0 + lane);
+            // Jacobi scales of the point's three columns: loaded, or -- first linearisation of a solve -- formed here from the
+            // column norms this lane has just summed (s = 1 / (1 + ||J_col||), [Ceres-upstream] EstimateScale)
+            if (ps_mode != 0) {
+                sp[0] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[0])) : 1.0;
+                sp[1] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[2])) : 1.0;
+                sp[2] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[5])) : 1.0;
+                db.pscale[3 * i] = sp[0]; db.pscale[3 * i + 1] = sp[1]; db.pscale[3 * i + 2] = sp[2];
+            }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c] / db.pscale[3 * i + c]));
+            for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c]));           // gradient of the unscaled problem
+            V[0] *= sp[0] * sp[0]; V[1] *= sp[1] * sp[0]; V[2] *= sp[1] * sp[1];
+            V[3] *= sp[2] * sp[0]; V[4] *= sp[2] * sp[1]; V[5] *= sp[2] * sp[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { bp[c] *= sp[c]; Ef[c] *= sp[c]; }
             // LM damping D^2 = clamp(diag(J~^T J~)) / radius   [LevenbergMarquardtStrategy::ComputeStep]
             V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
             V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
@@ -432,8 +446,9 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
             sff -= y0 * y0 + y1 * y1 + y2 * y2;
             rhsf -= y0 * t0 + y1 * t1 + y2 * t2;
             if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2)) bad = 1.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) sl[w][lane][c] = (T)Li[c];
+            // L^-1 with the point scales folded in: the record sweep forms C = B~ L^-T = B diag(s) L^-T from the UNSCALED blocks
+            sl[w][lane][0] = (T)(Li[0] * sp[0]); sl[w][lane][1] = (T)(Li[1] * sp[0]); sl[w][lane][2] = (T)(Li[2] * sp[1]);
+            sl[w][lane][3] = (T)(Li[3] * sp[0]); sl[w][lane][4] = (T)(Li[4] * sp[1]); sl[w][lane][5] = (T)(Li[5] * sp[2]);
             st_yf[w][lane][0] = (T)t0; st_yf[w][lane][1] = (T)t1; st_yf[w][lane][2] = (T)t2;
             st_yf[w][lane][3] = (T)y0; st_yf[w][lane][4] = (T)y1; st_yf[w][lane][5] = (T)y2;
         }
@@ -445,14 +460,11 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
             if (!single) {      // more than 64 observations on one point: recompute this round's blocks
                 ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
                 const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
-                spk[0] = (T)db.pscale[3 * (size_t)ik]; spk[1] = (T)db.pscale[3 * (size_t)ik + 1]; spk[2] = (T)db.pscale[3 * (size_t)ik + 2];
                 const CamRow ct = { tab + 4 * (size_t)(jk), ds.ncam };
                 prk = project_point(ct, CT_R, CT_T, X);
                 { double ox, oy; load_obs<T>(ds.obs_xy, q, ox, oy); rk0 = (T)(focal * prk.xp - ox); rk1 = (T)(focal * prk.yp - oy); }
                 point_block<T>(ct, prk, focal, Bk);
                 camera_block<T>(ct, prk, focal, X, Bk, Ak);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { Bk[c] *= spk[c]; Bk[3 + c] *= spk[c]; }
             }
             const T* Lp = sl[w][ik - pt0];
             const T l00 = Lp[0], l10 = Lp[1], l11 = Lp[2], l20 = Lp[3], l21 = Lp[4], l22 = Lp[5];
@@ -1023,11 +1035,11 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
 
 
 template <typename T>
-void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, db);
+void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int ps_mode) {
+    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, db, ps_mode);
 }
-template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
+template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 
 template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {

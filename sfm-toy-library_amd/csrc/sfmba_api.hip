@@ -217,7 +217,8 @@ void launch_linearise_setup(sfmba_problem* p, int jacobi, bool begun = false) {
     launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
     launch_xnorm(p->stream, p->ds, p->db);
     launch_iter0(p->stream, p->ds, p->db);
-    launch_colnorm<T>(p->stream, p->ds, p->db, jacobi, /*clear_udiag=*/!begun);
+    // inside a solve (begun) the point scales are formed by the first k_point_build itself: no point pass here
+    launch_colnorm<T>(p->stream, p->ds, p->db, jacobi, /*clear_udiag=*/!begun, /*points=*/!begun);
     launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
 }
 
@@ -250,6 +251,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     int term = -1, msg = MSG_NONE;
     int host_iter = 0;
     bool state_mirrored = false;
+    bool first_linearisation = true;
     bool first_linear_solve = true;
     const char* gate_env = std::getenv("SFMBA_PCG_GATED");
     const bool gated_cg = !(gate_env && gate_env[0] == '0');
@@ -276,7 +278,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             p->db.pcg_F32 = (p->precision == SFMBA_PRECISION_F32J && f32_matrix) ? dense_pcg_want_f32(&p->solver) : nullptr;
             p->solver.use_f32 = p->db.pcg_F32 != nullptr;
         }
-        { ProfScope ps(prof, KID_POINT_BUILD, p->stream); launch_point_build<T>(p->stream, p->ds, p->db); }
+        { ProfScope ps(prof, KID_POINT_BUILD, p->stream);
+          launch_point_build<T>(p->stream, p->ds, p->db, first_linearisation ? (o.jacobi_scaling ? 1 : 2) : 0); }
+        first_linearisation = false;
         { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
         launch_schur_pairs<T>(p->stream, p->ds, p->db, 2);      // duplicate pairs inside diagonal blocks (usually none)
         if (pcg) {
