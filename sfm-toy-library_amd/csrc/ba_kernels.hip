@@ -1328,6 +1328,10 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
         const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
         const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
+        double sp[3] = { 1.0, 1.0, 1.0 };      // Jacobi scales of this lane's point, issued with the first loads
+        if (lane < npts) {
+            sp[0] = db.pscale[3 * (size_t)(pt0 + lane)]; sp[1] = db.pscale[3 * (size_t)(pt0 + lane) + 1]; sp[2] = db.pscale[3 * (size_t)(pt0 + lane) + 2];
+        }
         // kept for the second sweep when single
         Proj prk = { 0.0, 0.0, 0.0 };
         double r0k = 0, r1k = 0, dpk[3] = { 0, 0, 0 }, oxk = 0, oyk = 0;
@@ -1340,7 +1344,6 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
                 double ox, oy;
                 load_obs<T>(ds.obs_xy, q, ox, oy);
                 const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
-                const T sp[3] = { (T)db.pscale[3 * (size_t)i], (T)db.pscale[3 * (size_t)i + 1], (T)db.pscale[3 * (size_t)i + 2] };
                 const CamRow stb = { tab + 4 * (size_t)(j), ds.ncam };
                 const Proj pr = project_point(stb, ST_R, ST_T, X);
                 const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
@@ -1352,8 +1355,7 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
                 const double fz = focal * pr.iz;
                 const double u0 = fz * (dp0 - pr.xp * dp2) + pr.xp * dfoc;
                 const double u1 = fz * (dp1 - pr.yp * dp2) + pr.yp * dfoc;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { B[c] *= sp[c]; B[3 + c] *= sp[c]; }
+                // (point scales are applied to the per-point sums below)
                 T* o = sv[w][lane];
                 o[0] = B[0] * B[0] + B[3] * B[3];
                 o[1] = B[1] * B[0] + B[4] * B[3];
@@ -1380,6 +1382,10 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
         }
         if (lane < npts) {
             const size_t i = (size_t)(pt0 + lane);
+            V[0] *= sp[0] * sp[0]; V[1] *= sp[1] * sp[0]; V[2] *= sp[1] * sp[1];
+            V[3] *= sp[2] * sp[0]; V[4] *= sp[2] * sp[1]; V[5] *= sp[2] * sp[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bp[c] *= sp[c];
             V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
             V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
             V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
@@ -1392,7 +1398,7 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
             const double y2 = Li[5] * t2;
             const double y1 = Li[2] * t1 + Li[4] * t2;
             const double y0 = Li[0] * t0 + Li[1] * t1 + Li[3] * t2;
-            const double dX[3] = { db.pscale[3 * i] * y0, db.pscale[3 * i + 1] * y1, db.pscale[3 * i + 2] * y2 };
+            const double dX[3] = { sp[0] * y0, sp[1] * y1, sp[2] * y2 };
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const double x = pts[3 * i + c];
