@@ -107,6 +107,27 @@ void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuff
 template void launch_cam_setup<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 template void launch_cam_setup<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 
+// First launch of a solve: the LM state arrives as a kernel argument (no H2D copy); the same launch clears the linear-solver
+// status word, the Jacobi scales, the column-norm accumulators and the slotted accumulators and builds the camera tables
+// (instead of a copy, two memsets, a fill kernel, k_cam_setup and k_iter0).
+__global__ void k_begin(LMState st, DeviceStructure ds, DeviceBuffers db) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) { *db.st = st; *db.lin_info = 0; *db.fin_counter = 0; }
+    if (e < 6 * ds.ncam) db.cscale[e] = 1.0;
+    if (e < ds.ld) db.udiag[e] = 0.0;
+    if (e < NSLOT * SLOT_W) db.slots[e] = 0.0;
+    if (e < ds.ncam) {
+        double c6[6], ct[CT_STRIDE];
+        for (int k = 0; k < 6; ++k) c6[k] = db.cam[st.cur][6 * e + k];
+        make_cam_table(c6, nullptr, ct);
+        for (int k = 0; k < CT_STRIDE; ++k) db.camtab[st.cur][cam_tab_index(k, e, ds.ncam)] = ct[k];
+    }
+}
+void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, const LMState& st) {
+    const int nb = std::max(std::max(6 * ds.ncam, ds.ld), NSLOT * SLOT_W);
+    hipLaunchKernelGGL(k_begin, dim3((nb + 255) / 256), dim3(256), 0, s, st, ds, db);
+}
+
 // ||x||^2 of the current parameters -> acc[ACC_XNEW2]
 __global__ void k_xnorm(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[BLK / 64];
@@ -189,11 +210,15 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
     }
 }
 
-__global__ void k_colnorm_finish(DeviceStructure ds, DeviceBuffers db, int jacobi) {
+__global__ void k_colnorm_finish(DeviceStructure ds, DeviceBuffers db, int jacobi, int finish_xnorm) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 64) {      // focal column: summed over the slots by one wave
         const double n2 = slots_take(db, ACC_UDF);
         if (threadIdx.x == 0) db.st->fscale = jacobi ? 1.0 / (1.0 + sqrt(n2)) : 1.0;
+        if (finish_xnorm) {                          // ||x|| of the starting point (k_iter0's job outside a solve)
+            const double x2 = slots_take(db, ACC_XNEW2);
+            if (threadIdx.x == 0) db.st->x_norm = sqrt(x2);
+        }
     }
     if (e >= ds.d - 1) return;
     db.cscale[e] = jacobi ? 1.0 / (1.0 + sqrt(db.udiag[e])) : 1.0;
@@ -210,18 +235,18 @@ void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const De
     else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
 }
 void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi) {
-    hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi);
+    hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi, 0);
 }
 
 template <typename T>
-void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, bool clear_udiag, bool points) {
+void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, bool clear_udiag, bool points, bool finish_xnorm) {
     if (clear_udiag) (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
     if (points) hipLaunchKernelGGL(k_colnorm_points<T>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
     if (jacobi) hipLaunchKernelGGL(k_colnorm_cams<T>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
-    hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi);
+    hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi, finish_xnorm ? 1 : 0);
 }
-template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool);
-template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool);
+template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool, bool);
+template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool, bool);
 
 // ------------------------------------------------------------------------------------------
 // 3x3 SPD: L^-1 (lower, 6 values l00 l10 l11 l20 l21 l22 of the INVERSE factor). Returns false if not PD.

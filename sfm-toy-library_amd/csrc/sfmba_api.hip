@@ -77,15 +77,6 @@ template <typename T> hipError_t dev_upload(T** p, const std::vector<T>& v) {
     return e;
 }
 
-// First launch of a solve: the LM state arrives as a kernel argument (no H2D copy), the linear-solver status word, the Jacobi
-// scales and the column-norm accumulators are cleared in the same launch (instead of a copy, two memsets and a fill kernel).
-__global__ void k_begin(LMState st, DeviceBuffers db, int n_cscale, int ld) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e == 0) { *db.st = st; *db.lin_info = 0; }
-    if (e < n_cscale) db.cscale[e] = 1.0;
-    if (e < ld) db.udiag[e] = 0.0;
-}
-
 // Host loops over the observation list of a large problem, split over a few threads (structure build of the one-shot call).
 template <typename F>
 void parallel_for(int n, F fn) {
@@ -212,14 +203,19 @@ int ensure_trace(sfmba_problem* p, int rows) {
 
 template <typename T>
 void launch_linearise_setup(sfmba_problem* p, int jacobi, bool begun = false) {
+    if (begun) {
+        // inside a solve: k_begin has written the LM state, cleared the accumulators and built the camera tables; the point
+        // scales are formed by the first k_point_build; ||x|| is finished by k_colnorm_finish
+        launch_xnorm(p->stream, p->ds, p->db);
+        launch_colnorm<T>(p->stream, p->ds, p->db, jacobi, /*clear_udiag=*/false, /*points=*/false, /*finish_xnorm=*/true);
+        return;
+    }
     const size_t n = 6 * (size_t)p->ds.ncam;
-    if (!begun) hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
     launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
     launch_xnorm(p->stream, p->ds, p->db);
     launch_iter0(p->stream, p->ds, p->db);
-    // inside a solve (begun) the point scales are formed by the first k_point_build itself: no point pass here
-    launch_colnorm<T>(p->stream, p->ds, p->db, jacobi, /*clear_udiag=*/!begun, /*points=*/!begun);
-    launch_cam_setup<T>(p->stream, p->ds, p->db, p->cur);
+    launch_colnorm<T>(p->stream, p->ds, p->db, jacobi);
 }
 
 template <typename T>
@@ -244,8 +240,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     init_state(p, st, o);
     *p->h_state = st;
     { ProfScope ps(p->prof.on ? &p->prof : nullptr, KID_SETUP, p->stream);
-      const int nb = std::max(6 * p->ds.ncam, p->ds.ld);
-      hipLaunchKernelGGL(k_begin, dim3((nb + 255) / 256), dim3(256), 0, p->stream, st, p->db, 6 * p->ds.ncam, p->ds.ld);
+      launch_begin(p->stream, p->ds, p->db, st);
       launch_linearise_setup<T>(p, o.jacobi_scaling, /*begun=*/true); }
 
     int term = -1, msg = MSG_NONE;
