@@ -111,3 +111,17 @@ def test_invalid_arguments_are_reported_not_crashed(capi, sfm):
     # the library is still usable afterwards
     s = capi.solve(prob)[3]
     assert s["termination_name"] == "CONVERGENCE"
+
+
+def test_truncated_linear_solves_still_converge(capi, sfm):
+    """pcg_max_iters caps every CG solve (the gated kernels behind a too-short batch are forced once the cap is spent): LM then
+    works with inexact steps -- more iterations, same minimum."""
+    prob = sfm.make_problem("cfg2")
+    ref = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=0))[3]
+    s = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_max_iters=3, max_iters=50))[3]
+    assert s["termination_name"] == "CONVERGENCE"
+    assert s["iterations"] > ref["iterations"]
+    assert s["linear_iters"] == 3 * s["iterations"]
+    assert abs(s["final_cost"] - ref["final_cost"]) <= 1e-5 * ref["final_cost"]
+    s1 = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_max_iters=1, max_iters=20))[3]
+    assert s1["termination_name"] == "NO_CONVERGENCE" and s1["iterations"] == 20
