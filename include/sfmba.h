@@ -53,11 +53,15 @@ enum {
 
 enum { SFMBA_LINEAR_CHOLESKY = 0,   /* exact Schur + dense LLT == DENSE_SCHUR (BA.cpp:172) */
        SFMBA_LINEAR_PCG      = 1,   /* exact Schur + block-Jacobi PCG on the dense reduced system */
-       SFMBA_LINEAR_AUTO     = 2 }; /* the shim's choice: CHOLESKY while the reduced system is small (<= 256 unknowns: a handful of
-                                       panels, exact), PCG above (parameters agree with the exact solve to ~2e-7, cost to 1e-12) */
+       SFMBA_LINEAR_AUTO     = 2 }; /* CHOLESKY while the reduced system is small (<= 256 unknowns: a handful of panels, exact),
+                                       PCG above (parameters agree with the exact solve to ~2e-7, cost to 1e-12).  The drop-in shim
+                                       uses CHOLESKY like the reference; PCG / AUTO are opt-in there (SFMBA_LINEAR) */
 
 enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
-       SFMBA_PRECISION_F32J = 1 };  /* fp32 Jacobian blocks, fp64 residual/cost and accumulation */
+       SFMBA_PRECISION_F32J = 1 };  /* fp32 Jacobian blocks AND fp32 observation coordinates (BASELINE config 3; the reference's
+                                       observations are cv::Point2f anyway, BA.cpp:149-153 -- a caller holding genuinely double
+                                       observations loses ~1e-4 px at 2k-px coordinates); residuals, cost, sums and the reduced
+                                       system in fp64 */
 
 /* Return codes of every entry point. */
 enum {
@@ -135,9 +139,10 @@ SFMBA_API long long   sfmba_release_cache(void);
 
 /*
  * One-shot solve == the ceres::Problem build + ceres::Solve of BA.cpp:109-179.
- * Parameters are updated in place whatever the termination (as Ceres does); the
- * shim applies the reference's "discard unless CONVERGENCE" rule (BA.cpp:182-185).
- * trace may be NULL; at most trace_cap rows are written, *trace_len receives the count.
+ * Parameters are updated in place for CONVERGENCE and NO_CONVERGENCE and left untouched for FAILURE (as Ceres
+ * does); the shim applies the reference's "discard unless CONVERGENCE" rule (BA.cpp:182-185).
+ * trace may be NULL; at most trace_cap rows are written and *trace_len receives the number written (with trace == NULL:
+ * the number of rows the solve produced).
  */
 SFMBA_API int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3,
                 int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,

@@ -969,7 +969,7 @@ bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int 
     const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
     const bool fits = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && 2 * d <= 256 * PCG_GPT && rows_per_wg <= 4 * PCG_RPW;
-    if (!fits || !ws->gran) return false;
+    if (!fits || !ws->gran || ws->coop_refused) return false;
     if (ws->n_cu == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); ws->n_cu = -1; }
@@ -987,9 +987,18 @@ bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int 
     if (ws->h_mailbox) { ws->h_mailbox[0] = -1; ws->h_mailbox[1] = 0; }
     const size_t lds = sizeof(double) * (size_t)(2 * ld + 16);
     double* bt = ws->vec + (size_t)8 * ld;
+    // The in-kernel exchange needs EVERY workgroup resident at the same time: a cooperative launch makes the runtime
+    // guarantee that (or refuse), whatever other streams / concurrent problems occupy the device.  A refusal falls back
+    // to the launch-per-iteration path (the caller sees `false`).
+    int d_ = d, ld_ = ld, max_iters_ = max_iters, rows_ = rows_per_wg, anchor_ = anchor;
+    unsigned epoch_ = epoch0;
+    double tol2_ = tol * tol, cap_ = pcg_cap(tol);
+    const double* F_ = ws->Sfull; const double* bt_ = bt;
+    void* args[] = { &d_, &ld_, &F_, &bt_, &ws->vec, &ws->gran, &epoch_, &max_iters_, &tol2_, &rows_, &ws->flags, &info_dev,
+                     &ws->d_mailbox, &ws->tmo, &ws->scal, &anchor_, &cap_ };
     ProfScope ps(prof, KID_PCG_ITER, s);
-    hipLaunchKernelGGL(k_pcg_persistent, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, bt, ws->vec, ws->gran, epoch0, max_iters, tol * tol,
-                       rows_per_wg, ws->flags, info_dev, ws->d_mailbox, ws->tmo, ws->scal, anchor, pcg_cap(tol));
+    const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_pcg_persistent), dim3(nwg), dim3(256), args, (unsigned)lds, s);
+    if (le != hipSuccess) { (void)hipGetLastError(); ws->coop_refused = true; return false; }
     return true;
 }
 

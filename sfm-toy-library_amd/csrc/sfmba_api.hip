@@ -87,6 +87,35 @@ void parallel_for(int n, F fn) {
     for (auto& th : pool) th.join();
 }
 
+// Host side of the one meeting point per LM iteration: wait until the device has posted sequence number `want` to a
+// host-mapped mailbox word.  Three phases so that a solve does not pin a core: a short pause-spin (the common case: the
+// post arrives within microseconds of the host getting here), then yielding, then short sleeps.  While waiting, the
+// stream is queried now and then: a stream that has drained WITHOUT the post means a launch failed or was lost --
+// reported instead of waiting on a wall clock.  Returns 0 = posted, 1 = stream idle and nothing posted, 2 = HIP error.
+int wait_mailbox(volatile int* word, int want, hipStream_t stream) {
+    const double t0 = now_seconds();
+    unsigned spins = 0;
+    double next_query = 2e-3;
+    for (;;) {
+        if (*word >= want) { __sync_synchronize(); return 0; }
+        ++spins;
+        if ((spins & 63u) != 0u) { __builtin_ia32_pause(); continue; }
+        const double waited = now_seconds() - t0;
+        if (waited < 30e-6) continue;
+        if (waited >= next_query) {
+            next_query = waited * 1.5;
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) {
+                __sync_synchronize();
+                return *word >= want ? 0 : 1;
+            }
+            if (q != hipErrorNotReady) return 2;
+        }
+        if (waited < 1e-3) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
 __global__ void k_fill(double* p, size_t n, double v) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) p[e] = v;
@@ -319,36 +348,32 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, dbu); }
             { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
             ++launched_controls;
+            // every launch of this LM iteration is in the queue: a failed launch must not leave the host waiting for a post
+            if (hipError_t le = hipGetLastError(); le != hipSuccess)
+                return fail(SFMBA_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
             // wait for k_lm_control's mailbox post (system-scope stores to host-mapped memory)
             volatile int* mb = p->h_lm_mail;
-            const double t_end = now_seconds() + 5.0;
-            bool timed_out = false;
-            while (mb[0] < launched_controls) {
-                if (now_seconds() > t_end) { timed_out = true; break; }
+            const int wrc = wait_mailbox(mb, launched_controls, p->stream);
+            if (wrc != 0) {
+                const hipError_t se = hipStreamSynchronize(p->stream);
+                return fail(SFMBA_ERR_HIP, std::string("LM iteration did not complete on the device: ") +
+                                           (se != hipSuccess ? hipGetErrorString(se) : "stream drained without the control kernel's post"));
             }
-            __sync_synchronize();
-            if (!timed_out && mb[1] == -2) {
+            if (mb[1] == -2) {
                 // the CG batch was too short: enqueue more iterations (or force the step once max_iters are spent), then the trio again
                 if (dense_pcg_more(p->stream, &p->solver, 8, prof) == 0) dbu.cg_force = 1;
                 continue;
             }
             lm_done = true;
-            state_mirrored = !timed_out;
-            if (timed_out) {
-                rc = download_state(p);
-                if (rc) return rc;
-                host_iter = p->h_state->iter;
-                if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; }
-            } else {
-                host_iter = mb[3];
-                if (mb[1] != -1) { term = mb[1]; msg = mb[2]; }
-            }
+            state_mirrored = true;
+            host_iter = mb[3];
+            if (mb[1] != -1) { term = mb[1]; msg = mb[2]; }
             if (pcg_async) {      // posted before k_lm_control ran (same stream)
                 const int it = p->solver.h_mailbox[1] != 0 ? p->solver.h_mailbox[0] : 0;
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
             } else if (pcg_gated) {
-                const int it = timed_out ? p->solver.run.launched : mb[4];
+                const int it = mb[4];
                 dense_pcg_note(&p->solver, (int)lin_hist.size(), it);
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
@@ -394,7 +419,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         static_assert(sizeof(TraceRow) == sizeof(sfmba_iteration), "trace row layout");
         std::memcpy(trace, tr.data(), sizeof(TraceRow) * (size_t)n);
     }
-    if (trace_len) *trace_len = rows;
+    if (trace_len) *trace_len = trace ? std::min(rows, std::max(trace_cap, 0)) : rows;     // rows written (all rows if only the count was asked for)
     if (summary) *summary = sum;
     return SFMBA_OK;
 }
@@ -862,11 +887,13 @@ int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3, int64_t n_obs, c
     if (rc) return rc;
     const double setup = now_seconds() - t0;
     sfmba_summary sum;
+    std::memset(&sum, 0, sizeof(sum));
     rc = sfmba_problem_solve(p, &o, &sum, trace, trace_cap, trace_len);
+    // Ceres leaves the user's parameter blocks untouched when the solve terminates with FAILURE (solver.cc: "do not update
+    // user state" [Ceres-upstream]); every other termination writes the best accepted point back
     if (rc == SFMBA_OK && sum.termination != SFMBA_FAILURE) rc = sfmba_problem_get_params(p, cam6, pt3, focal);
-    else if (rc == SFMBA_OK) rc = sfmba_problem_get_params(p, cam6, pt3, focal);
     sum.setup_seconds = setup;
-    if (summary) *summary = sum;
+    if (summary && rc == SFMBA_OK) *summary = sum;
     sfmba_problem_destroy(p);
     return rc;
 }

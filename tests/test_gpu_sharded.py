@@ -1,6 +1,7 @@
 """Sharded solve through the HIP C ABI (-m gpu): two ranks (two processes) share the one MI355X of the
 test box, each holds half of the points, the reduced camera system is all-reduced between them (gloo
-on device tensors here; RCCL when every rank has its own GPU).  Must reproduce the single-GPU solve."""
+on device tensors here; RCCL when every rank has its own GPU).  Must reproduce the ORACLE's solve of the
+whole problem (and, as a consistency check, the single-GPU HIP solve)."""
 import os
 import sys
 
@@ -12,7 +13,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, name, linear, out):
+CASES = {
+    # name: (make_problem kwargs, precision, linear solver, options)
+    "small": (dict(name="small"), 0, 0, dict()),
+    "cfg2": (dict(name="cfg2"), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
+    # 230 cameras: reduced dimension 1381 > 1280 -> streaming CG (fp32-stored matrix in F32J mode); ~10 pairs per 6x6
+    # block -> the sixteen-lane pair pass k_schur_pairs_sub; sharded ranks transform the all-reduced system (k_pcg_transform)
+    "wide": (dict(name="cfg3", n_cam=230, n_pt=6000, seed=77), 1, 1, dict()),
+}
+
+
+def _worker(rank, world, port, case, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -22,9 +33,10 @@ def _worker(rank, world, port, name, linear, out):
     import sfm_toy_library_amd as sfm
     from sfm_toy_library_amd import capi
     from sfm_toy_library_amd.sharded import HipShardBackend, solve_sharded
-    prob = sfm.make_problem(name)
-    backend = HipShardBackend(prob, rank, world, device=0, precision=0)
-    opt = capi.default_options(max_seconds=0.0, linear_solver=linear, pcg_tolerance=1e-12, pcg_anchored=0)
+    kw, precision, linear, okw = CASES[case]
+    prob = sfm.make_problem(**kw)
+    backend = HipShardBackend(prob, rank, world, device=0, precision=precision)
+    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw)
     summ = solve_sharded(backend, dist, opt)
     cam, pt, f = backend.get_params()
     out.put((rank, summ, cam, pt, f, backend._point_range))
@@ -33,29 +45,39 @@ def _worker(rank, world, port, name, linear, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,linear", [("small", 0), ("cfg2", 1)])
-def test_two_rank_sharded_hip_solve(sfm, name, linear):
+@pytest.mark.parametrize("case", ["small", "cfg2", "wide"])
+def test_two_rank_sharded_hip_solve(sfm, oracle, case):
     from sfm_toy_library_amd import capi
+    kw, precision, linear, okw = CASES[case]
     world, port = 2, 29711 + (os.getpid() % 500)
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, linear, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([out.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    prob = sfm.make_problem(name)
-    cam_s, pt_s, f_s, s_s, _ = capi.solve(prob, capi.default_options(max_seconds=0.0, linear_solver=linear, pcg_tolerance=1e-12, pcg_anchored=0))
+    prob = sfm.make_problem(**kw)
     (r0, s0, cam0, pt0, f0, rng0), (r1, s1, cam1, pt1, f1, rng1) = results
-    assert s0["termination_name"] == s1["termination_name"] == s_s["termination_name"] == "CONVERGENCE"
-    assert s0["iterations"] == s1["iterations"] == s_s["iterations"]
-    assert np.isclose(s0["initial_cost"], s_s["initial_cost"], rtol=1e-12)
-    assert abs(s0["final_cost"] - s_s["final_cost"]) <= 1e-9 * s_s["final_cost"]
-    assert s0["final_cost"] == s1["final_cost"]
-    assert np.array_equal(cam0, cam1) and f0 == f1                      # replicas stay bit-identical
-    assert np.allclose(cam0, cam_s, atol=1e-8) and np.isclose(f0, f_s, rtol=1e-10)
     pts = np.vstack([pt0, pt1])
     assert rng0 == (0, prob.n_pt // 2) and rng1[1] == prob.n_pt
-    assert np.allclose(pts, pt_s, atol=1e-8)
+    assert s0["final_cost"] == s1["final_cost"]
+    assert np.array_equal(cam0, cam1) and f0 == f1                      # replicas stay bit-identical
+    # --- against the oracle's solve of the WHOLE problem (Ceres-equivalent LM + DENSE_SCHUR on one host) ---
+    cam_o, pt_o, f_o, s_o, _ = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    exact = precision == 0
+    assert s0["termination_name"] == s1["termination_name"] == s_o["termination_name"] == "CONVERGENCE"
+    assert s0["iterations"] == s1["iterations"] == s_o["iterations"]
+    assert np.isclose(s0["initial_cost"], s_o["initial_cost"], rtol=1e-12 if exact else 1e-9)
+    assert abs(s0["final_cost"] - s_o["final_cost"]) <= (1e-9 if exact else 1e-6) * s_o["final_cost"]
+    assert abs(np.sqrt(2 * s0["final_cost"] / prob.n_obs) - np.sqrt(2 * s_o["final_cost"] / prob.n_obs)) < 1e-4
+    atol = 1e-7 if exact else 5e-6
+    assert np.abs(cam0 - cam_o).max() <= atol and np.isclose(f0, f_o, rtol=1e-9 if exact else 1e-7)
+    assert np.abs(pts - pt_o).max() <= atol
+    # --- and against the unsharded HIP solve with the same options ---
+    cam_s, pt_s, f_s, s_s, _ = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw))
+    assert s0["iterations"] == s_s["iterations"]
+    assert abs(s0["final_cost"] - s_s["final_cost"]) <= (1e-9 if exact else 1e-7) * s_s["final_cost"]
+    assert np.allclose(cam0, cam_s, atol=1e-8 if exact else 5e-6) and np.allclose(pts, pt_s, atol=1e-8 if exact else 5e-6)

@@ -73,6 +73,28 @@ def test_shim_matches_reference_restatement(sfm, oracle, name, monkeypatch):
     assert not np.array_equal(pts_g, pts)
 
 
+@pytest.mark.parametrize("linear", ["default", "cholesky", "auto", "pcg"])
+def test_shim_with_sixty_views_all_linear_solvers(sfm, oracle, linear, monkeypatch):
+    """60 views (reduced dimension 361): the shim's default is the reference's exact DENSE_SCHUR-equivalent Cholesky;
+    SFMBA_LINEAR=auto|pcg opts into the block-Jacobi PCG branch a many-view caller would pick.  Both against the oracle's
+    restatement of adjustBundle() (BA.cpp:99-222) to float round-off of the written-back containers."""
+    monkeypatch.setenv("SFMBA_MAX_SECONDS", "0")
+    if linear == "default":
+        monkeypatch.delenv("SFMBA_LINEAR", raising=False)
+    else:
+        monkeypatch.setenv("SFMBA_LINEAR", linear)
+    prob = sfm.make_problem("cfg2", n_cam=60, n_pt=2000, views=6, seed=4343)
+    poses, K, pts, views, feats = _containers(prob, sfm, n_extra_views=2)
+    p_o, K_o, pts_o, summ = oracle.adjust_bundle(poses, K, pts, views, feats, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    assert summ["termination_name"] == "CONVERGENCE"
+    p_g, K_g, pts_g = _call_shim(poses, K, pts, views, feats)
+    assert np.array_equal(p_g[-1], np.zeros((3, 4), np.float32)) and np.array_equal(p_g[-2], np.zeros((3, 4), np.float32))
+    assert not np.array_equal(pts_g, pts)
+    assert np.allclose(K_g, K_o, rtol=2e-7, atol=0)
+    assert np.allclose(p_g, p_o, rtol=0, atol=2e-6)
+    assert np.allclose(pts_g, pts_o, rtol=0, atol=2e-6)
+
+
 def test_shim_leaves_everything_untouched_without_convergence(sfm, monkeypatch, tmp_path):
     """BA.cpp:182-185: a point on the camera plane makes the first evaluation fail -> FAILURE -> no write-back."""
     monkeypatch.setenv("SFMBA_MAX_SECONDS", "0")
