@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SFMBA_ABI_VERSION 2
+#define SFMBA_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define SFMBA_API __attribute__((visibility("default")))
@@ -69,7 +69,8 @@ enum {
     SFMBA_ERR_INVALID_ARG = 1,
     SFMBA_ERR_NO_DEVICE   = 2,   /* HIP runtime/device missing: the product path never falls back to CPU */
     SFMBA_ERR_HIP         = 3,
-    SFMBA_ERR_ALLOC       = 4
+    SFMBA_ERR_ALLOC       = 4,
+    SFMBA_ERR_CAPACITY    = 5    /* an output array is too small: the required length was returned, nothing else written */
 };
 
 typedef struct sfmba_options {
@@ -256,6 +257,41 @@ SFMBA_API int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);
 SFMBA_API int sfmba_triangulate(int device, int64_t n, const float* left_xy, const float* right_xy, const float* K,
                                 const float* P_left, const float* P_right, float max_reproj_px,
                                 float* points3d, unsigned char* keep, float* reproj_err);
+
+/*
+ * The two association loops of the incremental pipeline, results identical to the reference's loops
+ * entry for entry and in the same order.
+ *
+ * Shared encodings
+ *   cloud views   CSR over the cloud points: view_ptr [n_pt + 1]; entries view_idx / feat_idx = the point's originatingViews
+ *                 (SfMCommon.h:87) in ASCENDING view index (std::map iteration order)
+ *   match matrix  SfM::mFeatureMatchMatrix (SfM.h:50) flattened: pair p = [pair_left[p]][pair_right[p]], its cv::DMatch list is
+ *                 entries pair_ptr[p] .. pair_ptr[p+1] of query_idx / train_idx (/ distance), in list order.  Only entries with
+ *                 left <= right are ever consulted by the reference (SfM.cpp:489-490, 555-558); others are ignored here too.
+ *
+ * sfmba_find_2d3d_matches == SfM::find2D3DMatches (SfMToyLib/SfM.cpp:471-528): for every view v with view_done[v] == 0 and
+ * every cloud point, the first originating view (ascending) that has a match to v for the point's feature -- the FIRST such
+ * match in list order, matches whose other index is negative skipped (SfM.cpp:508) -- yields one entry
+ * (cloud point index, feature index in view v).  Output: out_ptr [n_views + 1] (done views: empty ranges), entries in cloud
+ * order inside a view; the reference's points2D / points3D are features[v].points[out_feature] / cloud[out_point].p.
+ * *total receives the number of entries; SFMBA_ERR_CAPACITY (out_ptr and *total valid, nothing else written) if cap < *total.
+ */
+SFMBA_API int sfmba_find_2d3d_matches(int device, int n_views, const unsigned char* view_done,
+                int n_pt, const int64_t* view_ptr, const int32_t* view_idx, const int32_t* feat_idx,
+                int n_pairs, const int32_t* pair_left, const int32_t* pair_right, const int64_t* pair_ptr,
+                const int32_t* query_idx, const int32_t* train_idx,
+                int64_t* out_ptr, int32_t* out_point, int32_t* out_feature, int64_t cap, int64_t* total);
+/*
+ * The O(n^2) part of SfM::mergeNewPointCloud (SfMToyLib/SfM.cpp:538-544): which points of the cloud are closer than max_dist
+ * (MERGE_CLOUD_POINT_MIN_MATCH_DISTANCE, SfM.cpp:50) to new point k.  "The cloud" as of new point k is the existing points
+ * followed by the new points 0 .. k-1 that were appended before it (SfM.cpp:596-600), so the candidates of k are indices j of
+ * the sequence [existing 0 .. n_exist-1, new 0 .. k-1] (j >= n_exist means new point j - n_exist) with
+ * cv::norm(seq[j] - new[k]) < max_dist in the reference's arithmetic (float difference, double norm), ASCENDING -- the order
+ * the reference's scan meets them in.  cand_ptr [n_new + 1], cand_idx [cap].  The sequential, data-dependent remainder of the
+ * function (feature-match confirmation, views added to existing points) is host code: host/SfMAssociation.cpp.
+ */
+SFMBA_API int sfmba_merge_candidates(int device, int n_exist, const float* exist_xyz, int n_new, const float* new_xyz, float max_dist,
+                int64_t* cand_ptr, int32_t* cand_idx, int64_t cap, int64_t* total);
 
 #ifdef __cplusplus
 }

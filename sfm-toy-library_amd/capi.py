@@ -27,6 +27,7 @@ SYMBOLS = [
     "sfmba_shard_scalars_buf", "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish",
     "sfmba_shard_end", "sfmba_problem_set_profiling", "sfmba_problem_get_profile",
     "sfmba_problem_create_sharded", "sfmba_shard_setup_finish", "sfmba_shard_setup_len", "sfmba_shard_setup_buf", "sfmba_release_cache", "sfmba_triangulate",
+    "sfmba_find_2d3d_matches", "sfmba_merge_candidates",
 ]
 
 
@@ -44,6 +45,79 @@ def triangulate(K, P_left, P_right, left_xy, right_xy, max_reproj_px=10.0, devic
                                    Pl.ctypes.data_as(fp), Pr.ctypes.data_as(fp), C.c_float(max_reproj_px), X.ctypes.data_as(fp),
                                    keep.ctypes.data_as(C.POINTER(C.c_ubyte)), err.ctypes.data_as(fp)))
     return X, keep.astype(bool), err
+
+
+SFMBA_ERR_CAPACITY = 5
+
+
+def _flat_views(views):
+    """list of {view: feature} per cloud point -> CSR arrays in ascending view order (std::map iteration order)."""
+    ptr = np.zeros(len(views) + 1, dtype=np.int64)
+    vi, fi = [], []
+    for i, m in enumerate(views):
+        for v in sorted(m):
+            vi.append(v)
+            fi.append(m[v])
+        ptr[i + 1] = len(vi)
+    return ptr, np.asarray(vi, dtype=np.int32), np.asarray(fi, dtype=np.int32)
+
+
+def _flat_matches(match_matrix):
+    """{(left, right): [(query, train, distance), ...]} -> flattened pair arrays (any key order, every key kept)."""
+    left, right, ptr, q, t, d = [], [], [0], [], [], []
+    for (l, r), lst in match_matrix.items():
+        left.append(l)
+        right.append(r)
+        for m in lst:
+            q.append(m[0]); t.append(m[1]); d.append(m[2] if len(m) > 2 else 0.0)
+        ptr.append(len(q))
+    return (np.asarray(left, np.int32), np.asarray(right, np.int32), np.asarray(ptr, np.int64), np.asarray(q, np.int32),
+            np.asarray(t, np.int32), np.asarray(d, np.float32))
+
+
+def find_2d3d_matches(n_views, done_views, view_ptr, view_idx, feat_idx, pair_left, pair_right, pair_ptr, query_idx, train_idx,
+                      cap=None, device=0):
+    """sfmba_find_2d3d_matches on flat arrays: (out_ptr [n_views+1], out_point, out_feature)."""
+    done = np.zeros(n_views, dtype=np.uint8)
+    done[np.asarray(list(done_views), dtype=np.int64)] = 1
+    view_ptr = np.ascontiguousarray(view_ptr, np.int64); view_idx = _i(view_idx); feat_idx = _i(feat_idx)
+    pair_left = _i(pair_left); pair_right = _i(pair_right); pair_ptr = np.ascontiguousarray(pair_ptr, np.int64)
+    query_idx = _i(query_idx); train_idx = _i(train_idx)
+    n_pt = len(view_ptr) - 1
+    cap = int(n_pt if cap is None else cap)
+    lp = C.POINTER(C.c_int64)
+    out_ptr = np.zeros(n_views + 1, dtype=np.int64)
+    total = C.c_int64(0)
+    for _ in range(2):
+        op, of = np.zeros(max(cap, 1), np.int32), np.zeros(max(cap, 1), np.int32)
+        rc = lib().sfmba_find_2d3d_matches(
+            C.c_int(device), C.c_int(n_views), done.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_int(n_pt), _p(view_ptr, lp), _p(view_idx, _ip),
+            _p(feat_idx, _ip), C.c_int(len(pair_left)), _p(pair_left, _ip), _p(pair_right, _ip), _p(pair_ptr, lp), _p(query_idx, _ip),
+            _p(train_idx, _ip), _p(out_ptr, lp), _p(op, _ip), _p(of, _ip), C.c_int64(cap), C.byref(total))
+        if rc != SFMBA_ERR_CAPACITY:
+            break
+        cap = int(total.value)
+    _check(rc)
+    return out_ptr, op[:total.value].copy(), of[:total.value].copy()
+
+
+def merge_candidates(exist_xyz, new_xyz, max_dist=0.01, cap=None, device=0):
+    """sfmba_merge_candidates: (cand_ptr [n_new+1], cand_idx) -- see include/sfmba.h."""
+    ex = np.ascontiguousarray(exist_xyz, np.float32).reshape(-1, 3)
+    nw = np.ascontiguousarray(new_xyz, np.float32).reshape(-1, 3)
+    cap = int(4 * len(nw) + 1024 if cap is None else cap)
+    lp, fp = C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    ptr = np.zeros(len(nw) + 1, dtype=np.int64)
+    total = C.c_int64(0)
+    for _ in range(2):
+        idx = np.zeros(max(cap, 1), np.int32)
+        rc = lib().sfmba_merge_candidates(C.c_int(device), C.c_int(len(ex)), _p(ex, fp), C.c_int(len(nw)), _p(nw, fp), C.c_float(max_dist),
+                                          _p(ptr, lp), _p(idx, _ip), C.c_int64(cap), C.byref(total))
+        if rc != SFMBA_ERR_CAPACITY:
+            break
+        cap = int(total.value)
+    _check(rc)
+    return ptr, idx[:total.value].copy()
 
 
 def release_cache():

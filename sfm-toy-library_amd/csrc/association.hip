@@ -24,6 +24,7 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <cfloat>
 #include <climits>
 #include <cmath>
 #include <cstdint>

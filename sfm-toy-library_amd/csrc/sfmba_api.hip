@@ -10,6 +10,7 @@
 // There is NO CPU fallback in this file: without a HIP device every entry point returns
 // SFMBA_ERR_NO_DEVICE.
 #include "../../include/sfmba.h"
+#include "association.h"
 #include "ba_kernels.h"
 #include "dense_solver.h"
 #include "device_arena.h"
@@ -1215,6 +1216,51 @@ int sfmba_triangulate(int device, int64_t n, const float* left_xy, const float* 
     if (reproj_err) HIP_TRY(hipMemcpyAsync(reproj_err, d_e, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, kit.stream));
     HIP_TRY(hipStreamSynchronize(kit.stream));
     return SFMBA_OK;
+}
+
+// ---- association joins -----------------------------------------------------------------------
+static int assoc_result(int rc, const char* what) {
+    if (rc == 0) return SFMBA_OK;
+    if (rc == ASSOC_ERR_CAPACITY) return fail(SFMBA_ERR_CAPACITY, std::string(what) + ": output capacity too small");
+    if (rc == ASSOC_ERR_TOO_LARGE) return fail(SFMBA_ERR_INVALID_ARG, std::string(what) + ": problem too large for 32-bit indices");
+    if (rc == (int)hipErrorOutOfMemory) return fail(SFMBA_ERR_ALLOC, std::string(what) + ": device allocation failed");
+    return fail(SFMBA_ERR_HIP, std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
+}
+
+int sfmba_find_2d3d_matches(int device, int n_views, const unsigned char* view_done, int n_pt, const int64_t* view_ptr,
+                            const int32_t* view_idx, const int32_t* feat_idx, int n_pairs, const int32_t* pair_left,
+                            const int32_t* pair_right, const int64_t* pair_ptr, const int32_t* query_idx, const int32_t* train_idx,
+                            int64_t* out_ptr, int32_t* out_point, int32_t* out_feature, int64_t cap, int64_t* total) {
+    if (n_views < 0 || n_pt < 0 || n_pairs < 0 || cap < 0 || !out_ptr || !total || (n_views > 0 && !view_done) || !view_ptr ||
+        (n_pairs > 0 && (!pair_left || !pair_right || !pair_ptr)) || (cap > 0 && (!out_point || !out_feature)))
+        return fail(SFMBA_ERR_INVALID_ARG, "bad argument");
+    if (view_ptr[0] != 0 || (n_pairs > 0 && pair_ptr[0] != 0)) return fail(SFMBA_ERR_INVALID_ARG, "CSR pointers must start at 0");
+    for (int i = 0; i < n_pt; ++i) if (view_ptr[i + 1] < view_ptr[i]) return fail(SFMBA_ERR_INVALID_ARG, "view_ptr not monotone");
+    for (int p = 0; p < n_pairs; ++p) if (pair_ptr[p + 1] < pair_ptr[p]) return fail(SFMBA_ERR_INVALID_ARG, "pair_ptr not monotone");
+    if ((view_ptr[n_pt] > 0 && (!view_idx || !feat_idx)) || (n_pairs > 0 && pair_ptr[n_pairs] > 0 && (!query_idx || !train_idx)))
+        return fail(SFMBA_ERR_INVALID_ARG, "NULL array");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    HostKit kit;
+    if (!hostkit_acquire(device, &kit)) return fail(SFMBA_ERR_HIP, "stream creation failed");
+    struct KitGuard { HostKit k; ~KitGuard() { if (k.stream) (void)hipStreamSynchronize(k.stream); hostkit_release(k); } } kg{ kit };
+    return assoc_result(assoc_find_2d3d(kit.stream, device, n_views, view_done, n_pt, view_ptr, view_idx, feat_idx, n_pairs, pair_left, pair_right,
+                                        pair_ptr, query_idx, train_idx, out_ptr, out_point, out_feature, cap, total), "find_2d3d_matches");
+}
+
+int sfmba_merge_candidates(int device, int n_exist, const float* exist_xyz, int n_new, const float* new_xyz, float max_dist,
+                           int64_t* cand_ptr, int32_t* cand_idx, int64_t cap, int64_t* total) {
+    if (n_exist < 0 || n_new < 0 || cap < 0 || !cand_ptr || !total || (n_exist > 0 && !exist_xyz) || (n_new > 0 && !new_xyz) || (cap > 0 && !cand_idx))
+        return fail(SFMBA_ERR_INVALID_ARG, "bad argument");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    HostKit kit;
+    if (!hostkit_acquire(device, &kit)) return fail(SFMBA_ERR_HIP, "stream creation failed");
+    struct KitGuard { HostKit k; ~KitGuard() { if (k.stream) (void)hipStreamSynchronize(k.stream); hostkit_release(k); } } kg{ kit };
+    return assoc_result(assoc_radius_candidates(kit.stream, device, n_exist, exist_xyz, n_new, new_xyz, max_dist, cand_ptr, cand_idx, cap, total),
+                        "merge_candidates");
 }
 
 }  // extern "C"
