@@ -134,6 +134,8 @@ struct DeviceBuffers {
     float* pcg_F32;           // the same in fp32 instead (streaming CG path, d > 1280: the matvec is HBM-bound); else null
     double* pcg_bt;           // [ld]    Lb^-1 rhs
     double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
+    double* pcg_W;            // [8][ld] gauge vectors in the transformed unknowns (coarse space of the two-level CG preconditioner,
+                              //         dense_solver.hip), written by k_finalize (PCG mode); null = not wanted
     int* lm_mailbox;          // host-mapped {seq, termination, message, iter}: polled by the host instead of a D2H copy + sync
     double shared_weight;     // 1 normally; 0 on ranks > 0 of a sharded solve (replicated cameras/focal counted once)
 };

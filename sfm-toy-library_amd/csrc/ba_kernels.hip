@@ -1125,6 +1125,70 @@ __device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffer
     }
 }
 
+// Rows of camera j in the 8 gauge vectors of the problem, in the unknowns of the block-Jacobi transformed reduced system
+// (coarse space of the two-level CG preconditioner, dense_solver.hip).  adjustBundle() holds no block constant
+// (BA.cpp:160-164), so the undamped problem does not change under a similarity transform of the scene; in camera
+// parameters (p = R X + t), to first order:
+//   world translation a   (X -> X + a):        dt = -R a,  dw = 0
+//   world rotation phi    (X -> Exp(phi) X):   R -> R Exp(-phi)  =>  dw = -Jr(w)^-1 phi,  dt = 0
+//                         Jr^-1 = I + [w]x / 2 + (1/theta^2 - (1 + cos theta) / (2 theta sin theta)) [w]x^2
+//   scale s               (X -> s X):          dt = t
+// plus the weakly determined focal / depth direction (df = f, dt_z = t_z: a longer lens further away).  Unknowns are
+// Jacobi-scaled (x = s x_s) and transformed by the block factor (x~ = Lb^T x_s, Lb^-1 = Li): w~ solves Li^T w~ = w / s.
+// Values are rounded to fp32 so that every consumer (LDS copies included) sees the same numbers; any vectors are a valid
+// coarse space, they only have to be close to the slow directions.
+__device__ void gauge_vectors(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Li)[6][6]) {
+    const LMState* st = db.st;
+    const int cur = st->cur;
+    const CamRow ct = { db.camtab[cur] + 4 * (size_t)j, ds.ncam };
+    const double* cam = db.cam[cur] + 6 * (size_t)j;
+    const double w0 = cam[0], w1 = cam[1], w2 = cam[2];
+    const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+    double cq = 1.0 / 12.0;                              // limit of the [w]x^2 coefficient for theta -> 0
+    if (th2 > 1e-8) {
+        const double th = sqrt(th2);
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        const double den = 2.0 * th * sn;
+        cq = fabs(den) > 1e-12 ? 1.0 / th2 - (1.0 + cs) / den : 0.0;     // theta near pi: drop the term, any vector will do
+    }
+    const double K[3][3] = { { 0.0, -w2, w1 }, { w2, 0.0, -w0 }, { -w1, w0, 0.0 } };
+    double Ji[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double k2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) k2 += K[r][m] * K[m][c];
+            Ji[r][c] = (r == c ? 1.0 : 0.0) + 0.5 * K[r][c] + cq * k2;
+        }
+    double s6[6], ild[6];       // 1 / Jacobi scale; 1 / Li[r][r]: reciprocals once, not a division per back-substitution step
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { s6[e] = fast_rcp(db.cscale[6 * j + e]); ild[e] = fast_rcp(Li[e][e]); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        double wv[6] = { 0, 0, 0, 0, 0, 0 };
+        if (k < 3) { for (int r = 0; r < 3; ++r) wv[3 + r] = -ct[CT_R + 3 * r + k]; }
+        else if (k < 6) { for (int r = 0; r < 3; ++r) wv[r] = -Ji[r][k - 3]; }
+        else if (k == 6) { for (int r = 0; r < 3; ++r) wv[3 + r] = cam[3 + r]; }
+        else wv[5] = cam[5];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) wv[e] *= s6[e];
+        // back substitution with the upper triangular Li^T
+        double wt[6];
+#pragma unroll
+        for (int r = 5; r >= 0; --r) {
+            double v = wv[r];
+#pragma unroll
+            for (int t = 5; t > r; --t) v -= Li[t][r] * wt[t];
+            wt[r] = v * ild[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) db.pcg_W[(size_t)k * ds.ld + 6 * j + r] = (double)(float)wt[r];
+    }
+}
+
 // damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding; in PCG mode also
 // Linv of every damped 6x6 diagonal block (the block-Jacobi preconditioner).  One thread per camera, then per
 // padding row; the focal entries are owned by the last wave of the last workgroup.  The last workgroup to arrive
@@ -1146,6 +1210,14 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             if (gg > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), gg);
             if (!finite_d(sff + dd) || !finite_d(rhsf)) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
             if (pcg && !(sff + dd > 0.0)) atomicCAS(db.lin_info, 0, ds.d);
+            if (pcg && db.pcg_W) {
+                // focal row of the gauge vectors: only the focal/depth vector (7) touches the focal; x~_f = sqrt(S_ff) x_f
+                const double lf = sqrt(sff + dd > 0.0 ? sff + dd : 1.0);
+                for (int k = 0; k < 8; ++k) {
+                    db.pcg_W[(size_t)k * ds.ld + fo] = k == 7 ? (double)(float)(lf * st->focal[st->cur] / st->fscale) : 0.0;
+                    for (int e = ds.d; e < ds.ld; ++e) db.pcg_W[(size_t)k * ds.ld + e] = 0.0;
+                }
+            }
         }
     }
     double gm = 0.0;
@@ -1200,6 +1272,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             for (int r = 0; r < 6; ++r)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) db.pcg_binv[(size_t)g * 36 + r * 6 + c] = Li[r][c];
+            if (db.pcg_W) gauge_vectors(ds, db, g, Li);
         }
     } else if (g - ds.ncam < ds.ld - ds.d) {
         const int e = ds.d + (g - ds.ncam);

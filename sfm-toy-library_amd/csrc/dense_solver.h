@@ -19,10 +19,15 @@ struct DenseSolver {
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
     float* Sfull32 = nullptr; // fp32 copy for the streaming path (allocated by dense_pcg_want_f32)
     // launch parameters of the running CG solve (dense_pcg_solve ... dense_pcg_more)
-    struct CgRun { int nwg = 0, rows_per_wg = 0; size_t lds = 0; bool fast = false, f32 = false; double tol2 = 0.0; int in = 1, launched = 0, max_iters = 0; int* info = nullptr; } run;
+    struct CgRun { int nwg = 0, rows_per_wg = 0; size_t lds = 0; bool fast = false, f32 = false, coarse = false; double tol2 = 0.0; int in = 1, launched = 0, max_iters = 0; int* info = nullptr; } run;
     bool use_f32 = false;     // set by the caller per solve: the preconditioned matrix of THIS solve lives in Sfull32
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
-    double* part = nullptr;   // [2][256] per-workgroup partial p.q
+    double* part = nullptr;   // [2][9][1024] per-workgroup partial sums of one iteration (p_r.q, W~^T q), by iteration parity
+    // coarse space of the two-level preconditioner (dense_solver.hip): 8 gauge vectors in the transformed unknowns
+    double* W = nullptr;      // [8][ld] W~, written by the linearisation (k_finalize); fp32-representable values
+    double* AW = nullptr;     // [d][8]  S~ W~
+    double* epart = nullptr;  // [72][1024] per-workgroup partials of E = W~^T S~ W~ and c_0 = W~^T b~
+    double* coarse = nullptr; // [72] E^-1 (64) and c_0 (8)
     int last_iters = 0;       // CG iterations of the previous solve
     std::vector<int> hist;    // CG iterations of the previous call per caller key (LM iteration index): sizes the first launch batch
     double* binv = nullptr;   // [ld*6] inverses of the 6x6 diagonal blocks (+1x1 focal)
@@ -60,7 +65,8 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 // hist_key >= 0 selects the history slot used to size the first batch of launches.
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev,
                     Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false, int anchor = 0,
-                    bool no_wait = false);
+                    bool no_wait = false, bool coarse = false);
+// coarse = true: ws->W holds the 8 gauge vectors of this linearisation (written by k_finalize): two-level preconditioner
 // anchor: 0 = relative residual |r| <= tol |b~|; 1 = first solve of an LM run (remembers |b~|); 2 = later solve of the
 // same run: |r| <= tol * max(|b~|, |b~_first|), but never looser than max(tol, 1e-4) relative (see dense_solver.hip)
 // no_wait variant: dense_pcg_solve(..., no_wait = true) enqueues the first batch of iterations and returns at once (the

@@ -269,7 +269,7 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 #endif
 constexpr int PCG_MAXWG = SFMBA_PCG_MAXWG;        // workgroups of the fast path (one partial dot product per thread)
 constexpr int PCG_MAXWG_BIG = 1024;   // workgroups of the generic path
-constexpr int PCG_PART = 1024;        // stride of the two partial-dot-product buffers
+constexpr int PCG_PART = 1024;        // stride (workgroups) of the per-iteration partial-sum buffers
 enum { PF_DONE = 0, PF_ITERS = 1, PF_XBUF = 2 };
 enum { PS_RR0 = 0, PS_RRF = 1 };     // threshold base of the running solve; |b~|^2 of the FIRST solve of an anchored sequence
 
@@ -407,44 +407,303 @@ __device__ __forceinline__ void pcg_post(int* mailbox, int iters, int done) {
     __hip_atomic_store(mailbox, iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Coarse space ("gauge deflation").  adjustBundle() holds no parameter block constant (BA.cpp:160-164), so the
+// undamped problem is invariant under the 7 similarity transforms of the scene; the LM damping lifts those directions to
+// eigenvalues ~1/radius of S~ while the rest of the spectrum sits in [0.2, 2] (measured, cfg 3: seven eigenvalues
+// 2.3e-4 .. 2.8e-4, one at 3e-2 -- the focal/depth direction --, everything else >= 0.59).  Plain block-Jacobi CG spends
+// most of its iterations on those 8 directions (48 .. 68 iterations to 1e-8) and leaves its truncation error exactly
+// there (the "gauge drift" of the parameters).  With the 8 analytic vectors W~ (k_finalize writes them: world
+// translation x3, world rotation x3, scale, focal/depth) as a coarse space and the additive two-level preconditioner
+//      M^-1 = I + W~ E^-1 W~^T,      E = W~^T S~ W~   (8 x 8),
+// the same accuracy takes 8 .. 12 iterations and the coarse components are solved exactly.
+//
+// The preconditioner is never applied to a full vector: the search direction is kept split, p = p_r + W~ p_mu, so that
+//      q = S~ p   = S~ p_r + (S~ W~) p_mu          -- own rows of AW = S~ W~ only
+//      W~^T r     carried by the recurrence c <- c - alpha (W~^T q), with W~^T q summed from per-workgroup partials
+//      p . q      = p_r . q + p_mu . (W~^T q)
+// i.e. one CG iteration still streams r, q, p_r and S~ once; W~ and AW are touched only in the rows a workgroup owns.
+// k_pcg_coarse forms AW, E and c_0 = W~^T b~ (one extra pass over S~ per LM iteration), k_pcg_coarse_invert the scaled
+// 8 x 8 inverse.  A vector whose pivot vanishes (degenerate configurations, fewer cameras than gauge freedoms) is dropped.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PCG_NW = 8;                 // coarse vectors
+constexpr int PCG_NPART = 1 + PCG_NW;     // per-workgroup partials per iteration: p_r . q, W~^T q
+// scal: [PS_RR0] [PS_RRF] ... then per iteration parity PS_STATE_LEN doubles of solver state written by workgroup 0
+enum { PS_STATE = 8, PS_STATE_LEN = 32, PS_RZ = 0, PS_C = 1, PS_MU = 9, PS_PMU = 17 };      // c = W~^T r, mu = E^-1 c, p_mu
+constexpr int CO_TILE = 1024;             // columns of W~ staged in LDS (fp32) per pass of k_pcg_coarse
+constexpr int CO_MAXROWS = 4;             // rows per wave k_pcg_coarse can hold (rows_per_wg <= 16)
+
+__device__ __forceinline__ double* pcg_part(double* part, int parity, int v) { return part + ((size_t)parity * PCG_NPART + v) * PCG_PART; }
+
+template <typename FT>
+__global__ __launch_bounds__(256) void k_pcg_coarse(int d, int ld, const FT* __restrict__ F, const double* __restrict__ W, const double* __restrict__ bt,
+                                                    double* __restrict__ AW, double* __restrict__ epart, int rows_per_wg) {
+    __shared__ float wt[PCG_NW][CO_TILE];
+    __shared__ double awrow[4][PCG_NW];
+    __shared__ double esum[4][PCG_NW * PCG_NW + PCG_NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = blockIdx.x * rows_per_wg, row1 = min(d, row0 + rows_per_wg);
+    double acc[CO_MAXROWS][PCG_NW];
+#pragma unroll
+    for (int r = 0; r < CO_MAXROWS; ++r)
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) acc[r][k] = 0.0;
+    for (int t0 = 0; t0 < d; t0 += CO_TILE) {
+        __syncthreads();
+        for (int idx = tid; idx < PCG_NW * CO_TILE; idx += 256) {
+            const int k = idx / CO_TILE, c = idx - k * CO_TILE;
+            wt[k][c] = (t0 + c < d) ? (float)W[(size_t)k * ld + t0 + c] : 0.0f;       // W~ holds fp32-representable values: lossless
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CO_MAXROWS; ++r) {
+            const int row = row0 + w + 4 * r;
+            if (row >= row1) continue;
+            const FT* Fr = F + (size_t)row * ld + t0;
+            for (int c0 = 0; c0 < CO_TILE && t0 + c0 < d; c0 += 256) {      // four loads in flight per lane
+                FT f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; f[u] = (t0 + c < d) ? Fr[c] : (FT)0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 64 * u + lane;
+#pragma unroll
+                    for (int k = 0; k < PCG_NW; ++k) acc[r][k] = fma((double)f[u], (double)wt[k][c], acc[r][k]);
+                }
+            }
+        }
+    }
+    double e_acc = 0.0, c_acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < CO_MAXROWS; ++r) {
+        const int row = row0 + w + 4 * r;
+        if (row >= row1) continue;                        // wave-uniform
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) {
+            double v = acc[r][k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == k) { AW[(size_t)row * PCG_NW + k] = v; awrow[w][k] = v; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        e_acc = fma(W[(size_t)(lane >> 3) * ld + row], awrow[w][lane & 7], e_acc);
+        if (lane < PCG_NW) c_acc = fma(W[(size_t)lane * ld + row], bt[row], c_acc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    esum[w][lane] = e_acc;
+    if (lane < PCG_NW) esum[w][PCG_NW * PCG_NW + lane] = c_acc;
+    __syncthreads();
+    if (tid < PCG_NW * PCG_NW + PCG_NW) epart[(size_t)tid * PCG_PART + blockIdx.x] = esum[0][tid] + esum[1][tid] + esum[2][tid] + esum[3][tid];
+}
+
+// E = sum of the partials; Einv by a Jacobi-scaled Gauss-Jordan elimination spread over the 64 lanes of one wave (lane = one
+// entry; eight dependent steps instead of a ~600-deep serial chain: 28 -> ~3 us); c_0.  out = [Einv 64 | c_0 8].
+// A pivot below 1e-10 of the unit diagonal means the vector depends on the earlier ones (degenerate configuration, fewer
+// cameras than gauge freedoms): the vector is dropped (its row and column of Einv are zero).
+__global__ __launch_bounds__(256) void k_pcg_coarse_invert(int nwg, const double* __restrict__ epart, double* __restrict__ out) {
+    constexpr int N = PCG_NW, NV = N * N + N;
+    __shared__ double tot[NV];
+    __shared__ double sa[N][N], sb[N][N];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    {
+        // 18 values per wave, their lane-partials reduced in lock step
+        double part[18];
+#pragma unroll
+        for (int m = 0; m < 18; ++m) part[m] = 0.0;
+        for (int i0 = 0; i0 < nwg; i0 += 128) {               // 36 independent loads per lane and pass (clamped, branch-free)
+            double t[18][2];
+#pragma unroll
+            for (int m = 0; m < 18; ++m)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { const int wg = i0 + lane + 64 * i; t[m][i] = epart[(size_t)(w + 4 * m) * PCG_PART + (wg < nwg ? wg : nwg - 1)]; }
+#pragma unroll
+            for (int m = 0; m < 18; ++m)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) part[m] += (i0 + lane + 64 * i < nwg) ? t[m][i] : 0.0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int m = 0; m < 18; ++m) part[m] += __shfl_xor(part[m], off, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < 18; ++m) tot[w + 4 * m] = part[m];
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    if (lane < N) out[N * N + lane] = tot[N * N + lane];
+    const int i = lane >> 3, j = lane & 7;
+    const double dii = tot[i * N + i], djj = tot[j * N + j];
+    const bool ki = dii > 0.0 && dii <= 1.7e308, kj = djj > 0.0 && djj <= 1.7e308;
+    const double si = ki ? fast_rsq(dii) : 0.0, sj = kj ? fast_rsq(djj) : 0.0;
+    double a = (i == j) ? 1.0 : 0.5 * (tot[i * N + j] + tot[j * N + i]) * si * sj;
+    double b = (i == j) ? 1.0 : 0.0;
+    unsigned dropped = 0;                                 // bit k: vector k dropped (identical in every lane)
+#pragma unroll
+    for (int k = 0; k < N; ++k) if (!(tot[k * N + k] > 0.0 && tot[k * N + k] <= 1.7e308)) dropped |= 1u << k;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        sa[i][j] = a; sb[i][j] = b;
+        chol_wave_fence();
+        double piv = sa[k][k];
+        const bool ok = !((dropped >> k) & 1u) && piv > 1e-10;
+        if (!ok) dropped |= 1u << k;
+        const double aik = ok ? sa[i][k] : 0.0;
+        const double akj = ok ? sa[k][j] : (k == j ? 1.0 : 0.0), bkj = ok ? sb[k][j] : 0.0;
+        const double ip = ok ? fast_rcp(piv) : 1.0;
+        if (i == k) { a = akj * ip; b = bkj * ip; }
+        else { a = fma(-aik * ip, akj, a); b = fma(-aik * ip, bkj, b); }
+        if (!ok && (i == k || j == k)) { a = (i == j) ? 1.0 : 0.0; b = 0.0; }
+        chol_wave_fence();
+    }
+    const bool gone = ((dropped >> i) & 1u) || ((dropped >> j) & 1u);
+    out[i * N + j] = gone ? 0.0 : b * si * sj;
+}
+
+// Sum of the per-workgroup partials of the previous launch.  Wave w owns values w, w + 4, w + 8: `mine` holds this lane's
+// share (loaded up front by the caller), the totals land in red[0 .. NV) after the caller's next __syncthreads().  The
+// (up to three) wave reductions advance in lock step: a shuffle is ~50 cycles of latency, three dependent chains of six
+// would sit on the critical path of every CG iteration.
+template <int NV>
+__device__ __forceinline__ void reduce_partials(double (&mine)[3], double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (4 * j < NV) mine[j] += __shfl_xor(mine[j], off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (w + 4 * j < NV) red[w + 4 * j] = mine[j];
+    }
+}
+
+// 8-term dot product as two chains of four (a dependent DFMA is ~32 cycles)
+__device__ __forceinline__ double dot8(const double (&a)[PCG_NW], const double (&b)[PCG_NW]) {
+    double s0 = a[0] * b[0], s1 = a[1] * b[1];
+    s0 = fma(a[2], b[2], s0); s1 = fma(a[3], b[3], s1);
+    s0 = fma(a[4], b[4], s0); s1 = fma(a[5], b[5], s1);
+    s0 = fma(a[6], b[6], s0); s1 = fma(a[7], b[7], s1);
+    return s0 + s1;
+}
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// out = E^-1 v in every lane: lane t (mod 8) forms row t, eight lane broadcasts distribute the result inside the wave
+// (no workgroup barrier).  einv_s: the 64 entries in LDS.
+__device__ __forceinline__ void einv_apply(const double* einv_s, const double (&v)[PCG_NW], double (&out)[PCG_NW]) {
+    const int t = threadIdx.x & 7;
+    double row[PCG_NW];
+#pragma unroll
+    for (int j = 0; j < PCG_NW; ++j) row[j] = einv_s[t * PCG_NW + j];
+    const double r = dot8(row, v);
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) out[k] = lane_bcast(r, k);
+}
+
+// LDS scratch of the CG kernels behind the search direction: [0..9) partial totals, [16..20) rrn per wave,
+// [32..40) p_mu of this iteration, [40..76) end-of-kernel partials per wave (4 x 9), [80..144) E^-1
+constexpr int PCG_RED = 144;
+
 // Generic path of one CG iteration (any d).  Vector phase as in the fast path but looped; the matvec streams two rows
 // of S~ per wave with 16-byte loads, four deep, so that a wave keeps 128 B per lane in flight (the rows are HBM/MALL
 // traffic: d*ld*8 bytes per iteration, 289 MB at d = 6001).  Up to PCG_MAXWG_BIG workgroups.
-template <bool INIT, typename FT>
+template <bool INIT, typename FT, bool COARSE>
 __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __restrict__ F, double* __restrict__ vec,
                                                   const double* __restrict__ bt, double* __restrict__ part, double* scal,
-                                                  int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap) {
+                                                  int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap,
+                                                  const double* __restrict__ W, const double* __restrict__ AW, const double* __restrict__ coarse) {
     extern __shared__ __align__(16) double sm[];
-    double* pl = sm;            // [ld] new search direction
-    double* red = sm + ld;      // [8]
+    double* pl = sm;            // [ld] new search direction (p_r)
+    double* red = sm + ld;      // [PCG_RED]
     if (!INIT && flags[PF_DONE]) return;
-    const int tid = threadIdx.x, out = in ^ 1;
+    constexpr int NV = COARSE ? PCG_NPART : 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
     const int row0 = blockIdx.x * rows_per_wg;
     const int row1 = min(d, row0 + rows_per_wg);
+    const int nwg = (int)gridDim.x;
     double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld);
     double* p_out = pcg_vec(vec, 2, out, ld); double* q_out = pcg_vec(vec, 3, out, ld);
+    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = INIT ? bt : pcg_vec(vec, 1, in, ld);
+    const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
+    const double* st_in = scal + PS_STATE + PS_STATE_LEN * in;
+    double* st_out = scal + PS_STATE + PS_STATE_LEN * out;
+    if (COARSE && tid < PCG_NW * PCG_NW) red[80 + tid] = coarse[tid];
+    double c_new[PCG_NW], mu_new[PCG_NW], pmu_new[PCG_NW], pmu_in[PCG_NW];
+    double rz_new = 0.0;
     if (INIT) {
-        double rr = 0.0, dummy = 0.0;
+        double rr = 0.0;
         for (int e = tid; e < d; e += 256) { const double v = bt[e]; pl[e] = v; rr += v * v; }
-        block_sum2(rr, dummy, red);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
+        if (lane == 0) red[16 + w] = rr;
+        __syncthreads();
+        rr = red[16] + red[17] + red[18] + red[19];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = COARSE ? coarse[PCG_NW * PCG_NW + k] : 0.0; mu_new[k] = 0.0; pmu_in[k] = 0.0; }
+        if (COARSE) einv_apply(red + 80, c_new, mu_new);
+        rz_new = rr + (COARSE ? dot8(c_new, mu_new) : 0.0);
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = mu_new[k];
         for (int e = row0 + tid; e < row1; e += 256) { x_out[e] = 0.0; r_out[e] = pl[e]; p_out[e] = pl[e]; }
         if (blockIdx.x == 0 && tid == 0) {
             scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
             if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
         }
     } else {
-        const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = pcg_vec(vec, 1, in, ld);
-        const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
-        double pq = 0.0;
-        for (int i = tid; i < (int)gridDim.x; i += 256) pq += part[in * PCG_PART + i];
-        double rr = 0.0;
-        for (int e = tid; e < d; e += 256) { const double v = r_in[e]; pl[e] = v; rr += v * v; }
-        block_sum2(pq, rr, red);
-        const double alpha = rr / pq;
-        double rrn = 0.0, dummy = 0.0;
-        for (int e = tid; e < d; e += 256) { const double v = pl[e] - alpha * q_in[e]; pl[e] = v; rrn += v * v; }   // own elements only
-        block_sum2(rrn, dummy, red);
-        for (int e = row0 + tid; e < row1; e += 256) x_out[e] = x_in[e] + alpha * p_in[e];
+        double mine[3] = { 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int v = w + 4 * j;
+            if (4 * j < NV) {
+                const double* pp = pcg_part(part, in, v < NV ? v : 0);
+                for (int i0 = 0; i0 < nwg; i0 += 256) {       // four loads in flight per value, never a `+= load` chain
+                    double t[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const int wg = i0 + lane + 64 * i; t[i] = pp[wg < nwg ? wg : nwg - 1]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mine[j] += (i0 + lane + 64 * i < nwg && v < NV) ? t[i] : 0.0;
+                }
+            }
+        }
+        reduce_partials<NV>(mine, red);
+        __syncthreads();
+        double g[PCG_NW], Eg[PCG_NW], c_in[PCG_NW], mu_in[PCG_NW];
+        const double rz_in = st_in[PS_RZ];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) {
+            g[k] = COARSE ? red[1 + k] : 0.0;
+            pmu_in[k] = COARSE ? st_in[PS_PMU + k] : 0.0;
+            c_in[k] = COARSE ? st_in[PS_C + k] : 0.0;
+            mu_in[k] = COARSE ? st_in[PS_MU + k] : 0.0;
+            Eg[k] = 0.0;
+        }
+        if (COARSE) einv_apply(red + 80, g, Eg);
+        const double pq = red[0] + (COARSE ? dot8(pmu_in, g) : 0.0);
+        const double alpha = rz_in / pq;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = fma(-alpha, g[k], c_in[k]); mu_new[k] = fma(-alpha, Eg[k], mu_in[k]); }
+        const double cmu = COARSE ? dot8(c_new, mu_new) : 0.0;
+        double rrn = 0.0;
+        for (int e = tid; e < d; e += 256) { const double v = r_in[e] - alpha * q_in[e]; pl[e] = v; rrn += v * v; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rrn += __shfl_xor(rrn, off, 64);
+        if (lane == 0) red[16 + w] = rrn;
+        // x += alpha p  with p = p_r + W~ p_mu, own rows
+        for (int e = row0 + tid; e < row1; e += 256) {
+            double pe = p_in[e];
+            if (COARSE) {
+#pragma unroll
+                for (int k = 0; k < PCG_NW; ++k) pe = fma(W[(size_t)k * ld + e], pmu_in[k], pe);
+            }
+            x_out[e] = x_in[e] + alpha * pe;
+        }
+        __syncthreads();
+        rrn = red[16] + red[17] + red[18] + red[19];
+        rz_new = rrn + cmu;
         const bool broke = !(pq > 0.0) || !(rrn == rrn);
         if (rrn <= tol2 * scal[PS_RR0] || broke) {
             if (blockIdx.x == 0 && tid == 0) {
@@ -454,26 +713,37 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
             }
             return;
         }
-        const double beta = rrn / rr;
-        for (int e = row0 + tid; e < row1; e += 256) r_out[e] = pl[e];      // pl holds r_new (synced by block_sum2)
+        const double beta = rz_new / rz_in;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = fma(beta, pmu_in[k], mu_new[k]);
+        for (int e = row0 + tid; e < row1; e += 256) r_out[e] = pl[e];      // pl holds r_new
         __syncthreads();
         for (int e = tid; e < d; e += 256) pl[e] = pl[e] + beta * p_in[e];
         __syncthreads();
         for (int e = row0 + tid; e < row1; e += 256) p_out[e] = pl[e];
         if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
     }
+    if (blockIdx.x == 0 && tid == 0) {
+        st_out[PS_RZ] = rz_new;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { st_out[PS_C + k] = c_new[k]; st_out[PS_MU + k] = mu_new[k]; st_out[PS_PMU + k] = pmu_new[k]; }
+    }
+    if (COARSE && tid < PCG_NW) red[32 + tid] = pmu_new[tid];
     __syncthreads();
-    // q = S~ p for the rows this workgroup owns: each wave takes rows (row0 + w + 4k), two at a time
-    const int lane = tid & 63, w = tid >> 6;
-    double pqp = 0.0;
-    if (sizeof(FT) == 8) {
-        const int nd2 = d >> 1;                                     // full double2 columns; an odd last column is added by lane 0
-        const double2* pl2 = reinterpret_cast<const double2*>(pl);
-        for (int row = row0 + w; row < row1; row += 8) {
-            const int rowb = (row + 4 < row1) ? row + 4 : row;
+    // q = S~ p_r + AW p_mu for the rows this workgroup owns: each wave takes rows (row0 + w + 4k), two at a time
+    double pqp = 0.0, gacc = 0.0;
+    const int nd2 = d >> 1, nd4 = d >> 2;
+    for (int row = row0 + w; row < row1; row += 8) {
+        const int rowb = (row + 4 < row1) ? row + 4 : row;
+        double sa = 0.0, sb = 0.0;
+        if (COARSE && lane < PCG_NW) {
+            sa = AW[(size_t)row * PCG_NW + lane] * red[32 + lane];
+            sb = AW[(size_t)rowb * PCG_NW + lane] * red[32 + lane];
+        }
+        if (sizeof(FT) == 8) {
+            const double2* pl2 = reinterpret_cast<const double2*>(pl);
             const double2* Fa = reinterpret_cast<const double2*>(F + (size_t)row * ld);
             const double2* Fb = reinterpret_cast<const double2*>(F + (size_t)rowb * ld);
-            double sa = 0.0, sb = 0.0;
             int c = lane;
             for (; c + 192 < nd2; c += 256) {
                 double2 a[4], b[4];
@@ -495,22 +765,10 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
                 sa += (double)F[(size_t)row * ld + d - 1] * pl[d - 1];
                 sb += (double)F[(size_t)rowb * ld + d - 1] * pl[d - 1];
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
-            if (lane == 0) {
-                q_out[row] = sa; pqp += pl[row] * sa;
-                if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
-            }
-        }
-    } else {
-        // fp32 matrix: 16-byte loads of four columns, products and sums in fp64
-        const int nd4 = d >> 2;
-        const float4* dummy4 = nullptr; (void)dummy4;
-        for (int row = row0 + w; row < row1; row += 8) {
-            const int rowb = (row + 4 < row1) ? row + 4 : row;
+        } else {
+            // fp32 matrix: 16-byte loads of four columns, products and sums in fp64
             const float4* Fa = reinterpret_cast<const float4*>(F + (size_t)row * ld);
             const float4* Fb = reinterpret_cast<const float4*>(F + (size_t)rowb * ld);
-            double sa = 0.0, sb = 0.0;
             int c = lane;
             for (; c + 192 < nd4; c += 256) {
                 float4 a[4], b[4];
@@ -535,42 +793,53 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
                     sb += (double)F[(size_t)rowb * ld + cc] * pl[cc];
                 }
             }
+        }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
-            if (lane == 0) {
-                q_out[row] = sa; pqp += pl[row] * sa;
-                if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
-            }
+        for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
+        if (lane == 0) {
+            q_out[row] = sa; pqp += pl[row] * sa;
+            if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
+        }
+        if (COARSE && lane >= 8 && lane < 8 + PCG_NW) {
+            gacc = fma(W[(size_t)(lane - 8) * ld + row], sa, gacc);
+            if (rowb != row) gacc = fma(W[(size_t)(lane - 8) * ld + rowb], sb, gacc);
         }
     }
+    if (lane == 0) red[40 + 9 * w] = pqp;
+    if (COARSE && lane >= 8 && lane < 8 + PCG_NW) red[40 + 9 * w + 1 + (lane - 8)] = gacc;
     __syncthreads();
-    if (lane == 0) red[w] = pqp;
-    __syncthreads();
-    if (tid == 0) part[out * PCG_PART + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (tid < NV) pcg_part(part, out, tid)[blockIdx.x] = red[40 + tid] + red[49 + tid] + red[58 + tid] + red[67 + tid];
 }
 
 // Fast path of one CG iteration for d <= 1280 (all BASELINE single-GPU configs): every global load of
-// the iteration -- the three length-d vectors, the partial dot products and this wave's rows of S~ --
+// the iteration -- the three length-d vectors, the partial sums and this wave's rows of S~ --
 // is issued up front into registers, so the launch pays ONE memory round trip; the rest is LDS + ALU.
+// The special roles are spread over the waves (wave 0..3: partial sums; last wave: this workgroup's own rows of x, r, p_r) and
+// everything about the 8-dimensional coarse space that does not need alpha (E^-1 g) is formed while alpha is on its way.
 constexpr int PCG_EPT = 5;    // vector elements per thread  (256 * 5 >= d)
 constexpr int PCG_RPW = 2;    // rows of S~ per wave         (rows_per_wg <= 8)
 constexpr int PCG_CPL = 20;   // columns per lane            (64 * 20 >= d)
 
-template <bool INIT>
+template <bool INIT, bool COARSE>
 __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
                                                        const double* __restrict__ bt, double* __restrict__ part, double* __restrict__ scal,
-                                                       int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap) {
+                                                       int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap,
+                                                       const double* __restrict__ W, const double* __restrict__ AW, const double* __restrict__ coarse) {
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;
     double* red = sm + ld;
     if (!INIT && flags[PF_DONE]) return;
+    constexpr int NV = COARSE ? PCG_NPART : 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
     const int row0 = blockIdx.x * rows_per_wg;
     const int row1 = min(d, row0 + rows_per_wg);
+    const int nwg = (int)gridDim.x;
     const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = INIT ? bt : pcg_vec(vec, 1, in, ld);
     const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
     double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld);
     double* p_out = pcg_vec(vec, 2, out, ld); double* q_out = pcg_vec(vec, 3, out, ld);
+    const double* st_in = scal + PS_STATE + PS_STATE_LEN * in;
+    double* st_out = scal + PS_STATE + PS_STATE_LEN * out;
 
     // ---- all global loads of this iteration ----
     double rv[PCG_EPT], qv[PCG_EPT], pv[PCG_EPT];
@@ -580,9 +849,40 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         const bool ok = e < d;
         rv[m] = ok ? r_in[e] : 0.0; qv[m] = (ok && !INIT) ? q_in[e] : 0.0; pv[m] = (ok && !INIT) ? p_in[e] : 0.0;
     }
-    double pq = (!INIT && tid < (int)gridDim.x) ? part[in * PCG_PART + tid] : 0.0;
+    double mine[3] = { 0.0, 0.0, 0.0 };           // partial sums of the previous launch: wave w owns values w, w + 4, w + 8
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int v = w + 4 * j;
+        if (!INIT && 4 * j < NV) {
+            // branch-free, clamped: a conditional `+= load` makes the compiler wait for every load in turn (measured: twelve
+            // dependent memory round trips, +3 us per iteration)
+            const double* pp = pcg_part(part, in, v < NV ? v : 0);
+            double t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int wg = lane + 64 * i; t[i] = pp[wg < nwg ? wg : nwg - 1]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mine[j] += (lane + 64 * i < nwg && v < NV) ? t[i] : 0.0;
+        }
+    }
+    const double einv_mine = (COARSE && tid < PCG_NW * PCG_NW) ? coarse[tid] : 0.0;
     const double rr0 = INIT ? 0.0 : scal[PS_RR0];
+    const double rz_in = INIT ? 0.0 : st_in[PS_RZ];
+    double c_in[PCG_NW], mu_in[PCG_NW], pmu_in[PCG_NW];
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) {
+        c_in[k] = !COARSE ? 0.0 : INIT ? coarse[PCG_NW * PCG_NW + k] : st_in[PS_C + k];
+        mu_in[k] = (COARSE && !INIT) ? st_in[PS_MU + k] : 0.0;
+        pmu_in[k] = (COARSE && !INIT) ? st_in[PS_PMU + k] : 0.0;
+    }
+    // own rows (the last wave's lanes < rows): what the x update and the stores of r, p_r need
+    const int eo = row0 + (tid - 192);
+    const bool own = tid >= 192 && eo < row1;
+    double xo = 0.0, po = 0.0, ro = 0.0, qo = 0.0, wo[PCG_NW];
+    if (own) { ro = r_in[eo]; if (!INIT) { xo = x_in[eo]; po = p_in[eo]; qo = q_in[eo]; } }
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) wo[k] = (COARSE && own && !INIT) ? W[(size_t)k * ld + eo] : 0.0;
     double2 fv[PCG_RPW][PCG_CPL / 2];          // 16-byte loads: lane takes columns 2*(lane + 64 m), +1
+    double awv[PCG_RPW];                       // lanes 0..7: AW[row][lane]; lanes 8..15: W~[lane - 8][row]
 #pragma unroll
     for (int k = 0; k < PCG_RPW; ++k) {
         const int row = row0 + w + 4 * k;
@@ -595,44 +895,61 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             if (2 * c2 + 1 >= d) v.y = 0.0;                 // padding column: never multiply garbage
             fv[k][m] = v;
         }
+        awv[k] = 0.0;
+        if (COARSE && row < row1 && lane < 2 * PCG_NW) awv[k] = lane < PCG_NW ? AW[(size_t)row * PCG_NW + lane] : W[(size_t)(lane - PCG_NW) * ld + row];
     }
-    // ---- alpha, r_new, beta, p_new ----
-    double rr = 0.0;
-#pragma unroll
-    for (int m = 0; m < PCG_EPT; ++m) rr += rv[m] * rv[m];
-    block_sum2(pq, rr, red);
+    if (COARSE && tid < PCG_NW * PCG_NW) red[80 + tid] = einv_mine;
+    double c_new[PCG_NW], mu_new[PCG_NW], pmu_new[PCG_NW];
+    double rz_new;
     if (INIT) {
-        // x0 = 0, r0 = p0 = b~
+        // x0 = 0, r0 = b~, z0 = r0 + W~ E^-1 c0, p0 = z0
+        double rr = 0.0;
 #pragma unroll
-        for (int m = 0; m < PCG_EPT; ++m) {
-            const int e = tid + 256 * m;
-            if (e < d) {
-                pl[e] = rv[m];
-                if (e >= row0 && e < row1) { x_out[e] = 0.0; r_out[e] = rv[m]; p_out[e] = rv[m]; }
-            }
-        }
+        for (int m = 0; m < PCG_EPT; ++m) rr += rv[m] * rv[m];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
+        if (lane == 0) red[16 + w] = rr;
+        __syncthreads();
+        rr = red[16] + red[17] + red[18] + red[19];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = c_in[k]; mu_new[k] = 0.0; }
+        if (COARSE) einv_apply(red + 80, c_new, mu_new);
+        rz_new = rr + (COARSE ? dot8(c_new, mu_new) : 0.0);
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = mu_new[k];
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; if (e < d) pl[e] = rv[m]; }
+        if (own) { x_out[eo] = 0.0; r_out[eo] = ro; p_out[eo] = ro; }
         if (blockIdx.x == 0 && tid == 0) {
             scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
             if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
         }
     } else {
-        const double alpha = rr * fast_rcp(pq);          // rcp + 2 Newton steps: the generic fp64 division is a ~15-deep dependent chain on the critical path
-        double rrn = 0.0, dummy = 0.0;
+        reduce_partials<NV>(mine, red);
+        __syncthreads();
+        double g[PCG_NW], Eg[PCG_NW];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { g[k] = COARSE ? red[1 + k] : 0.0; Eg[k] = 0.0; }
+        const double pq = red[0] + (COARSE ? dot8(pmu_in, g) : 0.0);
+        const double alpha = rz_in * fast_rcp(pq);       // rcp + 2 Newton steps: the generic fp64 division is a ~15-deep dependent chain on the critical path
+        if (COARSE) einv_apply(red + 80, g, Eg);          // independent of alpha: overlaps the reciprocal
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = fma(-alpha, g[k], c_in[k]); mu_new[k] = fma(-alpha, Eg[k], mu_in[k]); }
+        double rrn = 0.0;
 #pragma unroll
         for (int m = 0; m < PCG_EPT; ++m) { rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
-        block_sum2(rrn, dummy, red);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rrn += __shfl_xor(rrn, off, 64);
+        if (lane == 0) red[16 + w] = rrn;
+        const double cmu = COARSE ? dot8(c_new, mu_new) : 0.0;
+        if (own) {                                       // x += alpha (p_r + W~ p_mu)
+            x_out[eo] = xo + alpha * (po + (COARSE ? dot8(wo, pmu_in) : 0.0));
+        }
+        __syncthreads();
+        rrn = red[16] + red[17] + red[18] + red[19];
+        rz_new = rrn + cmu;
         const bool broke = !(pq > 0.0) || !(rrn == rrn);
         const bool done = rrn <= tol2 * rr0 || broke;
-        const double beta = rrn * fast_rcp(rr);
-#pragma unroll
-        for (int m = 0; m < PCG_EPT; ++m) {
-            const int e = tid + 256 * m;
-            if (e < d) {
-                const double pn = rv[m] + beta * pv[m];
-                pl[e] = pn;
-                if (e >= row0 && e < row1) { x_out[e] = x_in[e] + alpha * pv[m]; if (!done) { r_out[e] = rv[m]; p_out[e] = pn; } }
-            }
-        }
         if (done) {
             if (blockIdx.x == 0 && tid == 0) {
                 flags[PF_DONE] = 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
@@ -641,15 +958,27 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             }
             return;
         }
+        const double beta = rz_new * fast_rcp(rz_in);
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = fma(beta, pmu_in[k], mu_new[k]);
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; if (e < d) pl[e] = rv[m] + beta * pv[m]; }
+        if (own) { const double rn = ro - alpha * qo; r_out[eo] = rn; p_out[eo] = rn + beta * po; }
         if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
     }
+    if (blockIdx.x == 0 && tid == 64) {
+        st_out[PS_RZ] = rz_new;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { st_out[PS_C + k] = c_new[k]; st_out[PS_MU + k] = mu_new[k]; st_out[PS_PMU + k] = pmu_new[k]; }
+    }
+    if (COARSE && tid < PCG_NW) red[32 + tid] = pmu_new[tid];
     __syncthreads();
-    // ---- q = S~ p for the rows of this workgroup ----
-    double pqp = 0.0;
+    // ---- q = S~ p_r + AW p_mu for the rows of this workgroup ----
+    double pqp = 0.0, gacc = 0.0;
 #pragma unroll
     for (int k = 0; k < PCG_RPW; ++k) {
         const int row = row0 + w + 4 * k;
-        double sacc = 0.0, sacc2 = 0.0;                    // two chains: a dependent DFMA is ~32 cycles
+        double sacc = (COARSE && lane < PCG_NW) ? awv[k] * red[32 + lane] : 0.0, sacc2 = 0.0;       // two chains: a dependent DFMA is ~32 cycles
 #pragma unroll
         for (int m = 0; m < PCG_CPL / 2; ++m) {
             const int c2 = lane + 64 * m;
@@ -662,13 +991,89 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
         if (lane == 0 && row < row1) { q_out[row] = sacc; pqp += pl[row] * sacc; }
+        if (COARSE && lane >= PCG_NW && lane < 2 * PCG_NW && row < row1) gacc = fma(awv[k], sacc, gacc);
     }
+    if (lane == 0) red[40 + 9 * w] = pqp;
+    if (COARSE && lane >= PCG_NW && lane < 2 * PCG_NW) red[40 + 9 * w + 1 + (lane - PCG_NW)] = gacc;
     __syncthreads();
-    if (lane == 0) red[w] = pqp;
-    __syncthreads();
-    if (tid == 0) part[out * PCG_PART + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (tid < NV) pcg_part(part, out, tid)[blockIdx.x] = red[40 + tid] + red[49 + tid] + red[58 + tid] + red[67 + tid];
 }
 
+// AW = S~ W~, E = W~^T AW, c_0 = W~^T b~ for d <= 1280, same workgroup geometry as k_pcg_iter_fast: the rows of S~ and this
+// thread's share of W~ are loaded up front, W~ goes to LDS in fp32 (its values are fp32-representable: lossless).
+__global__ __launch_bounds__(256) void k_pcg_coarse_fast(int d, int ld, const double* __restrict__ F, const double* __restrict__ W,
+                                                         const double* __restrict__ bt, double* __restrict__ AW, double* __restrict__ epart, int rows_per_wg) {
+    __shared__ __align__(16) float wt[PCG_NW][64 * PCG_CPL];
+    __shared__ double esum[4][PCG_NW * PCG_NW + PCG_NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = blockIdx.x * rows_per_wg, row1 = min(d, row0 + rows_per_wg);
+    double wreg[PCG_NW][PCG_EPT];
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k)
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; wreg[k][m] = W[(size_t)k * ld + (e < d ? e : 0)]; }      // clamped, branch-free:
+                                                                    // a conditional load whose consumer is sunk into the branch is waited for on its own
+    double2 fv[PCG_RPW][PCG_CPL / 2];
+    double wrow[PCG_RPW], wcol[PCG_RPW], btr[PCG_RPW];
+#pragma unroll
+    for (int k = 0; k < PCG_RPW; ++k) {
+        const int row = row0 + w + 4 * k;
+        const bool have = row < row1;
+        const double2* Fr = reinterpret_cast<const double2*>(F + (size_t)(have ? row : row0) * ld);
+#pragma unroll
+        for (int m = 0; m < PCG_CPL / 2; ++m) {
+            const int c2 = lane + 64 * m;
+            double2 v = make_double2(0.0, 0.0);
+            if (have && 2 * c2 < d) v = Fr[c2];
+            if (2 * c2 + 1 >= d) v.y = 0.0;
+            fv[k][m] = v;
+        }
+        wrow[k] = have ? W[(size_t)(lane >> 3) * ld + row] : 0.0;           // E[k1][k2] += W~[k1][row] AW[row][k2], lane = 8 k1 + k2
+        wcol[k] = have ? W[(size_t)(lane & 7) * ld + row] : 0.0;            // c_0[k] += W~[k][row] b~[row], lanes 0..7
+        btr[k] = have ? bt[row] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k)
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) wt[k][tid + 256 * m] = (tid + 256 * m < d) ? (float)wreg[k][m] : 0.0f;
+    __syncthreads();
+    double acc[PCG_RPW][PCG_NW];
+#pragma unroll
+    for (int r = 0; r < PCG_RPW; ++r)
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) acc[r][k] = 0.0;
+#pragma unroll
+    for (int m = 0; m < PCG_CPL / 2; ++m) {
+        const int c2 = lane + 64 * m;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) {
+            const float2 wv = reinterpret_cast<const float2*>(&wt[k][0])[c2];
+#pragma unroll
+            for (int r = 0; r < PCG_RPW; ++r) acc[r][k] = fma(fv[r][m].x, (double)wv.x, fma(fv[r][m].y, (double)wv.y, acc[r][k]));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < PCG_RPW; ++r)
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) acc[r][k] += __shfl_xor(acc[r][k], off, 64);
+    double e_acc = 0.0, c_acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < PCG_RPW; ++r) {
+        const int row = row0 + w + 4 * r;
+        double mine = 0.0;                               // AW[row][lane & 7]
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) mine = ((lane & 7) == k) ? acc[r][k] : mine;
+        if (row < row1 && lane < PCG_NW) AW[(size_t)row * PCG_NW + lane] = mine;
+        e_acc = fma(wrow[r], mine, e_acc);               // rows beyond row1 contribute wrow = 0
+        c_acc = fma(wcol[r], btr[r], c_acc);
+    }
+    esum[w][lane] = e_acc;
+    if (lane < PCG_NW) esum[w][PCG_NW * PCG_NW + lane] = c_acc;
+    __syncthreads();
+    if (tid < PCG_NW * PCG_NW + PCG_NW) epart[(size_t)tid * PCG_PART + blockIdx.x] = esum[0][tid] + esum[1][tid] + esum[2][tid] + esum[3][tid];
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent CG (d <= 1280, one workgroup per CU): the WHOLE solve in one launch.
@@ -854,24 +1259,34 @@ __global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, cons
     z[e] = v;
 }
 
+// one CG launch of the running solve (init = the first one)
+template <bool INIT>
+static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, double cap) {
+    const DenseSolver::CgRun& r = ws->run;
+    const int d = ws->d, ld = ws->ld;
+    double* bt = ws->vec + (size_t)8 * ld;
+    const int in = INIT ? 0 : r.in;
+#define CG_ARGS(Fptr) d, ld, Fptr, ws->vec, bt, ws->part, ws->scal, ws->flags, r.rows_per_wg, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->AW, ws->coarse
+    if (r.fast) {
+        if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull));
+        else hipLaunchKernelGGL((k_pcg_iter_fast<INIT, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull));
+    } else if (r.f32) {
+        if (r.coarse) hipLaunchKernelGGL((k_pcg_iter<INIT, float, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
+        else hipLaunchKernelGGL((k_pcg_iter<INIT, float, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
+    } else {
+        if (r.coarse) hipLaunchKernelGGL((k_pcg_iter<INIT, double, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull));
+        else hipLaunchKernelGGL((k_pcg_iter<INIT, double, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull));
+    }
+#undef CG_ARGS
+}
+
 int dense_pcg_more(hipStream_t s, DenseSolver* ws, int n, Profiler* prof) {
     DenseSolver::CgRun& r = ws->run;
     n = std::min(n, r.max_iters - r.launched);
     if (n <= 0) return 0;
-    const int d = ws->d, ld = ws->ld;
-    double* bt = ws->vec + (size_t)8 * ld;
-    int* mb_dev = ws->d_mailbox;
     ProfScope psb(prof, KID_PCG_ITER, s, n);
     for (int b = 0; b < n; ++b) {
-        if (r.fast)
-            hipLaunchKernelGGL(k_pcg_iter_fast<false>, dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                               r.rows_per_wg, r.tol2, r.in, r.info, mb_dev, 0, 1.0);
-        else if (r.f32)
-            hipLaunchKernelGGL((k_pcg_iter<false, float>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull32, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                               r.rows_per_wg, r.tol2, r.in, r.info, mb_dev, 0, 1.0);
-        else
-            hipLaunchKernelGGL((k_pcg_iter<false, double>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                               r.rows_per_wg, r.tol2, r.in, r.info, mb_dev, 0, 1.0);
+        launch_cg_iteration<false>(s, ws, 0, 1.0);
         r.in ^= 1;
     }
     r.launched += n;
@@ -890,7 +1305,7 @@ void dense_pcg_note(DenseSolver* ws, int hist_key, int iters) {
 static double pcg_cap(double tol) { const double t2 = tol * tol; return t2 > 0.0 ? fmax(t2, 1e-8) / t2 : 1.0; }
 
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof,
-                    bool finish, int hist_key, bool pretransformed, int anchor, bool no_wait) {
+                    bool finish, int hist_key, bool pretransformed, int anchor, bool no_wait, bool coarse) {
     const double cap = pcg_cap(tol);
     const int ld = ws->ld, d = ws->d;
     if (dense_pcg_ensure_workspace(ws)) return -1;
@@ -900,7 +1315,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
     if (!fast) rows_per_wg = std::max(8, ((d + PCG_MAXWG_BIG - 1) / PCG_MAXWG_BIG + 7) / 8 * 8);   // two rows per wave at a time
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
-    const size_t lds = sizeof(double) * (size_t)(ld + 8);
+    const size_t lds = sizeof(double) * (size_t)(ld + PCG_RED);
     double* bt = ws->vec + (size_t)8 * ld;
     // fp32 storage of S~ on the streaming path whenever the caller asked for it (dense_pcg_want_f32 allocated the buffer)
     const bool f32 = !fast && ws->use_f32 && ws->Sfull32 != nullptr;
@@ -908,21 +1323,19 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
       if (f32) hipLaunchKernelGGL(k_pcg_transform<float>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull32, bt);
       else hipLaunchKernelGGL(k_pcg_transform<double>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
+    // coarse space: the caller's linearisation wrote W~ (ws->W); AW, E^-1 and c_0 are formed here, one pass over S~
+    coarse = coarse && ws->W && ws->AW && rows_per_wg <= 4 * CO_MAXROWS;
+    if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, 2);
+      if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
+      else if (f32) hipLaunchKernelGGL(k_pcg_coarse<float>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
+      else hipLaunchKernelGGL(k_pcg_coarse<double>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
+      hipLaunchKernelGGL(k_pcg_coarse_invert, dim3(1), dim3(256), 0, s, nwg, ws->epart, ws->coarse); }
     volatile int* mb = ws->h_mailbox;
-    int* mb_dev = ws->d_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }
-    { ProfScope ps(prof, KID_PCG_ITER, s);
-      if (fast)
-          hipLaunchKernelGGL(k_pcg_iter_fast<true>, dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                             rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap);
-      else if (f32)
-          hipLaunchKernelGGL((k_pcg_iter<true, float>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull32, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                             rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap);
-      else
-          hipLaunchKernelGGL((k_pcg_iter<true, double>), dim3(nwg), dim3(256), lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags,
-                             rows_per_wg, tol * tol, 0, info_dev, mb_dev, anchor, cap); }
-    ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32;
+    ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32; ws->run.coarse = coarse;
     ws->run.tol2 = tol * tol; ws->run.in = 1; ws->run.launched = 0; ws->run.max_iters = max_iters; ws->run.info = info_dev;
+    { ProfScope ps(prof, KID_PCG_ITER, s);
+      launch_cg_iteration<true>(s, ws, anchor, cap); }
     int batch = 24;
     static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 2; }();
     // history + 2: a solve that needs one more iteration than last time costs a host round trip, a surplus (early-exit) launch ~2 us
@@ -1022,6 +1435,12 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
     if (!ws->Sfull) {
         if (ws_alloc(ws, &ws->Sfull, sizeof(double) * (size_t)ws->d * ws->ld)) return -1;
     }
+    if (!ws->W) {
+        if (ws_alloc(ws, &ws->W, sizeof(double) * (size_t)PCG_NW * ws->ld)) return -1;
+        if (ws_alloc(ws, &ws->AW, sizeof(double) * (size_t)PCG_NW * ws->ld)) return -1;
+        if (ws_alloc(ws, &ws->epart, sizeof(double) * (size_t)(PCG_NW * PCG_NW + PCG_NW) * PCG_PART)) return -1;
+        if (ws_alloc(ws, &ws->coarse, sizeof(double) * (size_t)(PCG_NW * PCG_NW + PCG_NW))) return -1;
+    }
     return 0;
 }
 
@@ -1031,9 +1450,9 @@ int dense_solver_create(DenseSolver* ws, int d, int ld, DeviceArena* arena, char
     if (ws_alloc(ws, &ws->minv, sizeof(double) * (size_t)nblk * NB * NB)) return -1;
     if (ws_alloc(ws, &ws->y, sizeof(double) * ld)) return -1;
     if (ws_alloc(ws, &ws->vec, sizeof(double) * 9 * (size_t)ld)) return -1;
-    if (ws_alloc(ws, &ws->part, sizeof(double) * 2 * PCG_PART)) return -1;
+    if (ws_alloc(ws, &ws->part, sizeof(double) * 2 * PCG_NPART * PCG_PART)) return -1;
     if (ws_alloc(ws, &ws->binv, sizeof(double) * 36 * (size_t)(ld / 6 + 2))) return -1;
-    if (ws_alloc(ws, &ws->scal, sizeof(double) * 8)) return -1;
+    if (ws_alloc(ws, &ws->scal, sizeof(double) * (PS_STATE + 2 * PS_STATE_LEN))) return -1;
     if (ws_alloc(ws, &ws->flags, sizeof(int) * 4)) return -1;
     if (pinned) {
         ws->pinned_external = true;
@@ -1063,6 +1482,10 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->Sfull32) (void)hipFree(ws->Sfull32);
         if (ws->gran) (void)hipFree(ws->gran);
         if (ws->tmo) (void)hipFree(ws->tmo);
+        if (ws->W) (void)hipFree(ws->W);
+        if (ws->AW) (void)hipFree(ws->AW);
+        if (ws->epart) (void)hipFree(ws->epart);
+        if (ws->coarse) (void)hipFree(ws->coarse);
     }
     if (!ws->pinned_external) {
         if (ws->h_flags) (void)hipHostFree(ws->h_flags);

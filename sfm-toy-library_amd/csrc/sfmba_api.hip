@@ -284,6 +284,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     const bool f32_matrix = !(f32m_env && f32m_env[0] == '0');
     const char* anchor_env = std::getenv("SFMBA_PCG_ANCHOR");
     const bool anchored_cg = o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
+    // two-level preconditioner (8 gauge vectors as a coarse space, dense_solver.hip): on unless SFMBA_PCG_COARSE=0
+    const char* coarse_env = std::getenv("SFMBA_PCG_COARSE");
+    const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
     const char* pcg_env = std::getenv("SFMBA_PCG_PERSISTENT");
     // One persistent launch per CG solve wins where the solve is launch-bound (small reduced systems: 0.67 -> 0.50 ms per
     // solve at 20 cameras) and loses 2.7 % at d = 1201: automatic below d = 640, SFMBA_PCG_PERSISTENT=0|1 forces it.
@@ -299,6 +302,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (pcg) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
+            p->db.pcg_W = coarse_cg ? p->solver.W : nullptr;
             // fp32 Jacobian mode + streaming CG path: the preconditioned matrix is stored in fp32 (halves the HBM-bound matvec)
             p->db.pcg_F32 = (p->precision == SFMBA_PRECISION_F32J && f32_matrix) ? dense_pcg_want_f32(&p->solver) : nullptr;
             p->solver.use_f32 = p->db.pcg_F32 != nullptr;
@@ -331,7 +335,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 // not wait for the linear solve.  If the batch was too short k_lm_control says so and more is enqueued.
                 pcg_gated = gated_cg;
                 const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
-                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/pcg_gated);
+                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/pcg_gated, /*coarse=*/coarse_cg);
                 if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
                 if (!pcg_gated) { sum.linear_iters += it; lin_hist.push_back(it); }
             }
@@ -792,7 +796,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     db.lin_info = p->d_info;
     db.fin_counter = p->d_info + 1;
     db.pcg_vec = nullptr; db.pcg_linv = nullptr; db.pcg_flags = nullptr;
-    db.pcg_F = nullptr; db.pcg_F32 = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr;
+    db.pcg_F = nullptr; db.pcg_F32 = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr; db.pcg_W = nullptr;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
     db.lm_mailbox = reinterpret_cast<int*>(p->d_pinned + 1024);
     db.st_mirror = reinterpret_cast<LMState*>(p->d_pinned);

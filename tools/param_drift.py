@@ -1,14 +1,20 @@
-"""Parameter-level difference between the exact (Cholesky) reduced solve and PCG at several tolerances."""
+"""Parameter-level difference between the exact (Cholesky) reduced solve and PCG at several tolerances, anchored and
+plain-relative, with and without the gauge coarse space (SFMBA_PCG_COARSE)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sfm_toy_library_amd as sfm
 from sfm_toy_library_amd import capi
-for name in sys.argv[1:] or ["tiny", "crazyhorse_like", "cfg2", "cfg3"]:
-    prob = sfm.make_problem(name)
-    ref = capi.solve(prob, capi.default_options(max_seconds=0.0, linear_solver=0))
-    for tol in (1e-6, 1e-7, 1e-8, 1e-10):
-        r = capi.solve(prob, capi.default_options(max_seconds=0.0, linear_solver=1, pcg_tolerance=tol))
-        print("%-16s tol %.0e: iters %d/%d  lin %3d  |dcam| %.2e  |dpt| %.2e  |df| %.2e  dcost/cost %.1e" % (
-            name, tol, r[3]["iterations"], ref[3]["iterations"], r[3]["linear_iters"], np.abs(r[0] - ref[0]).max(), np.abs(r[1] - ref[1]).max(),
-            abs(r[2] - ref[2]), abs(r[3]["final_cost"] - ref[3]["final_cost"]) / ref[3]["final_cost"]), flush=True)
+for name in sys.argv[1:] or ["cfg2", "cfg3"]:
+    prob = sfm.make_problem(name) if name != "wide" else sfm.make_problem("cfg3", n_cam=230, n_pt=6000, seed=77)
+    prec = 1 if prob.n_obs > 100000 else 0
+    ref = capi.solve(prob, capi.default_options(max_seconds=0.0, linear_solver=0, precision=prec))
+    for coarse in ("0", "1"):
+        os.environ["SFMBA_PCG_COARSE"] = coarse
+        os.environ["SFMBA_PCG_PERSISTENT"] = "0"
+        for anchored in (1, 0):
+            for tol in (1e-4, 1e-5, 1e-6, 1e-7, 1e-8):
+                r = capi.solve(prob, capi.default_options(max_seconds=0.0, linear_solver=1, pcg_tolerance=tol, pcg_anchored=anchored, precision=prec))
+                print("%-8s coarse %s anchored %d tol %.0e: LM %d/%d  cg %3d  |dcam| %.2e  |dpt| %.2e  |df| %.2e  dcost/cost %.1e" % (
+                    name, coarse, anchored, tol, r[3]["iterations"], ref[3]["iterations"], r[3]["linear_iters"], np.abs(r[0] - ref[0]).max(),
+                    np.abs(r[1] - ref[1]).max(), abs(r[2] - ref[2]), abs(r[3]["final_cost"] - ref[3]["final_cost"]) / ref[3]["final_cost"]), flush=True)
