@@ -159,6 +159,19 @@ SFMBA_API int  sfmba_problem_create(int device, int precision,
                           int n_cam, const double* cam6, int n_pt, const double* pt3,
                           int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                           double focal, sfmba_problem** out);
+/*
+ * Grows a resident problem in place -- the incremental caller re-runs BA after every added view (SfM.cpp:464-466) with a
+ * cloud that only ever GROWS (new points, new views of existing points, SfM.cpp:530-629): n_cam >= the previous n_cam and
+ * n_pt >= the previous n_pt (new cameras / points at the END of the arrays), n_obs_new NEW observations (of old or new cameras
+ * and points; indices into the full arrays).  The observations given before stay.  The parameters of ALL cameras and points
+ * and the focal are replaced from cam6 / pt3 / focal (full arrays, as at create time): the caller's containers hold the
+ * float-rounded result of the previous solve plus the new entries (BA.cpp:187-221).  The observation list never leaves the
+ * device: the new observations are uploaded, merged into the point-major order by a device sort, and the dependent lists
+ * (camera-major index, camera-pair lists, launch descriptors) are rebuilt on the device.  Result identical to
+ * sfmba_problem_create on the concatenated observation list (old observations first, then the new ones).
+ */
+SFMBA_API int  sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_pt, const double* pt3,
+                          int64_t n_obs_new, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, double focal);
 /* Restore the parameters given at create time (device-to-device copy). */
 SFMBA_API int  sfmba_problem_reset(sfmba_problem* p);
 /* Overwrite the current parameters from host arrays (full-size arrays, as at create). */

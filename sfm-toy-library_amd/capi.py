@@ -27,7 +27,7 @@ SYMBOLS = [
     "sfmba_shard_scalars_buf", "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish",
     "sfmba_shard_end", "sfmba_problem_set_profiling", "sfmba_problem_get_profile",
     "sfmba_problem_create_sharded", "sfmba_shard_setup_finish", "sfmba_shard_setup_len", "sfmba_shard_setup_buf", "sfmba_release_cache", "sfmba_triangulate",
-    "sfmba_find_2d3d_matches", "sfmba_merge_candidates",
+    "sfmba_find_2d3d_matches", "sfmba_merge_candidates", "sfmba_problem_append",
 ]
 
 
@@ -149,7 +149,7 @@ def lib():
         L.sfmba_shard_setup_buf.restype = C.c_void_p
         L.sfmba_release_cache.restype = C.c_longlong
         for name in ("sfmba_problem_reset", "sfmba_problem_set_params", "sfmba_problem_solve", "sfmba_problem_get_params",
-                     "sfmba_problem_destroy", "sfmba_problem_stream", "sfmba_problem_reduced_dim",
+                     "sfmba_problem_destroy", "sfmba_problem_stream", "sfmba_problem_reduced_dim", "sfmba_problem_append",
                      "sfmba_problem_eval_residuals", "sfmba_problem_eval_jacobian", "sfmba_problem_build_reduced",
                      "sfmba_shard_begin", "sfmba_shard_reduce_len", "sfmba_shard_reduce_buf", "sfmba_shard_scalars_buf",
                      "sfmba_shard_partial_build", "sfmba_shard_solve_update", "sfmba_shard_finish", "sfmba_shard_end"):
@@ -266,6 +266,16 @@ class Problem:
     def set_params(self, cam6, pt3, focal):
         cam6, pt3 = _d(cam6), _d(pt3)
         _check(lib().sfmba_problem_set_params(self._h, _p(cam6, _dp), _p(pt3, _dp), C.c_double(focal)))
+
+    def append(self, cam6, pt3, focal, obs_cam, obs_pt, obs_xy):
+        """sfmba_problem_append: grow the resident problem by new observations (and, at the end of the arrays, new cameras /
+        points); cam6 / pt3 are the FULL current parameter arrays."""
+        cam6, pt3 = _d(cam6), _d(pt3)
+        oc, op, oxy = _i(obs_cam), _i(obs_pt), _d(obs_xy)
+        _check(lib().sfmba_problem_append(self._h, C.c_int(cam6.shape[0]), _p(cam6, _dp), C.c_int(pt3.shape[0]), _p(pt3, _dp),
+                                          C.c_int64(len(oc)), _p(oc, _ip), _p(op, _ip), _p(oxy, _dp), C.c_double(focal)))
+        self.n_cam, self.n_pt, self.n_obs = cam6.shape[0], pt3.shape[0], self.n_obs + len(oc)
+        self._template = (cam6.copy(), pt3.copy())
 
     def get_params(self):
         cam6, pt3 = self._template[0].copy(), self._template[1].copy()

@@ -172,13 +172,23 @@ void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const Devic
 void launch_mirror_scale(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* S_full, double* scale_out);
 
 
-// structure_build.hip: camera-pair lists of the Schur pass, built on the device (pair_off_host: npt + 1 prefix counts)
+// structure_build.hip: the problem structure is built on the device
 class DeviceArena;
+struct PointMajor {            // point-major observation list (build_point_major)
+    int* obs_pt = nullptr;     // [2 n] point slot per sorted position, then the caller index of that observation
+    int* obs_cam = nullptr;    // [n]
+    void* obs_xy = nullptr;    // [n] float2 / double2
+    int* pt_ptr = nullptr;     // [npt + 1]
+    long long* pair_off = nullptr;   // [npt + 1] pairs of the points before i
+};
+int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int xy_bytes, const int* u_pt, const int* u_cam,
+                      const int* u_perm, const void* u_xy, PointMajor* out, long long* npair);
+// camera-pair lists of the Schur pass (d_pair_off: npt + 1 prefix counts on the device)
 int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
-                     const int* d_obs_cam, const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr);
+                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr);
 
 int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
-                       int** d_cam_obs, int** d_cam_obs_pt);
+                       int** d_cam_obs, int** d_cam_obs_pt, int** d_cam_ptr);
 
 // triangulate.hip: two-view DLT triangulation + reprojection filter (SfMStereoUtilities::triangulateViews), device pointers
 void launch_triangulate(hipStream_t s, long long n, const float* d_left, const float* d_right, const float K[9], const float Pl[12],

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <utility>
 #include <vector>
 
 namespace sfmba {
@@ -32,6 +33,8 @@ public:
     // Returns every chunk to the cache (or to HIP when the cache is full).  All pointers handed out become invalid.
     void release();
     size_t bytes_reserved() const;
+    // exchange the contents (chunks) of two arenas
+    void swap(DeviceArena& o) { std::swap(device_, o.device_); chunks_.swap(o.chunks_); std::swap(off_, o.off_); }
 
 private:
     int device_;

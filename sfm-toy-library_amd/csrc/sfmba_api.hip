@@ -131,14 +131,15 @@ struct sfmba_problem {
     int n_cam_full = 0, n_pt_full = 0;
     int64_t n_obs = 0;
     std::vector<int> acam_id, apt_id;     // active slot -> caller index
-    std::vector<int> perm;                // point-major position -> caller observation index
+    std::vector<int> cam_slot, pt_slot;   // caller index -> slot (-1: not observed)
+    bool sharded = false;
     DeviceStructure ds = {};
     DeviceBuffers db = {};
     DenseSolver solver;
     DeviceArena arena;                    // every device array below except db.trace
     HostKit kit;                          // stream + pinned block (recycled)
     // owned device arrays behind ds
-    int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;
+    int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;   // (all in `arena`)
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_wv_desc = nullptr, *d_pwg_desc = nullptr;
@@ -497,106 +498,103 @@ int sfmba_problem_create_sharded(int device, int precision, int n_cam, const dou
     return create_impl(device, precision, n_cam, cam6, cam_active, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal, rank, world, out);
 }
 
-static int create_impl(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
-                       int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
-                       double focal, int rank, int world, sfmba_problem** out) {
-    if (!out) return fail(SFMBA_ERR_INVALID_ARG, "out is NULL");
-    *out = nullptr;
-    if (n_cam < 0 || n_pt < 0 || n_obs < 0 || n_obs >= (int64_t)1 << 31) return fail(SFMBA_ERR_INVALID_ARG, "bad sizes");
-    if (precision != SFMBA_PRECISION_F64 && precision != SFMBA_PRECISION_F32J) return fail(SFMBA_ERR_INVALID_ARG, "bad precision");
-    if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs > 0 && (!obs_cam || !obs_pt || !obs_xy)))
-        return fail(SFMBA_ERR_INVALID_ARG, "NULL array");
-    int rc = check_device(device);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(device));
+int sfmba_problem_reset(sfmba_problem* p);
 
-    sfmba_problem* p = new sfmba_problem();
-    p->device = device;
-    p->arena.set_device(device);
-    ArenaScope arena_scope(&p->arena);
-    p->precision = precision;
-    p->n_cam_full = n_cam; p->n_pt_full = n_pt; p->n_obs = n_obs;
-    p->focal0 = p->focal = focal;
-    p->shard_rank = rank; p->shard_world = world;
-    struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
+// Observations a (re)build starts from: the point-major arrays of the previous structure (device, old arena) and / or new
+// observations on the host (caller indices, mapped through the slot tables of the problem).
+struct ObsSource {
+    int n_old = 0;
+    const int* d_old_pt = nullptr; const int* d_old_cam = nullptr; const void* d_old_xy = nullptr; const int* d_old_perm = nullptr;
+    int n_new = 0;
+    const int32_t* cam = nullptr; const int32_t* pt = nullptr; const double* xy = nullptr;
+};
 
-    // ---- structure (host) ----
+// Builds everything that depends on the observation list into p->arena (which must be empty of structure): point-major order,
+// camera-major index, pair lists, launch descriptors, parameter / record / reduced-system buffers, dense-solver workspace;
+// uploads the parameters.  All sorting and list building runs on the device (structure_build.hip); the host only derives
+// the launch descriptors from three small CSR pointer arrays.  The counterpart of the reference's AddResidualBlock loop
+// (BA.cpp:142-166) -- and, for sfmba_problem_append, of re-running it after a view was added (SfM.cpp:464-466).
+static int build_structure(sfmba_problem* p, const ObsSource& src, const double* cam6, const double* pt3, double focal, bool sharded) {
+    const int device = p->device, precision = p->precision;
     const bool bt_on = std::getenv("SFMBA_BUILD_TIMING") != nullptr;
     auto bt_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double bt_t = bt_now();
     auto bt_mark = [&](const char* what) { if (bt_on) { const double t = bt_now(); std::fprintf(stderr, "[sfmba build] %-18s %.2f ms\n", what, 1e3 * (t - bt_t)); bt_t = t; } };
-    std::vector<int> cam_slot((size_t)n_cam, -1), pt_slot((size_t)n_pt, -1);
-    for (int64_t k = 0; k < n_obs; ++k) {
-        if (obs_cam[k] < 0 || obs_cam[k] >= n_cam || obs_pt[k] < 0 || obs_pt[k] >= n_pt)
-            return fail(SFMBA_ERR_INVALID_ARG, "observation index out of range");
-        cam_slot[obs_cam[k]] = 0;
-        pt_slot[obs_pt[k]] = 0;
-    }
-    if (cam_active)   // sharded: every globally observed camera is part of every rank's reduced system
-        for (int j = 0; j < n_cam; ++j) if (cam_active[j]) cam_slot[j] = 0;
-    for (int j = 0; j < n_cam; ++j) if (cam_slot[j] == 0) { cam_slot[j] = (int)p->acam_id.size(); p->acam_id.push_back(j); }
-    for (int i = 0; i < n_pt; ++i) if (pt_slot[i] == 0) { pt_slot[i] = (int)p->apt_id.size(); p->apt_id.push_back(i); }
-    const int ncam = (int)p->acam_id.size(), npt = (int)p->apt_id.size(), nobs = (int)n_obs;
-    static_assert(sizeof(LMState) <= 1024, "LMState must fit its slice of the pinned block");
-    if (!hostkit_acquire(device, &p->kit)) return fail(SFMBA_ERR_HIP, "stream / pinned memory creation failed");
-    p->stream = p->kit.stream;
-    p->h_state = reinterpret_cast<LMState*>(p->kit.pinned);                        // [0, 1024)
-    p->h_lm_mail = reinterpret_cast<volatile int*>(p->kit.pinned + 1024);          // [1024, 1088)
-    if (nobs == 0 && !cam_active) {
-        p->empty = true;
-        guard.p = nullptr;
-        *out = p;
-        return SFMBA_OK;
-    }
+    ArenaScope arena_scope(&p->arena);
+    const int ncam = (int)p->acam_id.size(), npt = (int)p->apt_id.size();
+    const long long nobs64 = (long long)src.n_old + src.n_new;
+    if (nobs64 >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observations");
+    const int nobs = (int)nobs64;
+    const bool f32 = precision == SFMBA_PRECISION_F32J;
+    const int xy_bytes = f32 ? 8 : 16;
 
-    bt_mark("compaction+stream");
-    std::vector<int> pt_ptr((size_t)npt + 1, 0);
-    std::vector<int> pm_cam((size_t)nobs), pm_pt((size_t)nobs);
-    p->perm.resize((size_t)nobs);
-    // adjustBundle() adds its residual blocks point-major with ascending view index (BA.cpp:142-166, std::map order):
-    // that input needs no sort, only the slot mapping.  Anything else goes through a counting sort.
-    bool presorted = true;
+    // ---- unsorted observations on the device: old ones copied device to device, new ones mapped to slots and uploaded ----
+    PointMajor pm;
+    long long npair_total = 0;
     {
-        // (measured: splitting these two passes over threads does not pay -- spawn cost and shared counters eat the gain)
-        int prev_i = -1, prev_c = -1;
-        for (int k = 0; k < nobs; ++k) {
-            const int i = pt_slot[obs_pt[k]], c = cam_slot[obs_cam[k]];
-            if (i < prev_i || (i == prev_i && c < prev_c)) { presorted = false; break; }
-            pm_pt[k] = i; pm_cam[k] = c; p->perm[k] = k;
-            pt_ptr[(size_t)i + 1]++;
-            prev_i = i; prev_c = c;
+        DeviceArena staging(device);
+        int* u_pt = staging.alloc_n<int>((size_t)nobs);
+        int* u_cam = staging.alloc_n<int>((size_t)nobs);
+        int* u_perm = staging.alloc_n<int>((size_t)nobs);
+        char* u_xy = static_cast<char*>(staging.alloc((size_t)xy_bytes * std::max(nobs, 1)));
+        if (!u_pt || !u_cam || !u_perm || !u_xy) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+        if (src.n_old > 0) {
+            HIP_TRY(hipMemcpyAsync(u_pt, src.d_old_pt, sizeof(int) * (size_t)src.n_old, hipMemcpyDeviceToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(u_cam, src.d_old_cam, sizeof(int) * (size_t)src.n_old, hipMemcpyDeviceToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(u_perm, src.d_old_perm, sizeof(int) * (size_t)src.n_old, hipMemcpyDeviceToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(u_xy, src.d_old_xy, (size_t)xy_bytes * src.n_old, hipMemcpyDeviceToDevice, p->stream));
         }
+        std::vector<int> h_pt((size_t)src.n_new), h_cam((size_t)src.n_new), h_perm((size_t)src.n_new);
+        std::vector<char> h_xy((size_t)xy_bytes * src.n_new);
+        if (src.n_new > 0) {
+            const int perm0 = (int)p->n_obs - src.n_new;           // caller index of the first new observation
+            parallel_for(src.n_new, [&](int k0, int k1) {
+                for (int k = k0; k < k1; ++k) {
+                    h_pt[(size_t)k] = p->pt_slot[(size_t)src.pt[k]]; h_cam[(size_t)k] = p->cam_slot[(size_t)src.cam[k]]; h_perm[(size_t)k] = perm0 + k;
+                    if (f32) { float* d = reinterpret_cast<float*>(h_xy.data()) + 2 * (size_t)k; d[0] = (float)src.xy[2 * (size_t)k]; d[1] = (float)src.xy[2 * (size_t)k + 1]; }
+                    else { double* d = reinterpret_cast<double*>(h_xy.data()) + 2 * (size_t)k; d[0] = src.xy[2 * (size_t)k]; d[1] = src.xy[2 * (size_t)k + 1]; }
+                }
+            });
+            HIP_TRY(hipMemcpyAsync(u_pt + src.n_old, h_pt.data(), sizeof(int) * h_pt.size(), hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(u_cam + src.n_old, h_cam.data(), sizeof(int) * h_cam.size(), hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(u_perm + src.n_old, h_perm.data(), sizeof(int) * h_perm.size(), hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(u_xy + (size_t)xy_bytes * src.n_old, h_xy.data(), h_xy.size(), hipMemcpyHostToDevice, p->stream));
+        }
+        bt_mark("slots+upload obs");
+        const int brc = build_point_major(p->stream, &p->arena, device, nobs, npt, xy_bytes, u_pt, u_cam, u_perm, u_xy, &pm, &npair_total);
+        if (brc) return fail(SFMBA_ERR_HIP, std::string("point-major build: ") + hipGetErrorString((hipError_t)brc));
+        // (build_point_major synchronised the stream: the staging arrays and the host vectors may go)
     }
-    if (presorted) {
-        for (int i = 0; i < npt; ++i) pt_ptr[(size_t)i + 1] += pt_ptr[i];
-    } else {
-        std::fill(pt_ptr.begin(), pt_ptr.end(), 0);
-        for (int k = 0; k < nobs; ++k) pt_ptr[(size_t)pt_slot[obs_pt[k]] + 1]++;
-        for (int i = 0; i < npt; ++i) pt_ptr[(size_t)i + 1] += pt_ptr[i];
-        std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1);
-        for (int k = 0; k < nobs; ++k) {
-            const int i = pt_slot[obs_pt[k]];
-            const int q = fill[i]++;
-            pm_cam[q] = cam_slot[obs_cam[k]];
-            pm_pt[q] = i;
-            p->perm[q] = k;
-        }
-        // ascending camera slot inside each point (stable insertion sort: segments are short)
-        for (int i = 0; i < npt; ++i) {
-            for (int a = pt_ptr[i] + 1; a < pt_ptr[(size_t)i + 1]; ++a) {
-                const int c = pm_cam[a], pk = p->perm[a];
-                int b = a - 1;
-                while (b >= pt_ptr[i] && pm_cam[b] > c) { pm_cam[b + 1] = pm_cam[b]; p->perm[b + 1] = p->perm[b]; --b; }
-                pm_cam[b + 1] = c; p->perm[b + 1] = pk;
-            }
-        }
-    }
+    p->d_pt_ptr = pm.pt_ptr; p->d_obs_cam = pm.obs_cam; p->d_obs_pt = pm.obs_pt; p->d_perm = pm.obs_pt + nobs; p->d_obs_xy = pm.obs_xy;
+    if (npair_total >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
+    std::vector<int> pt_ptr((size_t)npt + 1, 0);
+    HIP_TRY(hipMemcpy(pt_ptr.data(), pm.pt_ptr, sizeof(int) * pt_ptr.size(), hipMemcpyDeviceToHost));
     bt_mark("point-major sort");
+
+    // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the self pairs are folded
+    // into the camera-diagonal pass) goes to block (ja, jb) of the upper triangle of S
+    const int64_t nblock64 = (int64_t)ncam * (ncam + 1) / 2;
+    if (nblock64 >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many cameras");
+    const int nblock = (int)nblock64;
+    auto block_of = [ncam](int ja, int jb) { return (int)((int64_t)ja * ncam - (int64_t)ja * (ja - 1) / 2 + (jb - ja)); };
+    {
+        const int brc = build_pair_lists(p->stream, &p->arena, device, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pm.pair_off, npair_total,
+                                         &p->d_pairs, &p->d_blk_ptr);
+        if (brc) return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc));
+    }
+    std::vector<int> blk_ptr((size_t)nblock + 1, 0);
+    HIP_TRY(hipMemcpy(blk_ptr.data(), p->d_blk_ptr, sizeof(int) * blk_ptr.size(), hipMemcpyDeviceToHost));
+    bt_mark("pair lists");
+    {
+        const int crc = build_camera_major(p->stream, &p->arena, device, nobs, ncam, p->d_obs_cam, p->d_obs_pt, &p->d_cam_obs, &p->d_cam_obs_pt, &p->d_cam_ptr);
+        if (crc) return fail(SFMBA_ERR_HIP, std::string("camera-major build: ") + hipGetErrorString((hipError_t)crc));
+    }
     std::vector<int> cam_ptr((size_t)ncam + 1, 0);
-    for (int q = 0; q < nobs; ++q) cam_ptr[(size_t)pm_cam[q] + 1]++;
-    for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] += cam_ptr[j];
-    // (the camera-major lists themselves are built on the device from the uploaded point-major arrays, structure_build.hip)
-    // chunks of the camera-major list (used by the column-norm pass): (camera, entry range)
+    HIP_TRY(hipMemcpy(cam_ptr.data(), p->d_cam_ptr, sizeof(int) * cam_ptr.size(), hipMemcpyDeviceToHost));
+    bt_mark("camera-major");
+
+    // ---- launch descriptors (host, from the three CSR pointer arrays) ----
+    // chunks of the camera-major list: (camera, entry range)
     const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
     std::vector<int4> chunks, chunks_coarse;
     for (int j = 0; j < ncam; ++j) {
@@ -609,46 +607,15 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
             chunks_coarse.push_back(c);
         }
     }
-    // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the
-    // self pairs are folded into the camera-diagonal pass)
-    // goes to block (ja, jb) of the upper triangle of S; counting sort by block.
-    const int64_t nblock64 = (int64_t)ncam * (ncam + 1) / 2;
-    if (nblock64 >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many cameras");
-    const int nblock = (int)nblock64;
-    auto block_of = [ncam](int ja, int jb) { return (int)((int64_t)ja * ncam - (int64_t)ja * (ja - 1) / 2 + (jb - ja)); };
-    // The lists themselves are built on the device (structure_build.hip); the host only supplies the per-point offsets.
-    std::vector<long long> pair_off((size_t)npt + 1, 0);
-    for (int i = 0; i < npt; ++i) {
-        const long long n = pt_ptr[(size_t)i + 1] - pt_ptr[i];
-        pair_off[(size_t)i + 1] = pair_off[i] + n * (n - 1) / 2;
-    }
-    if (pair_off[npt] >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
-    HIP_TRY(dev_upload(&p->d_pt_ptr, pt_ptr));
-    HIP_TRY(dev_upload(&p->d_obs_cam, pm_cam));
-    {
-        std::vector<int> both((size_t)2 * nobs);
-        std::copy(pm_pt.begin(), pm_pt.end(), both.begin());
-        std::copy(p->perm.begin(), p->perm.end(), both.begin() + nobs);
-        HIP_TRY(dev_upload(&p->d_obs_pt, both));
-        p->d_perm = p->d_obs_pt + nobs;
-    }
-    {
-        const int brc = build_pair_lists(p->stream, &p->arena, device, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pair_off, &p->d_pairs, &p->d_blk_ptr);
-        if (brc) return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc));
-    }
-    std::vector<int> blk_ptr((size_t)nblock + 1, 0);
-    HIP_TRY(hipMemcpy(blk_ptr.data(), p->d_blk_ptr, sizeof(int) * blk_ptr.size(), hipMemcpyDeviceToHost));
-    bt_mark("pair lists");
     std::vector<int2> blk_cams((size_t)nblock);
     for (int ja = 0; ja < ncam; ++ja)
         for (int jb = ja; jb < ncam; ++jb) { int2 c; c.x = ja; c.y = jb; blk_cams[(size_t)block_of(ja, jb)] = c; }
-    // workgroups of the pair pass: 4 consecutive blocks of ONE block-row each; rows are dealt to the 8
+    // workgroups of the pair pass: consecutive blocks of ONE block-row each; rows are dealt to the 8
     // XCDs (blockIdx % 8, the observed dispatch order) so a row's records stay in one L2.  Performance
     // only: any placement gives the same result.
     // Lanes per block of the pair pass, from the mean number of pairs of an off-diagonal block: a whole wave (64 pairs per
     // round) or 16 lanes (4 blocks per wave).  Measured on MI355X: 16 lanes win at 56 pairs per block (110 vs 139 us) and
     // below (280 vs 738 us at 5.6), the whole wave wins at 226 (77 vs 105 us).  SFMBA_PAIR_LPB overrides.
-    const long long npair_total = pair_off[npt];
     const double mean_pairs = (double)npair_total / (double)std::max(1, nblock - ncam);
     int pair_lpb = mean_pairs >= 128.0 ? 64 : 16;
     if (const char* e = std::getenv("SFMBA_PAIR_LPB")) { const int v = std::atoi(e); if (v == 64 || v == 16) pair_lpb = v; }
@@ -698,14 +665,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         }
         wv_ptr.push_back(npt);
     }
-
     bt_mark("maps");
-    // ---- upload ----
-    HIP_TRY(dev_upload(&p->d_cam_ptr, cam_ptr));
-    {
-        const int crc = build_camera_major(p->stream, &p->arena, device, nobs, ncam, p->d_obs_cam, p->d_obs_pt, &p->d_cam_obs, &p->d_cam_obs_pt);
-        if (crc) return fail(SFMBA_ERR_HIP, std::string("camera-major build: ") + hipGetErrorString((hipError_t)crc));
-    }
     HIP_TRY(dev_upload(&p->d_chunks, chunks));
     HIP_TRY(dev_upload(&p->d_chunks_coarse, chunks_coarse));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
@@ -721,31 +681,16 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
         }
         HIP_TRY(dev_upload(&p->d_wv_desc, wv_desc));
     }
-    if (precision == SFMBA_PRECISION_F32J) {
-        std::vector<float> xy((size_t)2 * nobs);
-        parallel_for(nobs, [&](int q0, int q1) {
-            for (int q = q0; q < q1; ++q) { xy[2 * (size_t)q] = (float)obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = (float)obs_xy[2 * (size_t)p->perm[q] + 1]; }
-        });
-        float* d = nullptr;
-        HIP_TRY(dev_upload(&d, xy));
-        p->d_obs_xy = d;
-    } else {
-        std::vector<double> xy((size_t)2 * nobs);
-        parallel_for(nobs, [&](int q0, int q1) {
-            for (int q = q0; q < q1; ++q) { xy[2 * (size_t)q] = obs_xy[2 * (size_t)p->perm[q]]; xy[2 * (size_t)q + 1] = obs_xy[2 * (size_t)p->perm[q] + 1]; }
-        });
-        double* d = nullptr;
-        HIP_TRY(dev_upload(&d, xy));
-        p->d_obs_xy = d;
-    }
     bt_mark("upload structure");
     std::vector<double> cam0((size_t)6 * ncam), pts0((size_t)3 * npt);
     for (int j = 0; j < ncam; ++j) std::memcpy(&cam0[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
     for (int i = 0; i < npt; ++i) std::memcpy(&pts0[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
     HIP_TRY(dev_upload(&p->d_cam0, cam0));
     HIP_TRY(dev_upload(&p->d_pts0, pts0));
+    p->focal0 = p->focal = focal;
 
     DeviceStructure& ds = p->ds;
+    ds = DeviceStructure{};
     ds.ncam = ncam; ds.npt = npt; ds.nobs = nobs;
     ds.d = 6 * ncam + 1;
     ds.ld = dense_padded_dim(ds.d);
@@ -762,6 +707,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
 
     bt_mark("upload params");
     DeviceBuffers& db = p->db;
+    db = DeviceBuffers{};
     for (int b = 0; b < 2; ++b) {
         HIP_TRY(dev_alloc(&db.cam[b], (size_t)6 * ncam));
         HIP_TRY(dev_alloc(&db.pts[b], (size_t)3 * npt));
@@ -770,7 +716,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_alloc(&db.steptab, (size_t)ST_STRIDE * ncam));
     HIP_TRY(dev_alloc(&db.cscale, (size_t)6 * ncam));
     HIP_TRY(dev_alloc(&db.pscale, (size_t)3 * npt));
-    const size_t ybytes = (size_t)nobs * YREC * (precision == SFMBA_PRECISION_F32J ? sizeof(float) : sizeof(double));
+    const size_t ybytes = (size_t)std::max(nobs, 1) * YREC * (f32 ? sizeof(float) : sizeof(double));
     db.Y = p->arena.alloc(ybytes);
     db.Z = p->arena.alloc(ybytes / 2);
     if (!db.Y || !db.Z) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
@@ -778,7 +724,8 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
     HIP_TRY(dev_alloc(&p->d_sys, sys_len));
-    if (cam_active) HIP_TRY(dev_alloc(&p->d_red, (size_t)ds.ld * (ds.ld + 1) / 2 + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS));
+    p->d_red = nullptr;
+    if (sharded) HIP_TRY(dev_alloc(&p->d_red, (size_t)ds.ld * (ds.ld + 1) / 2 + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS));
     db.S = p->d_sys;
     db.rhs = db.S + (size_t)ds.ld * ds.ld;
     db.udiag = db.rhs + ds.ld;
@@ -795,23 +742,114 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     HIP_TRY(hipMemset(p->d_info, 0, 2 * sizeof(int)));
     db.lin_info = p->d_info;
     db.fin_counter = p->d_info + 1;
-    db.pcg_vec = nullptr; db.pcg_linv = nullptr; db.pcg_flags = nullptr;
-    db.pcg_F = nullptr; db.pcg_F32 = nullptr; db.pcg_bt = nullptr; db.pcg_binv = nullptr; db.pcg_W = nullptr;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
     db.lm_mailbox = reinterpret_cast<int*>(p->d_pinned + 1024);
     db.st_mirror = reinterpret_cast<LMState*>(p->d_pinned);
-    db.trace = nullptr; db.trace_cap = 0;
+    db.trace = nullptr; db.trace_cap = 0; p->trace_mapped = false;
+    dense_solver_destroy(&p->solver);
     if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
-
     bt_mark("alloc buffers");
-    rc = sfmba_problem_reset(p);
-    if (rc) return rc;
+    const int rc = sfmba_problem_reset(p);
     bt_mark("reset");
+    return rc;
+}
+
+static int create_impl(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
+                       int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                       double focal, int rank, int world, sfmba_problem** out) {
+    if (!out) return fail(SFMBA_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_cam < 0 || n_pt < 0 || n_obs < 0 || n_obs >= (int64_t)1 << 31) return fail(SFMBA_ERR_INVALID_ARG, "bad sizes");
+    if (precision != SFMBA_PRECISION_F64 && precision != SFMBA_PRECISION_F32J) return fail(SFMBA_ERR_INVALID_ARG, "bad precision");
+    if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs > 0 && (!obs_cam || !obs_pt || !obs_xy)))
+        return fail(SFMBA_ERR_INVALID_ARG, "NULL array");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+
+    sfmba_problem* p = new sfmba_problem();
+    p->device = device;
+    p->arena.set_device(device);
+    p->precision = precision;
+    p->n_cam_full = n_cam; p->n_pt_full = n_pt; p->n_obs = n_obs;
+    p->focal0 = p->focal = focal;
+    p->shard_rank = rank; p->shard_world = world;
+    p->sharded = cam_active != nullptr;
+    struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
+
+    // active (observed) cameras / points -> slots, ascending caller index
+    p->cam_slot.assign((size_t)n_cam, -1); p->pt_slot.assign((size_t)n_pt, -1);
+    for (int64_t k = 0; k < n_obs; ++k) {
+        if (obs_cam[k] < 0 || obs_cam[k] >= n_cam || obs_pt[k] < 0 || obs_pt[k] >= n_pt)
+            return fail(SFMBA_ERR_INVALID_ARG, "observation index out of range");
+        p->cam_slot[obs_cam[k]] = 0;
+        p->pt_slot[obs_pt[k]] = 0;
+    }
+    if (cam_active)   // sharded: every globally observed camera is part of every rank's reduced system
+        for (int j = 0; j < n_cam; ++j) if (cam_active[j]) p->cam_slot[j] = 0;
+    for (int j = 0; j < n_cam; ++j) if (p->cam_slot[j] == 0) { p->cam_slot[j] = (int)p->acam_id.size(); p->acam_id.push_back(j); }
+    for (int i = 0; i < n_pt; ++i) if (p->pt_slot[i] == 0) { p->pt_slot[i] = (int)p->apt_id.size(); p->apt_id.push_back(i); }
+    static_assert(sizeof(LMState) <= 1024, "LMState must fit its slice of the pinned block");
+    if (!hostkit_acquire(device, &p->kit)) return fail(SFMBA_ERR_HIP, "stream / pinned memory creation failed");
+    p->stream = p->kit.stream;
+    p->h_state = reinterpret_cast<LMState*>(p->kit.pinned);                        // [0, 1024)
+    p->h_lm_mail = reinterpret_cast<volatile int*>(p->kit.pinned + 1024);          // [1024, 1088)
+    if (n_obs == 0 && !cam_active) {
+        p->empty = true;
+        guard.p = nullptr;
+        *out = p;
+        return SFMBA_OK;
+    }
+    ObsSource src;
+    src.n_new = (int)n_obs; src.cam = obs_cam; src.pt = obs_pt; src.xy = obs_xy;
+    rc = build_structure(p, src, cam6, pt3, focal, p->sharded);
+    if (rc) return rc;
     guard.p = nullptr;
     *out = p;
     return SFMBA_OK;
+}
+
+int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_pt, const double* pt3,
+                         int64_t n_obs_new, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, double focal) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "a sharded problem cannot grow in place");
+    if (n_cam < p->n_cam_full || n_pt < p->n_pt_full || n_obs_new < 0 || p->n_obs + n_obs_new >= (int64_t)1 << 31)
+        return fail(SFMBA_ERR_INVALID_ARG, "bad sizes: cameras and points can only be added at the end");
+    if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs_new > 0 && (!obs_cam || !obs_pt || !obs_xy)))
+        return fail(SFMBA_ERR_INVALID_ARG, "NULL array");
+    HIP_TRY(hipSetDevice(p->device));
+    for (int64_t k = 0; k < n_obs_new; ++k)
+        if (obs_cam[k] < 0 || obs_cam[k] >= n_cam || obs_pt[k] < 0 || obs_pt[k] >= n_pt)
+            return fail(SFMBA_ERR_INVALID_ARG, "observation index out of range");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    // cameras / points that become observed get the next free slot (slot order = order of first observation)
+    p->cam_slot.resize((size_t)n_cam, -1); p->pt_slot.resize((size_t)n_pt, -1);
+    for (int64_t k = 0; k < n_obs_new; ++k) {
+        int& cs = p->cam_slot[(size_t)obs_cam[k]];
+        if (cs < 0) { cs = (int)p->acam_id.size(); p->acam_id.push_back(obs_cam[k]); }
+        int& ps = p->pt_slot[(size_t)obs_pt[k]];
+        if (ps < 0) { ps = (int)p->apt_id.size(); p->apt_id.push_back(obs_pt[k]); }
+    }
+    p->n_cam_full = n_cam; p->n_pt_full = n_pt;
+    ObsSource src;
+    src.n_old = p->empty ? 0 : p->ds.nobs;
+    src.d_old_pt = p->d_obs_pt; src.d_old_cam = p->d_obs_cam; src.d_old_xy = p->d_obs_xy; src.d_old_perm = p->d_perm;
+    src.n_new = (int)n_obs_new; src.cam = obs_cam; src.pt = obs_pt; src.xy = obs_xy;
+    p->n_obs += n_obs_new;
+    if (p->n_obs == 0) { p->focal0 = p->focal = focal; return SFMBA_OK; }
+    p->empty = false;
+    // the new structure is built in a fresh arena (reading the old point-major arrays); the old arena then goes back to the chunk
+    // cache, where the next append finds it: steady state performs no hipMalloc / hipFree
+    DeviceArena old(p->device);
+    old.swap(p->arena);
+    if (p->db.trace && !p->trace_mapped) { (void)hipFree(p->db.trace); }
+    p->db.trace = nullptr; p->db.trace_cap = 0; p->trace_mapped = false;
+    p->cur = 0;
+    const int rc = build_structure(p, src, cam6, pt3, focal, false);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return rc;      // `old` releases the previous structure here
 }
 
 int sfmba_problem_reset(sfmba_problem* p) {

@@ -56,12 +56,11 @@ __global__ void k_block_ptr(int nblock, int npair, const unsigned* __restrict__ 
 
 }  // namespace
 
-// pair_off_host[i] = number of pairs of the points before i (npt + 1 entries).  On success *d_pairs (npair int2) and
+// d_pair_off[i] = number of pairs of the points before i (npt + 1 entries, device; build_point_major), npair their total.  On success *d_pairs (npair int2) and
 // *d_blk_ptr (nblock + 1 ints) live in `arena`; the sort's temporaries come from a scratch arena whose chunks go back to
 // the cache on return (the caller's next allocations pick them up).  Returns 0, or a hipError_t value.
 int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
-                     const int* d_obs_cam, const std::vector<long long>& pair_off_host, int2** d_pairs, int** d_blk_ptr) {
-    const long long npair = pair_off_host.empty() ? 0 : pair_off_host.back();
+                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr) {
     *d_pairs = nullptr; *d_blk_ptr = nullptr;
     hipError_t e;
     DeviceArena scratch(device);
@@ -77,14 +76,12 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int
         SB_TRY(hipStreamSynchronize(s));
         return 0;
     }
-    long long* d_off = nullptr;
+    const long long* d_off = d_pair_off;
     unsigned *d_k0 = nullptr, *d_k1 = nullptr;
     unsigned long long* d_v0 = nullptr;
-    SB_ALLOC(d_off, &scratch, long long, pair_off_host.size());
     SB_ALLOC(d_k0, &scratch, unsigned, np);
     SB_ALLOC(d_k1, &scratch, unsigned, np);
     SB_ALLOC(d_v0, &scratch, unsigned long long, np);
-    SB_TRY(hipMemcpyAsync(d_off, pair_off_host.data(), sizeof(long long) * pair_off_host.size(), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pair_gen, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, ncam, d_pt_ptr, d_obs_pt, d_obs_cam, d_off, d_k0, d_v0);
     int end_bit = 1;
     while (end_bit < 32 && ((unsigned long long)1 << end_bit) < (unsigned long long)nblock) ++end_bit;
@@ -102,6 +99,88 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int
 }
 
 namespace {
+__global__ __launch_bounds__(256) void k_pm_keys(int n, const int* __restrict__ u_pt, const int* __restrict__ u_cam, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { keys[k] = ((unsigned long long)(unsigned)u_pt[k] << 32) | (unsigned)u_cam[k]; vals[k] = k; }
+}
+template <typename XY>
+__global__ __launch_bounds__(256) void k_pm_gather(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ src, const int* __restrict__ u_perm,
+                                                   const XY* __restrict__ u_xy, int* __restrict__ obs_pt, int* __restrict__ perm, int* __restrict__ obs_cam, XY* __restrict__ obs_xy) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const unsigned long long key = keys[q];
+    const int k = src[q];
+    obs_pt[q] = (int)(key >> 32); obs_cam[q] = (int)(key & 0xffffffffull);
+    perm[q] = u_perm[k]; obs_xy[q] = u_xy[k];
+}
+// pt_ptr[i] = first sorted position whose point slot is >= i; cnt[i] = pairs of point i
+__global__ __launch_bounds__(256) void k_pm_ptr(int npt, int n, const int* __restrict__ obs_pt, int* __restrict__ pt_ptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > npt) return;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1); if (obs_pt[mid] < i) lo = mid + 1; else hi = mid; }
+    pt_ptr[i] = lo;
+}
+__global__ __launch_bounds__(256) void k_pm_paircount(int npt, const int* __restrict__ pt_ptr, long long* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > npt) return;
+    const long long m = i < npt ? pt_ptr[i + 1] - pt_ptr[i] : 0;
+    cnt[i] = m * (m - 1) / 2;
+}
+}  // namespace
+
+// Point-major order of n observations given as unsorted device arrays of (point slot, camera slot, caller index, xy): stable
+// radix sort on (point, camera) -- the order adjustBundle() adds its residual blocks in (BA.cpp:142-166: points in cloud order,
+// std::map iteration = ascending view inside a point); equal keys keep their input order.  Outputs (from `arena`): the
+// sorted arrays, the CSR pointers and the per-point prefix of the pair counts; *npair = total number of pairs.
+int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int xy_bytes, const int* u_pt, const int* u_cam,
+                      const int* u_perm, const void* u_xy, PointMajor* out, long long* npair) {
+    *npair = 0;
+    out->obs_pt = arena->alloc_n<int>((size_t)2 * n);
+    out->obs_cam = arena->alloc_n<int>((size_t)n);
+    out->obs_xy = arena->alloc((size_t)xy_bytes * (n ? n : 1));
+    out->pt_ptr = arena->alloc_n<int>((size_t)npt + 1);
+    out->pair_off = arena->alloc_n<long long>((size_t)npt + 1);
+    if (!out->obs_pt || !out->obs_cam || !out->obs_xy || !out->pt_ptr || !out->pair_off) return (int)hipErrorOutOfMemory;
+    hipError_t e;
+    if (n == 0) {
+        if ((e = hipMemsetAsync(out->pt_ptr, 0, sizeof(int) * ((size_t)npt + 1), s)) != hipSuccess) return (int)e;
+        return (int)hipMemsetAsync(out->pair_off, 0, sizeof(long long) * ((size_t)npt + 1), s);
+    }
+    DeviceArena scratch(device);
+    unsigned long long* k0 = scratch.alloc_n<unsigned long long>((size_t)n);
+    unsigned long long* k1 = scratch.alloc_n<unsigned long long>((size_t)n);
+    int* v0 = scratch.alloc_n<int>((size_t)n);
+    int* v1 = scratch.alloc_n<int>((size_t)n);
+    long long* cnt = scratch.alloc_n<long long>((size_t)npt + 1);
+    if (!k0 || !k1 || !v0 || !v1 || !cnt) return (int)hipErrorOutOfMemory;
+    hipLaunchKernelGGL(k_pm_keys, dim3((n + 255) / 256), dim3(256), 0, s, n, u_pt, u_cam, k0, v0);
+    int end_bit = 33;
+    while (end_bit < 64 && ((unsigned long long)1 << (end_bit - 32)) < (unsigned long long)npt) ++end_bit;
+    size_t tmp_bytes = 0;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, n, 0, end_bit, s)) != hipSuccess) return (int)e;
+    void* tmp = scratch.alloc(tmp_bytes ? tmp_bytes : 1);
+    if (!tmp) return (int)hipErrorOutOfMemory;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, n, 0, end_bit, s)) != hipSuccess) return (int)e;
+    if (xy_bytes == 8)
+        hipLaunchKernelGGL(k_pm_gather<float2>, dim3((n + 255) / 256), dim3(256), 0, s, n, k1, v1, u_perm, static_cast<const float2*>(u_xy), out->obs_pt, out->obs_pt + n,
+                           out->obs_cam, static_cast<float2*>(out->obs_xy));
+    else
+        hipLaunchKernelGGL(k_pm_gather<double2>, dim3((n + 255) / 256), dim3(256), 0, s, n, k1, v1, u_perm, static_cast<const double2*>(u_xy), out->obs_pt, out->obs_pt + n,
+                           out->obs_cam, static_cast<double2*>(out->obs_xy));
+    hipLaunchKernelGGL(k_pm_ptr, dim3((npt + 1 + 255) / 256), dim3(256), 0, s, npt, n, out->obs_pt, out->pt_ptr);
+    hipLaunchKernelGGL(k_pm_paircount, dim3((npt + 1 + 255) / 256), dim3(256), 0, s, npt, out->pt_ptr, cnt);
+    size_t sb = 0;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(nullptr, sb, cnt, out->pair_off, npt + 1, s)) != hipSuccess) return (int)e;
+    void* st = scratch.alloc(sb ? sb : 1);
+    if (!st) return (int)hipErrorOutOfMemory;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(st, sb, cnt, out->pair_off, npt + 1, s)) != hipSuccess) return (int)e;
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    if ((e = hipMemcpyAsync(npair, out->pair_off + npt, sizeof(long long), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(s);          // the scratch arena is recycled on return
+}
+
+namespace {
 __global__ void k_iota_cam(int n, const int* __restrict__ obs_cam, unsigned* __restrict__ keys, int* __restrict__ vals) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) { keys[q] = (unsigned)obs_cam[q]; vals[q] = q; }
@@ -115,11 +194,12 @@ __global__ void k_gather_pt(int n, const int* __restrict__ cam_obs, const int* _
 // Camera-major index of the observations on the device: cam_obs[e] = point-major position q, grouped by camera with a stable
 // radix sort (ascending q, i.e. ascending point, inside a camera -- the order the host loop produced), cam_obs_pt[e] = its point.
 int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
-                       int** d_cam_obs, int** d_cam_obs_pt) {
+                       int** d_cam_obs, int** d_cam_obs_pt, int** d_cam_ptr) {
     *d_cam_obs = arena->alloc_n<int>((size_t)nobs);
     *d_cam_obs_pt = arena->alloc_n<int>((size_t)nobs);
-    if (!*d_cam_obs || !*d_cam_obs_pt) return (int)hipErrorOutOfMemory;
-    if (nobs == 0) return 0;
+    *d_cam_ptr = arena->alloc_n<int>((size_t)ncam + 1);
+    if (!*d_cam_obs || !*d_cam_obs_pt || !*d_cam_ptr) return (int)hipErrorOutOfMemory;
+    if (nobs == 0) return (int)hipMemsetAsync(*d_cam_ptr, 0, sizeof(int) * ((size_t)ncam + 1), s);
     DeviceArena scratch(device);
     unsigned* k0 = scratch.alloc_n<unsigned>((size_t)nobs);
     unsigned* k1 = scratch.alloc_n<unsigned>((size_t)nobs);
@@ -136,6 +216,7 @@ int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, 
     e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, *d_cam_obs, nobs, 0, end_bit, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_gather_pt, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, *d_cam_obs, d_obs_pt, *d_cam_obs_pt);
+    hipLaunchKernelGGL(k_block_ptr, dim3((ncam + 1 + 255) / 256), dim3(256), 0, s, ncam, nobs, k1, *d_cam_ptr);      // CSR pointers from the sorted keys
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     e = hipStreamSynchronize(s);          // the scratch arena is recycled on return

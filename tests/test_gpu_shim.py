@@ -110,3 +110,58 @@ def test_shim_leaves_everything_untouched_without_convergence(sfm, monkeypatch, 
     back = sfm.load_problem(dump)
     assert back.n_cam == poses.shape[0] and back.n_pt == prob.n_pt and back.n_obs == prob.n_obs
     assert np.allclose(back.obs_xy, prob.obs_xy, atol=1e-4)
+
+
+def test_shim_resident_cache_follows_a_growing_reconstruction(sfm, oracle, monkeypatch, capfd):
+    """The reference re-runs adjustBundle() after every added view (SfM.cpp:464-466) on a cloud that only grows.  The shim
+    keeps the previous problem resident and appends the difference; every call must still equal a fresh run of the oracle's
+    restatement of adjustBundle() on that call's containers.  Then a call that does NOT contain the previous one (a point
+    lost a view) must fall back to a rebuild and still be right."""
+    monkeypatch.setenv("SFMBA_MAX_SECONDS", "0")
+    monkeypatch.setenv("SFMBA_SHIM_TIMING", "1")
+    monkeypatch.delenv("SFMBA_SHIM_CACHE", raising=False)
+    prob = sfm.make_problem("cfg2", n_cam=9, n_pt=500, views=(2, 5), seed=77)
+    poses, K, pts, views, feats = _containers(prob, sfm)
+
+    def call(n_registered):
+        # views >= n_registered are not registered yet: empty poses, their observations not in the cloud; points with fewer
+        # than two registered views are not in the cloud at all (appended at the END when they appear, like the reference does)
+        keep = [i for i, v in enumerate(views) if sum(1 for k in v if k < n_registered) >= 2]
+        return keep
+
+    order = []                                   # cloud order = order of first appearance
+    paths = []
+    for n_reg in (4, 5, 6, 7, 8, 9):
+        for i in call(n_reg):
+            if i not in order:
+                order.append(i)
+        vs = [{k: f for k, f in views[i].items() if k < n_reg} for i in order]
+        ps = poses.copy(); ps[n_reg:] = 0
+        cloud = pts[order]
+        p_o, K_o, pts_o, summ = oracle.adjust_bundle(ps, K, cloud, vs, feats, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+        assert summ["termination_name"] == "CONVERGENCE"
+        p_g, K_g, pts_g = _call_shim(ps, K, cloud, vs, feats)
+        err = capfd.readouterr().err
+        paths.append([l.split("path:")[1].strip() for l in err.splitlines() if "path:" in l][-1])
+        assert np.allclose(K_g, K_o, rtol=2e-7, atol=0)
+        assert np.allclose(p_g, p_o, rtol=0, atol=2e-6) and np.allclose(pts_g, pts_o, rtol=0, atol=2e-6)
+        assert np.array_equal(p_g[n_reg:], np.zeros_like(p_g[n_reg:]))
+    assert paths[1:] == ["append"] * 5, paths
+    # same containers again: nothing to add
+    _call_shim(ps, K, cloud, vs, feats)
+    assert "path: resident" in capfd.readouterr().err
+    # a point loses a view: not a superset of the cached list -> rebuild, result still the oracle's
+    vs2 = [dict(v) for v in vs]
+    victim = next(i for i, v in enumerate(vs2) if len(v) >= 3)
+    vs2[victim].pop(max(vs2[victim]))
+    p_o, K_o, pts_o, summ = oracle.adjust_bundle(ps, K, cloud, vs2, feats, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    p_g, K_g, pts_g = _call_shim(ps, K, cloud, vs2, feats)
+    assert "path: rebuild" in capfd.readouterr().err
+    assert np.allclose(p_g, p_o, rtol=0, atol=2e-6) and np.allclose(pts_g, pts_o, rtol=0, atol=2e-6)
+    # a changed observation coordinate is caught as well
+    feats2 = [f.copy() for f in feats]
+    v0 = min(vs2[0]); feats2[v0][vs2[0][v0]] += 0.25
+    p_o, K_o, pts_o, summ = oracle.adjust_bundle(ps, K, cloud, vs2, feats2, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    p_g, K_g, pts_g = _call_shim(ps, K, cloud, vs2, feats2)
+    assert "path: rebuild" in capfd.readouterr().err
+    assert np.allclose(pts_g, pts_o, rtol=0, atol=2e-6)
