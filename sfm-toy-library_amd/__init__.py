@@ -14,11 +14,11 @@ from .structs import (SfmbaOptions, SfmbaSummary, SfmbaIteration, TERMINATION_NA
                       CONVERGENCE, NO_CONVERGENCE, FAILURE, LINEAR_CHOLESKY, LINEAR_PCG,
                       PRECISION_F64, PRECISION_F32J)
 from .synthetic import make_problem, BAProblem, CONFIGS
-from .problem_io import save_problem, load_problem
+from .problem_io import save_problem, load_problem, save_bal, load_bal
 
 __all__ = [
     "SfmbaOptions", "SfmbaSummary", "SfmbaIteration", "TERMINATION_NAMES",
     "CONVERGENCE", "NO_CONVERGENCE", "FAILURE", "LINEAR_CHOLESKY", "LINEAR_PCG",
     "PRECISION_F64", "PRECISION_F32J",
-    "make_problem", "BAProblem", "CONFIGS", "save_problem", "load_problem",
+    "make_problem", "BAProblem", "CONFIGS", "save_problem", "load_problem", "save_bal", "load_bal",
 ]

@@ -8,6 +8,7 @@
 #include "SfMBundleAdjustmentUtils.h"
 #include "SfMStereoUtilities.h"
 #include "SfMAssociation.h"
+#include "SfMExport.h"
 
 extern "C" __attribute__((visibility("default")))
 void sfmba_shim_adjust_bundle(int n_views, float* poses /*[n_views][12]*/, float* K /*[9]*/, int n_pts, float* points /*[n_pts][3]*/,
@@ -156,4 +157,26 @@ int sfmba_shim_merge(int n_views, int n_exist, const float* ex_xyz, const int64_
             }
     *n_merge = m;
     return 0;
+}
+
+// Flat-array driver of sfmtoylib::SfMExport::saveCloudAndCamerasToPLY (tests/test_ply_export.py).  images: n_views images of
+// img_rows x img_cols BGR bytes, concatenated.
+extern "C" __attribute__((visibility("default")))
+int sfmba_shim_save_ply(const char* prefix, int n_views, const float* poses /*[n_views][12]*/, int n_pt, const float* xyz, const int64_t* view_ptr,
+                        const int32_t* view_idx, const int32_t* feat_idx, const int64_t* feat_ptr, const float* feat_xy, int img_rows, int img_cols,
+                        const unsigned char* images) {
+    using namespace sfmtoylib;
+    const PointCloud cloud = buildCloud(n_pt, xyz, view_ptr, view_idx, feat_idx);
+    std::vector<cv::Matx34f> cams((size_t)n_views);
+    for (int v = 0; v < n_views; ++v) for (int e = 0; e < 12; ++e) cams[v].val[e] = poses[12 * v + e];
+    std::vector<Features> feats((size_t)n_views);
+    std::vector<ImageBGR> imgs((size_t)n_views);
+    for (int v = 0; v < n_views; ++v) {
+        for (int64_t f = feat_ptr[v]; f < feat_ptr[v + 1]; ++f) feats[v].points.push_back(cv::Point2f(feat_xy[2 * f], feat_xy[2 * f + 1]));
+#ifndef SFMBA_HAVE_OPENCV
+        imgs[v].rows = img_rows; imgs[v].cols = img_cols;
+        imgs[v].data.assign(images + (size_t)v * img_rows * img_cols * 3, images + (size_t)(v + 1) * img_rows * img_cols * 3);
+#endif
+    }
+    return SfMExport::saveCloudAndCamerasToPLY(prefix, cloud, cams, feats, imgs) ? 0 : -1;
 }
