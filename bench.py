@@ -14,6 +14,10 @@ is quoted on: synthetic 200 cams / 100k pts / 1M obs, fp32 Jacobian blocks + fp6
 seeded generator of sfm-toy-library_amd/synthetic.py.  With N > 1 every rank solves an independent
 problem of that size (different seed): the reference has no exchange step between independent
 reconstructions, so there is no data-path collective and scaling is "weak".
+The same invocation then ALSO runs the path that does have an exchange step -- ONE problem (cfg 3, then the
+1000-camera cfg 5) with its points sharded over the N ranks and the reduced camera system all-reduced over
+RCCL / xGMI once per LM iteration (sfmba_problem_solve_sharded, strong scaling) -- and reports it in the
+"sharded" object of the same JSON line (--sharded-extras 0 turns that off; at N = 1 it is off unless asked for).
 
 value = LM iterations (successful + unsuccessful) of all ranks / max-over-ranks wall time.
 """
@@ -44,6 +48,9 @@ def parse():
                     help="N > 1: 'independent' = one whole problem per GPU (weak scaling, no data-path collective; the default the "
                          "driver runs); 'sharded' = ONE problem with its points sharded over the ranks and the reduced camera "
                          "system all-reduced over RCCL every LM iteration (strong scaling; BASELINE config 5 is quoted this way)")
+    ap.add_argument("--sharded-extras", type=int, default=-1,
+                    help="after the headline run also time ONE problem sharded over all ranks (cfg3 and cfg5) with the RCCL all-reduce "
+                         "of the reduced camera system: 1 = yes, 0 = no, -1 (default) = only when N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="LM iterations of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = min(nproc,16))")
@@ -217,56 +224,99 @@ def main():
                                         for k, v in profile.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, sub, args, rms)
-        print(json.dumps(line), flush=True)
     P.close()
+    # ---- the path with a real exchange step: one problem, points sharded over the ranks (all ranks take part) ----
+    want_sharded = args.sharded_extras == 1 or (args.sharded_extras == -1 and world > 1)
+    sh = None
+    if want_sharded:
+        sh = {}
+        for wl in (["cfg3", "cfg5"] if args.workload == "cfg3" else [args.workload]):
+            try:
+                sh[wl] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)))
+            except Exception as e:                       # never lose the headline line to the extras
+                sh[wl] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0:
+        if sh is not None:
+            line["sharded"] = sh
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear):
-    """ONE problem, points sharded over the ranks (sfm-toy-library_amd/sharded.py); every rank times the same K solves."""
+def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps):
+    """ONE problem, points sharded over the ranks; the LM loop runs inside the C library (sfmba_problem_solve_sharded) with
+    ncclAllReduce on the solver's stream (sharded.RcclComm); every rank times the same K solves.  Returns the result dict."""
     from sfm_toy_library_amd import sharded
-    if dist is None:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 2000), rank=0, world_size=1,
-                                device_id=torch.device("cuda", local_rank))
-    prob = sfm.make_problem(args.workload)
+    import ctypes as C
+    prob = sfm.make_problem(workload)
     be = sharded.HipShardBackend(prob, rank, world, device=local_rank, precision=precision)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol)
+    comm = sharded.RcclComm(dist, rank, world, device=local_rank)
 
     def barrier():
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        be.reset(); sharded.solve_sharded(be, dist, opt)
-    barrier()
-    t0 = time.perf_counter()
-    iters = 0
-    summ = None
-    for _ in range(args.steps):
-        be.reset()
-        summ = sharded.solve_sharded(be, dist, opt)
-        iters += summ["iterations"]
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    g_dt = float(tmax.item())
+    try:
+        for _ in range(2):
+            be.reset(); sharded.solve_sharded_native(be, opt, comm=comm)
+        barrier()
+        t0 = time.perf_counter()
+        iters = 0
+        summ = None
+        for _ in range(steps):
+            be.reset()
+            summ = sharded.solve_sharded_native(be, opt, comm=comm)
+            iters += summ["iterations"]
+        barrier()
+        dt = time.perf_counter() - t0
+        # the exchange step on its own: the packed upper triangle of S (+ rhs, diagonals, scalars), K back-to-back all-reduces
+        L = be.L
+        n_red = int(L.sfmba_shard_reduce_len(be._h))
+        stream = C.c_void_p(L.sfmba_problem_stream(be._h))
+        buf = C.c_void_p(L.sfmba_shard_reduce_buf(be._h))
+        reps = 10
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            L.sfmba_comm_allreduce(comm._h, buf, C.c_int64(n_red), stream)
+        barrier()
+        t_ar = (time.perf_counter() - t1) / reps
+        tmax = torch.tensor([dt, t_ar], dtype=torch.float64, device="cuda")
+        if dist is not None and world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        g_dt, g_ar = [float(v) for v in tmax.tolist()]
+        return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
+                "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
+                "ms_per_step": 1e3 * g_dt / steps, "lm_iterations_per_step": iters / steps,
+                "allreduce_bytes_per_lm_iteration": 8 * (n_red + 80), "allreduce_ms": 1e3 * g_ar,
+                "allreduce_GBps_algorithmic": 8.0 * n_red / g_ar / 1e9,
+                "collective": "ncclAllReduce(SUM, fp64) of [packed upper triangle of S | rhs | diagonals | scalars] on the solver stream, once per "
+                              "LM iteration, + an 80-double all-reduce of the trial-step scalars; every rank solves the reduced system redundantly",
+                "final_rms_px": float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)), "final_cost": summ["final_cost"],
+                "termination": summ["termination_name"], "linear_iters_per_step": summ["linear_iters"]}
+    finally:
+        comm.close()
+        be.close()
+
+
+def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear):
+    """--mode sharded: the sharded run IS the headline line (strong scaling)."""
+    r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps)
     if rank == 0:
         print(json.dumps({
-            "metric": "BA LM iterations/sec", "value": iters / g_dt, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * g_dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if precision == 0 else "f32 Jacobian blocks, f64 residual/accumulate/solve",
-            "data": "synthetic",
-            "config": {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d ranks, reduced camera system "
-                                   "all-reduced (RCCL) once per LM iteration" % (args.workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
-                       "step": "one full LM solve to ceres CONVERGENCE", "lm_iterations_per_step": iters / args.steps},
-            "final_rms_px": float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)), "final_cost": summ["final_cost"],
-            "termination": summ["termination_name"]}), flush=True)
-    be.close()
-    dist.barrier()
-    dist.destroy_process_group()
+            "data": "synthetic", "config": {"workload": r["workload"], "step": "one full LM solve to ceres CONVERGENCE",
+                                            "lm_iterations_per_step": r["lm_iterations_per_step"], "collective": r["collective"]},
+            "sharded": r, "final_rms_px": r["final_rms_px"], "final_cost": r["final_cost"], "termination": r["termination"]}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 PMC_KERNEL_NAMES = {"pcg_iter": "k_pcg_iter_fast", "schur_pairs": "k_schur_pairs", "cam_diag": "k_cam_diag",
@@ -296,26 +346,41 @@ def pmc_traffic(kernel):
     return None
 
 
+LIMITERS = {
+    "pcg_iter": "L2 / Infinity-Cache latency + the dependent-launch boundary (one launch per CG iteration; the 11.5 MB matrix never leaves the "
+                "256 MiB Infinity Cache, so FETCH_SIZE counts cache hits): not an HBM-bandwidth-bound kernel",
+    "schur_pairs": "random 64-byte record gathers from L2 / MALL (measured ceiling ~80 G lines/s) + VALU",
+    "cam_diag": "L2 misses on the camera-major record gather (latency)",
+    "point_build": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
+    "point_update": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
+    "chol_panel": "serial pivot chain (latency)", "chol_update": "fp64 MFMA, short launches",
+}
+
+
 def roofline_one(name, profile, model, overhead_us):
     avg_us = profile[name]["avg_us"]
-    net_us = avg_us
     m = model.get(name)
     tr = pmc_traffic(name)
     base = {"kernel": name, "avg_launch_us": avg_us, "empty_event_bracket_us": overhead_us,
             "launches": profile[name]["launches"], "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr,
+            "traffic_is_static": True,          # PMC passes cannot run inside bench.py: builder-committed rocprofv3 --pmc summary of this command
+            "limiter": LIMITERS.get(name),
             "timing": ("HIP events on the solver stream around batches of back-to-back launches (per-launch average includes the "
-                       "~1.5-2.6 us launch boundary)" if name == "pcg_iter" else
+                       "~1.5-2.6 us launch boundary and the early-exit surplus launches of a batch)" if name == "pcg_iter" else
                        "HIP events on the solver stream around every launch; an event pair around nothing reads empty_event_bracket_us, "
                        "so launches shorter than ~10 us are overstated -- compare with the rocprofv3 average in profiles/")}
     if m is None:
         base.update({"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None})
         return base
     if m["bound"] == "hbm":
-        ach = m["bytes"] / (net_us * 1e-6) / 1e9
+        ach = m["bytes"] / (avg_us * 1e-6) / 1e9
         base.update({"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                      "algorithmic_bytes_per_launch": m["bytes"], "note": m["note"]})
+        if "moved" in m:     # bytes this design moves by construction (materialised records, index lists): NOT algorithmic
+            base.update({"design_bytes_per_launch": m["moved"], "overhead_ratio": m["moved"] / max(m["bytes"], 1.0),
+                         "frac_on_design_bytes": m["moved"] / (avg_us * 1e-6) / 8.0e12})
     else:
-        ach = m["flops"] / (net_us * 1e-6) / 1e12
+        ach = m["flops"] / (avg_us * 1e-6) / 1e12
         base.update({"bound": "mfma", "achieved": ach, "peak": m["peak_tflops"], "unit": "TFLOP/s", "frac": ach / m["peak_tflops"],
                      "algorithmic_flops_per_launch": m["flops"], "note": m["note"]})
     return base
@@ -331,30 +396,51 @@ def roofline_entry(profile, prob, precision, all_kernels=False):
     overhead = profile.get("empty_bracket", {}).get("avg_us", 0.0)
     names = [k for k in profile if k != "empty_bracket"]
     if all_kernels:
-        return [roofline_one(k, profile, model, overhead) for k in sorted(names, key=lambda k: -profile[k]["total_us"])
-                if k in model]
+        out = [roofline_one(k, profile, model, overhead) for k in sorted(names, key=lambda k: -profile[k]["total_us"]) if k in model]
+        # the linearisation stage as a whole against SURVEY 8(d)'s FUSED model (no stored Jacobian): what the four kernels together
+        # would have to move, what they do move by design, and the measured counter traffic
+        stage = [k for k in ("point_build", "cam_diag", "finalize", "schur_pairs") if k in profile]
+        if len(stage) >= 3:
+            launches = max(profile["point_build"]["launches"], 1)
+            us = sum(profile[k]["total_us"] for k in stage) / launches
+            alg = prob.n_obs * (8 + 2 * t) + 24 * prob.n_pt + 48 * prob.n_cam + 8 * (6 * prob.n_cam + 1) ** 2
+            moved = sum(model[k].get("moved", model[k].get("bytes", 0)) for k in stage if k in model)
+            tr = [pmc_traffic(k) for k in stage]
+            counter = sum(x["bytes"] for x in tr if x) if all(x is not None for x in tr if True) and any(tr) else None
+            out.append({"kernel": "linearisation stage (point_build + cam_diag + finalize + schur_pairs)", "us_per_lm_iteration": us,
+                        "bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": alg / (us * 1e-6) / 8.0e12, "design_bytes": moved, "overhead_ratio": moved / alg,
+                        "counter_traffic_bytes": counter, "counter_overhead_ratio": None if counter is None else counter / alg,
+                        "note": "algorithmic = SURVEY 8(d) fused model: observations once, points once, cameras once, S written once; "
+                                "design bytes add the materialised 96 B/obs records (written once, re-read by two passes) and the pair list"})
+        return out
     name = max(names, key=lambda k: profile[k]["total_us"])
     return roofline_one(name, profile, model, overhead)
 
 
 def kernel_models(n_obs, n_pt, n_cam, d, t):
-    """Algorithmic bytes (or flops) per launch of each kernel; derivations in DESIGN.md."""
+    """Per launch: ALGORITHMIC bytes after SURVEY 8(d) (fused model, no stored Jacobian) -- what `roofline.frac` is priced on --
+    and, where this design materialises intermediate data, the bytes it moves by construction (`moved`).  Derivations in DESIGN.md."""
     yrec = 16 * t
     npair = n_obs * (n_obs / max(n_pt, 1) - 1) / 2      # pairs of observations of one point, a < b
     nb = 64
     nblk = (d + 1 + nb - 1) // nb
+    b_res = n_obs * (8 + 2 * t) + 24 * n_pt + 48 * n_cam          # one residual evaluation (SURVEY 8d: B_res)
     return {
-        "point_build": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_obs * (yrec + yrec // 2) + n_pt * (24 + 24 + 48 + 4),
-                        "note": "reads obs (cam idx + xy), points, scales; writes one packed record (16 values) and one side "
-                                "record (8 values) per obs + per-point t, y_f"},
-        "schur_pairs": {"bound": "hbm", "bytes": n_obs * yrec + 8 * npair + 8 * d * d,
-                        "note": "reads every record once and the pair list once, writes the preconditioned reduced matrix S~ "
-                                "(both triangles) once (each record is in fact gathered ~k-1 times from L2/MALL: non-algorithmic "
-                                "re-reads; the measured ceiling for random 64-B lines is ~80 G lines/s)"},
-        "cam_diag": {"bound": "hbm", "bytes": n_obs * (4 + yrec + yrec // 2),
-                     "note": "reads the camera-major index list and, per observation, its packed record and side record"},
-        "point_update": {"bound": "hbm", "bytes": n_obs * (4 + 2 * t) + n_pt * (24 + 24 + 24 + 4),
-                         "note": "reads obs, points, scales; writes trial points"},
+        "point_build": {"bound": "hbm", "bytes": b_res,
+                        "moved": n_obs * (4 + 2 * t) + n_obs * (yrec + yrec // 2) + n_pt * (24 + 24 + 48 + 4),
+                        "note": "algorithmic: one pass over observations, points and cameras (B_res); moved: + one packed record (16 values) "
+                                "and one side record (8 values) written per observation + per-point t, y_f (materialised Jacobian data)"},
+        "schur_pairs": {"bound": "hbm", "bytes": 8 * d * d,
+                        "moved": n_obs * yrec + 8 * npair + 8 * d * d,
+                        "note": "algorithmic: the reduced matrix written once (8 d^2); moved: + every record read once and the pair list once "
+                                "(each record is in fact gathered ~k-1 times from L2 / MALL)"},
+        "cam_diag": {"bound": "hbm", "bytes": 96 * n_cam + 8 * d,
+                     "moved": n_obs * (4 + yrec + yrec // 2),
+                     "note": "algorithmic: the camera-diagonal blocks and right-hand side written once -- in a fused design this pass would "
+                             "not exist; moved: the camera-major index list and, per observation, its packed record and side record"},
+        "point_update": {"bound": "hbm", "bytes": b_res + 24 * n_pt,
+                         "note": "one residual evaluation (B_res) + the trial points written"},
         "pcg_iter": {"bound": "hbm", "bytes": 8 * d * d + 9 * 8 * d,
                      "note": "one CG iteration = one launch: reads its rows of the preconditioned reduced matrix S~ once "
                              "(8 d^2 bytes) + the x/r/p/q vectors; launch/latency bound (d = %d): the matrix is re-read from "

@@ -260,6 +260,24 @@ SFMBA_API int     sfmba_shard_finish(sfmba_problem* p, int* done);      /* after
 SFMBA_API int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);
 
 /*
+ * The whole sharded LM loop in one call (the phase functions above remain for callers that drive the choreography themselves).
+ * The three all-reduces per LM iteration go through `allreduce(ctx, device_buf, n_doubles, hip_stream)` -- in-place SUM over the
+ * ranks, enqueued on hip_stream, return 0 on success -- which may be NULL when world == 1.  sfmba_comm_* is the built-in one:
+ * ncclAllReduce (RCCL, xGMI) bound with dlopen at first use; one communicator per rank, created from the 128-byte unique id
+ * that rank 0 draws (sfmba_comm_unique_id) and the launcher distributes (bench.py: a torch.distributed broadcast).
+ * The host meets the GPU once per LM iteration, at the control kernel's mailbox post; nothing is copied back inside the loop.
+ */
+#define SFMBA_COMM_ID_BYTES 128
+typedef struct sfmba_comm sfmba_comm;
+typedef int (*sfmba_allreduce_fn)(void* ctx, void* device_buf, int64_t n_doubles, void* hip_stream);
+SFMBA_API int  sfmba_comm_unique_id(unsigned char id[SFMBA_COMM_ID_BYTES]);
+SFMBA_API int  sfmba_comm_create(const unsigned char id[SFMBA_COMM_ID_BYTES], int rank, int world, int device, sfmba_comm** out);
+SFMBA_API void sfmba_comm_destroy(sfmba_comm* comm);
+SFMBA_API int  sfmba_comm_allreduce(void* comm /* sfmba_comm* */, void* device_buf, int64_t n_doubles, void* hip_stream);   /* an sfmba_allreduce_fn */
+SFMBA_API int  sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx,
+                                 sfmba_summary* summary);
+
+/*
  * The step in front of bundle adjustment: SfMStereoUtilities::triangulateViews
  * (SfMToyLib/SfMStereoUtilities.cpp:120-206) for n ALIGNED matches -- normalise with K (no distortion), DLT
  * triangulation (cv::triangulatePoints), de-homogenise, re-project into both views, keep[i] = both reprojection errors

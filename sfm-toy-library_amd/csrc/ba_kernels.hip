@@ -1189,6 +1189,32 @@ __device__ void gauge_vectors(const DeviceStructure& ds, const DeviceBuffers& db
     }
 }
 
+// The gauge vectors for a reduced system whose block factors were formed outside k_finalize (sharded solve: the factors come
+// from the all-reduced system, dense_pcg_transform): Linv of every camera block from db.pcg_binv, focal row from its last entry.
+__global__ __launch_bounds__(64) void k_gauge(DeviceStructure ds, DeviceBuffers db) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < ds.ncam) {
+        double Li[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Li[r][c] = db.pcg_binv[(size_t)j * 36 + r * 6 + c];
+        gauge_vectors(ds, db, j, Li);
+    }
+    if (j == 0) {
+        const LMState* st = db.st;
+        const int fo = ds.d - 1;
+        const double lf = 1.0 / db.pcg_binv[(size_t)ds.ncam * 36];        // sqrt(S_ff)
+        for (int k = 0; k < 8; ++k) {
+            db.pcg_W[(size_t)k * ds.ld + fo] = k == 7 ? (double)(float)(lf * st->focal[st->cur] / st->fscale) : 0.0;
+            for (int e = ds.d; e < ds.ld; ++e) db.pcg_W[(size_t)k * ds.ld + e] = 0.0;
+        }
+    }
+}
+void launch_gauge(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+    if (db.pcg_W) hipLaunchKernelGGL(k_gauge, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);
+}
+
 // damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding; in PCG mode also
 // Linv of every damped 6x6 diagonal block (the block-Jacobi preconditioner).  One thread per camera, then per
 // padding row; the focal entries are owned by the last wave of the last workgroup.  The last workgroup to arrive

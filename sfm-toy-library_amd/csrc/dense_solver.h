@@ -66,6 +66,9 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev,
                     Profiler* prof = nullptr, bool finish = true, int hist_key = -1, bool pretransformed = false, int anchor = 0,
                     bool no_wait = false, bool coarse = false);
+// dense_pcg_transform: the block-Jacobi transform on its own (block factors -> ws->binv, S~ -> ws->Sfull / Sfull32, b~), for callers that
+// need the factors before the solve (sharded path: gauge vectors are formed from them); follow with dense_pcg_solve(pretransformed = true).
+int dense_pcg_transform(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof = nullptr);
 // coarse = true: ws->W holds the 8 gauge vectors of this linearisation (written by k_finalize): two-level preconditioner
 // anchor: 0 = relative residual |r| <= tol |b~|; 1 = first solve of an LM run (remembers |b~|); 2 = later solve of the
 // same run: |r| <= tol * max(|b~|, |b~_first|), but never looser than max(tol, 1e-4) relative (see dense_solver.hip)

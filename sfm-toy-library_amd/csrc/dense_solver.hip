@@ -1304,6 +1304,28 @@ void dense_pcg_note(DenseSolver* ws, int hist_key, int iters) {
 // cap of the anchored stopping rule: every solve at least max(tol, 1e-4) relative
 static double pcg_cap(double tol) { const double t2 = tol * tol; return t2 > 0.0 ? fmax(t2, 1e-8) / t2 : 1.0; }
 
+// same path selection as dense_pcg_solve
+static void pcg_geometry(const DenseSolver* ws, bool* fast, bool* f32) {
+    const int d = ws->d;
+    const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
+    *fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
+    *f32 = !*fast && ws->use_f32 && ws->Sfull32 != nullptr;
+}
+
+int dense_pcg_transform(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof) {
+    if (dense_pcg_ensure_workspace(ws)) return -1;
+    const int ld = ws->ld, d = ws->d;
+    const int nb6 = (d - 1) / 6, nB = nb6 + (d - 6 * nb6);
+    bool fast, f32;
+    pcg_geometry(ws, &fast, &f32);
+    double* bt = ws->vec + (size_t)8 * ld;
+    ProfScope ps(prof, KID_PCG_SETUP, s);
+    hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
+    if (f32) hipLaunchKernelGGL(k_pcg_transform<float>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull32, bt);
+    else hipLaunchKernelGGL(k_pcg_transform<double>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt);
+    return 0;
+}
+
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof,
                     bool finish, int hist_key, bool pretransformed, int anchor, bool no_wait, bool coarse) {
     const double cap = pcg_cap(tol);
@@ -1319,10 +1341,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     double* bt = ws->vec + (size_t)8 * ld;
     // fp32 storage of S~ on the streaming path whenever the caller asked for it (dense_pcg_want_f32 allocated the buffer)
     const bool f32 = !fast && ws->use_f32 && ws->Sfull32 != nullptr;
-    if (!pretransformed) { ProfScope ps(prof, KID_PCG_SETUP, s);
-      hipLaunchKernelGGL(k_pcg_blockchol, dim3((nB + 63) / 64), dim3(64), 0, s, S, ld, d, ws->binv, info_dev);
-      if (f32) hipLaunchKernelGGL(k_pcg_transform<float>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull32, bt);
-      else hipLaunchKernelGGL(k_pcg_transform<double>, dim3((nB + 63) / 64, nB), dim3(64), 0, s, S, ld, d, ws->binv, rhs, ws->Sfull, bt); }
+    if (!pretransformed) dense_pcg_transform(s, ws, S, rhs, info_dev, prof);
     // coarse space: the caller's linearisation wrote W~ (ws->W); AW, E^-1 and c_0 are formed here, one pass over S~
     coarse = coarse && ws->W && ws->AW && rows_per_wg <= 4 * CO_MAXROWS;
     if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, 2);

@@ -17,6 +17,9 @@
 #include "profiler.h"
 #include "sfmba_device.h"
 
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -1167,8 +1170,14 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     if (o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) {
         // fp32 Jacobian mode: the streaming CG path keeps the preconditioned matrix in fp32 (k_pcg_transform writes it)
         p->solver.use_f32 = p->precision == SFMBA_PRECISION_F32J && dense_pcg_want_f32(&p->solver) != nullptr;
+        // block factors and S~ from the all-reduced system, then the gauge vectors from those factors (two-level preconditioner)
+        if (dense_pcg_transform(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, nullptr)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+        const char* coarse_env = std::getenv("SFMBA_PCG_COARSE");
+        const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
+        if (coarse_cg) { p->db.pcg_W = p->solver.W; launch_gauge(p->stream, p->ds, p->db); }
         const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
-                                       false, p->shard_host_iter, /*pretransformed=*/false, /*anchor=*/!o.pcg_anchored ? 0 : p->shard_host_iter == 0 ? 1 : 2);
+                                       false, p->shard_host_iter, /*pretransformed=*/true, /*anchor=*/!o.pcg_anchored ? 0 : p->shard_host_iter == 0 ? 1 : 2,
+                                       /*no_wait=*/false, /*coarse=*/coarse_cg);
         if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
         p->shard_sum.linear_iters += it;
         dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
@@ -1229,6 +1238,127 @@ int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) {
     sum.initial_cost = row0.cost;
     if (summary) *summary = sum;
     return SFMBA_OK;
+}
+
+// ---- the sharded LM loop in one call: collectives through a callback (RCCL below, or the caller's) ----
+int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx, sfmba_summary* summary) {
+    if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
+    if (!p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "not a sharded problem (sfmba_problem_create_sharded)");
+    if (p->shard_world > 1 && !allreduce) return fail(SFMBA_ERR_INVALID_ARG, "world > 1 needs an all-reduce");
+    auto reduce = [&](void* buf, int64_t n) -> int {
+        if (!allreduce) return SFMBA_OK;          // (a communicator of one rank is still called: the RCCL path is exercised on a one-GPU box)
+        const int arc = allreduce(ctx, buf, n, (void*)p->stream);
+        return arc == 0 ? SFMBA_OK : fail(SFMBA_ERR_HIP, "all-reduce failed (rc " + std::to_string(arc) + ")");
+    };
+    int rc = sfmba_shard_begin(p, opt);
+    if (rc) return rc;
+    p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
+    if ((rc = reduce(sfmba_shard_setup_buf(p), sfmba_shard_setup_len(p)))) return rc;
+    if ((rc = sfmba_shard_setup_finish(p))) return rc;
+    const sfmba_options& o = p->shard_opt;
+    int controls = 0;
+    for (;;) {
+        if ((rc = sfmba_shard_partial_build(p))) return rc;
+        if ((rc = reduce(sfmba_shard_reduce_buf(p), sfmba_shard_reduce_len(p)))) return rc;
+        if ((rc = sfmba_shard_solve_update(p))) return rc;
+        if ((rc = reduce(sfmba_shard_scalars_buf(p), SFMBA_SHARD_SCALARS))) return rc;
+        // accept / reject on the device; the host meets the GPU at the control kernel's mailbox post (no copy, no stream sync)
+        launch_shard_unpack(p->stream, p->db, p->d_scal, 2, p->shard_world);
+        launch_control(p->stream, p->ds, p->db);
+        if (hipError_t le = hipGetLastError(); le != hipSuccess) return fail(SFMBA_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
+        ++controls;
+        volatile int* mb = p->h_lm_mail;
+        if (wait_mailbox(mb, controls, p->stream) != 0) {
+            const hipError_t se = hipStreamSynchronize(p->stream);
+            return fail(SFMBA_ERR_HIP, std::string("sharded LM iteration did not complete: ") + (se != hipSuccess ? hipGetErrorString(se) : "no control post"));
+        }
+        p->shard_host_iter = mb[3];
+        if (mb[1] != -1) {
+            p->shard_sum.termination = mb[1];
+            std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(mb[2]));
+            break;
+        }
+        if (p->shard_host_iter >= o.max_iters) {
+            p->shard_sum.termination = SFMBA_NO_CONVERGENCE;
+            std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(MSG_MAX_ITERS));
+            break;
+        }
+    }
+    return sfmba_shard_end(p, summary);
+}
+
+// ---- RCCL (ncclAllReduce over xGMI) bound at run time: the library has no link-time dependency on librccl ----
+struct sfmba_comm { ncclComm_t comm = nullptr; int rank = 0, world = 1; };
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (api.handle) break; }
+        if (api.handle) {
+            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+            api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+            if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.handle = nullptr;
+        }
+    }
+    return api.handle ? &api : nullptr;
+}
+}  // namespace
+
+int sfmba_comm_unique_id(unsigned char id[SFMBA_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == SFMBA_COMM_ID_BYTES, "ncclUniqueId size");
+    RcclApi* a = rccl();
+    if (!a || !id) return fail(SFMBA_ERR_HIP, "RCCL (librccl.so) is not available");
+    ncclUniqueId u;
+    const ncclResult_t r = a->GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(SFMBA_ERR_HIP, std::string("ncclGetUniqueId: ") + (a->GetErrorString ? a->GetErrorString(r) : "error"));
+    std::memcpy(id, &u, sizeof(u));
+    return SFMBA_OK;
+}
+
+int sfmba_comm_create(const unsigned char id[SFMBA_COMM_ID_BYTES], int rank, int world, int device, sfmba_comm** out) {
+    if (!out || !id || world < 1 || rank < 0 || rank >= world) return fail(SFMBA_ERR_INVALID_ARG, "bad argument");
+    *out = nullptr;
+    RcclApi* a = rccl();
+    if (!a) return fail(SFMBA_ERR_HIP, "RCCL (librccl.so) is not available");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    sfmba_comm* c = new sfmba_comm();
+    c->rank = rank; c->world = world;
+    const ncclResult_t r = a->CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(SFMBA_ERR_HIP, std::string("ncclCommInitRank: ") + (a->GetErrorString ? a->GetErrorString(r) : "error")); }
+    *out = c;
+    return SFMBA_OK;
+}
+
+void sfmba_comm_destroy(sfmba_comm* c) {
+    if (!c) return;
+    RcclApi* a = rccl();
+    if (a && c->comm) (void)a->CommDestroy(c->comm);
+    delete c;
+}
+
+int sfmba_comm_allreduce(void* comm, void* device_buf, int64_t n_doubles, void* hip_stream) {
+    sfmba_comm* c = static_cast<sfmba_comm*>(comm);
+    RcclApi* a = rccl();
+    if (!c || !a) return -1;
+    const ncclResult_t r = a->AllReduce(device_buf, device_buf, (size_t)n_doubles, ncclDouble, ncclSum, c->comm, static_cast<hipStream_t>(hip_stream));
+    return r == ncclSuccess ? 0 : (int)r;
 }
 
 int sfmba_triangulate(int device, int64_t n, const float* left_xy, const float* right_xy, const float* K, const float* P_left,

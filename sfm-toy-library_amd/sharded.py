@@ -101,6 +101,62 @@ class HipShardBackend:
             self._h = C.c_void_p()
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class RcclComm:
+    """One RCCL communicator per rank, owned by the C library (sfmba_comm_*: ncclAllReduce over xGMI).  Rank 0 draws the unique
+    id; `dist` (torch.distributed, any backend) only carries those 128 bytes to the other ranks."""
+
+    def __init__(self, dist, rank, world, device=0):
+        import torch
+        L = capi.lib()
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            capi._check(L.sfmba_comm_unique_id(ident))
+        if world > 1:
+            obj = [bytes(ident)]
+            dist.broadcast_object_list(obj, src=0)
+            ident = (C.c_ubyte * 128).from_buffer_copy(obj[0])
+        self._h = C.c_void_p()
+        torch.cuda.set_device(device)
+        capi._check(L.sfmba_comm_create(ident, C.c_int(rank), C.c_int(world), C.c_int(device), C.byref(self._h)))
+        self.L = L
+
+    def close(self):
+        if self._h:
+            self.L.sfmba_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
+    """The same LM loop inside the C library (sfmba_problem_solve_sharded): ONE call per solve, the collectives enqueued on the
+    solver's stream by the library itself -- `comm` (RcclComm): ncclAllReduce; otherwise a callback into torch.distributed
+    (any backend; used by the gloo tests).  world == 1 needs neither."""
+    L = backend.L
+    summ = SfmbaSummary()
+    keep = None
+    if comm is not None:
+        fn, ctx = C.cast(L.sfmba_comm_allreduce, ALLREDUCE_FN), comm._h
+    elif dist is not None and backend.world > 1:
+        by_ptr = {int(L.sfmba_shard_setup_buf(backend._h)): "setup", int(L.sfmba_shard_reduce_buf(backend._h)): "reduce",
+                  int(L.sfmba_shard_scalars_buf(backend._h)): "scalars"}
+
+        def _cb(_ctx, buf, n, _stream):
+            try:
+                backend.all_reduce(dist, by_ptr[int(buf)], group)
+                return 0
+            except Exception:                      # never let an exception cross the C boundary
+                return 1
+        keep = fn = ALLREDUCE_FN(_cb)
+        ctx = None
+    else:
+        fn, ctx = C.cast(None, ALLREDUCE_FN), None
+    capi._check(L.sfmba_problem_solve_sharded(backend._h, C.byref(opt), fn, ctx, C.byref(summ)))
+    del keep
+    return summ.as_dict()
+
+
 def solve_sharded(backend, dist, opt, group=None):
     """The LM loop of one rank.  `dist` is torch.distributed (or any object with the same all_reduce API).
     Exactly three collectives are issued: one before the first iteration (column norms for the Jacobi

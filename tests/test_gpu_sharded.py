@@ -23,7 +23,7 @@ CASES = {
 }
 
 
-def _worker(rank, world, port, case, out):
+def _worker(rank, world, port, case, out, native=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -32,12 +32,12 @@ def _worker(rank, world, port, case, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sfm_toy_library_amd as sfm
     from sfm_toy_library_amd import capi
-    from sfm_toy_library_amd.sharded import HipShardBackend, solve_sharded
+    from sfm_toy_library_amd.sharded import HipShardBackend, solve_sharded, solve_sharded_native
     kw, precision, linear, okw = CASES[case]
     prob = sfm.make_problem(**kw)
     backend = HipShardBackend(prob, rank, world, device=0, precision=precision)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw)
-    summ = solve_sharded(backend, dist, opt)
+    summ = solve_sharded_native(backend, opt, dist=dist) if native else solve_sharded(backend, dist, opt)
     cam, pt, f = backend.get_params()
     out.put((rank, summ, cam, pt, f, backend._point_range))
     dist.barrier()
@@ -45,14 +45,15 @@ def _worker(rank, world, port, case, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["small", "cfg2", "wide"])
-def test_two_rank_sharded_hip_solve(sfm, oracle, case):
+@pytest.mark.parametrize("case,native", [("small", False), ("cfg2", False), ("wide", False), ("cfg2", True), ("wide", True)])
+def test_two_rank_sharded_hip_solve(sfm, oracle, case, native):
+    """native: the LM loop runs inside the C library (sfmba_problem_solve_sharded), the collectives come back through a callback."""
     from sfm_toy_library_amd import capi
     kw, precision, linear, okw = CASES[case]
     world, port = 2, 29711 + (os.getpid() % 500)
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, native)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([out.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
@@ -81,3 +82,26 @@ def test_two_rank_sharded_hip_solve(sfm, oracle, case):
     assert s0["iterations"] == s_s["iterations"]
     assert abs(s0["final_cost"] - s_s["final_cost"]) <= (1e-9 if exact else 1e-7) * s_s["final_cost"]
     assert np.allclose(cam0, cam_s, atol=1e-8 if exact else 5e-6) and np.allclose(pts, pt_s, atol=1e-8 if exact else 5e-6)
+
+
+def test_one_rank_rccl_communicator_and_native_loop(sfm, oracle):
+    """The box has one GPU: an RCCL communicator of ONE rank still goes through ncclCommInitRank / ncclAllReduce on the solver's
+    stream (sfmba_comm_*).  Result = the oracle's; the native loop without any collective (world 1, no communicator) as well."""
+    import torch.distributed as dist
+    from sfm_toy_library_amd import capi
+    from sfm_toy_library_amd.sharded import HipShardBackend, RcclComm, solve_sharded_native
+    prob = sfm.make_problem("cfg2")
+    want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    be = HipShardBackend(prob, 0, 1, device=0, precision=0)
+    opt = capi.default_options(max_seconds=0.0, linear_solver=1)
+    comm = RcclComm(None, 0, 1, device=0)
+    try:
+        for c in (comm, None):
+            be.reset()
+            s = solve_sharded_native(be, opt, comm=c)
+            cam, pt, f = be.get_params()
+            assert s["termination_name"] == "CONVERGENCE" and s["iterations"] == want[3]["iterations"]
+            assert abs(s["final_cost"] - want[3]["final_cost"]) <= 1e-9 * want[3]["final_cost"]
+            assert np.abs(cam - want[0]).max() < 1e-6 and np.abs(pt - want[1]).max() < 1e-6
+    finally:
+        comm.close(); be.close()
