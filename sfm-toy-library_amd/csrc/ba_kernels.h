@@ -112,6 +112,7 @@ struct DeviceBuffers {
     void* Z;                  // [nobs][8] float or double: C t, C y_f, residual (side record for the camera-diagonal pass)
     double* pt_t;             // [npt][3] L^-1 b_p
     double* pt_yf;            // [npt][3] L^-1 E_f
+    double* pt_M;             // [npt][6] diag(s_p) L^-T (upper triangle, row-major): dX = M z maps the reduced point right-hand side to the unscaled step
     double* S;                // [ld*ld] reduced system: upper triangle of the row-major matrix
     double* rhs;              // [ld]  (overwritten by the solution)
     double* udiag;            // [ld]  diag(J~^T J~) of the reduced unknowns, undamped

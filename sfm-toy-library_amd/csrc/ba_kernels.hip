@@ -28,6 +28,29 @@ __device__ __forceinline__ double wave_max(double v) {
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; }
 
+// N block-wide sums at once: the wave reductions advance in lock step (a shuffle is ~50 cycles of latency: N dependent chains
+// of six in sequence, each with its own pair of barriers, were ~1 us at the tail of every wave of the point passes), one
+// barrier; thread t < N returns the sum of value t (other threads: 0).  scratch: >= (blockDim.x / 64) * N doubles.
+template <int N>
+__device__ __forceinline__ double block_sums(double (&v)[N], double* scratch) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += __shfl_xor(v[k], off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) scratch[w * N + k] = v[k];
+    }
+    __syncthreads();
+    double s = 0.0;
+    if ((int)threadIdx.x < N) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) s += scratch[i * N + threadIdx.x];
+    }
+    return s;
+}
+
 // slotted accumulators: one atomic per value per workgroup, spread over NSLOT addresses
 __device__ __forceinline__ double* slot_ptr(const DeviceBuffers& db, int which) {
     return db.slots + (size_t)(blockIdx.x % NSLOT) * SLOT_W + which;
@@ -336,6 +359,15 @@ __device__ __forceinline__ void rec_camera_block(const T rec[YREC], T A[12]) {
 #define PBK 128
 #endif
 #define WPB (PBK / 64)
+// minimum waves per SIMD the point passes are compiled for (register budget 512 / this); 0 = let the compiler decide
+#ifndef SFMBA_PB_WAVES
+#define SFMBA_PB_WAVES 0
+#endif
+#if SFMBA_PB_WAVES > 0
+#define PB_BOUNDS __launch_bounds__(PBK, SFMBA_PB_WAVES)
+#else
+#define PB_BOUNDS __launch_bounds__(PBK)
+#endif
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS traffic of one wave is processed in order; this only stops the compiler from moving the
@@ -345,12 +377,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <typename T>
-__global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode) {
+__global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode) {
     __shared__ T sv[WPB][64][PB_LD];
     __shared__ double sb[WPB][64][3];
     __shared__ T sl[WPB][64][6];
     __shared__ T st_yf[WPB][64][6];          // per local point: t = L^-1 b_p (3), y_f = L^-1 E_f (3)
-    __shared__ double scratch[WPB];
+    __shared__ double scratch[WPB * 4];
     const LMState* st = db.st;
     const int cur = st->cur;
     const double* tab = db.camtab[cur];
@@ -467,6 +499,9 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
             const double y1 = Li[1] * Ef[0] + Li[2] * Ef[1];
             const double y2 = Li[3] * Ef[0] + Li[4] * Ef[1] + Li[5] * Ef[2];
             db.pt_t[3 * i] = t0; db.pt_t[3 * i + 1] = t1; db.pt_t[3 * i + 2] = t2;
+            // M = diag(s_p) L^-T for the back-substitution (k_point_update): dX = M (t - sum C^T u)
+            db.pt_M[6 * i] = sp[0] * Li[0]; db.pt_M[6 * i + 1] = sp[0] * Li[1]; db.pt_M[6 * i + 2] = sp[0] * Li[3];
+            db.pt_M[6 * i + 3] = sp[1] * Li[2]; db.pt_M[6 * i + 4] = sp[1] * Li[4]; db.pt_M[6 * i + 5] = sp[2] * Li[5];
             db.pt_yf[3 * i] = y0; db.pt_yf[3 * i + 1] = y1; db.pt_yf[3 * i + 2] = y2;
             sff -= y0 * y0 + y1 * y1 + y2 * y2;
             rhsf -= y0 * t0 + y1 * t1 + y2 * t2;
@@ -527,17 +562,13 @@ __global__ __launch_bounds__(PBK) void k_point_build(DeviceStructure ds, DeviceB
     }
     if (!finite_d(lin_cost)) bad = 1.0;
     // block reductions -> global accumulators
-    const double c_sum = block_sum(lin_cost, scratch);
-    const double f_sum = block_sum(sff, scratch);
-    const double r_sum = block_sum(rhsf, scratch);
-    const double b_sum = block_sum(bad, scratch);
     const double gm = wave_max(gmax);
     if ((threadIdx.x & 63) == 0 && gm > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), gm);
-    if (threadIdx.x == 0) {
-        atomicAdd(slot_ptr(db, ACC_LIN_COST), c_sum);
-        atomicAdd(slot_ptr(db, ACC_SFF), f_sum);
-        atomicAdd(slot_ptr(db, ACC_RHSF), r_sum);
-        if (b_sum != 0.0) atomicAdd(slot_ptr(db, ACC_BAD_LIN), b_sum);
+    double sums[4] = { lin_cost, sff, rhsf, bad };
+    const double tot = block_sums<4>(sums, scratch);
+    if (threadIdx.x < 4) {
+        const int which = threadIdx.x == 0 ? ACC_LIN_COST : threadIdx.x == 1 ? ACC_SFF : threadIdx.x == 2 ? ACC_RHSF : ACC_BAD_LIN;
+        if (threadIdx.x < 3 || tot != 0.0) atomicAdd(slot_ptr(db, which), tot);
     }
 }
 
@@ -1376,15 +1407,8 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
         make_cam_table(cn, db.cscale + 6 * j, ctn);
         for (int e = 0; e < CT_STRIDE; ++e) db.camtab[nxt][cam_tab_index(e, j, ds.ncam)] = ctn[e];
         double stb[ST_STRIDE] = {};
-        for (int e = 0; e < 9; ++e) { stb[ST_R + e] = ct[CT_R + e]; stb[ST_RN + e] = ctn[CT_R + e]; }
-        for (int e = 0; e < 3; ++e) { stb[ST_T + e] = ct[CT_T + e]; stb[ST_TN + e] = ctn[CT_T + e]; stb[ST_DT + e] = dlt[3 + e]; }
-        if (ct[CT_SMALL] != 0.0) {
-            for (int e = 0; e < 3; ++e) stb[ST_KV + e] = dlt[e];
-        } else {
-            for (int r = 0; r < 3; ++r)
-                stb[ST_KV + r] = ct[CT_K + 3 * r] * dlt[0] + ct[CT_K + 3 * r + 1] * dlt[1] + ct[CT_K + 3 * r + 2] * dlt[2];
-        }
-        stb[ST_SMALL] = ct[CT_SMALL];
+        for (int e = 0; e < 9; ++e) stb[ST_RN + e] = ctn[CT_R + e];
+        for (int e = 0; e < 3; ++e) { stb[ST_DW + e] = dlt[e]; stb[ST_DT + e] = dlt[3 + e]; stb[ST_TN + e] = ctn[CT_T + e]; }
         for (int e = 0; e < ST_STRIDE; ++e) db.steptab[cam_tab_index(e, j, ds.ncam)] = stb[e];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1403,42 +1427,30 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
 }
 
 // Obs-parallel back-substitution: same workgroup/point ownership as k_point_build.
-//   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost
-
+//   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost.
+// Nothing of the linearisation is recomputed: with V + D^2 = L L^T, t = L^-1 b_p and C = B~ L^-T (all left behind by
+// k_point_build: pt_t, the packed record, M = diag(s_p) L^-T),
+//   u   = A (camera step) + g (focal step)     per observation, from the record's A_w, f/p_z, x_p, y_p and the camera's step
+//   z   = t - sum_obs C^T u                      per point (three sums through the wave's LDS instead of nine)
+//   dX  = M z ;   J step = -(u + C z)            (model cost change; B~ y_p = C L^T y_p = C z)
+// so the pass streams the 64-byte record of every observation once and gathers 6 + 12 values per camera (step, trial pose)
+// instead of re-projecting every observation and rebuilding its blocks from a 31-value table row (285 -> ~110 fp64
+// instructions per observation; the pass was VALU-bound: SQ_ACTIVE_INST_VALU = 57 % of the SIMD time).  Only the TRIAL
+// residual is a true re-evaluation (fp64).  The model cost change uses the residual f x_p - obs with the record's x_p
+// (fp32 in F32J mode: ~3e-5 px, i.e. ~1e-4 relative on the model term that only feeds the accept / reject ratio; exact in F64 mode).
 template <typename T>
-struct ObsStep {   // what both sweeps of k_point_update need about one observation
-    Proj pr;
-    double r0, r1;
-    double dp0, dp1, dp2;   // unscaled change of p caused by the camera step: G dw + dt
-};
-
-template <typename CamPtr>
-__device__ __forceinline__ void camera_step_dp(CamPtr stb, const double X[3], double& dp0, double& dp1, double& dp2) {
-    const double kx = stb[ST_KV], ky = stb[ST_KV + 1], kz = stb[ST_KV + 2];
-    const double c0 = ky * X[2] - kz * X[1], c1 = kz * X[0] - kx * X[2], c2 = kx * X[1] - ky * X[0];
-    if (stb[ST_SMALL] != 0.0) { dp0 = c0; dp1 = c1; dp2 = c2; }
-    else {
-        dp0 = stb[ST_R + 0] * c0 + stb[ST_R + 1] * c1 + stb[ST_R + 2] * c2;
-        dp1 = stb[ST_R + 3] * c0 + stb[ST_R + 4] * c1 + stb[ST_R + 5] * c2;
-        dp2 = stb[ST_R + 6] * c0 + stb[ST_R + 7] * c1 + stb[ST_R + 8] * c2;
-    }
-    dp0 += stb[ST_DT]; dp1 += stb[ST_DT + 1]; dp2 += stb[ST_DT + 2];
-}
-
-template <typename T>
-__global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ T sv[WPB][64][6];
-    __shared__ double sb[WPB][64][3];
-    __shared__ double sx[WPB][64][6];      // dX(3), Xn(3) per local point
-    __shared__ double scratch[WPB];
+__global__ PB_BOUNDS void k_point_update(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double sz[WPB][64][3];      // per observation of the round: C^T u
+    __shared__ double sx[WPB][64][6];      // per local point: z (3), Xn (3)
+    __shared__ double scratch[WPB * 5];
     if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // see k_cam_update
     const LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
     const double* tab = db.steptab;
     const double focal = st->focal[cur], focal_n = st->focal[nxt];
     const double dfoc = focal - focal_n;           // unscaled focal step to SUBTRACT (= fscale * y_f)
-    const double radius = st->radius;
     const double* pts = db.pts[cur];
+    const T* Y = reinterpret_cast<const T*>(db.Y);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int gw = blockIdx.x * WPB + w;
     double trial = 0.0, model = 0.0, step2 = 0.0, xn2 = 0.0, bad = 0.0;
@@ -1449,134 +1461,96 @@ __global__ __launch_bounds__(PBK) void k_point_update(DeviceStructure ds, Device
         const int npts = pt1 - pt0;
         const int o0 = wd.z, o1 = wd.w;
         const bool single = (o1 - o0) <= 64;
-        double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 };
         const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
         const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
-        double sp[3] = { 1.0, 1.0, 1.0 };      // Jacobi scales of this lane's point, issued with the first loads
+        // this lane's point (issued with the first loads, used after the reduction)
+        double tp[3] = { 0, 0, 0 }, Mp[6] = { 0, 0, 0, 0, 0, 0 }, Xp[3] = { 0, 0, 0 };
         if (lane < npts) {
-            sp[0] = db.pscale[3 * (size_t)(pt0 + lane)]; sp[1] = db.pscale[3 * (size_t)(pt0 + lane) + 1]; sp[2] = db.pscale[3 * (size_t)(pt0 + lane) + 2];
+            const size_t i = (size_t)(pt0 + lane);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { tp[c] = db.pt_t[3 * i + c]; Xp[c] = pts[3 * i + c]; }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Mp[c] = db.pt_M[6 * i + c];
         }
+        double zacc[3] = { 0, 0, 0 };
         // kept for the second sweep when single
-        Proj prk = { 0.0, 0.0, 0.0 };
-        double r0k = 0, r1k = 0, dpk[3] = { 0, 0, 0 }, oxk = 0, oyk = 0;
+        double u0k = 0, u1k = 0, oxk = 0, oyk = 0, xpk = 0, ypk = 0, Ck[6] = { 0, 0, 0, 0, 0, 0 };
         int ik = 0, jk = 0;
+
+        auto obs_terms = [&](int q, int& i, int& j, double& ox, double& oy, double& xp, double& yp, double (&C)[6], double& u0, double& u1) {
+            i = ds.obs_pt[q]; j = ds.obs_cam[q];
+            load_obs<T>(ds.obs_xy, q, ox, oy);
+            T rec[YREC];
+            load_rec<T>(Y, q, rec);
+            const CamRow stb = { tab + 4 * (size_t)(j), ds.ncam };
+            const double dw0 = stb[ST_DW], dw1 = stb[ST_DW + 1], dw2 = stb[ST_DW + 2];
+            const double dt0 = stb[ST_DT], dt1 = stb[ST_DT + 1], dt2 = stb[ST_DT + 2];
+            const double fz = (double)rec[6];
+            xp = (double)rec[7]; yp = (double)rec[8];
+            u0 = (double)rec[0] * dw0 + (double)rec[1] * dw1 + (double)rec[2] * dw2 + fz * (dt0 - xp * dt2) + xp * dfoc;
+            u1 = (double)rec[3] * dw0 + (double)rec[4] * dw1 + (double)rec[5] * dw2 + fz * (dt1 - yp * dt2) + yp * dfoc;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) C[c] = (double)rec[9 + c];
+        };
 
         for (int c0 = o0; c0 < o1; c0 += 64) {
             const int q = c0 + lane;
             if (q < o1) {
-                const int i = ds.obs_pt[q], j = ds.obs_cam[q];
-                double ox, oy;
-                load_obs<T>(ds.obs_xy, q, ox, oy);
-                const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
-                const CamRow stb = { tab + 4 * (size_t)(j), ds.ncam };
-                const Proj pr = project_point(stb, ST_R, ST_T, X);
-                const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
-                T B[6];
-                point_block<T>(stb, pr, focal, B);     // ST_R == CT_R == 0
-                double dp0, dp1, dp2;
-                camera_step_dp(stb, X, dp0, dp1, dp2);
-                // u = A (scale*y_c) + g (fscale*y_f) = Aproj dp + (xp,yp) dfoc
-                const double fz = focal * pr.iz;
-                const double u0 = fz * (dp0 - pr.xp * dp2) + pr.xp * dfoc;
-                const double u1 = fz * (dp1 - pr.yp * dp2) + pr.yp * dfoc;
-                // (point scales are applied to the per-point sums below)
-                T* o = sv[w][lane];
-                o[0] = B[0] * B[0] + B[3] * B[3];
-                o[1] = B[1] * B[0] + B[4] * B[3];
-                o[2] = B[1] * B[1] + B[4] * B[4];
-                o[3] = B[2] * B[0] + B[5] * B[3];
-                o[4] = B[2] * B[1] + B[5] * B[4];
-                o[5] = B[2] * B[2] + B[5] * B[5];
+                obs_terms(q, ik, jk, oxk, oyk, xpk, ypk, Ck, u0k, u1k);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) sb[w][lane][c] = (double)B[c] * (r0 - u0) + (double)B[3 + c] * (r1 - u1);
-                prk = pr; r0k = r0; r1k = r1; dpk[0] = dp0; dpk[1] = dp1; dpk[2] = dp2; oxk = ox; oyk = oy; ik = i; jk = j;
+                for (int c = 0; c < 3; ++c) sz[w][lane][c] = Ck[c] * u0k + Ck[3 + c] * u1k;
             }
             wave_lds_fence();
             if (lane < npts) {
                 const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
                 for (int e = a; e < b; ++e) {
-                    const T* o = sv[w][e];
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) V[c] += (double)o[c];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) bp[c] += sb[w][e][c];
+                    for (int c = 0; c < 3; ++c) zacc[c] += sz[w][e][c];
                 }
             }
             wave_lds_fence();
         }
         if (lane < npts) {
             const size_t i = (size_t)(pt0 + lane);
-            V[0] *= sp[0] * sp[0]; V[1] *= sp[1] * sp[0]; V[2] *= sp[1] * sp[1];
-            V[3] *= sp[2] * sp[0]; V[4] *= sp[2] * sp[1]; V[5] *= sp[2] * sp[2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) bp[c] *= sp[c];
-            V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
-            V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
-            V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
-            double Li[6];
-            chol3_inverse(V, Li);
-            // y_p = L^-T L^-1 (b_p - W^T y_c)
-            const double t0 = Li[0] * bp[0];
-            const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
-            const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
-            const double y2 = Li[5] * t2;
-            const double y1 = Li[2] * t1 + Li[4] * t2;
-            const double y0 = Li[0] * t0 + Li[1] * t1 + Li[3] * t2;
-            const double dX[3] = { sp[0] * y0, sp[1] * y1, sp[2] * y2 };
+            const double z0 = tp[0] - zacc[0], z1 = tp[1] - zacc[1], z2 = tp[2] - zacc[2];
+            const double dX[3] = { Mp[0] * z0 + Mp[1] * z1 + Mp[2] * z2, Mp[3] * z1 + Mp[4] * z2, Mp[5] * z2 };
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const double x = pts[3 * i + c];
+                const double x = Xp[c];
                 const double xn = x - dX[c];
                 const double df = x - xn;
                 step2 += df * df;
                 xn2 += xn * xn;
                 db.pts[nxt][3 * i + c] = xn;
-                sx[w][lane][c] = dX[c];
                 sx[w][lane][3 + c] = xn;
             }
+            sx[w][lane][0] = z0; sx[w][lane][1] = z1; sx[w][lane][2] = z2;
         }
         wave_lds_fence();
         for (int c0 = o0; c0 < o1; c0 += 64) {
             const int q = c0 + lane;
             if (q >= o1) continue;
-            if (!single) {
-                ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
-                load_obs<T>(ds.obs_xy, q, oxk, oyk);
-                const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
-                const CamRow stb2 = { tab + 4 * (size_t)(jk), ds.ncam };
-                prk = project_point(stb2, ST_R, ST_T, X);
-                r0k = focal * prk.xp - oxk; r1k = focal * prk.yp - oyk;
-                camera_step_dp(stb2, X, dpk[0], dpk[1], dpk[2]);
-            }
+            if (!single) obs_terms(q, ik, jk, oxk, oyk, xpk, ypk, Ck, u0k, u1k);
             const CamRow stb = { tab + 4 * (size_t)(jk), ds.ncam };
             const double* pl = sx[w][ik - pt0];
-            const double dX[3] = { pl[0], pl[1], pl[2] };
+            const double z0 = pl[0], z1 = pl[1], z2 = pl[2];
             const double Xn[3] = { pl[3], pl[4], pl[5] };
-            // model residual m = J step = -(u + B dX): total unscaled change of p, then Aproj
-            const double dp0 = dpk[0] + stb[ST_R + 0] * dX[0] + stb[ST_R + 1] * dX[1] + stb[ST_R + 2] * dX[2];
-            const double dp1 = dpk[1] + stb[ST_R + 3] * dX[0] + stb[ST_R + 4] * dX[1] + stb[ST_R + 5] * dX[2];
-            const double dp2 = dpk[2] + stb[ST_R + 6] * dX[0] + stb[ST_R + 7] * dX[1] + stb[ST_R + 8] * dX[2];
-            const double fz = focal * prk.iz;
-            const double m0 = -(fz * (dp0 - prk.xp * dp2) + prk.xp * dfoc);
-            const double m1 = -(fz * (dp1 - prk.yp * dp2) + prk.yp * dfoc);
-            model -= m0 * (r0k + 0.5 * m0) + m1 * (r1k + 0.5 * m1);
+            // model residual m = J step = -(u + C z)
+            const double m0 = -(u0k + Ck[0] * z0 + Ck[1] * z1 + Ck[2] * z2);
+            const double m1 = -(u1k + Ck[3] * z0 + Ck[4] * z1 + Ck[5] * z2);
+            const double r0 = focal * xpk - oxk, r1 = focal * ypk - oyk;
+            model -= m0 * (r0 + 0.5 * m0) + m1 * (r1 + 0.5 * m1);
             const Proj pn = project_point(stb, ST_RN, ST_TN, Xn);
             const double n0 = focal_n * pn.xp - oxk, n1 = focal_n * pn.yp - oyk;
             if (!finite_d(n0) || !finite_d(n1)) bad = 1.0;
             trial += n0 * n0 + n1 * n1;
         }
     }
-    const double a = block_sum(trial, scratch);
-    const double b = block_sum(model, scratch);
-    const double c = block_sum(step2, scratch);
-    const double d = block_sum(xn2, scratch);
-    const double e = block_sum(bad, scratch);
-    if (threadIdx.x == 0) {
-        atomicAdd(slot_ptr(db, ACC_TRIAL_COST), a);
-        atomicAdd(slot_ptr(db, ACC_MODEL), b);
-        atomicAdd(slot_ptr(db, ACC_STEP2), c);
-        atomicAdd(slot_ptr(db, ACC_XNEW2), d);
-        if (e != 0.0) atomicAdd(slot_ptr(db, ACC_BAD_TRIAL), e);
+    double sums[5] = { trial, model, step2, xn2, bad };
+    const double tot = block_sums<5>(sums, scratch);
+    if (threadIdx.x < 5) {
+        const int which = threadIdx.x == 0 ? ACC_TRIAL_COST : threadIdx.x == 1 ? ACC_MODEL : threadIdx.x == 2 ? ACC_STEP2 : threadIdx.x == 3 ? ACC_XNEW2 : ACC_BAD_TRIAL;
+        if (threadIdx.x < 4 || tot != 0.0) atomicAdd(slot_ptr(db, which), tot);
     }
 }
 

@@ -36,7 +36,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 //   solve  (every wave, one tile each):               for j: x = a_j / L(j,j);      a_c -= x * L(c,j), c > j
 // i.e. the same rank-1 sweep with a different scalar; no __syncthreads inside the 64 steps.
 // Tasks of step k: task 0 = identity tile (gives M_k = L_kk^-T for the back substitution),
-// task t >= 1 = tile row k + t.  Four tasks per workgroup.
+// task t >= 1 = tile row k + t.  Three tasks per workgroup (waves 1..3; wave 0 factors the diagonal tile).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void chol_wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256, 1) void k_chol_panel(double* __restrict__ A, i
         }
     }
     __syncthreads();
-    const int task = blockIdx.x * 4 + w;
+    // wave 0 has just spent a whole sweep on the diagonal tile: the tiles of the panel go to waves 1..3 (three per workgroup), so
+    // that a panel costs one factor sweep + one solve sweep instead of two sweeps back to back on wave 0
+    if (w == 0) return;
+    const int task = blockIdx.x * 3 + (w - 1);
     if (task >= ntask) return;
     if (task == 0) {
 #pragma unroll
@@ -239,7 +242,7 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
     for (int k = 0; k < nblk; ++k) {
         { ProfScope ps(prof, KID_CHOL_PANEL, s);
           const int ntask = nblk - k;
-          hipLaunchKernelGGL(k_chol_panel, dim3((ntask + 3) / 4), dim3(256), 0, s, S, ld, k, d, ntask, ws->minv, info_dev); }
+          hipLaunchKernelGGL(k_chol_panel, dim3((ntask + 2) / 3), dim3(256), 0, s, S, ld, k, d, ntask, ws->minv, info_dev); }
         const int m = nblk - k - 1;
         if (m > 0) { ProfScope ps(prof, KID_CHOL_UPDATE, s);
           hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k); }

@@ -725,6 +725,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     if (!db.Y || !db.Z) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
+    HIP_TRY(dev_alloc(&db.pt_M, (size_t)6 * npt));
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
     HIP_TRY(dev_alloc(&p->d_sys, sys_len));
     p->d_red = nullptr;

@@ -26,15 +26,12 @@ constexpr int CT_SMALL = 21;   // 1.0 if theta^2 <= DBL_EPSILON
 constexpr int CT_SCALE = 22;   // Jacobi column scale of the 6 camera parameters
 constexpr int CT_STRIDE = 28;
 
-// ---- per-camera step table used by the back-substitution / trial-point kernel ----
-constexpr int ST_R = 0;        // R[9] at the current point
-constexpr int ST_T = 9;        // t[3]
-constexpr int ST_KV = 12;      // K' * dw  (dw = unscaled rotation step); dw itself when small-angle
-constexpr int ST_DT = 15;      // dt (unscaled translation step)
-constexpr int ST_SMALL = 18;
-constexpr int ST_RN = 19;      // R[9] at the trial point
-constexpr int ST_TN = 28;      // t[3] at the trial point
-constexpr int ST_STRIDE = 32;
+// ---- per-camera step table used by the back-substitution / trial-point kernel (component quads like the camera tables) ----
+constexpr int ST_DW = 0;       // dw[3]: unscaled rotation step (the step is SUBTRACTED: trial = current - step)
+constexpr int ST_DT = 3;       // dt[3]: unscaled translation step            (quads 0, 1; two pad values)
+constexpr int ST_RN = 8;       // R[9] at the trial point
+constexpr int ST_TN = 17;      // t[3] at the trial point                     (quads 2, 3, 4)
+constexpr int ST_STRIDE = 20;
 
 // One packed record per observation written by the point pass and read by the reduced-system passes
 // (layout in ba_kernels.hip): 16 values = 64 B in fp32 (one sector), 128 B in fp64 (one line).
