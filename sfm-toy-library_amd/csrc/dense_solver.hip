@@ -501,43 +501,41 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(int d, int ld, const FT* __r
     if (tid < PCG_NW * PCG_NW + PCG_NW) epart[(size_t)tid * PCG_PART + blockIdx.x] = esum[0][tid] + esum[1][tid] + esum[2][tid] + esum[3][tid];
 }
 
-// E = sum of the partials; Einv by a Jacobi-scaled Gauss-Jordan elimination spread over the 64 lanes of one wave (lane = one
-// entry; eight dependent steps instead of a ~600-deep serial chain: 28 -> ~3 us); c_0.  out = [Einv 64 | c_0 8].
-// A pivot below 1e-10 of the unit diagonal means the vector depends on the earlier ones (degenerate configuration, fewer
-// cameras than gauge freedoms): the vector is dropped (its row and column of Einv are zero).
-__global__ __launch_bounds__(256) void k_pcg_coarse_invert(int nwg, const double* __restrict__ epart, double* __restrict__ out) {
-    constexpr int N = PCG_NW, NV = N * N + N;
-    __shared__ double tot[NV];
-    __shared__ double sa[N][N], sb[N][N];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    {
-        // 18 values per wave, their lane-partials reduced in lock step
-        double part[18];
+// E and c_0 = sums of the per-workgroup partials of k_pcg_coarse*: 18 values per wave, their lane-partials reduced in lock
+// step; tot[0 .. 72) (LDS) is complete after the caller's next __syncthreads().  All 256 threads.
+__device__ __forceinline__ void coarse_sum_partials(int nwg, const double* __restrict__ epart, double* tot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double part[18];
 #pragma unroll
-        for (int m = 0; m < 18; ++m) part[m] = 0.0;
-        for (int i0 = 0; i0 < nwg; i0 += 128) {               // 36 independent loads per lane and pass (clamped, branch-free)
-            double t[18][2];
+    for (int m = 0; m < 18; ++m) part[m] = 0.0;
+    for (int i0 = 0; i0 < nwg; i0 += 128) {               // 36 independent loads per lane and pass (clamped, branch-free)
+        double t[18][2];
 #pragma unroll
-            for (int m = 0; m < 18; ++m)
+        for (int m = 0; m < 18; ++m)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { const int wg = i0 + lane + 64 * i; t[m][i] = epart[(size_t)(w + 4 * m) * PCG_PART + (wg < nwg ? wg : nwg - 1)]; }
+            for (int i = 0; i < 2; ++i) { const int wg = i0 + lane + 64 * i; t[m][i] = epart[(size_t)(w + 4 * m) * PCG_PART + (wg < nwg ? wg : nwg - 1)]; }
 #pragma unroll
-            for (int m = 0; m < 18; ++m)
+        for (int m = 0; m < 18; ++m)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) part[m] += (i0 + lane + 64 * i < nwg) ? t[m][i] : 0.0;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-            for (int m = 0; m < 18; ++m) part[m] += __shfl_xor(part[m], off, 64);
-        if (lane == 0) {
-#pragma unroll
-            for (int m = 0; m < 18; ++m) tot[w + 4 * m] = part[m];
-        }
+            for (int i = 0; i < 2; ++i) part[m] += (i0 + lane + 64 * i < nwg) ? t[m][i] : 0.0;
     }
-    __syncthreads();
-    if (tid >= 64) return;
-    if (lane < N) out[N * N + lane] = tot[N * N + lane];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int m = 0; m < 18; ++m) part[m] += __shfl_xor(part[m], off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < 18; ++m) tot[w + 4 * m] = part[m];
+    }
+}
+
+// Einv by a Jacobi-scaled Gauss-Jordan elimination spread over the 64 lanes of ONE wave (lane = one entry; eight dependent
+// steps instead of a ~600-deep serial chain: 28 -> ~3 us).  Returns this lane's entry (row lane / 8, column lane % 8).
+// A pivot below 1e-10 of the unit diagonal means the vector depends on the earlier ones (degenerate configuration, fewer
+// cameras than gauge freedoms): the vector is dropped (its row and column of Einv are zero).  sa, sb: 64 doubles of LDS each.
+__device__ __forceinline__ double coarse_invert_wave(const double* tot, double* sa, double* sb) {
+    constexpr int N = PCG_NW;
+    const int lane = threadIdx.x & 63;
     const int i = lane >> 3, j = lane & 7;
     const double dii = tot[i * N + i], djj = tot[j * N + j];
     const bool ki = dii > 0.0 && dii <= 1.7e308, kj = djj > 0.0 && djj <= 1.7e308;
@@ -549,13 +547,13 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_invert(int nwg, const double
     for (int k = 0; k < N; ++k) if (!(tot[k * N + k] > 0.0 && tot[k * N + k] <= 1.7e308)) dropped |= 1u << k;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        sa[i][j] = a; sb[i][j] = b;
+        sa[i * N + j] = a; sb[i * N + j] = b;
         chol_wave_fence();
-        double piv = sa[k][k];
+        const double piv = sa[k * N + k];
         const bool ok = !((dropped >> k) & 1u) && piv > 1e-10;
         if (!ok) dropped |= 1u << k;
-        const double aik = ok ? sa[i][k] : 0.0;
-        const double akj = ok ? sa[k][j] : (k == j ? 1.0 : 0.0), bkj = ok ? sb[k][j] : 0.0;
+        const double aik = ok ? sa[i * N + k] : 0.0;
+        const double akj = ok ? sa[k * N + j] : (k == j ? 1.0 : 0.0), bkj = ok ? sb[k * N + j] : 0.0;
         const double ip = ok ? fast_rcp(piv) : 1.0;
         if (i == k) { a = akj * ip; b = bkj * ip; }
         else { a = fma(-aik * ip, akj, a); b = fma(-aik * ip, bkj, b); }
@@ -563,7 +561,19 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_invert(int nwg, const double
         chol_wave_fence();
     }
     const bool gone = ((dropped >> i) & 1u) || ((dropped >> j) & 1u);
-    out[i * N + j] = gone ? 0.0 : b * si * sj;
+    return gone ? 0.0 : b * si * sj;
+}
+
+// stand-alone version (streaming CG path: up to 1024 workgroups of partials): out = [Einv 64 | c_0 8]
+__global__ __launch_bounds__(256) void k_pcg_coarse_invert(int nwg, const double* __restrict__ epart, double* __restrict__ out) {
+    constexpr int N = PCG_NW, NV = N * N + N;
+    __shared__ double tot[NV];
+    __shared__ double sa[N * N], sb[N * N];
+    coarse_sum_partials(nwg, epart, tot);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    if (threadIdx.x < N) out[N * N + threadIdx.x] = tot[N * N + threadIdx.x];
+    out[threadIdx.x] = coarse_invert_wave(tot, sa, sb);
 }
 
 // Sum of the per-workgroup partials of the previous launch.  Wave w owns values w, w + 4, w + 8: `mine` holds this lane's
@@ -608,8 +618,9 @@ __device__ __forceinline__ void einv_apply(const double* einv_s, const double (&
 }
 
 // LDS scratch of the CG kernels behind the search direction: [0..9) partial totals, [16..20) rrn per wave,
-// [32..40) p_mu of this iteration, [40..76) end-of-kernel partials per wave (4 x 9), [80..144) E^-1
-constexpr int PCG_RED = 144;
+// [32..40) p_mu of this iteration, [40..76) end-of-kernel partials per wave (4 x 9), [80..144) E^-1; first launch of the fast
+// path only: [144..216) E and c_0 summed from the partials, [216..344) work space of the 8 x 8 inversion
+constexpr int PCG_RED = 344;
 
 // Generic path of one CG iteration (any d).  Vector phase as in the fast path but looped; the matvec streams two rows
 // of S~ per wave with 16-byte loads, four deep, so that a wave keeps 128 B per lane in flight (the rows are HBM/MALL
@@ -827,13 +838,17 @@ template <bool INIT, bool COARSE>
 __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
                                                        const double* __restrict__ bt, double* __restrict__ part, double* __restrict__ scal,
                                                        int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap,
-                                                       const double* __restrict__ W, const double* __restrict__ AW, const double* __restrict__ coarse) {
+                                                       const double* __restrict__ W, const double* __restrict__ AW, double* __restrict__ coarse,
+                                                       const double* __restrict__ epart) {
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;
     double* red = sm + ld;
     if (!INIT && flags[PF_DONE]) return;
     constexpr int NV = COARSE ? PCG_NPART : 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
+    // first launch of a solve: E^-1 and c_0 from the partials k_pcg_coarse_fast left behind -- formed by EVERY workgroup for
+    // itself (no launch of its own: the 8 x 8 inversion is ~3 us of one wave), published by workgroup 0 for the launches that follow
+    if (INIT && COARSE) coarse_sum_partials((int)gridDim.x, epart, red + 144);
     const int row0 = blockIdx.x * rows_per_wg;
     const int row1 = min(d, row0 + rows_per_wg);
     const int nwg = (int)gridDim.x;
@@ -867,13 +882,13 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             for (int i = 0; i < 4; ++i) mine[j] += (lane + 64 * i < nwg && v < NV) ? t[i] : 0.0;
         }
     }
-    const double einv_mine = (COARSE && tid < PCG_NW * PCG_NW) ? coarse[tid] : 0.0;
+    const double einv_mine = (COARSE && !INIT && tid < PCG_NW * PCG_NW) ? coarse[tid] : 0.0;
     const double rr0 = INIT ? 0.0 : scal[PS_RR0];
     const double rz_in = INIT ? 0.0 : st_in[PS_RZ];
     double c_in[PCG_NW], mu_in[PCG_NW], pmu_in[PCG_NW];
 #pragma unroll
     for (int k = 0; k < PCG_NW; ++k) {
-        c_in[k] = !COARSE ? 0.0 : INIT ? coarse[PCG_NW * PCG_NW + k] : st_in[PS_C + k];
+        c_in[k] = (COARSE && !INIT) ? st_in[PS_C + k] : 0.0;
         mu_in[k] = (COARSE && !INIT) ? st_in[PS_MU + k] : 0.0;
         pmu_in[k] = (COARSE && !INIT) ? st_in[PS_PMU + k] : 0.0;
     }
@@ -901,10 +916,18 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         awv[k] = 0.0;
         if (COARSE && row < row1 && lane < 2 * PCG_NW) awv[k] = lane < PCG_NW ? AW[(size_t)row * PCG_NW + lane] : W[(size_t)(lane - PCG_NW) * ld + row];
     }
-    if (COARSE && tid < PCG_NW * PCG_NW) red[80 + tid] = einv_mine;
+    if (COARSE && !INIT && tid < PCG_NW * PCG_NW) red[80 + tid] = einv_mine;
     double c_new[PCG_NW], mu_new[PCG_NW], pmu_new[PCG_NW];
     double rz_new;
     if (INIT) {
+        if (COARSE) {
+            __syncthreads();                              // E, c_0 complete in red[144 ..)
+            if (w == 0) {
+                const double e = coarse_invert_wave(red + 144, red + 216, red + 280);
+                red[80 + lane] = e;
+                if (blockIdx.x == 0) { coarse[lane] = e; if (lane < PCG_NW) coarse[PCG_NW * PCG_NW + lane] = red[144 + PCG_NW * PCG_NW + lane]; }
+            }
+        }
         // x0 = 0, r0 = b~, z0 = r0 + W~ E^-1 c0, p0 = z0
         double rr = 0.0;
 #pragma unroll
@@ -915,7 +938,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         __syncthreads();
         rr = red[16] + red[17] + red[18] + red[19];
 #pragma unroll
-        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = c_in[k]; mu_new[k] = 0.0; }
+        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = COARSE ? red[144 + PCG_NW * PCG_NW + k] : 0.0; mu_new[k] = 0.0; }
         if (COARSE) einv_apply(red + 80, c_new, mu_new);
         rz_new = rr + (COARSE ? dot8(c_new, mu_new) : 0.0);
 #pragma unroll
@@ -1271,8 +1294,8 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
     const int in = INIT ? 0 : r.in;
 #define CG_ARGS(Fptr) d, ld, Fptr, ws->vec, bt, ws->part, ws->scal, ws->flags, r.rows_per_wg, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->AW, ws->coarse
     if (r.fast) {
-        if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull));
-        else hipLaunchKernelGGL((k_pcg_iter_fast<INIT, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull));
+        if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
+        else hipLaunchKernelGGL((k_pcg_iter_fast<INIT, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
     } else if (r.f32) {
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter<INIT, float, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
         else hipLaunchKernelGGL((k_pcg_iter<INIT, float, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
@@ -1347,11 +1370,12 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     if (!pretransformed) dense_pcg_transform(s, ws, S, rhs, info_dev, prof);
     // coarse space: the caller's linearisation wrote W~ (ws->W); AW, E^-1 and c_0 are formed here, one pass over S~
     coarse = coarse && ws->W && ws->AW && rows_per_wg <= 4 * CO_MAXROWS;
-    if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, 2);
+    if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
       else if (f32) hipLaunchKernelGGL(k_pcg_coarse<float>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
       else hipLaunchKernelGGL(k_pcg_coarse<double>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
-      hipLaunchKernelGGL(k_pcg_coarse_invert, dim3(1), dim3(256), 0, s, nwg, ws->epart, ws->coarse); }
+      // fast path: the first CG launch sums the partials and inverts E itself (one launch fewer per LM iteration)
+      if (!fast) hipLaunchKernelGGL(k_pcg_coarse_invert, dim3(1), dim3(256), 0, s, nwg, ws->epart, ws->coarse); }
     volatile int* mb = ws->h_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }
     ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32; ws->run.coarse = coarse;
