@@ -81,7 +81,8 @@ struct DeviceStructure {
     int nchunk;
     const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), 0}: SFMBA_CAM_CHUNK entries each (k_cam_diag)
     int nchunk_coarse;
-    const int4* chunks_coarse; // the same list cut every 1024 entries (column-norm pass: a block loops over its chunk)
+    const int4* chunks_coarse; // the same list cut every 1024 entries (column-norm pass: a block loops over its chunk); deterministic mode: one chunk per camera
+    const int* cam_chunk_ptr;  // [ncam+1] first k_cam_diag chunk of every camera (deterministic mode)
     // camera-pair lists of the reduced-system pass: block b = (ja <= jb); pairs sorted by block
     int nblock;
     const int2* blk_cams;     // [nblock] {ja, jb}
@@ -117,7 +118,10 @@ struct DeviceBuffers {
     double* rhs;              // [ld]  (overwritten by the solution)
     double* udiag;            // [ld]  diag(J~^T J~) of the reduced unknowns, undamped
     double* bc;               // [ld]  scaled gradient of the reduced unknowns
-    double* slots;            // [NSLOT][SLOT_W] slotted accumulators (cost, norms, gradient max, focal-focal sums)
+    double* slots;            // [nslot][SLOT_W] slotted accumulators (cost, norms, gradient max, focal-focal sums)
+    int nslot;                // NSLOT (64) normally; deterministic mode: >= the largest grid, so every workgroup of a launch owns its slot
+                              // and the sums no longer depend on the order the atomics arrive in
+    double* cd_part;          // deterministic mode: [nchunk][48] per-chunk sums of k_cam_diag, added in chunk order by k_finalize; else null
     LMState* st;
     TraceRow* trace;
     int trace_cap;

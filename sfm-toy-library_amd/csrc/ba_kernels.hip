@@ -53,19 +53,31 @@ __device__ __forceinline__ double block_sums(double (&v)[N], double* scratch) {
 
 // slotted accumulators: one atomic per value per workgroup, spread over NSLOT addresses
 __device__ __forceinline__ double* slot_ptr(const DeviceBuffers& db, int which) {
-    return db.slots + (size_t)(blockIdx.x % NSLOT) * SLOT_W + which;
+    return db.slots + (size_t)(blockIdx.x % (unsigned)db.nslot) * SLOT_W + which;
 }
 // sum (or max for ACC_GMAX) of one accumulator over the NSLOT (= 64) slots, then clear it.
 // Must be called by all 64 lanes of one wave; every lane returns the result.
 __device__ double slots_take(const DeviceBuffers& db, int which) {
-    double* p = db.slots + (size_t)(threadIdx.x & 63) * SLOT_W + which;
-    double v = *p;
-    *p = 0.0;
+    const int lane = threadIdx.x & 63;
     if (which == ACC_GMAX) {
-        v = __longlong_as_double((long long)__double_as_longlong(v));
+        double v = 0.0;
+        for (int i = lane; i < db.nslot; i += 64) {
+            double* p = db.slots + (size_t)i * SLOT_W + which;
+            const double o = *p;
+            *p = 0.0;
+            v = (o > v || o != o) ? o : v;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = (o > v || o != o) ? o : v; }
         return v;
+    }
+    double v = 0.0;
+    for (int i0 = lane; i0 < db.nslot; i0 += 512) {    // fixed order: lane-strided (eight loads in flight), then the butterfly
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; t[u] = db.slots[(size_t)(i < db.nslot ? i : lane) * SLOT_W + which]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; if (i < db.nslot) { v += t[u]; db.slots[(size_t)i * SLOT_W + which] = 0.0; } }
     }
     return wave_sum(v);
 }
@@ -138,7 +150,7 @@ __global__ void k_begin(LMState st, DeviceStructure ds, DeviceBuffers db) {
     if (e == 0) { *db.st = st; *db.lin_info = 0; *db.fin_counter = 0; }
     if (e < 6 * ds.ncam) db.cscale[e] = 1.0;
     if (e < ds.ld) db.udiag[e] = 0.0;
-    if (e < NSLOT * SLOT_W) db.slots[e] = 0.0;
+    for (int k = e; k < db.nslot * SLOT_W; k += gridDim.x * blockDim.x) db.slots[k] = 0.0;
     if (e < ds.ncam) {
         double c6[6], ct[CT_STRIDE];
         for (int k = 0; k < 6; ++k) c6[k] = db.cam[st.cur][6 * e + k];
@@ -147,7 +159,7 @@ __global__ void k_begin(LMState st, DeviceStructure ds, DeviceBuffers db) {
     }
 }
 void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, const LMState& st) {
-    const int nb = std::max(std::max(6 * ds.ncam, ds.ld), NSLOT * SLOT_W);
+    const int nb = std::max(std::max(6 * ds.ncam, ds.ld), NSLOT * SLOT_W);      // (a larger slot array is cleared by a strided loop)
     hipLaunchKernelGGL(k_begin, dim3((nb + 255) / 256), dim3(256), 0, s, st, ds, db);
 }
 
@@ -1066,6 +1078,7 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
 #pragma unroll
         for (int ww = 0; ww < CD_BLK / 64; ++ww) s += red[ww][k];
         const int row0 = 6 * j, fo = ds.d - 1;
+        if (db.cd_part && k < 45) { db.cd_part[(size_t)blockIdx.x * 48 + k] = s; return; }      // deterministic mode: k_finalize adds the chunks in order
         if (k < 21) {
             int a = 0, rem = k;
             while (rem >= 6 - a) { rem -= 6 - a; ++a; }
@@ -1280,6 +1293,29 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
     double gm = 0.0;
     if (g < ds.ncam) {
         const int row0 = 6 * g;
+        if (db.cd_part) {
+            // deterministic mode: this camera's k_cam_diag chunks, in chunk order, on top of what the (single-writer) passes left
+            double acc[45];
+#pragma unroll
+            for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+            for (int c = ds.cam_chunk_ptr[g]; c < ds.cam_chunk_ptr[g + 1]; ++c) {
+#pragma unroll
+                for (int k = 0; k < 45; ++k) acc[k] += db.cd_part[(size_t)c * 48 + k];
+            }
+            const int fo = ds.d - 1;
+            int u = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) db.S[(size_t)(row0 + a) * ds.ld + row0 + b] += acc[u++];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                db.udiag[row0 + a] += acc[21 + a];
+                db.S[(size_t)(row0 + a) * ds.ld + fo] += acc[27 + a];
+                db.bc[row0 + a] += acc[33 + a];
+                db.rhs[row0 + a] += acc[39 + a];
+            }
+        }
         bool bad = false;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {

@@ -147,6 +147,8 @@ struct sfmba_problem {
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_wv_desc = nullptr, *d_pwg_desc = nullptr;
     int* d_blk_ptr = nullptr;
+    int* d_cam_chunk_ptr = nullptr;
+    bool deterministic = false;             // SFMBA_DETERMINISTIC=1 at build time
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pwg_ptr = nullptr;
     double* d_facc = nullptr;
@@ -599,17 +601,22 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     // ---- launch descriptors (host, from the three CSR pointer arrays) ----
     // chunks of the camera-major list: (camera, entry range)
     const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
+    { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e && e[0] == '1'; }
+    const int coarse_len = p->deterministic ? (1 << 30) : 1024;      // deterministic mode: one column-norm workgroup per camera (single writer)
     std::vector<int4> chunks, chunks_coarse;
+    std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0);
     for (int j = 0; j < ncam; ++j) {
+        cam_chunk_ptr[(size_t)j] = (int)chunks.size();
         for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
             int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = 0;
             chunks.push_back(c);
         }
-        for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += 1024) {
-            int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + 1024, cam_ptr[(size_t)j + 1]); c.w = 0;
+        for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += coarse_len) {
+            int4 c; c.x = j; c.y = e0; c.z = (int)std::min<long long>((long long)e0 + coarse_len, cam_ptr[(size_t)j + 1]); c.w = 0;
             chunks_coarse.push_back(c);
         }
     }
+    cam_chunk_ptr[(size_t)ncam] = (int)chunks.size();
     std::vector<int2> blk_cams((size_t)nblock);
     for (int ja = 0; ja < ncam; ++ja)
         for (int jb = ja; jb < ncam; ++jb) { int2 c; c.x = ja; c.y = jb; blk_cams[(size_t)block_of(ja, jb)] = c; }
@@ -671,6 +678,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     bt_mark("maps");
     HIP_TRY(dev_upload(&p->d_chunks, chunks));
     HIP_TRY(dev_upload(&p->d_chunks_coarse, chunks_coarse));
+    HIP_TRY(dev_upload(&p->d_cam_chunk_ptr, cam_chunk_ptr));
     HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
     HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
     HIP_TRY(dev_upload(&p->d_pwg_desc, pwg_desc));
@@ -700,7 +708,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.pt_ptr = p->d_pt_ptr; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
     ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt;
     ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
-    ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse;
+    ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
     ds.obs_pt = p->d_obs_pt;
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
@@ -737,8 +745,18 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     p->d_scal = db.bc + ds.ld;
     db.shared_weight = 1.0;
     HIP_TRY(dev_alloc(&db.st, 1));
-    HIP_TRY(dev_alloc(&p->d_facc, (size_t)NSLOT * SLOT_W));
-    HIP_TRY(hipMemset(p->d_facc, 0, sizeof(double) * NSLOT * SLOT_W));
+    // Opt-in deterministic accumulation (SFMBA_DETERMINISTIC=1 when the problem is built): every workgroup of a launch owns its
+    // accumulator slot and the multi-chunk camera sums are added in chunk order, so that no result depends on the order in which
+    // fp64 atomics arrive -- two runs give bit-identical trajectories.  Costs ~10 % (longer slot sweeps, a serial chunk loop).
+    db.nslot = NSLOT;
+    db.cd_part = nullptr;
+    if (p->deterministic) {
+        const int grid = std::max(std::max(1024, (ds.nwv + 1) / 2 + 1), std::max(ds.nchunk, ds.nchunk_coarse));
+        db.nslot = (grid + 63) / 64 * 64;
+        HIP_TRY(dev_alloc(&db.cd_part, (size_t)std::max(ds.nchunk, 1) * 48));
+    }
+    HIP_TRY(dev_alloc(&p->d_facc, (size_t)db.nslot * SLOT_W));
+    HIP_TRY(hipMemset(p->d_facc, 0, sizeof(double) * (size_t)db.nslot * SLOT_W));
     db.slots = p->d_facc;
     // padding of the reduced system (rows/columns >= d) is zero apart from the identity diagonal set by k_finalize
     HIP_TRY(hipMemset(p->d_sys, 0, sizeof(double) * sys_len));

@@ -223,3 +223,35 @@ def test_coarse_space_with_degenerate_camera_sets(capi, sfm, oracle, monkeypatch
         assert got[3]["termination_name"] == want[3]["termination_name"]
         assert got[3]["iterations"] == want[3]["iterations"]
         assert abs(got[3]["final_cost"] - want[3]["final_cost"]) <= 1e-8 * max(want[3]["final_cost"], 1e-30)
+
+
+def test_deterministic_mode_is_bitwise_reproducible(capi, sfm, cfg3, monkeypatch):
+    """SFMBA_DETERMINISTIC=1 (a determinism bound): every accumulator has a single writer per launch or a fixed
+    summation order, so two solves of the same problem -- resident re-solves and freshly built problems alike -- agree in
+    every bit of every parameter and of the per-iteration trace.  The default mode (fp64 atomics into 64 slots) agrees with
+    it to rounding."""
+    monkeypatch.setenv("SFMBA_DETERMINISTIC", "1")
+    opt = capi.default_options(max_seconds=0.0, precision=1, linear_solver=1)
+    runs = []
+    for fresh in range(2):
+        with capi.Problem(cfg3, precision=1) as P:
+            for rep in range(2):
+                P.reset()
+                s, tr = P.solve(opt)
+                runs.append((P.get_params(), s, tr))
+    (cam0, pt0, f0), s0, tr0 = runs[0]
+    for (cam, pt, f), s, tr in runs[1:]:
+        assert np.array_equal(cam, cam0) and np.array_equal(pt, pt0) and f == f0
+        assert s["final_cost"] == s0["final_cost"] and s["linear_iters"] == s0["linear_iters"]
+        assert [r["cost"] for r in tr] == [r["cost"] for r in tr0]
+        assert [r["trust_region_radius"] for r in tr] == [r["trust_region_radius"] for r in tr0]
+    monkeypatch.setenv("SFMBA_DETERMINISTIC", "0")
+    ref = capi.solve(cfg3, opt)
+    assert ref[3]["iterations"] == s0["iterations"] and abs(ref[3]["final_cost"] - s0["final_cost"]) <= 1e-11 * s0["final_cost"]
+    assert np.allclose(ref[0], cam0, rtol=0, atol=1e-7) and np.allclose(ref[1], pt0, rtol=0, atol=1e-7)
+    # ... and the exact (Cholesky, fp64) configuration on a small problem, one-shot calls
+    monkeypatch.setenv("SFMBA_DETERMINISTIC", "1")
+    small = sfm.make_problem("cfg2")
+    a = capi.solve(small, capi.default_options(max_seconds=0.0))
+    b = capi.solve(small, capi.default_options(max_seconds=0.0))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3]["final_cost"] == b[3]["final_cost"]
