@@ -405,12 +405,14 @@ def roofline_entry(profile, prob, precision, all_kernels=False):
             us = sum(profile[k]["total_us"] for k in stage) / launches
             alg = prob.n_obs * (8 + 2 * t) + 24 * prob.n_pt + 48 * prob.n_cam + 8 * (6 * prob.n_cam + 1) ** 2
             moved = sum(model[k].get("moved", model[k].get("bytes", 0)) for k in stage if k in model)
-            tr = [pmc_traffic(k) for k in stage]
-            counter = sum(x["bytes"] for x in tr if x) if all(x is not None for x in tr if True) and any(tr) else None
+            tr = {k: pmc_traffic(k) for k in stage}
+            covered = [k for k in stage if tr[k] is not None]
+            counter = sum(tr[k]["bytes"] for k in covered) if covered else None
             out.append({"kernel": "linearisation stage (point_build + cam_diag + finalize + schur_pairs)", "us_per_lm_iteration": us,
                         "bound": "hbm", "algorithmic_bytes": alg, "achieved": alg / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": alg / (us * 1e-6) / 8.0e12, "design_bytes": moved, "overhead_ratio": moved / alg,
-                        "counter_traffic_bytes": counter, "counter_overhead_ratio": None if counter is None else counter / alg,
+                        "counter_traffic_bytes": counter, "counter_traffic_kernels": covered,
+                        "counter_overhead_ratio": None if counter is None else counter / alg,
                         "note": "algorithmic = SURVEY 8(d) fused model: observations once, points once, cameras once, S written once; "
                                 "design bytes add the materialised 96 B/obs records (written once, re-read by two passes) and the pair list"})
         return out
