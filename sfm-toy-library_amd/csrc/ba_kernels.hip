@@ -593,28 +593,32 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
 // the in-place Cholesky destroyed the previous contents).  Workgroups are grouped so that all
 // blocks of one block-row run on one XCD (blockIdx % 8): the records of camera ja stay in that L2.
 // ------------------------------------------------------------------------------------------
-template <int N, int OFF>
-struct HalvingReduce {
-    static __device__ __forceinline__ void run(double* v, int lane, int& base, int& len) {
+// Sum of N per-lane values over the lanes that differ in the bits OFF, OFF/2, ..., 1: at every level a lane keeps one half of
+// the values and sends the other half to its partner, so the whole reduction moves N/2 + N/4 + ... values instead of N per level.
+// On return v[0 .. len) of this lane are the sums of values base .. base + len - 1 (len may be <= 0).
+template <typename V, int N, int OFF>
+struct HalvingReduceT {
+    static __device__ __forceinline__ void run(V* v, int lane, int& base, int& len) {
         constexpr int H = (N + 1) / 2;
         const bool up = (lane & OFF) != 0;
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-            const double lo = v[k];
-            const double hi = (H + k < N) ? v[H + k] : 0.0;
-            const double send = up ? lo : hi;
-            const double keep = up ? hi : lo;
+            const V lo = v[k];
+            const V hi = (H + k < N) ? v[H + k] : (V)0;
+            const V send = up ? lo : hi;
+            const V keep = up ? hi : lo;
             v[k] = keep + __shfl_xor(send, OFF, 64);
         }
         base += up ? H : 0;
         len = up ? len - H : (len < H ? len : H);
-        HalvingReduce<H, OFF / 2>::run(v, lane, base, len);
+        HalvingReduceT<V, H, OFF / 2>::run(v, lane, base, len);
     }
 };
-template <int N>
-struct HalvingReduce<N, 0> {
-    static __device__ __forceinline__ void run(double*, int, int&, int&) {}
+template <typename V, int N>
+struct HalvingReduceT<V, N, 0> {
+    static __device__ __forceinline__ void run(V*, int, int&, int&) {}
 };
+template <int N, int OFF> using HalvingReduce = HalvingReduceT<double, N, OFF>;
 
 // one pair of observations: acc += A_a^T (C_a C_b^T) A_b   (unscaled; the camera scales are applied once at the end)
 template <typename T>
@@ -765,14 +769,22 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = (T)0;
     const int p1 = pend;
+    // the pair indices of a round are fetched one round ahead: a round then costs ONE dependent memory level (the record
+    // gathers) instead of two (indices, then records)
+    int2 pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int p = pbeg + 16 * u + g; pr[u] = ds.pairs[pbeg < p1 ? (p < p1 ? p : p1 - 1) : 0]; }
     for (int p0 = pbeg; p0 < p1; p0 += 64) {
         T qa[4][4], qb[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int p = p0 + 16 * u + g;
-            const int2 pr = ds.pairs[p < p1 ? p : p1 - 1];
-            load_quarter<T>(Y, pr.x, s, qa[u]);
-            load_quarter<T>(Y, pr.y, s, qb[u]);
+            load_quarter<T>(Y, pr[u].x, s, qa[u]);
+            load_quarter<T>(Y, pr[u].y, s, qb[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {      // next round's indices (clamped: the last round re-reads its own)
+            const int p = p0 + 64 + 16 * u + g;
+            pr[u] = ds.pairs[p < p1 ? p : p1 - 1];
         }
         T ra[YREC], rb[YREC];
         quad_distribute<T>(qa, ra, b0, b1);
@@ -783,55 +795,21 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
         }
         pair_product<T>(ra, rb, MODE == 2, acc);
     }
-    // sum over the quad in T, then lane s keeps rows s and s+4 (as before) and the 16 quads are summed in fp64
-#pragma unroll
-    for (int e = 0; e < 36; ++e) {
-        T v = acc[e];
-        v += quad_xchg<0xB1>(v);
-        v += quad_xchg<0x4E>(v);
-        acc[e] = v;
-    }
-    double accd[12];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const T r0 = s == 0 ? acc[c] : s == 1 ? acc[6 + c] : s == 2 ? acc[12 + c] : acc[18 + c];
-        const T r1 = s == 0 ? acc[24 + c] : s == 1 ? acc[30 + c] : (T)0;
-        double v = (double)r0, w2 = (double)r1;
-        v += __shfl_xor(v, 4, 64);   w2 += __shfl_xor(w2, 4, 64);
-        v += __shfl_xor(v, 8, 64);   w2 += __shfl_xor(w2, 8, 64);
-        v += __shfl_xor(v, 16, 64);  w2 += __shfl_xor(w2, 16, 64);
-        v += __shfl_xor(v, 32, 64);  w2 += __shfl_xor(w2, 32, 64);
-        accd[c] = v; accd[6 + c] = w2;
-    }
-    const double* sa = db.cscale + 6 * cj.x;
-    const double* sb = db.cscale + 6 * cj.y;
+    // Sum of the 36 entries over the 64 lanes by a halving butterfly (38 shuffles instead of 72 + 96: the epilogue was as long as
+    // the pair loop): afterwards lane `base` -- 36 of the 64 lanes -- owns ONE entry of the 6x6 block.
+    int base = 0, len = 36;
+    HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
+    const bool owner = len >= 1;
+    const int er = owner ? base / 6 : 0, ec = owner ? base - 6 * (base / 6) : 0;
+    const double entry = owner ? -(double)acc[0] * db.cscale[6 * cj.x + er] * db.cscale[6 * cj.y + ec] : 0.0;
     if (MODE == 0 || MODE == 2) {
-        if (lane < 4) {
-            double* Srow0 = db.S + (size_t)(6 * cj.x + s) * ds.ld + 6 * cj.y;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const double v = -accd[c] * sa[s] * sb[c];
-                if (MODE == 0) Srow0[c] = v; else if (c >= s) atomicAdd(&Srow0[c], v);     // MODE 2: upper part of the diagonal block
-            }
-            if (s < 2) {
-                double* Srow1 = db.S + (size_t)(6 * cj.x + s + 4) * ds.ld + 6 * cj.y;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const double v = -accd[6 + c] * sa[s + 4] * sb[c];
-                    if (MODE == 0) Srow1[c] = v; else if (c >= s + 4) atomicAdd(&Srow1[c], v);
-                }
-            }
+        if (owner) {
+            double* dst = db.S + (size_t)(6 * cj.x + er) * ds.ld + 6 * cj.y + ec;
+            if (MODE == 0) *dst = entry; else if (ec >= er) atomicAdd(dst, entry);     // MODE 2: upper part of the diagonal block
         }
     } else {
         // S~_IJ = Linv_I S_IJ Linv_J^T written to both triangles of the preconditioned matrix
-        if (lane < 4) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) tile[w][6 * s + c] = -accd[c] * sa[s] * sb[c];
-            if (s < 2) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) tile[w][6 * (s + 4) + c] = -accd[6 + c] * sa[s + 4] * sb[c];
-            }
-        }
+        if (owner) tile[w][base] = entry;
         wave_lds_fence();
         if (lane < 36) {
             const int r = lane / 6, c = lane - 6 * r;
