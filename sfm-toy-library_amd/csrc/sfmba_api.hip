@@ -294,9 +294,11 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     const char* coarse_env = std::getenv("SFMBA_PCG_COARSE");
     const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
     const char* pcg_env = std::getenv("SFMBA_PCG_PERSISTENT");
-    // One persistent launch per CG solve wins where the solve is launch-bound (small reduced systems: 0.67 -> 0.50 ms per
-    // solve at 20 cameras) and loses 2.7 % at d = 1201: automatic below d = 640, SFMBA_PCG_PERSISTENT=0|1 forces it.
-    const bool persistent_cg = pcg_env ? pcg_env[0] == '1' : p->ds.d <= 640;
+    // One persistent (cooperative) launch per CG solve: opt-in only (SFMBA_PCG_PERSISTENT=1).  It used to win below d = 640 where the
+    // solve is launch-bound; with the gauge coarse space the launch-per-iteration path needs half the iterations and is as fast or
+    // faster at every size measured (cfg 4, d = 151: 4990 vs 4820 LM it/s; cfg 2: 6300 vs 6220; 7 views: 6170 vs 6380), and it has
+    // no device-wide spin barrier in it.
+    const bool persistent_cg = pcg_env && pcg_env[0] == '1';
     int launched_controls = 0;
     std::vector<int> lin_hist;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;

@@ -100,7 +100,7 @@ def test_cfg4_subproblem_matches_oracle(capi, sfm, oracle, sub):
     prob = sfm.make_problem("cfg4", sub=sub)
     assert prob.n_cam == 25 and prob.n_obs == 125000
     want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
-    # bench mode of the replicas (F32J + anchored PCG; d = 151 -> the persistent one-launch CG kernel) ...
+    # bench mode of the replicas (F32J + anchored two-level PCG, d = 151) ...
     got = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1))
     assert_same_solve(prob, got, want, param_atol=2e-5, trace_rtol=5e-5)
     # ... and the exact fp64 configuration
