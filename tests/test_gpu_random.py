@@ -124,4 +124,10 @@ def test_truncated_linear_solves_still_converge(capi, sfm):
     assert s["linear_iters"] == 3 * s["iterations"]
     assert abs(s["final_cost"] - ref["final_cost"]) <= 1e-5 * ref["final_cost"]
     s1 = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_max_iters=1, max_iters=20))[3]
-    assert s1["termination_name"] == "NO_CONVERGENCE" and s1["iterations"] == 20
+    # ONE CG iteration per LM step: with the gauge coarse space even that is a usable step (the plain block-Jacobi CG of round 1
+    # ran out of LM iterations here) -- either outcome must be reported consistently
+    assert s1["iterations"] <= 20 and s1["linear_iters"] == s1["iterations"]
+    if s1["termination_name"] == "CONVERGENCE":
+        assert abs(s1["final_cost"] - ref["final_cost"]) <= 1e-4 * ref["final_cost"]
+    else:
+        assert s1["termination_name"] == "NO_CONVERGENCE" and s1["iterations"] == 20
