@@ -14,6 +14,7 @@
 // one trailing-update kernel; back substitution is one launch per block column (eager updates).
 #include "dense_solver.h"
 #include "sfmba_device.h"
+#include "chol_tile.h"
 #include <math.h>
 #include <stdio.h>
 #include <algorithm>
@@ -25,6 +26,7 @@ namespace sfmba {
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define NB CHOL_NB
+constexpr int CHOL_FUSED_MAX_BLOCKS = 40;
 #define AT(i, j) A[(size_t)(i) + (size_t)(j) * ld]
 
 // ------------------------------------------------------------------------------------------
@@ -188,6 +190,129 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
             }
 }
 
+// ------------------------------------------------------------------------------------------
+// One launch per block column (d up to ~2500): panel solve, trailing update and the factorisation of the next diagonal tile.
+//
+// Step k, workgroup (i, j) with i >= j > k owns tile A_ij:
+//   L_ik = A_ik M_k,  L_jk = A_jk M_k      (M_k = L_kk^-T from the previous launch: the triangular solves are GEMMs on the matrix
+//                                           cores, formed redundantly by every workgroup that needs them -- 64^3 flops, ~1 us)
+//   A_ij -= L_ik L_jk^T                    (written back; the workgroups of block column j = k + 1 also store L_ik: final values)
+//   (i, j) = (k+1, k+1) only: factor the updated tile in LDS and form M_{k+1} on the way (chol_tile.h), store both.
+// The factorisation of the diagonal tile is the serial chain of the whole algorithm (64 dependent pivots); everything else of a
+// step hangs off it with one launch boundary instead of two, and no workgroup but that one ever executes the 64-step sweep
+// (the panel kernel it replaces swept 64 steps in every workgroup: a factor sweep in wave 0, then a solve sweep per tile).
+// Launch k = -1 factors tile (0, 0) alone.
+// ------------------------------------------------------------------------------------------
+constexpr int CS_TILE = CT_NB * CT_LDT;
+constexpr int CS_LDS_DOUBLES = 3 * CS_TILE + CT_NB * CT_LDP + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP + (CT_NB / CT_PB) * CT_PB * CT_PB;
+static_assert(CT_NB == NB, "tile size");
+
+// acc[nb] (block row w of the product, block column nb) = sum_{t} A[r][t] E[t][c] over t < 16 (nb + 1): E is upper triangular.
+// D layout: register v of a lane = element (r = 16 w + (lane >> 4) + 4 v, c = 16 nb + (lane & 15)).
+__device__ __forceinline__ void tile_times_upper(const double* __restrict__ A, const double* __restrict__ E, mfma_d4 (&acc)[4], int w, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double av[NB / 4];
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) av[kk] = A[(16 * w + l15) * CT_LDT + 4 * kk + l4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        acc[nb] = (mfma_d4){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int kk = 0; kk < 4 * (nb + 1); ++kk)
+            acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], E[(4 * kk + l4) * CT_LDT + 16 * nb + l15], acc[nb], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void tile_store_rows(double* __restrict__ A, const mfma_d4 (&acc)[4], int w, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) A[(16 * w + l4 + 4 * v) * CT_LDT + 16 * nb + l15] = acc[nb][v];
+}
+
+__global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, int ld, int k, int d, double* __restrict__ minv, int* __restrict__ info) {
+    extern __shared__ __align__(16) double cs_lds[];
+    double* B0 = cs_lds;                 // M_k, later the tile being factored
+    double* B1 = B0 + CS_TILE;           // A_ik -> L_ik
+    double* B2 = B1 + CS_TILE;           // A_jk -> L_jk
+    double* X = B2 + CS_TILE;
+    double* ED = X + CT_NB * CT_LDP;
+    double* V = ED + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int t = blockIdx.x;
+    int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+    while (ii * (ii + 1) / 2 > t) --ii;
+    const int jj = t - ii * (ii + 1) / 2;
+    const int ib = (k + 1 + ii) * NB, jb = (k + 1 + jj) * NB, kb = k * NB;
+    const bool diag = ii == 0;           // jj <= ii: tile (k+1, k+1)
+    if (k >= 0) {
+        // the tile itself, straight into the accumulator layout of the update (m = column, n = row: 16 lanes = 16 consecutive rows)
+        mfma_d4 acc[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[cb][v] = (!diag || cb <= w) ? AT(ib + 16 * w + l15, jb + 16 * cb + l4 + 4 * v) : 0.0;
+        const double* M = minv + (size_t)k * NB * NB;
+        for (int idx = tid; idx < NB * NB; idx += 256) {
+            const int r = idx % NB, c = idx / NB;
+            B0[r * CT_LDT + c] = M[r + c * NB];
+            B1[r * CT_LDT + c] = AT(ib + r, kb + c);
+            if (ii != jj) B2[r * CT_LDT + c] = AT(jb + r, kb + c);
+        }
+        __syncthreads();
+        {
+            mfma_d4 li[4];
+            tile_times_upper(B1, B0, li, w, lane);
+            tile_store_rows(B1, li, w, lane);      // wave w is the only reader of its block row of A_ik
+            if (ii != jj) {
+                tile_times_upper(B2, B0, li, w, lane);
+                tile_store_rows(B2, li, w, lane);
+            }
+        }
+        __syncthreads();
+        const double* Lj = ii != jj ? B2 : B1;
+        if (jj == 0) {
+            for (int idx = tid; idx < NB * NB; idx += 256) { const int r = idx % NB, c = idx / NB; AT(ib + r, kb + c) = B1[r * CT_LDT + c]; }
+        }
+        // A_ij -= L_ik L_jk^T, product formed transposed: D[m = column][n = row] = sum_t L_jk[c][t] L_ik[r][t]
+        double bv[NB / 4];
+#pragma unroll
+        for (int kk = 0; kk < NB / 4; ++kk) bv[kk] = B1[(16 * w + l15) * CT_LDT + 4 * kk + l4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            if (diag && cb > w) continue;
+#pragma unroll
+            for (int kk = 0; kk < NB / 4; ++kk)
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lj[(16 * cb + l15) * CT_LDT + 4 * kk + l4], bv[kk], acc[cb], 0, 0, 0);
+        }
+        if (!diag) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) AT(ib + 16 * w + l15, jb + 16 * cb + l4 + 4 * v) = acc[cb][v];
+            return;
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) if (cb <= w) B0[(16 * w + l15) * CT_LDT + 16 * cb + l4 + 4 * v] = acc[cb][v];
+    } else {
+        for (int idx = tid; idx < NB * NB; idx += 256) { const int r = idx % NB, c = idx / NB; B0[r * CT_LDT + c] = r >= c ? AT(ib + r, ib + c) : 0.0; }
+    }
+    __syncthreads();
+    const int bad = chol_tile_factor(B0, X, ED, V, ib, d);
+    if (bad != 0 && lane == 0 && w == 0) atomicCAS(info, 0, bad);
+    double* Mn = minv + (size_t)(k + 1) * NB * NB;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx % NB, c = idx / NB, q = r >> 4, cb = c >> 4;
+        const double u = B0[r * CT_LDT + c];
+        if (r >= c) AT(ib + r, ib + c) = u;
+        Mn[r + c * NB] = q < cb ? u : q == cb ? ED[(q * CT_PB + (r & 15)) * CT_LDP + (c & 15)] : 0.0;
+    }
+}
+
 // rhs -> augmented row d (row-major column d); padded diagonal is already 1
 __global__ void k_augment(double* __restrict__ A, int ld, int d, const double* __restrict__ rhs) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,6 +364,18 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
     const int ld = ws->ld, d = ws->d, nblk = ld / NB;
     { ProfScope ps(prof, KID_CHOL_AUGMENT, s);
       hipLaunchKernelGGL(k_augment, dim3((d + 255) / 256), dim3(256), 0, s, S, ld, d, rhs); }
+    static const bool fused_env = [] { const char* e = std::getenv("SFMBA_CHOL_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused_env && nblk <= CHOL_FUSED_MAX_BLOCKS) {
+        // one launch per block column (k_chol_step); beyond ~2500 unknowns the redundant panel GEMMs of the fused step cost more than
+        // the launch they save and the two-kernel form below takes over
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CS_LDS_DOUBLES)); attr_set = true; }
+        for (int k = -1; k < nblk - 1; ++k) {
+            ProfScope ps(prof, KID_CHOL_PANEL, s);
+            const int m = nblk - k - 1;          // block rows below block column k
+            hipLaunchKernelGGL(k_chol_step, dim3(k < 0 ? 1 : m * (m + 1) / 2), dim3(256), sizeof(double) * CS_LDS_DOUBLES, s, S, ld, k, d, ws->minv, info_dev);
+        }
+    } else
     for (int k = 0; k < nblk; ++k) {
         { ProfScope ps(prof, KID_CHOL_PANEL, s);
           const int ntask = nblk - k;
