@@ -33,7 +33,7 @@ constexpr int CT_LDP = CT_PB + 1;  // LDS row pitch of the panel
 #define SFMBA_CT_NEWTON 2          // Newton steps on v_rcp_f64 on the pivot chain (estimate ~5e-8 relative; one step ~4e-15, two ~2e-16)
 #endif
 // LDS of chol_tile_factor (doubles): U tile, X panel, ED diagonal blocks of E, V published columns of one panel
-constexpr int CT_LDS_DOUBLES = CT_NB * CT_LDT + CT_NB * CT_LDP + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP + (CT_NB / CT_PB) * CT_PB * CT_PB;
+constexpr int CT_LDS_DOUBLES = CT_NB * CT_LDT + CT_NB * CT_LDP + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP + (CT_NB / CT_PB + 1) * CT_PB * CT_PB;
 
 // value of lane L of the caller's row of 16 lanes
 template <int L> __device__ __forceinline__ double ct_bcast16(double v) {
@@ -51,7 +51,8 @@ template <int L> __device__ __forceinline__ double ct_bcast16(double v) {
 // execute in order -- and their updates are deferred by one step: they fill the issue slots under the NEXT pivot's reciprocal
 // chain.  The wave issues in order, so the interleaving is spelled out (scheduling barriers between the groups): left to itself
 // the compiler emits the 4-deep reciprocal chain and, worse, the 7-deep 1/sqrt chain of the column scaling back to back
-// (measured 407 cycles per pivot instead of ~250).  1/sqrt(p) and the scaling of all 16 columns happen once, after the sweep.
+// (measured 407 cycles per pivot instead of ~250).  Columns stay UNSCALED throughout the tile (L(:, c) = v_c / sqrt(p_c) is applied
+// by whoever stores the result): nothing inside the tile needs the square roots, only v v^T / p.
 // The reciprocal chain as volatile asm: plain builtins are sunk to their first use by the compiler's own passes (the scheduling
 // barriers only bind the machine scheduler), which puts the whole chain back to back at the end of the step.
 __device__ __forceinline__ double ct_chain_rcp(double p) {
@@ -69,10 +70,22 @@ __device__ __forceinline__ double ct_chain_fix(double y, double e) {      // y +
     asm volatile("v_fma_f64 %0, %1, %2, %1" : "=v"(z) : "v"(y), "v"(e));
     return z;
 }
+// pivot as the sweep used it (a non-positive or non-finite one is replaced by 1), its reciprocal and 1 / sqrt
+__device__ __forceinline__ double ct_pivot_fixed(double p) { return __builtin_amdgcn_class(p, 0x100 | 0x080) ? p : 1.0; }
+__device__ __forceinline__ double ct_rcp(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    y = fma(y, fma(-p, y, 1.0), y);
+    return fma(y, fma(-p, y, 1.0), y);
+}
+__device__ __forceinline__ double ct_rsqrt(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    y = fma(0.5 * y, fma(-p * y, y, 1.0), y);
+    return fma(0.5 * y, fma(-p * y, y, 1.0), y);
+}
 struct CtCarry { double u, ux; };       // (own entry of the previous pivot column) / (previous pivot), both register sets
 
 template <int I>
-__device__ __forceinline__ void ct_pivot_step(double (&dc)[CT_PB], double (&x)[CT_PB], double (&piv)[CT_PB], CtCarry& prev,
+__device__ __forceinline__ void ct_pivot_step(double (&dc)[CT_PB], double (&x)[CT_PB], CtCarry& prev,
                                               double* __restrict__ V, int q, int r, unsigned& badbits) {
     // columns I + 1 .. 15 of the previous pivot column (published one step ago)
     double vf[CT_PB];
@@ -120,47 +133,78 @@ __device__ __forceinline__ void ct_pivot_step(double (&dc)[CT_PB], double (&x)[C
         x[I + 1] = fma(-wx, y, x[I + 1]);
     }
     prev.u = v * y; prev.ux = xi * y;
-    piv[I] = ok ? p : 1.0;
+    V[((CT_NB / CT_PB) * CT_PB + I) * CT_PB + r] = y;      // 1 / pivot for the trailing update (16 copies: no branch, no conflict)
 }
 
 template <int... Is>
 __device__ __forceinline__ unsigned ct_sweep(double (&dc)[CT_PB], double (&x)[CT_PB], double* __restrict__ V, int q, int r,
                                              std::integer_sequence<int, Is...>) {
-    double piv[CT_PB];
     CtCarry prev = { 0.0, 0.0 };
     unsigned badbits = 0;      // bit I: pivot I of this panel was not positive and finite
-    (ct_pivot_step<Is>(dc, x, piv, prev, V, q, r, badbits), ...);
-    // column scaling: L(:, c) = v_c / sqrt(p_c), 16 independent chains advanced stage by stage
-    double y[CT_PB], e[CT_PB];
-#pragma unroll
-    for (int c = 0; c < CT_PB; ++c) y[c] = __builtin_amdgcn_rsq(piv[c]);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-#pragma unroll
-        for (int c = 0; c < CT_PB; ++c) e[c] = piv[c] * y[c];
-#pragma unroll
-        for (int c = 0; c < CT_PB; ++c) e[c] = fma(-e[c], y[c], 1.0);
-#pragma unroll
-        for (int c = 0; c < CT_PB; ++c) y[c] = fma(0.5 * y[c], e[c], y[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < CT_PB; ++c) { dc[c] *= y[c]; x[c] *= y[c]; }
+    (ct_pivot_step<Is>(dc, x, prev, V, q, r, badbits), ...);
     return badbits;
 }
 
+// Trailing update of panel b: at most NJ blocks per wave, entries w, w + 4, w + 8 of the packed list (4 bits per block: q | cb << 2).
+// No branch between the loads and the last matrix instruction: a wave with fewer than NJ blocks repeats its first one and skips
+// the store (a branch per block makes the compiler shuttle every accumulator through the AGPRs around every v_mfma).
+template <int NJ>
+__device__ __forceinline__ void ct_trailing(double* __restrict__ U, const double* __restrict__ X, const double* __restrict__ V,
+                                            unsigned long long list, int nblk, int b, int w, int lane) {
+    typedef double ct_d4 __attribute__((ext_vector_type(4)));
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int n = (nblk - w + 3) >> 2;
+    int bq[NJ], bc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const unsigned e = (unsigned)(list >> (4 * (w + (j < n ? 4 * j : 0)))) & 15u;
+        bq[j] = e & 3; bc[j] = e >> 2;
+    }
+    double yv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) yv[kk] = -V[((CT_NB / CT_PB) * CT_PB + 4 * kk + l4) * CT_PB];
+    ct_d4 acc[NJ];
+    double av[NJ][4], bv[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double* Y = U + (bq[j] * CT_PB + l4) * CT_LDT + bc[j] * CT_PB + l15;
+        const double* Xa = X + (bq[j] * CT_PB + l15) * CT_LDP + l4;
+        const double* Xb = X + (bc[j] * CT_PB + l15) * CT_LDP + l4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const double y0 = Y[4 * v * CT_LDT]; acc[j][v] = bq[j] == b ? 0.0 : y0; }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { av[j][kk] = Xa[4 * kk]; bv[j][kk] = Xb[4 * kk]; }
+    }
+    // k outermost: the accumulators are independent, so the matrix instructions issue back to back
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j][kk] * yv[kk], bv[j][kk], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j < n) {
+            double* Y = U + (bq[j] * CT_PB + l4) * CT_LDT + bc[j] * CT_PB + l15;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Y[4 * v * CT_LDT] = acc[j][v];
+        }
+    }
+}
+
 // U: LDS tile [CT_NB][CT_LDT] holding the SPD tile (lower triangle significant), X: panel [CT_NB][CT_LDP], ED: [4 + 1][CT_PB][CT_LDP] (the last
-// block is a dump), V: [4][CT_PB][CT_PB] scratch.
-// On return, with q = row / 16 and cb = column / 16:
-//   L(row, col)      = U[row][col]                      for q >= cb  (the strict upper part of the diagonal blocks: garbage)
-//   L^-T(row, col)   = U[row][col]                      for q <  cb
-//                    = ED[q][row % 16][col % 16]        for q == cb  (upper triangular: zeros below the diagonal)
-//                    = 0                                for q >  cb
+// block is a dump), V: [4 + 1][CT_PB][CT_PB] scratch
+// (four copies of the published pivot columns, then the reciprocal pivots of the panel).
+// On return, with q = row / 16, cb = column / 16 and the column scale s(col) = X[col] = 1 / sqrt(pivot of that column):
+//   L(row, col)      = s(col) U[row][col]                      for q >= cb  (the strict upper part of the diagonal blocks: garbage)
+//   L^-T(row, col)   = s(col) U[row][col]                      for q <  cb
+//                    = s(col) ED[q][row % 16][col % 16]        for q == cb  (upper triangular: zeros below the diagonal)
+//                    = 0                                       for q >  cb
 // col0: global index of the tile's first column, d: number of true columns (a non-positive pivot in a column >= d -- padding,
 // the augmented right-hand side -- is replaced by 1 without a report).  Returns, in every thread of wave 0 (0 elsewhere), the
 // 1-based global column of the first non-positive pivot, or 0.  Must be called by all 256 threads; U must be complete
 // (__syncthreads() before the call is the caller's business); ends with a __syncthreads().
 __device__ __forceinline__ int chol_tile_factor(double* __restrict__ U, double* __restrict__ X, double* __restrict__ ED, double* __restrict__ V, int col0, int d) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a scalar: branches on it are uniform, and the compiler must know
     const int q = lane >> 4, r = lane & 15;
     int badcol = 0;
 #ifdef CT_DEBUG_CLK
@@ -206,39 +250,23 @@ __device__ __forceinline__ int chol_tile_factor(double* __restrict__ U, double* 
 #ifdef CT_DEBUG_CLK
         const long long k3 = ct_clk();
 #endif
-        // trailing update on the fp64 matrix cores: Y[row][cc] -= sum_i X[row][i] X[cc][i] for cc >= c0 + 16, in 16 x 16 blocks
-        // (q, cb): Y = T for the blocks on and below the diagonal (q >= cb), Y = E = L^-T for the block rows q <= b (a block row
-        // of E enters as zero in its own panel).  X[cc] is a row of the T panel.  One block = 4 x v_mfma_f64_16x16x4_f64 (k = 16),
-        // blocks dealt round-robin to the four waves.  Operand layout (cdna_hip_programming.md): A[m = lane & 15][k = lane >> 4],
-        // B[k = lane >> 4][n = lane & 15], D[m = (lane >> 4) + 4 v][n = lane & 15] in register v.
-        {
-            typedef double ct_d4 __attribute__((ext_vector_type(4)));
-            const int l15 = lane & 15, l4 = lane >> 4;
-            int cnt = 0;
-            for (int cb = b + 1; cb < CT_NB / CT_PB; ++cb)
-                for (int qq = 0; qq < CT_NB / CT_PB; ++qq) {
-                    if (!(qq <= b || qq >= cb)) continue;
-                    if ((cnt++ & 3) != w) continue;
-                    double* Y = U + (qq * CT_PB + l4) * CT_LDT + cb * CT_PB + l15;
-                    ct_d4 acc;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[v] = qq == b ? 0.0 : Y[4 * v * CT_LDT];
-                    const double* Xa = X + (qq * CT_PB + l15) * CT_LDP + l4;
-                    const double* Xb = X + (cb * CT_PB + l15) * CT_LDP + l4;
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) { av[kk] = -Xa[4 * kk]; bv[kk] = Xb[4 * kk]; }
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) Y[4 * v * CT_LDT] = acc[v];
-                }
-        }
+        // trailing update on the fp64 matrix cores: Y[row][cc] -= sum_i X[row][i] X[cc][i] / p_i for cc >= c0 + 16, in 16 x 16
+        // blocks (q, cb): Y = T for the blocks on and below the diagonal (q >= cb), Y = E = L^-T for the block rows q <= b (a block
+        // row of E enters as zero in its own panel).  X[cc] is a row of the T panel; 1 / p_i was left in V by the sweep.  One block =
+        // 4 x v_mfma_f64_16x16x4_f64 (k = 16); the blocks are dealt round-robin to the four waves (at most three each) and a wave
+        // issues the operand loads of all its blocks before the first matrix instruction.  Operand layout
+        // (cdna_hip_programming.md): A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15], D[m = (lane >> 4) + 4 v][n = lane & 15].
+        if (b == 0) ct_trailing<3>(U, X, V, 0xFCBA87654ull, 9, 0, w, lane);
+        else if (b == 1) ct_trailing<2>(U, X, V, 0xFDCBA98ull, 7, 1, w, lane);
+        else if (b == 2) ct_trailing<1>(U, X, V, 0xFEDCull, 4, 2, w, lane);
         __syncthreads();
 #ifdef CT_DEBUG_CLK
         const long long k4 = ct_clk(); clk_load += k1 - k0; clk_sweep += k2 - k1; clk_store += k3 - k2; clk_trail += k4 - k3;
 #endif
     }
+    // column scales 1 / sqrt(p_c) for whoever stores the result (the panel buffer is free now)
+    if (tid < CT_NB) X[tid] = ct_rsqrt(ct_pivot_fixed(U[tid * (CT_LDT + 1)]));
+    __syncthreads();
 #ifdef CT_DEBUG_CLK
     if (tid == 0 && blockIdx.x == 0) { CT_DEBUG_CLK[0] = clk_load; CT_DEBUG_CLK[1] = clk_sweep; CT_DEBUG_CLK[2] = clk_trail; CT_DEBUG_CLK[3] = clk_store; }
 #endif

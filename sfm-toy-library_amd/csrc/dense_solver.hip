@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 // Launch k = -1 factors tile (0, 0) alone.
 // ------------------------------------------------------------------------------------------
 constexpr int CS_TILE = CT_NB * CT_LDT;
-constexpr int CS_LDS_DOUBLES = 3 * CS_TILE + CT_NB * CT_LDP + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP + (CT_NB / CT_PB) * CT_PB * CT_PB;
+constexpr int CS_LDS_DOUBLES = 3 * CS_TILE + CT_NB * CT_LDP + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP + (CT_NB / CT_PB + 1) * CT_PB * CT_PB;
 static_assert(CT_NB == NB, "tile size");
 
 // acc[nb] (block row w of the product, block column nb) = sum_{t} A[r][t] E[t][c] over t < 16 (nb + 1): E is upper triangular.
@@ -230,6 +230,13 @@ __device__ __forceinline__ void tile_store_rows(double* __restrict__ A, const mf
         for (int v = 0; v < 4; ++v) A[(16 * w + l4 + 4 * v) * CT_LDT + 16 * nb + l15] = acc[nb][v];
 }
 
+#ifdef SFMBA_CHOL_CLK
+__device__ long long g_chol_clk[16];
+#define CS_STAMP(n) do { __builtin_amdgcn_sched_barrier(0); if (diag && k == 5 && tid == 0) g_chol_clk[n] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" __attribute__((visibility("default"))) void sfmba_debug_chol_clk(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chol_clk), sizeof(long long) * 16); }
+#else
+#define CS_STAMP(n) do { } while (0)
+#endif
 __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, int ld, int k, int d, double* __restrict__ minv, int* __restrict__ info) {
     extern __shared__ __align__(16) double cs_lds[];
     double* B0 = cs_lds;                 // M_k, later the tile being factored
@@ -238,7 +245,8 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, in
     double* X = B2 + CS_TILE;
     double* ED = X + CT_NB * CT_LDP;
     double* V = ED + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the per-wave block assignments below are uniform branches
     const int l15 = lane & 15, l4 = lane >> 4;
     const int t = blockIdx.x;
     int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -247,21 +255,50 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, in
     const int jj = t - ii * (ii + 1) / 2;
     const int ib = (k + 1 + ii) * NB, jb = (k + 1 + jj) * NB, kb = k * NB;
     const bool diag = ii == 0;           // jj <= ii: tile (k+1, k+1)
+    CS_STAMP(0);
     if (k >= 0) {
         // the tile itself, straight into the accumulator layout of the update (m = column, n = row: 16 lanes = 16 consecutive rows)
+        // (diagonal tile: the 10 blocks on and below the diagonal, dealt 3 / 3 / 2 / 2 to the waves:
+        //   wave 0: (3,0) (3,1) (0,0)   wave 1: (3,2) (3,3) (1,1)   wave 2: (2,0) (2,1)   wave 3: (2,2) (1,0) )
+        const int rb0 = w < 2 ? 3 : 2, cbA = w == 0 ? 0 : w == 1 ? 2 : w == 2 ? 0 : 2;
+        const int rb1 = w == 0 ? 0 : 1, cb1 = w == 0 ? 0 : w == 1 ? 1 : 0;     // third block of waves 0, 1; second of wave 3
+        const int rowB = w == 3 ? rb1 : rb0, colB = w == 3 ? cb1 : cbA + 1;
         mfma_d4 acc[4];
+        if (!diag) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[cb][v] = (!diag || cb <= w) ? AT(ib + 16 * w + l15, jb + 16 * cb + l4 + 4 * v) : 0.0;
+                for (int v = 0; v < 4; ++v) acc[cb][v] = AT(ib + 16 * w + l15, jb + 16 * cb + l4 + 4 * v);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                acc[0][v] = AT(ib + 16 * rb0 + l15, ib + 16 * cbA + l4 + 4 * v);
+                acc[1][v] = AT(ib + 16 * rowB + l15, ib + 16 * colB + l4 + 4 * v);
+                acc[2][v] = w < 2 ? AT(ib + 16 * rb1 + l15, ib + 16 * cb1 + l4 + 4 * v) : 0.0;
+            }
+        }
         const double* M = minv + (size_t)k * NB * NB;
-        for (int idx = tid; idx < NB * NB; idx += 256) {
-            const int r = idx % NB, c = idx / NB;
-            B0[r * CT_LDT + c] = M[r + c * NB];
-            B1[r * CT_LDT + c] = AT(ib + r, kb + c);
-            if (ii != jj) B2[r * CT_LDT + c] = AT(jb + r, kb + c);
+        {
+            // all global loads of the three operand tiles in flight at once (48 per thread), then the LDS stores
+            const int r = tid & (NB - 1), cq = tid >> 6;        // column c = cq + 4 m
+            double mv[NB / 4], iv[NB / 4], jv[NB / 4];
+#pragma unroll
+            for (int m = 0; m < NB / 4; ++m) {
+                const int c = cq + 4 * m;
+                mv[m] = M[r + c * NB];
+                iv[m] = AT(ib + r, kb + c);
+                jv[m] = ii != jj ? AT(jb + r, kb + c) : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < NB / 4; ++m) {
+                const int c = cq + 4 * m;
+                B0[r * CT_LDT + c] = mv[m];
+                B1[r * CT_LDT + c] = iv[m];
+                if (ii != jj) B2[r * CT_LDT + c] = jv[m];
+            }
         }
         __syncthreads();
+        CS_STAMP(1);
         {
             mfma_d4 li[4];
             tile_times_upper(B1, B0, li, w, lane);
@@ -272,45 +309,74 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, in
             }
         }
         __syncthreads();
+        CS_STAMP(2);
         const double* Lj = ii != jj ? B2 : B1;
-        if (jj == 0) {
-            for (int idx = tid; idx < NB * NB; idx += 256) { const int r = idx % NB, c = idx / NB; AT(ib + r, kb + c) = B1[r * CT_LDT + c]; }
+        // block column k + 1: L_ik is final, store it (the diagonal workgroup does that later, under its first panel sweep)
+        if (jj == 0 && !diag) {
+#pragma unroll
+            for (int m = 0; m < NB / 4; ++m) { const int r = tid & (NB - 1), c = (tid >> 6) + 4 * m; AT(ib + r, kb + c) = B1[r * CT_LDT + c]; }
         }
+        CS_STAMP(3);
         // A_ij -= L_ik L_jk^T, product formed transposed: D[m = column][n = row] = sum_t L_jk[c][t] L_ik[r][t]
-        double bv[NB / 4];
-#pragma unroll
-        for (int kk = 0; kk < NB / 4; ++kk) bv[kk] = B1[(16 * w + l15) * CT_LDT + 4 * kk + l4];
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            if (diag && cb > w) continue;
-#pragma unroll
-            for (int kk = 0; kk < NB / 4; ++kk)
-                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lj[(16 * cb + l15) * CT_LDT + 4 * kk + l4], bv[kk], acc[cb], 0, 0, 0);
-        }
         if (!diag) {
+            double bv[NB / 4];
+#pragma unroll
+            for (int kk = 0; kk < NB / 4; ++kk) bv[kk] = B1[(16 * w + l15) * CT_LDT + 4 * kk + l4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int kk = 0; kk < NB / 4; ++kk)
+                    acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lj[(16 * cb + l15) * CT_LDT + 4 * kk + l4], bv[kk], acc[cb], 0, 0, 0);
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) AT(ib + 16 * w + l15, jb + 16 * cb + l4 + 4 * v) = acc[cb][v];
             return;
         }
+        {
+            mfma_d4 t0 = acc[0], t1 = acc[1], t2 = acc[2];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+            for (int kk = 0; kk < NB / 4; ++kk) {
+                const double b0 = B1[(16 * rb0 + l15) * CT_LDT + 4 * kk + l4];
+                t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-B1[(16 * cbA + l15) * CT_LDT + 4 * kk + l4], b0, t0, 0, 0, 0);
+                const double b1 = w == 3 ? B1[(16 * rowB + l15) * CT_LDT + 4 * kk + l4] : b0;
+                t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-B1[(16 * colB + l15) * CT_LDT + 4 * kk + l4], b1, t1, 0, 0, 0);
+                if (w < 2) t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-B1[(16 * cb1 + l15) * CT_LDT + 4 * kk + l4], B1[(16 * rb1 + l15) * CT_LDT + 4 * kk + l4], t2, 0, 0, 0);
+            }
+            // B0 (M_k) is free since the barrier above
 #pragma unroll
-            for (int v = 0; v < 4; ++v) if (cb <= w) B0[(16 * w + l15) * CT_LDT + 16 * cb + l4 + 4 * v] = acc[cb][v];
+            for (int v = 0; v < 4; ++v) {
+                B0[(16 * rb0 + l15) * CT_LDT + 16 * cbA + l4 + 4 * v] = t0[v];
+                B0[(16 * rowB + l15) * CT_LDT + 16 * colB + l4 + 4 * v] = t1[v];
+                if (w < 2) B0[(16 * rb1 + l15) * CT_LDT + 16 * cb1 + l4 + 4 * v] = t2[v];
+            }
+        }
     } else {
         for (int idx = tid; idx < NB * NB; idx += 256) { const int r = idx % NB, c = idx / NB; B0[r * CT_LDT + c] = r >= c ? AT(ib + r, ib + c) : 0.0; }
     }
     __syncthreads();
+    CS_STAMP(4);
+    if (k >= 0 && w != 0) {
+        // L_{k+1,k}: stored by waves 1..3 while wave 0 sweeps the first panel (they would wait at its barrier anyway)
+        for (int idx = tid - 64; idx < NB * NB; idx += 192) { const int r = idx & (NB - 1), c = idx >> 6; AT(ib + r, kb + c) = B1[r * CT_LDT + c]; }
+    }
     const int bad = chol_tile_factor(B0, X, ED, V, ib, d);
+    CS_STAMP(5);
     if (bad != 0 && lane == 0 && w == 0) atomicCAS(info, 0, bad);
     double* Mn = minv + (size_t)(k + 1) * NB * NB;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx % NB, c = idx / NB, q = r >> 4, cb = c >> 4;
-        const double u = B0[r * CT_LDT + c];
-        if (r >= c) AT(ib + r, ib + c) = u;
-        Mn[r + c * NB] = q < cb ? u : q == cb ? ED[(q * CT_PB + (r & 15)) * CT_LDP + (c & 15)] : 0.0;
+    {
+        const int r = tid & (NB - 1), q = r >> 4;
+#pragma unroll
+        for (int m = 0; m < NB / 4; ++m) {
+            const int c = (tid >> 6) + 4 * m, cb = c >> 4;
+            const double sc = X[c];             // 1 / sqrt(pivot): the tile is factored with unscaled columns
+            const double u = sc * B0[r * CT_LDT + c];
+            const double e = sc * ED[(q * CT_PB + (r & 15)) * CT_LDP + (c & 15)];
+            if (r >= c) AT(ib + r, ib + c) = u;
+            Mn[r + c * NB] = q < cb ? u : q == cb ? e : 0.0;
+        }
     }
+    CS_STAMP(6);
 }
 
 // rhs -> augmented row d (row-major column d); padded diagonal is already 1

@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void k_factor(const double* __restrict__ A, do
     const long long t2 = clock64();
     for (int idx = threadIdx.x; idx < CT_NB * CT_NB; idx += 256) {
         const int r = idx % CT_NB, c = idx / CT_NB, q = r >> 4, cb = c >> 4;
-        L[(size_t)blockIdx.x * CT_NB * CT_NB + r + c * CT_NB] = r >= c ? U[r * CT_LDT + c] : 0.0;
-        Einv[(size_t)blockIdx.x * CT_NB * CT_NB + r + c * CT_NB] = q < cb ? U[r * CT_LDT + c] : q == cb ? ED[(q * CT_PB + (r & 15)) * CT_LDP + (c & 15)] : 0.0;
+        L[(size_t)blockIdx.x * CT_NB * CT_NB + r + c * CT_NB] = r >= c ? X[c] * U[r * CT_LDT + c] : 0.0;
+        Einv[(size_t)blockIdx.x * CT_NB * CT_NB + r + c * CT_NB] = X[c] * (q < cb ? U[r * CT_LDT + c] : q == cb ? ED[(q * CT_PB + (r & 15)) * CT_LDP + (c & 15)] : 0.0);
     }
     const long long t3 = clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = t2 - t1; clk[2] = t3 - t2; if (bad) *info = bad; }
