@@ -112,7 +112,8 @@ def test_shim_leaves_everything_untouched_without_convergence(sfm, monkeypatch, 
     assert np.allclose(back.obs_xy, prob.obs_xy, atol=1e-4)
 
 
-def test_shim_resident_cache_follows_a_growing_reconstruction(sfm, oracle, monkeypatch, capfd):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_shim_resident_cache_follows_a_growing_reconstruction(sfm, oracle, monkeypatch, capfd, overlap):
     """The reference re-runs adjustBundle() after every added view (SfM.cpp:464-466) on a cloud that only grows.  The shim
     keeps the previous problem resident and appends the difference; every call must still equal a fresh run of the oracle's
     restatement of adjustBundle() on that call's containers.  Then a call that does NOT contain the previous one (a point
@@ -120,6 +121,9 @@ def test_shim_resident_cache_follows_a_growing_reconstruction(sfm, oracle, monke
     monkeypatch.setenv("SFMBA_MAX_SECONDS", "0")
     monkeypatch.setenv("SFMBA_SHIM_TIMING", "1")
     monkeypatch.delenv("SFMBA_SHIM_CACHE", raising=False)
+    # overlap = 1: the lists that kept their length are walked and compared on worker threads WHILE the GPU solves (the default);
+    # 0: everything is marshalled and compared before the solve.  Same results, same paths.
+    monkeypatch.setenv("SFMBA_SHIM_OVERLAP", overlap)
     prob = sfm.make_problem("cfg2", n_cam=9, n_pt=500, views=(2, 5), seed=77)
     poses, K, pts, views, feats = _containers(prob, sfm)
 
@@ -165,3 +169,18 @@ def test_shim_resident_cache_follows_a_growing_reconstruction(sfm, oracle, monke
     p_g, K_g, pts_g = _call_shim(ps, K, cloud, vs2, feats2)
     assert "path: rebuild" in capfd.readouterr().err
     assert np.allclose(pts_g, pts_o, rtol=0, atol=2e-6)
+    # ... and so is a point that traded one view for another (same list length, different view): call it twice so that the second
+    # call starts from a resident problem built on feats2 / vs2
+    _call_shim(ps, K, cloud, vs2, feats2)
+    capfd.readouterr()
+    vs3 = [dict(v) for v in vs2]
+    victim = next(i for i, v in enumerate(vs3) if len(v) >= 3 and len(v) < 9)
+    gone = max(vs3[victim]); new_view = next(k for k in range(9) if k not in vs3[victim])
+    vs3[victim].pop(gone); vs3[victim][new_view] = 0
+    p_o, K_o, pts_o, summ = oracle.adjust_bundle(ps, K, cloud, vs3, feats2, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    p_g, K_g, pts_g = _call_shim(ps, K, cloud, vs3, feats2)
+    assert "path: rebuild" in capfd.readouterr().err
+    if summ["termination_name"] == "CONVERGENCE":
+        assert np.allclose(p_g, p_o, rtol=0, atol=2e-6) and np.allclose(pts_g, pts_o, rtol=0, atol=2e-6)
+    else:
+        assert np.array_equal(pts_g, cloud.astype(np.float32))
