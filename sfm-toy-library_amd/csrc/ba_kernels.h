@@ -143,6 +143,8 @@ struct DeviceBuffers {
                               //         dense_solver.hip), written by k_finalize (PCG mode); null = not wanted
     int* lm_mailbox;          // host-mapped {seq, termination, message, iter}: polled by the host instead of a D2H copy + sync
     double shared_weight;     // 1 normally; 0 on ranks > 0 of a sharded solve (replicated cameras/focal counted once)
+    double* shard_blocks;     // sharded CG path: the pair pass (MODE 1) stores the off-diagonal blocks of S~ here (all-reduce layout) instead of pcg_F
+    const double* shard_scal; // sharded solve: k_lm_control takes the trial sums from this all-reduced scalar block instead of the slots
 };
 
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
@@ -170,10 +172,16 @@ template <typename T> void launch_eval_jacobian(hipStream_t s, const DeviceStruc
 void launch_shard_pack(hipStream_t s, const DeviceBuffers& db, double* scal, int phase, int rank);
 void launch_shard_tri(hipStream_t s, double* sys, double* packed, int ld, long long tail, bool unpack);
 void launch_shard_unpack(hipStream_t s, const DeviceBuffers& db, const double* scal, int phase, int world);
+// two-phase all-reduce of the sharded CG path (ba_kernels.hip): (A) diagonal blocks + vectors + scalars, (B) off-diagonal blocks of S~
+long long shard_diag_len(const DeviceStructure& ds);
+void launch_shard_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* buf, bool unpack, int rank, int world);
+long long shard_offdiag_len(const DeviceStructure& ds);
+void launch_shard_offdiag(hipStream_t s, const DeviceStructure& ds, double* F, double* buf, bool unpack);
+void launch_narrow_matrix(hipStream_t s, const double* src, float* dst, long long n);
 void launch_clear_slots(hipStream_t s, const DeviceBuffers& db);
 void launch_shard_xnorm_finish(hipStream_t s, const DeviceBuffers& db);
 void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int precision_f32);
-void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int precision_f32);
+void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int precision_f32, bool clear_udiag = true);
 void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi);
 void launch_mirror_scale(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* S_full, double* scale_out);
 

@@ -263,8 +263,8 @@ void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const 
     if (f32) hipLaunchKernelGGL(k_colnorm_points<float>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
     else hipLaunchKernelGGL(k_colnorm_points<double>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
 }
-void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int f32) {
-    (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
+void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int f32, bool clear_udiag) {
+    if (clear_udiag) (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
     if (!jacobi) return;
     if (f32) hipLaunchKernelGGL(k_colnorm_cams<float>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
     else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
@@ -708,6 +708,14 @@ __device__ __forceinline__ void store_F(const DeviceBuffers& db, size_t idx, dou
     if (db.pcg_F32) db.pcg_F32[idx] = (float)v; else db.pcg_F[idx] = v;
 }
 
+// one entry of an off-diagonal block of the preconditioned matrix: both triangles of the CG's matrix, or -- sharded CG path -- the
+// block's slot in the all-reduce buffer (k_shard_offdiag's layout; the matrix is written after the sum over the ranks)
+__device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, const DeviceBuffers& db, int b, int2 cj, int r, int c, double v) {
+    if (db.shard_blocks) { db.shard_blocks[(size_t)(b - cj.x - 1) * 36 + 6 * r + c] = v; return; }
+    store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
+    store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
+}
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
@@ -823,8 +831,7 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
                 for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Lj[bb];
                 v += Li[a] * u;
             }
-            store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
-            store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
+            store_block_entry(ds, db, b, cj, r, c, v);
         }
     }
 }
@@ -960,8 +967,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
                     for (int bb = 0; bb < 6; ++bb) u += tile[sub][6 * a + bb] * Lj[bb];
                     v += Li[a] * u;
                 }
-                store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
-                store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
+                store_block_entry(ds, db, b, cj, r, c, v);
             }
         }
     }
@@ -1600,11 +1606,17 @@ __global__ void k_lm_control(DeviceBuffers db) {
         if (threadIdx.x == 0) { const int seq = ++st->mail_seq; lm_post(db.lm_mailbox, seq, -2, 0, st->iter); }
         return;
     }
-    const double trial2 = slots_take(db, ACC_TRIAL_COST);
-    const double model = slots_take(db, ACC_MODEL);
-    const double step2 = slots_take(db, ACC_STEP2);
-    const double xnew2 = slots_take(db, ACC_XNEW2);
-    const double bad_trial = slots_take(db, ACC_BAD_TRIAL);
+    double trial2, model, step2, xnew2, bad_trial;
+    if (db.shard_scal) {
+        // sharded solve: the sums over the ranks sit in the all-reduced scalar block (k_shard_pack emptied the slots)
+        trial2 = db.shard_scal[0]; model = db.shard_scal[1]; step2 = db.shard_scal[2]; xnew2 = db.shard_scal[3]; bad_trial = db.shard_scal[4];
+    } else {
+        trial2 = slots_take(db, ACC_TRIAL_COST);
+        model = slots_take(db, ACC_MODEL);
+        step2 = slots_take(db, ACC_STEP2);
+        xnew2 = slots_take(db, ACC_XNEW2);
+        bad_trial = slots_take(db, ACC_BAD_TRIAL);
+    }
     if (threadIdx.x != 0) return;
     st->lin_info = *db.lin_info;
     *db.lin_info = 0;
@@ -1690,7 +1702,8 @@ void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffer
 //   phase 1 (build):  [0] sum r^2  [1] bad linearisation  [2..5] focal-focal sums  [16 + rank] gradient max-norm
 //   phase 2 (update): [0] trial sum r^2  [1] model change  [2] step^2  [3] ||x_trial||^2  [4] bad trial
 // ------------------------------------------------------------------------------------------
-__global__ void k_shard_pack(DeviceBuffers db, double* scal, int phase, int rank) {
+// scalars of one phase out of the slotted accumulators into the all-reduce block (called by all 64 lanes of ONE wave)
+__device__ __forceinline__ void shard_pack_scalars(const DeviceBuffers& db, double* scal, int phase, int rank) {
     double v[6] = { 0, 0, 0, 0, 0, 0 };
     double gmax = 0.0;
     if (phase == 0) { v[0] = slots_take(db, ACC_XNEW2); v[1] = slots_take(db, ACC_UDF); }
@@ -1702,18 +1715,18 @@ __global__ void k_shard_pack(DeviceBuffers db, double* scal, int phase, int rank
         v[0] = slots_take(db, ACC_TRIAL_COST); v[1] = slots_take(db, ACC_MODEL); v[2] = slots_take(db, ACC_STEP2);
         v[3] = slots_take(db, ACC_XNEW2); v[4] = slots_take(db, ACC_BAD_TRIAL);
     }
-    const int t = threadIdx.x;
-    for (int e = t; e < SFMBA_SHARD_SCALARS; e += 64) scal[e] = 0.0;
-    __syncthreads();
-    if (t == 0) {
-        for (int k = 0; k < 6; ++k) scal[k] = v[k];
-        if (phase == 1) scal[16 + rank] = gmax;
+    // every entry of the block is written exactly once (the sums are uniform over the wave: each lane picks its own)
+    for (int e = threadIdx.x & 63; e < SFMBA_SHARD_SCALARS; e += 64) {
+        double val = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) val = e == k ? v[k] : val;
+        if (phase == 1 && e == 16 + rank) val = gmax;
+        scal[e] = val;
     }
 }
-
-__global__ void k_shard_unpack(DeviceBuffers db, const double* scal, int phase, int world) {
-    if (threadIdx.x != 0) return;
-    double* s0 = db.slots;   // slot 0 (all slots are empty after the pack)
+// and back, summed over the ranks, into slot 0 (all slots are empty after the pack); one thread
+__device__ __forceinline__ void shard_unpack_scalars(const DeviceBuffers& db, const double* scal, int phase, int world) {
+    double* s0 = db.slots;
     if (phase == 0) { s0[ACC_XNEW2] = scal[0]; s0[ACC_UDF] = scal[1]; }
     else if (phase == 1) {
         s0[ACC_LIN_COST] = scal[0]; s0[ACC_BAD_LIN] = scal[1];
@@ -1724,6 +1737,78 @@ __global__ void k_shard_unpack(DeviceBuffers db, const double* scal, int phase, 
     } else {
         s0[ACC_TRIAL_COST] = scal[0]; s0[ACC_MODEL] = scal[1]; s0[ACC_STEP2] = scal[2]; s0[ACC_XNEW2] = scal[3]; s0[ACC_BAD_TRIAL] = scal[4];
     }
+}
+
+__global__ void k_shard_pack(DeviceBuffers db, double* scal, int phase, int rank) { shard_pack_scalars(db, scal, phase, rank); }
+
+__global__ void k_shard_unpack(DeviceBuffers db, const double* scal, int phase, int world) {
+    if (threadIdx.x != 0) return;
+    shard_unpack_scalars(db, scal, phase, world);
+}
+
+// Sharded mode with the CG solver: TWO all-reduces per linearisation instead of one over the whole reduced system.
+//   (A) what the block-Jacobi factors and the LM bookkeeping need -- the 6x6 diagonal blocks, the camera-focal column, right-hand
+//       side, undamped diagonal, gradient, scalars (27 ncam + 3 ld + 80 doubles);
+//   (B) with the factors known on every rank, the off-diagonal blocks of the PRECONDITIONED matrix: S~ = Linv S Linv^T is linear in
+//       S, so every rank transforms its own partial blocks in the pair pass -- exactly what the one-GPU path does -- and the sum over
+//       the ranks is S~ (18 ncam (ncam - 1) doubles, as much as the packed triangle of S carried).
+// The transform, the block factorisation and the gauge vectors then cost what they cost on one GPU (fused into k_finalize and the
+// pair pass) instead of three more kernels over the reduced system behind the all-reduce.
+// Layout A: [ncam][21] upper triangles of the diagonal blocks | [ncam][6] S_jf | rhs[ld] udiag[ld] bc[ld] | scalars
+__global__ __launch_bounds__(256) void k_shard_diag(DeviceStructure ds, DeviceBuffers db, double* __restrict__ buf, int unpack, int rank, int world) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = ds.ncam, ld = ds.ld, fo = ds.d - 1;
+    const long long n_tri = 21ll * nc, n_f = 6ll * nc, n_tail = 3ll * ld;
+    double* scal = buf + n_tri + n_f + n_tail;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        if (!unpack) shard_pack_scalars(db, scal, 1, rank);
+        else if (threadIdx.x == 0) shard_unpack_scalars(db, scal, 1, world);
+    }
+    if (e < n_tri) {
+        const int j = (int)(e / 21), u = (int)(e - 21ll * j);
+        int r = 0, off = u;                          // u-th entry of the row-major upper triangle of a 6 x 6 block
+        while (off >= 6 - r) { off -= 6 - r; ++r; }
+        double* sp = db.S + (size_t)(6 * j + r) * ld + 6 * j + r + off;
+        if (unpack) *sp = buf[e]; else buf[e] = *sp;
+    } else if (e < n_tri + n_f) {
+        const long long k = e - n_tri;
+        double* sp = db.S + (size_t)k * ld + fo;     // row 6 j + a, focal column
+        if (unpack) *sp = buf[e]; else buf[e] = *sp;
+    } else if (e < n_tri + n_f + n_tail) {
+        const long long k = e - n_tri - n_f;         // rhs | udiag | bc are contiguous
+        if (unpack) db.rhs[k] = buf[e]; else buf[e] = db.rhs[k];
+    }
+}
+long long shard_diag_len(const DeviceStructure& ds) { return 27ll * ds.ncam + 3ll * ds.ld + SFMBA_SHARD_SCALARS; }
+void launch_shard_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* buf, bool unpack, int rank, int world) {
+    const long long n = 27ll * ds.ncam + 3ll * ds.ld;
+    hipLaunchKernelGGL(k_shard_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, db, buf, unpack ? 1 : 0, rank, world);
+}
+
+// Layout B: the 36 entries of every off-diagonal block (ja < jb) of the preconditioned matrix, blocks in list order.  Unpacking
+// writes both triangles of the CG's matrix.
+__global__ __launch_bounds__(256) void k_shard_offdiag(DeviceStructure ds, double* __restrict__ F, double* __restrict__ buf, int unpack) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(t / 36), e = (int)(t - 36ll * b);
+    if (b >= ds.nblock) return;
+    const int2 cj = ds.blk_cams[b];
+    if (cj.x == cj.y) return;
+    const int r = e / 6, c = e - 6 * r;
+    const size_t o = (size_t)(b - cj.x - 1) * 36 + e;        // block row ja holds ja + 1 diagonal blocks up to and including its own
+    const size_t up = (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, lo = (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r;
+    if (unpack) { const double v = buf[o]; F[up] = v; F[lo] = v; }
+    else buf[o] = F[up];
+}
+long long shard_offdiag_len(const DeviceStructure& ds) { return 36ll * (ds.nblock - ds.ncam); }
+void launch_shard_offdiag(hipStream_t s, const DeviceStructure& ds, double* F, double* buf, bool unpack) {
+    const long long n = 36ll * ds.nblock;
+    hipLaunchKernelGGL(k_shard_offdiag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, F, buf, unpack ? 1 : 0);
+}
+__global__ void k_narrow_matrix(const double* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dst[e] = (float)src[e];
+}
+void launch_narrow_matrix(hipStream_t s, const double* src, float* dst, long long n) {
+    hipLaunchKernelGGL(k_narrow_matrix, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, src, dst, n);
 }
 
 __global__ void k_clear_slots(DeviceBuffers db) {

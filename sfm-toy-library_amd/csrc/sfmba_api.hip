@@ -603,7 +603,8 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     // ---- launch descriptors (host, from the three CSR pointer arrays) ----
     // chunks of the camera-major list: (camera, entry range)
     const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
-    { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e && e[0] == '1'; }
+    // (not in sharded mode: the per-chunk partial sums of the deterministic camera pass are added behind the all-reduce point)
+    { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e && e[0] == '1' && !sharded; }
     const int coarse_len = p->deterministic ? (1 << 30) : 1024;      // deterministic mode: one column-norm workgroup per camera (single writer)
     std::vector<int4> chunks, chunks_coarse;
     std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0);
@@ -739,13 +740,18 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
     HIP_TRY(dev_alloc(&p->d_sys, sys_len));
     p->d_red = nullptr;
-    if (sharded) HIP_TRY(dev_alloc(&p->d_red, (size_t)ds.ld * (ds.ld + 1) / 2 + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS));
+    if (sharded) {
+        // the all-reduce buffer: packed triangle of S + tail (exact solver), or the two blocks of the CG path (ba_kernels.hip, k_shard_diag)
+        const size_t tri = (size_t)ds.ld * (ds.ld + 1) / 2 + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
+        HIP_TRY(dev_alloc(&p->d_red, std::max(tri, (size_t)std::max(shard_diag_len(ds), shard_offdiag_len(ds)))));
+    }
     db.S = p->d_sys;
     db.rhs = db.S + (size_t)ds.ld * ds.ld;
     db.udiag = db.rhs + ds.ld;
     db.bc = db.udiag + ds.ld;
     p->d_scal = db.bc + ds.ld;
     db.shared_weight = 1.0;
+    db.shard_blocks = nullptr; db.shard_scal = nullptr;
     HIP_TRY(dev_alloc(&db.st, 1));
     // Opt-in deterministic accumulation (SFMBA_DETERMINISTIC=1 when the problem is built): every workgroup of a launch owns its
     // accumulator slot and the multi-chunk camera sums are added in chunk order, so that no result depends on the order in which
@@ -1121,13 +1127,15 @@ int64_t sfmba_shard_setup_len(const sfmba_problem* p) { return p && !p->empty ? 
 void* sfmba_shard_setup_buf(sfmba_problem* p) { return p ? (void*)p->db.udiag : nullptr; }
 void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p ? (void*)p->d_scal : nullptr; }
 
-int sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt) {
+// fused = true (the C loop of sfmba_problem_solve_sharded, CG path): one k_begin launch carries the LM state and clears / builds what
+// five launches and two copies do otherwise, and the point scales are left to the first k_point_build, as in run_solve
+static int shard_begin_impl(sfmba_problem* p, const sfmba_options* opt, bool fused) {
     if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
     if (opt) p->shard_opt = *opt; else sfmba_options_default(&p->shard_opt);
     HIP_TRY(hipSetDevice(p->device));
     int rc = ensure_trace(p, std::min(std::max(p->shard_opt.max_iters, 0) + 2, 1 << 16));
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!fused) HIP_TRY(hipStreamSynchronize(p->stream));
     p->shard_t0 = now_seconds();
     p->shard_active = true;
     p->shard_host_iter = 0;
@@ -1135,21 +1143,29 @@ int sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt) {
     p->db.shared_weight = p->shard_rank == 0 ? 1.0 : 0.0;
     LMState st;
     init_state(p, st, p->shard_opt);
-    rc = upload_state(p, st);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
-    const size_t n = 6 * (size_t)p->ds.ncam;
     const int f32 = p->precision == SFMBA_PRECISION_F32J;
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
-    launch_clear_slots(p->stream, p->db);
-    launch_cam_setup<double>(p->stream, p->ds, p->db, p->cur);
-    launch_xnorm(p->stream, p->ds, p->db);
-    launch_colnorm_points_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32);
-    launch_colnorm_cams_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32);
+    if (fused) {
+        *p->h_state = st;
+        launch_begin(p->stream, p->ds, p->db, st);
+        launch_xnorm(p->stream, p->ds, p->db);
+        launch_colnorm_cams_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32, /*clear_udiag=*/false);
+    } else {
+        rc = upload_state(p, st);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
+        const size_t n = 6 * (size_t)p->ds.ncam;
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->db.cscale, n, 1.0);
+        launch_clear_slots(p->stream, p->db);
+        launch_cam_setup<double>(p->stream, p->ds, p->db, p->cur);
+        launch_xnorm(p->stream, p->ds, p->db);
+        launch_colnorm_points_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32);
+        launch_colnorm_cams_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32);
+    }
     HIP_TRY(hipMemsetAsync(p->db.bc, 0, sizeof(double) * p->ds.ld, p->stream));
     launch_shard_pack(p->stream, p->db, p->d_scal, 0, p->shard_rank);
     return SFMBA_OK;
 }
+int sfmba_shard_begin(sfmba_problem* p, const sfmba_options* opt) { return shard_begin_impl(p, opt, false); }
 
 int sfmba_shard_setup_finish(sfmba_problem* p) {
     if (!p || !p->shard_active) return fail(SFMBA_ERR_INVALID_ARG, "shard_begin was not called");
@@ -1271,13 +1287,89 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         const int arc = allreduce(ctx, buf, n, (void*)p->stream);
         return arc == 0 ? SFMBA_OK : fail(SFMBA_ERR_HIP, "all-reduce failed (rc " + std::to_string(arc) + ")");
     };
-    int rc = sfmba_shard_begin(p, opt);
+    sfmba_options o_in;
+    if (opt) o_in = *opt; else sfmba_options_default(&o_in);
+    const char* twophase_env = std::getenv("SFMBA_SHARD_TWO_PHASE");
+    const bool two_phase = (o_in.linear_solver == SFMBA_LINEAR_PCG || (o_in.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) &&
+                           !(twophase_env && twophase_env[0] == '0');
+    int rc = shard_begin_impl(p, opt, /*fused=*/two_phase);
     if (rc) return rc;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     if ((rc = reduce(sfmba_shard_setup_buf(p), sfmba_shard_setup_len(p)))) return rc;
     if ((rc = sfmba_shard_setup_finish(p))) return rc;
     const sfmba_options& o = p->shard_opt;
     int controls = 0;
+    if (two_phase) {
+        // CG solver: two all-reduces per linearisation (diagonal blocks + vectors, then the off-diagonal blocks of the preconditioned
+        // matrix, ba_kernels.hip k_shard_diag / k_shard_offdiag) and the same fused kernels as the one-GPU loop in run_solve:
+        // block factors and gauge vectors in k_finalize, transform in the pair pass, gated CG batches (no host wait on the solve).
+        const char* coarse_env = std::getenv("SFMBA_PCG_COARSE");
+        const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
+        const bool f32 = p->precision == SFMBA_PRECISION_F32J;
+        bool first_linear_solve = true;
+        int first_build = o.jacobi_scaling ? 1 : 2;          // the first point pass also forms the point scales
+        for (;;) {
+            if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+            p->db.pcg_F = p->solver.Sfull;
+            p->db.pcg_W = coarse_cg ? p->solver.W : nullptr;
+            p->db.pcg_F32 = nullptr;             // the partial blocks are summed in fp64; the streaming CG path gets its fp32 copy after the sum
+            float* F32 = f32 ? dense_pcg_want_f32(&p->solver) : nullptr;
+            p->solver.use_f32 = F32 != nullptr;
+            if (f32) { launch_point_build<float>(p->stream, p->ds, p->db, first_build); launch_cam_diag<float>(p->stream, p->ds, p->db); launch_schur_pairs<float>(p->stream, p->ds, p->db, 2); }
+            else { launch_point_build<double>(p->stream, p->ds, p->db, first_build); launch_cam_diag<double>(p->stream, p->ds, p->db); launch_schur_pairs<double>(p->stream, p->ds, p->db, 2); }
+            first_build = 0;
+            launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/false, p->shard_rank, p->shard_world);
+            if ((rc = reduce(p->d_red, shard_diag_len(p->ds)))) return rc;
+            launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/true, p->shard_rank, p->shard_world);
+            launch_finalize(p->stream, p->ds, p->db, 1);
+            p->db.shard_blocks = p->d_red;         // the pair pass stores its transformed blocks straight into the all-reduce buffer
+            if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 1); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 1);
+            p->db.shard_blocks = nullptr;
+            if ((rc = reduce(p->d_red, shard_offdiag_len(p->ds)))) return rc;
+            launch_shard_offdiag(p->stream, p->ds, p->solver.Sfull, p->d_red, /*unpack=*/true);
+            if (F32) launch_narrow_matrix(p->stream, p->solver.Sfull, F32, (long long)p->ds.d * p->ds.ld);
+            const int anchor = !o.pcg_anchored ? 0 : first_linear_solve ? 1 : 2;
+            first_linear_solve = false;
+            const int it0 = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
+                                            /*finish=*/false, /*hist_key=*/p->shard_host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/true, coarse_cg);
+            if (it0 < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+            DeviceBuffers dbu = p->db;
+            dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
+            dbu.cg_gate = p->solver.flags; dbu.cg_force = 0;
+            volatile int* mb = p->h_lm_mail;
+            for (;;) {
+                launch_cam_update(p->stream, p->ds, dbu);
+                if (f32) launch_point_update<float>(p->stream, p->ds, dbu); else launch_point_update<double>(p->stream, p->ds, dbu);
+                launch_shard_pack(p->stream, p->db, p->d_scal, 2, p->shard_rank);
+                if ((rc = reduce(sfmba_shard_scalars_buf(p), SFMBA_SHARD_SCALARS))) return rc;
+                dbu.shard_scal = p->d_scal;        // k_lm_control reads the sums from the all-reduced block
+                launch_control(p->stream, p->ds, dbu);
+                if (hipError_t le = hipGetLastError(); le != hipSuccess) return fail(SFMBA_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
+                ++controls;
+                if (wait_mailbox(mb, controls, p->stream) != 0) {
+                    const hipError_t se = hipStreamSynchronize(p->stream);
+                    return fail(SFMBA_ERR_HIP, std::string("sharded LM iteration did not complete: ") + (se != hipSuccess ? hipGetErrorString(se) : "no control post"));
+                }
+                if (mb[1] != -2) break;
+                // the CG batch was too short (identically on every rank: same matrix, same arithmetic): more iterations, then the trio again
+                if (dense_pcg_more(p->stream, &p->solver, 8, nullptr) == 0) dbu.cg_force = 1;
+            }
+            dense_pcg_note(&p->solver, p->shard_host_iter, mb[4]);
+            p->shard_sum.linear_iters += mb[4];
+            p->shard_host_iter = mb[3];
+            if (mb[1] != -1) {
+                p->shard_sum.termination = mb[1];
+                std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(mb[2]));
+                break;
+            }
+            if (p->shard_host_iter >= o.max_iters) {
+                p->shard_sum.termination = SFMBA_NO_CONVERGENCE;
+                std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(MSG_MAX_ITERS));
+                break;
+            }
+        }
+        return sfmba_shard_end(p, summary);
+    }
     for (;;) {
         if ((rc = sfmba_shard_partial_build(p))) return rc;
         if ((rc = reduce(sfmba_shard_reduce_buf(p), sfmba_shard_reduce_len(p)))) return rc;
