@@ -273,9 +273,12 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
             iters += summ["iterations"]
         barrier()
         dt = time.perf_counter() - t0
-        # the exchange step on its own: the packed upper triangle of S (+ rhs, diagonals, scalars), K back-to-back all-reduces
+        # the exchange step on its own, K back-to-back all-reduces of the large block.  CG path (csrc/ba_kernels.hip, k_shard_diag /
+        # k_shard_offdiag): (A) diagonal blocks + vectors + scalars, (B) the off-diagonal blocks of the preconditioned matrix, (C) 80 scalars
         L = be.L
-        n_red = int(L.sfmba_shard_reduce_len(be._h))
+        nc = prob.n_cam
+        ld = (int(L.sfmba_shard_setup_len(be._h)) - 80) // 2
+        n_a, n_red = 27 * nc + 3 * ld + 80, 18 * nc * (nc - 1)
         stream = C.c_void_p(L.sfmba_problem_stream(be._h))
         buf = C.c_void_p(L.sfmba_shard_reduce_buf(be._h))
         reps = 10
@@ -292,10 +295,11 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
         return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
                 "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
                 "ms_per_step": 1e3 * g_dt / steps, "lm_iterations_per_step": iters / steps,
-                "allreduce_bytes_per_lm_iteration": 8 * (n_red + 80), "allreduce_ms": 1e3 * g_ar,
+                "allreduce_bytes_per_lm_iteration": 8 * (n_a + n_red + 80), "allreduce_ms": 1e3 * g_ar,
                 "allreduce_GBps_algorithmic": 8.0 * n_red / g_ar / 1e9,
-                "collective": "ncclAllReduce(SUM, fp64) of [packed upper triangle of S | rhs | diagonals | scalars] on the solver stream, once per "
-                              "LM iteration, + an 80-double all-reduce of the trial-step scalars; every rank solves the reduced system redundantly",
+                "collective": "three ncclAllReduce(SUM, fp64) per LM iteration on the solver stream: [6x6 diagonal blocks | camera-focal column | rhs | "
+                              "diagonals | scalars] (%d doubles), the off-diagonal blocks of the block-Jacobi-preconditioned reduced matrix (%d doubles: the "
+                              "one timed here), 80 trial-step scalars; every rank runs the CG on the summed matrix redundantly" % (n_a, n_red),
                 "final_rms_px": float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)), "final_cost": summ["final_cost"],
                 "termination": summ["termination_name"], "linear_iters_per_step": summ["linear_iters"]}
     finally:

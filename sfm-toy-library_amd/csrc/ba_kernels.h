@@ -54,7 +54,7 @@ struct LMState {
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     double max_radius, min_radius, min_relative_decrease, min_diag, max_diag;
     int max_consecutive_invalid;
-    int pad1;
+    int retry;                // set by k_lm_control when it asked for more CG iterations (the LM iteration is not finished yet)
 };
 
 enum {

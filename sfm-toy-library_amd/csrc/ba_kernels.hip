@@ -389,7 +389,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <typename T>
-__global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode) {
+__global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode_flags) {
+    // bit 2: enqueued BEFORE the host saw the outcome of the control kernel in front of it (run_solve keeps the queue from draining
+    // across the mailbox round trip): nothing to do if the solve has ended there or the LM iteration is waiting for more CG
+    if ((ps_mode_flags & 4) && (db.st->termination != -1 || db.st->retry != 0)) return;
+    const int ps_mode = ps_mode_flags & 3;
     __shared__ T sv[WPB][64][PB_LD];
     __shared__ double sb[WPB][64][3];
     __shared__ T sl[WPB][64][6];
@@ -1603,7 +1607,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
     if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) {
         // the linear solve has not converged within the launches enqueued so far: tell the host (termination code -2),
         // touch nothing -- it will enqueue more CG iterations followed by the same three kernels
-        if (threadIdx.x == 0) { const int seq = ++st->mail_seq; lm_post(db.lm_mailbox, seq, -2, 0, st->iter); }
+        if (threadIdx.x == 0) { st->retry = 1; const int seq = ++st->mail_seq; lm_post(db.lm_mailbox, seq, -2, 0, st->iter); }
         return;
     }
     double trial2, model, step2, xnew2, bad_trial;
@@ -1618,6 +1622,7 @@ __global__ void k_lm_control(DeviceBuffers db) {
         bad_trial = slots_take(db, ACC_BAD_TRIAL);
     }
     if (threadIdx.x != 0) return;
+    st->retry = 0;
     st->lin_info = *db.lin_info;
     *db.lin_info = 0;
     const int seq = ++st->mail_seq;

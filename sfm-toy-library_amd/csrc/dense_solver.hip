@@ -426,6 +426,65 @@ __global__ __launch_bounds__(256) void k_chol_backstep(const double* __restrict_
     if (tid < NB) y[ib + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
+// Back substitution in ONE launch (fused path, <= CHOL_FUSED_MAX_BLOCKS block columns): workgroup j owns x_j = M_j (y_j - sum_{i>j} L_ij^T x_i).
+// It prefetches its tiles L_ij and M_j, then consumes the x_i in the order they appear (i = nblk-1 ... j+1), each announced by a flag
+// of the workgroup that produced it.  Workgroup j waits only for workgroups dispatched BEFORE it (block index nblk-1-j), so the
+// chain cannot deadlock however few of them are resident.  Per block column the chain is flag -> 64x64 product -> M_j product ->
+// flag (~2.5 us) instead of a kernel boundary plus the same products (4.2 us), and y = L(d, :) is read in place.
+// flags[j] == epoch means x_j of THIS solve is in memory (the epoch changes with every call: no reset pass).
+__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ A, int ld, int d, const double* __restrict__ minv,
+                                                        double* __restrict__ x, int* __restrict__ flags, int epoch, int nblk) {
+    __shared__ double xi[NB];
+    __shared__ double part[4][NB];
+    __shared__ double v[NB];
+    const int j = nblk - 1 - (int)blockIdx.x;
+    const int tid = threadIdx.x, c = tid & (NB - 1), seg = tid >> 6;
+    const int jb = j * NB;
+    const double* M = minv + (size_t)j * NB * NB;
+    double mreg[16], t[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) mreg[m] = M[c + (size_t)(seg * 16 + m) * NB];          // row c of M_j, this thread's 16 columns
+    if (nblk - 1 > j) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) t[m] = AT((nblk - 1) * NB + seg * 16 + m, jb + c);  // column c of L_ij, this thread's 16 rows
+    }
+    double acc = 0.0;
+    for (int i = nblk - 1; i > j; --i) {
+        double tn[16];
+        if (i - 1 > j) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) tn[m] = AT((i - 1) * NB + seg * 16 + m, jb + c);
+        }
+        if (tid == 0) { while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); }
+        __syncthreads();
+        if (tid < NB) xi[tid] = __hip_atomic_load(&x[i * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc = fma(t[m], xi[seg * 16 + m], acc);
+        if (i - 1 > j) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) t[m] = tn[m];
+        }
+    }
+    part[seg][c] = acc;
+    __syncthreads();
+    if (tid < NB) v[tid] = (jb + tid < d ? AT(d, jb + tid) : 0.0) - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+    __syncthreads();
+    double sx = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) sx = fma(mreg[m], v[seg * 16 + m], sx);
+    __syncthreads();
+    part[seg][c] = sx;
+    __syncthreads();
+    if (tid < NB) {
+        const double xr = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        __hip_atomic_store(&x[jb + tid], jb + tid < d ? xr : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&flags[j], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof) {
     const int ld = ws->ld, d = ws->d, nblk = ld / NB;
     { ProfScope ps(prof, KID_CHOL_AUGMENT, s);
@@ -449,6 +508,13 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
         const int m = nblk - k - 1;
         if (m > 0) { ProfScope ps(prof, KID_CHOL_UPDATE, s);
           hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k); }
+    }
+    static const bool backsolve_env = [] { const char* e = std::getenv("SFMBA_CHOL_BACKSOLVE"); return !(e && e[0] == '0'); }();
+    if (fused_env && backsolve_env && nblk <= CHOL_FUSED_MAX_BLOCKS && nblk <= 64) {
+        ProfScope ps(prof, KID_CHOL_BACKSTEP, s);
+        ws->back_epoch = ws->back_epoch == 0x7fffffff ? 1 : ws->back_epoch + 1;
+        hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, s, S, ld, d, ws->minv, rhs, ws->back_flags, ws->back_epoch, nblk);
+        return;
     }
     { ProfScope ps(prof, KID_CHOL_EXTRACT, s);
       hipLaunchKernelGGL(k_extract_y, dim3((ld + 255) / 256), dim3(256), 0, s, S, ld, d, ws->y); }
@@ -1698,6 +1764,9 @@ int dense_solver_create(DenseSolver* ws, int d, int ld, DeviceArena* arena, char
     const int nblk = ld / NB;
     if (ws_alloc(ws, &ws->minv, sizeof(double) * (size_t)nblk * NB * NB)) return -1;
     if (ws_alloc(ws, &ws->y, sizeof(double) * ld)) return -1;
+    if (ws_alloc(ws, &ws->back_flags, sizeof(int) * 64)) return -1;
+    if (hipMemset(ws->back_flags, 0, sizeof(int) * 64) != hipSuccess) return -1;
+    ws->back_epoch = 0;
     if (ws_alloc(ws, &ws->vec, sizeof(double) * 9 * (size_t)ld)) return -1;
     if (ws_alloc(ws, &ws->part, sizeof(double) * 2 * PCG_NPART * PCG_PART)) return -1;
     if (ws_alloc(ws, &ws->binv, sizeof(double) * 36 * (size_t)(ld / 6 + 2))) return -1;
@@ -1722,6 +1791,7 @@ void dense_solver_destroy(DenseSolver* ws) {
     if (!ws->arena) {
         if (ws->minv) (void)hipFree(ws->minv);
         if (ws->y) (void)hipFree(ws->y);
+        if (ws->back_flags) (void)hipFree(ws->back_flags);
         if (ws->vec) (void)hipFree(ws->vec);
         if (ws->part) (void)hipFree(ws->part);
         if (ws->binv) (void)hipFree(ws->binv);

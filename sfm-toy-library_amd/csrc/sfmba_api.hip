@@ -300,6 +300,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // no device-wide spin barrier in it.
     const bool persistent_cg = pcg_env && pcg_env[0] == '1';
     int launched_controls = 0;
+    const char* spec_env = std::getenv("SFMBA_EARLY_LINEARISE");
+    const bool speculate = !(spec_env && spec_env[0] == '0') && !p->prof.on;
+    bool build_enqueued = false;
     std::vector<int> lin_hist;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
@@ -315,8 +318,11 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             p->db.pcg_F32 = (p->precision == SFMBA_PRECISION_F32J && f32_matrix) ? dense_pcg_want_f32(&p->solver) : nullptr;
             p->solver.use_f32 = p->db.pcg_F32 != nullptr;
         }
-        { ProfScope ps(prof, KID_POINT_BUILD, p->stream);
-          launch_point_build<T>(p->stream, p->ds, p->db, first_linearisation ? (o.jacobi_scaling ? 1 : 2) : 0); }
+        if (!build_enqueued) {
+            ProfScope ps(prof, KID_POINT_BUILD, p->stream);
+            launch_point_build<T>(p->stream, p->ds, p->db, first_linearisation ? (o.jacobi_scaling ? 1 : 2) : 0);
+        }
+        build_enqueued = false;
         first_linearisation = false;
         { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
         launch_schur_pairs<T>(p->stream, p->ds, p->db, 2);      // duplicate pairs inside diagonal blocks (usually none)
@@ -364,6 +370,14 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             // every launch of this LM iteration is in the queue: a failed launch must not leave the host waiting for a post
             if (hipError_t le = hipGetLastError(); le != hipSuccess)
                 return fail(SFMBA_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
+            // The next linearisation's first kernel goes into the queue BEFORE the host waits for the control kernel's verdict: the
+            // mailbox round trip plus the launch latency into an empty queue were 16-19 us of idle GPU per LM iteration.  The kernel
+            // looks at the LM state itself and returns at once if the solve ended or the iteration wants more CG first (bit 2).
+            if (speculate && host_iter + 2 <= o.max_iters) {
+                ProfScope ps(prof, KID_POINT_BUILD, p->stream);
+                launch_point_build<T>(p->stream, p->ds, p->db, 4);
+                build_enqueued = true;
+            }
             // wait for k_lm_control's mailbox post (system-scope stores to host-mapped memory)
             volatile int* mb = p->h_lm_mail;
             const int wrc = wait_mailbox(mb, launched_controls, p->stream);
@@ -374,7 +388,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             }
             if (mb[1] == -2) {
                 // the CG batch was too short: enqueue more iterations (or force the step once max_iters are spent), then the trio again
+                // (the early linearisation kernel behind that control kernel has returned without doing anything)
                 if (dense_pcg_more(p->stream, &p->solver, 8, prof) == 0) dbu.cg_force = 1;
+                build_enqueued = false;
                 continue;
             }
             lm_done = true;
