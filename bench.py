@@ -324,7 +324,7 @@ def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precisio
 
 
 PMC_KERNEL_NAMES = {"pcg_iter": "k_pcg_iter_fast", "schur_pairs": "k_schur_pairs", "cam_diag": "k_cam_diag",
-                    "point_build": "k_point_build", "point_update": "k_point_update", "chol_panel": "k_chol_panel",
+                    "point_build": "k_point_build", "point_update": "k_point_update", "chol_panel": "k_chol_step",
                     "chol_update": "k_chol_update"}
 
 
@@ -357,7 +357,8 @@ LIMITERS = {
     "cam_diag": "L2 misses on the camera-major record gather (latency)",
     "point_build": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
     "point_update": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
-    "chol_panel": "serial pivot chain (latency)", "chol_update": "fp64 MFMA, short launches",
+    "chol_panel": "the serial chain of 64 pivots in the diagonal tile (one workgroup: ~250 cycles per pivot) + one launch boundary per block column",
+    "chol_update": "fp64 MFMA, short launches",
 }
 
 
@@ -454,8 +455,10 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
         "chol_update": {"bound": "mfma", "flops": 2.0 * d * d * d / 3.0 / max(nblk - 1, 1), "peak_tflops": 78.6,
                         "note": "fp64 trailing update on v_mfma_f64_16x16x4_f64; d^3/3 flops of the factorisation spread over its launches; "
                                 "peak = fp64 matrix 78.6 TF (171 tiles of 64^3 at most: latency bound, not MFMA bound)"},
-        "chol_panel": {"bound": "mfma", "flops": 2.0 * d * nb * nb / 2.0, "peak_tflops": 78.6,
-                       "note": "64-wide panel: diagonal factor + triangular solves (latency bound, not MFMA bound)"},
+        "chol_panel": {"bound": "mfma", "flops": 2.0 * d * d * d / 3.0 / max(nblk, 1), "peak_tflops": 78.6,
+                       "note": "k_chol_step, one launch per block column of 64: panel solve as GEMMs with the inverse of the diagonal factor, trailing "
+                               "update and the in-LDS factorisation of the next diagonal tile; d^3/3 flops of the factorisation spread over its launches; "
+                               "peak = fp64 matrix 78.6 TF (latency bound on the pivot chain, not MFMA bound)"},
     }
 
 
