@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 // Step k, workgroup (i, j) with i >= j > k owns tile A_ij:
 //   L_ik = A_ik M_k,  L_jk = A_jk M_k      (M_k = L_kk^-T from the previous launch: the triangular solves are GEMMs on the matrix
 //                                           cores, formed redundantly by every workgroup that needs them -- 64^3 flops, ~1 us)
-//   A_ij -= L_ik L_jk^T                    (written back; the workgroups of block column j = k + 1 also store L_ik: final values)
+//   A_ij -= L_ik L_jk^T                    (written back; the panel tiles A_ik themselves stay as they are: L_ik = A_ik M_k is implied)
 //   (i, j) = (k+1, k+1) only: factor the updated tile in LDS and form M_{k+1} on the way (chol_tile.h), store both.
 // The factorisation of the diagonal tile is the serial chain of the whole algorithm (64 dependent pivots); everything else of a
 // step hangs off it with one launch boundary instead of two, and no workgroup but that one ever executes the 64-step sweep
@@ -311,12 +311,9 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, in
         __syncthreads();
         CS_STAMP(2);
         const double* Lj = ii != jj ? B2 : B1;
-        // block column k + 1: L_ik is final, store it (the diagonal workgroup does that later, under its first panel sweep)
-        if (jj == 0 && !diag) {
-#pragma unroll
-            for (int m = 0; m < NB / 4; ++m) { const int r = tid & (NB - 1), c = (tid >> 6) + 4 * m; AT(ib + r, kb + c) = B1[r * CT_LDT + c]; }
-        }
-        CS_STAMP(3);
+        // (L_ik is NOT stored: the other workgroups of this launch still read the raw A_ik -- tile (i, k) belongs to every workgroup of
+        // block row i and to workgroup (i', i) -- and nobody needs it later: the back substitution works on the raw panel tiles,
+        // sum_i L_ij^T x_i = M_j^T sum_i A_ij^T x_i, see k_chol_backsolve)
         // A_ij -= L_ik L_jk^T, product formed transposed: D[m = column][n = row] = sum_t L_jk[c][t] L_ik[r][t]
         if (!diag) {
             double bv[NB / 4];
@@ -356,10 +353,6 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, in
     }
     __syncthreads();
     CS_STAMP(4);
-    if (k >= 0 && w != 0) {
-        // L_{k+1,k}: stored by waves 1..3 while wave 0 sweeps the first panel (they would wait at its barrier anyway)
-        for (int idx = tid - 64; idx < NB * NB; idx += 192) { const int r = idx & (NB - 1), c = idx >> 6; AT(ib + r, kb + c) = B1[r * CT_LDT + c]; }
-    }
     const int bad = chol_tile_factor(B0, X, ED, V, ib, d);
     CS_STAMP(5);
     if (bad != 0 && lane == 0 && w == 0) atomicCAS(info, 0, bad);
@@ -426,12 +419,15 @@ __global__ __launch_bounds__(256) void k_chol_backstep(const double* __restrict_
     if (tid < NB) y[ib + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
 }
 
-// Back substitution in ONE launch (fused path, <= CHOL_FUSED_MAX_BLOCKS block columns): workgroup j owns x_j = M_j (y_j - sum_{i>j} L_ij^T x_i).
-// It prefetches its tiles L_ij and M_j, then consumes the x_i in the order they appear (i = nblk-1 ... j+1), each announced by a flag
-// of the workgroup that produced it.  Workgroup j waits only for workgroups dispatched BEFORE it (block index nblk-1-j), so the
-// chain cannot deadlock however few of them are resident.  Per block column the chain is flag -> 64x64 product -> M_j product ->
-// flag (~2.5 us) instead of a kernel boundary plus the same products (4.2 us), and y = L(d, :) is read in place.
-// flags[j] == epoch means x_j of THIS solve is in memory (the epoch changes with every call: no reset pass).
+// Back substitution in ONE launch (fused path, <= CHOL_FUSED_MAX_BLOCKS block columns).  The fused factorisation leaves the
+// off-diagonal tiles of block column j as the RAW (fully updated) A_ij with L_ij = A_ij M_j implied, and the right-hand side as row d
+// of the last block row, so   y_j = M_j^T a_j (a_j = A(d, column block j)),   sum_{i>j} L_ij^T x_i = M_j^T sum_{i>j} A_ij^T x_i   and
+//   x_j = M_j M_j^T (a_j - sum_{i>j} A_ij^T x_i)                  (last block column: x = M y with y = row d of the stored factor).
+// Workgroup j prefetches its tiles A_ij and M_j, then consumes the x_i in the order they appear (i = nblk-1 ... j+1), each announced
+// by a flag of the workgroup that produced it.  Workgroup j waits only for workgroups dispatched BEFORE it (block index nblk-1-j),
+// so the chain cannot deadlock however few of them are resident.  Per block column the chain is flag -> 64x64 product -> two M_j
+// products -> flag instead of a kernel boundary plus the same products.  flags[j] == epoch means x_j of THIS solve is in memory
+// (the epoch changes with every call: no reset pass).
 __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ A, int ld, int d, const double* __restrict__ minv,
                                                         double* __restrict__ x, int* __restrict__ flags, int epoch, int nblk) {
     __shared__ double xi[NB];
@@ -440,13 +436,17 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
     const int j = nblk - 1 - (int)blockIdx.x;
     const int tid = threadIdx.x, c = tid & (NB - 1), seg = tid >> 6;
     const int jb = j * NB;
+    const bool last = j == nblk - 1;
     const double* M = minv + (size_t)j * NB * NB;
-    double mreg[16], t[16];
+    double mrow[16], mcol[16], t[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) mreg[m] = M[c + (size_t)(seg * 16 + m) * NB];          // row c of M_j, this thread's 16 columns
-    if (nblk - 1 > j) {
+    for (int m = 0; m < 16; ++m) {
+        mrow[m] = M[c + (size_t)(seg * 16 + m) * NB];          // row c of M_j, this thread's 16 columns
+        mcol[m] = M[(seg * 16 + m) + (size_t)c * NB];          // column c of M_j, this thread's 16 rows
+    }
+    if (!last) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) t[m] = AT((nblk - 1) * NB + seg * 16 + m, jb + c);  // column c of L_ij, this thread's 16 rows
+        for (int m = 0; m < 16; ++m) t[m] = AT((nblk - 1) * NB + seg * 16 + m, jb + c);  // column c of A_ij, this thread's 16 rows
     }
     double acc = 0.0;
     for (int i = nblk - 1; i > j; --i) {
@@ -468,11 +468,23 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
     }
     part[seg][c] = acc;
     __syncthreads();
+    // w = a_j - sum (raw row d of the panel tile; in the last block column row d of the stored factor, which is y itself)
     if (tid < NB) v[tid] = (jb + tid < d ? AT(d, jb + tid) : 0.0) - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
     __syncthreads();
+    if (!last) {
+        // y-part: v <- M_j^T w
+        double sy = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sy = fma(mcol[m], v[seg * 16 + m], sy);
+        __syncthreads();
+        part[seg][c] = sy;
+        __syncthreads();
+        if (tid < NB) v[tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        __syncthreads();
+    }
     double sx = 0.0;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) sx = fma(mreg[m], v[seg * 16 + m], sx);
+    for (int m = 0; m < 16; ++m) sx = fma(mrow[m], v[seg * 16 + m], sx);
     __syncthreads();
     part[seg][c] = sx;
     __syncthreads();
@@ -483,6 +495,30 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
     __threadfence();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&flags[j], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The fused factorisation followed by the step-by-step back substitution (SFMBA_CHOL_BACKSOLVE=0, or more than 64 block columns):
+// that one expects L_ik in place, so the panel tiles are multiplied by M_k once, after the last step (one workgroup per tile).
+__global__ __launch_bounds__(256) void k_chol_apply_minv(double* __restrict__ A, int ld, int nblk, const double* __restrict__ minv) {
+    __shared__ double Ti[NB][NB + 1];
+    __shared__ double Mk[NB][NB + 1];
+    // tile (i, k), i > k, from the linear index
+    const int t = blockIdx.x;
+    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    while (i * (i + 1) / 2 > t) --i;
+    const int k = t - i * (i + 1) / 2;
+    ++i;                                            // (i - 1, k) enumerates the lower triangle incl. its diagonal: shift to i > k
+    if (i >= nblk) return;
+    const double* M = minv + (size_t)k * NB * NB;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) { const int r = idx % NB, c = idx / NB; Ti[r][c] = AT(i * NB + r, k * NB + c); Mk[r][c] = M[r + c * NB]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        const int r = idx % NB, c = idx / NB;
+        double sum = 0.0;
+        for (int q = 0; q <= c; ++q) sum = fma(Ti[r][q], Mk[q][c], sum);       // M_k is upper triangular
+        AT(i * NB + r, k * NB + c) = sum;
+    }
 }
 
 void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof) {
@@ -516,6 +552,8 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
         hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, s, S, ld, d, ws->minv, rhs, ws->back_flags, ws->back_epoch, nblk);
         return;
     }
+    if (fused_env && nblk <= CHOL_FUSED_MAX_BLOCKS && nblk > 1)
+        hipLaunchKernelGGL(k_chol_apply_minv, dim3(nblk * (nblk - 1) / 2), dim3(256), 0, s, S, ld, nblk, ws->minv);
     { ProfScope ps(prof, KID_CHOL_EXTRACT, s);
       hipLaunchKernelGGL(k_extract_y, dim3((ld + 255) / 256), dim3(256), 0, s, S, ld, d, ws->y); }
     for (int k = nblk - 1; k >= 0; --k) {

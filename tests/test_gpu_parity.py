@@ -130,7 +130,9 @@ def test_reduced_system_without_jacobi_scaling(capi, sfm, oracle):
 # ---------------------------------------------------------------------------------------------
 # dense reduced-system solver in isolation
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 7, 63, 64, 121, 200, 1201])
+# 1215 / 1216: the augmented row fills the last tile / needs a tile of its own; 2559 / 2561: last size of the one-launch-per-block-column
+# factorisation (40 block columns) / first size of the two-kernel form
+@pytest.mark.parametrize("n", [1, 7, 63, 64, 121, 200, 1201, 1215, 1216, 2559, 2561])
 def test_dense_cholesky(capi, n):
     rng = np.random.default_rng(n)
     M = rng.normal(size=(n, n))
@@ -140,6 +142,39 @@ def test_dense_cholesky(capi, n):
     assert info == 0
     ref = np.linalg.solve(A, b)
     assert np.allclose(x, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cond", [1e4, 1e8, 1e11])
+def test_dense_cholesky_ill_conditioned(capi, cond):
+    """The fused factorisation solves the panel with the explicit inverse of the 64 x 64 diagonal factor (a GEMM on the matrix
+    cores) instead of a triangular sweep: the backward error must stay at the level of a plain Cholesky (numpy's, here) also when
+    the reduced system is as badly conditioned as a gauge-free BA makes it (1e8 and beyond)."""
+    n = 640
+    rng = np.random.default_rng(int(np.log10(cond)))
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    A = (Q * np.logspace(0, -np.log10(cond), n)) @ Q.T
+    A = 0.5 * (A + A.T)
+    b = A @ rng.normal(size=n)
+    x, info, _ = capi.dense_spd_solve(A, b, method=0)
+    assert info == 0
+    ref = np.linalg.solve(A, b)
+    res = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
+    res_ref = np.linalg.norm(A @ ref - b) / np.linalg.norm(b)
+    assert res <= max(50 * res_ref, 1e-13), (res, res_ref)
+
+
+@pytest.mark.parametrize("env", [{"SFMBA_CHOL_BACKSOLVE": "0"}, {"SFMBA_CHOL_FUSED": "0"}])
+def test_dense_cholesky_fallback_paths(env):
+    """The step-by-step back substitution behind the fused factorisation, and the two-kernel factorisation (the switches are read
+    once per process: a child process each)."""
+    import subprocess, sys, os
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from sfm_toy_library_amd import capi\n"
+            "rng = np.random.default_rng(5); n = 1201; M = rng.normal(size=(n, n)); A = M @ M.T + n * np.eye(n); b = rng.normal(size=n)\n"
+            "x, info, _ = capi.dense_spd_solve(A, b, method=0); ref = np.linalg.solve(A, b)\n"
+            "assert info == 0 and np.allclose(x, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max()), np.abs(x - ref).max()\nprint('ok')\n"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_dense_cholesky_flags_indefinite(capi):
