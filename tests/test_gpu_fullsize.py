@@ -255,3 +255,20 @@ def test_deterministic_mode_is_bitwise_reproducible(capi, sfm, cfg3, monkeypatch
     a = capi.solve(small, capi.default_options(max_seconds=0.0))
     b = capi.solve(small, capi.default_options(max_seconds=0.0))
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3]["final_cost"] == b[3]["final_cost"]
+
+
+def test_early_linearisation_launch_changes_nothing(capi, sfm, cfg3, monkeypatch):
+    """run_solve enqueues the next linearisation's first kernel before it waits for the control kernel's verdict (the kernel checks
+    the LM state itself).  Same kernels in the same order either way: the trajectory must not depend on the switch, also when the
+    iteration limit cuts the solve short (no early launch is allowed past the limit) and when CG batches come up short (the early
+    kernel must stand down while the iteration waits for more CG)."""
+    for okw in (dict(), dict(max_iters=2), dict(pcg_max_iters=200, pcg_tolerance=1e-13, pcg_anchored=0)):
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("SFMBA_EARLY_LINEARISE", flag)
+            out[flag] = capi.solve(cfg3, capi.default_options(max_seconds=0.0, linear_solver=1, precision=1, **okw))
+        (cam_a, pt_a, f_a, a, tr_a), (cam_b, pt_b, f_b, b, tr_b) = out["1"], out["0"]
+        assert a["termination_name"] == b["termination_name"] and a["iterations"] == b["iterations"]
+        assert abs(a["final_cost"] - b["final_cost"]) <= 1e-9 * b["final_cost"]
+        assert [r["step_is_successful"] for r in tr_a] == [r["step_is_successful"] for r in tr_b]
+        assert np.abs(cam_a - cam_b).max() < 1e-6 and np.abs(pt_a - pt_b).max() < 1e-6

@@ -105,3 +105,29 @@ def test_one_rank_rccl_communicator_and_native_loop(sfm, oracle):
             assert np.abs(cam - want[0]).max() < 1e-6 and np.abs(pt - want[1]).max() < 1e-6
     finally:
         comm.close(); be.close()
+
+
+@pytest.mark.parametrize("linear", [0, 1])
+def test_sharded_exchange_variants_agree(sfm, monkeypatch, linear):
+    """CG path: two all-reduces per linearisation (diagonal blocks + vectors, then the preconditioned off-diagonal blocks) against
+    the single all-reduce of the whole system followed by the transform (SFMBA_SHARD_TWO_PHASE=0); and both against the unsharded
+    solve.  linear = 0: the exact solver (always the single all-reduce) against the unsharded exact solve."""
+    from sfm_toy_library_amd import capi
+    from sfm_toy_library_amd.sharded import HipShardBackend, solve_sharded_native
+    prob = sfm.make_problem("cfg3", n_cam=60, n_pt=8000, seed=5)
+    opt = capi.default_options(max_seconds=0.0, linear_solver=linear, precision=1)
+    ref_cam, ref_pt, _, ref, _ = capi.solve(prob, opt)
+    be = HipShardBackend(prob, 0, 1, device=0, precision=1)
+    try:
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("SFMBA_SHARD_TWO_PHASE", flag)
+            be.reset()
+            s = solve_sharded_native(be, opt, comm=None)
+            got[flag] = (s, be.get_params())
+            assert s["termination_name"] == ref["termination_name"] and s["iterations"] == ref["iterations"]
+            assert abs(s["final_cost"] - ref["final_cost"]) <= 1e-9 * ref["final_cost"]
+            assert np.abs(got[flag][1][0] - ref_cam).max() < 2e-6 and np.abs(got[flag][1][1] - ref_pt).max() < 2e-6
+        assert np.abs(got["1"][1][0] - got["0"][1][0]).max() < 2e-6
+    finally:
+        be.close()
