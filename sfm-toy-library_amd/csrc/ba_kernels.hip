@@ -82,6 +82,44 @@ __device__ double slots_take(const DeviceBuffers& db, int which) {
     return wave_sum(v);
 }
 
+// N accumulators at once: all slot loads in flight together, then the clears, then the N butterflies in lock step.  Back-to-back
+// slots_take() calls cannot overlap (the clearing stores of one fence off the loads of the next): four of them were most of
+// k_finalize's 14 us (the focal wave), five of them of k_lm_control's 7.  Same summation order as slots_take (bitwise identical).
+template <int N>
+__device__ __forceinline__ void slots_take_n(const DeviceBuffers& db, const int (&which)[N], double (&out)[N]) {
+    const int lane = threadIdx.x & 63;
+    double v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = 0.0;
+    for (int i0 = lane; i0 < db.nslot; i0 += 512) {
+        double t[N][8];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; t[k][u] = (u == 0 || db.nslot > 64) ? db.slots[(size_t)(i < db.nslot ? i : lane) * SLOT_W + which[k]] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u;
+                if (i < db.nslot) {
+                    if (which[k] == ACC_GMAX) v[k] = (t[k][u] > v[k] || t[k][u] != t[k][u]) ? t[k][u] : v[k]; else v[k] += t[k][u];
+                    db.slots[(size_t)i * SLOT_W + which[k]] = 0.0;
+                }
+            }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double o = __shfl_xor(v[k], off, 64);
+            if (which[k] == ACC_GMAX) v[k] = (o > v[k] || o != o) ? o : v[k]; else v[k] += o;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = v[k];
+}
+
 // ------------------------------------------------------------------------------------------
 // camera tables
 // ------------------------------------------------------------------------------------------
@@ -1127,9 +1165,10 @@ template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const
 // after a linearisation: initial cost (iteration 0), gradient tolerance, evaluation failure.  One wave.
 __device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db) {
     LMState* st = db.st;
-    const double gmax = slots_take(db, ACC_GMAX);
-    const double bad_lin = slots_take(db, ACC_BAD_LIN);
-    const double lin_cost = slots_take(db, ACC_LIN_COST);
+    const int lin_acc[3] = { ACC_GMAX, ACC_BAD_LIN, ACC_LIN_COST };
+    double lin[3];
+    slots_take_n<3>(db, lin_acc, lin);
+    const double gmax = lin[0], bad_lin = lin[1], lin_cost = lin[2];
     if ((threadIdx.x & 63) != 0) return;
     if (st->termination != -1) return;
     if (bad_lin != 0.0) {
@@ -1257,8 +1296,10 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
     const LMState* st = db.st;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
         // focal-focal entries were accumulated in the slotted buffer: the last wave of the last block owns them
-        const double sff = slots_take(db, ACC_SFF), rhsf = slots_take(db, ACC_RHSF);
-        const double udf = slots_take(db, ACC_UDF), bcf = slots_take(db, ACC_BCF);
+        const int foc_acc[4] = { ACC_SFF, ACC_RHSF, ACC_UDF, ACC_BCF };
+        double foc[4];
+        slots_take_n<4>(db, foc_acc, foc);
+        const double sff = foc[0], rhsf = foc[1], udf = foc[2], bcf = foc[3];
         if (threadIdx.x == 192) {
             const int fo = ds.d - 1;
             const double dd = fmin(fmax(udf, st->min_diag), st->max_diag) / st->radius;
@@ -1615,11 +1656,10 @@ __global__ void k_lm_control(DeviceBuffers db) {
         // sharded solve: the sums over the ranks sit in the all-reduced scalar block (k_shard_pack emptied the slots)
         trial2 = db.shard_scal[0]; model = db.shard_scal[1]; step2 = db.shard_scal[2]; xnew2 = db.shard_scal[3]; bad_trial = db.shard_scal[4];
     } else {
-        trial2 = slots_take(db, ACC_TRIAL_COST);
-        model = slots_take(db, ACC_MODEL);
-        step2 = slots_take(db, ACC_STEP2);
-        xnew2 = slots_take(db, ACC_XNEW2);
-        bad_trial = slots_take(db, ACC_BAD_TRIAL);
+        const int ctl_acc[5] = { ACC_TRIAL_COST, ACC_MODEL, ACC_STEP2, ACC_XNEW2, ACC_BAD_TRIAL };
+        double ctl[5];
+        slots_take_n<5>(db, ctl_acc, ctl);
+        trial2 = ctl[0]; model = ctl[1]; step2 = ctl[2]; xnew2 = ctl[3]; bad_trial = ctl[4];
     }
     if (threadIdx.x != 0) return;
     st->retry = 0;
