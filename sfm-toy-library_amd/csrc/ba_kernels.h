@@ -151,7 +151,8 @@ template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure
 void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling, bool clear_udiag = true,
                                          bool points = true, bool finish_xnorm = false);
-void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, const LMState& st);
+void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, const LMState& st, const double* cam_src = nullptr,
+                  const double* pts_src = nullptr);
 template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
                                              int ps_mode = 0 /* 0: point scales from db.pscale; 1 / 2: form them here (Jacobi / unit) */);
 // mode 0: off-diagonal blocks of S (upper triangle);  mode 1: the same blocks written straight into S~ = Lb^-1 S Lb^-T

@@ -183,22 +183,28 @@ template void launch_cam_setup<double>(hipStream_t, const DeviceStructure&, cons
 // First launch of a solve: the LM state arrives as a kernel argument (no H2D copy); the same launch clears the linear-solver
 // status word, the Jacobi scales, the column-norm accumulators and the slotted accumulators and builds the camera tables
 // (instead of a copy, two memsets, a fill kernel, k_cam_setup and k_iter0).
-__global__ void k_begin(LMState st, DeviceStructure ds, DeviceBuffers db) {
+// cam_src / pts_src non-null: a pending sfmba_problem_reset() -- the initial parameters are copied into the current buffers by this
+// launch (instead of two device-to-device copies and a state upload enqueued ahead of it: three more host calls in front of a solve
+// whose first kernels are all a few microseconds long)
+__global__ void k_begin(LMState st, DeviceStructure ds, DeviceBuffers db, const double* __restrict__ cam_src, const double* __restrict__ pts_src) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e == 0) { *db.st = st; *db.lin_info = 0; *db.fin_counter = 0; }
     if (e < 6 * ds.ncam) db.cscale[e] = 1.0;
     if (e < ds.ld) db.udiag[e] = 0.0;
     for (int k = e; k < db.nslot * SLOT_W; k += gridDim.x * blockDim.x) db.slots[k] = 0.0;
+    if (pts_src) { for (size_t k = e; k < (size_t)3 * ds.npt; k += (size_t)gridDim.x * blockDim.x) db.pts[st.cur][k] = pts_src[k]; }
     if (e < ds.ncam) {
         double c6[6], ct[CT_STRIDE];
-        for (int k = 0; k < 6; ++k) c6[k] = db.cam[st.cur][6 * e + k];
+        for (int k = 0; k < 6; ++k) c6[k] = cam_src ? cam_src[6 * e + k] : db.cam[st.cur][6 * e + k];
+        if (cam_src) { for (int k = 0; k < 6; ++k) db.cam[st.cur][6 * e + k] = c6[k]; }
         make_cam_table(c6, nullptr, ct);
         for (int k = 0; k < CT_STRIDE; ++k) db.camtab[st.cur][cam_tab_index(k, e, ds.ncam)] = ct[k];
     }
 }
-void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, const LMState& st) {
-    const int nb = std::max(std::max(6 * ds.ncam, ds.ld), NSLOT * SLOT_W);      // (a larger slot array is cleared by a strided loop)
-    hipLaunchKernelGGL(k_begin, dim3((nb + 255) / 256), dim3(256), 0, s, st, ds, db);
+void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, const LMState& st, const double* cam_src, const double* pts_src) {
+    int nb = std::max(std::max(6 * ds.ncam, ds.ld), NSLOT * SLOT_W);      // (a larger slot array is cleared by a strided loop)
+    if (pts_src) nb = std::max(nb, std::min(3 * ds.npt, 1 << 20));         // one point coordinate per thread up to 4096 workgroups
+    hipLaunchKernelGGL(k_begin, dim3((nb + 255) / 256), dim3(256), 0, s, st, ds, db, cam_src, pts_src);
 }
 
 // ||x||^2 of the current parameters -> acc[ACC_XNEW2]

@@ -149,6 +149,8 @@ struct sfmba_problem {
     int* d_blk_ptr = nullptr;
     int* d_cam_chunk_ptr = nullptr;
     bool deterministic = false;             // SFMBA_DETERMINISTIC=1 at build time
+    bool reset_pending = false;             // sfmba_problem_reset() was called: the initial parameters are restored by the next solve's first kernel
+                                            // (or by flush_reset() if anything else looks at the problem first)
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pwg_ptr = nullptr;
     double* d_facc = nullptr;
@@ -276,7 +278,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     init_state(p, st, o);
     *p->h_state = st;
     { ProfScope ps(p->prof.on ? &p->prof : nullptr, KID_SETUP, p->stream);
-      launch_begin(p->stream, p->ds, p->db, st);
+      launch_begin(p->stream, p->ds, p->db, st, p->reset_pending ? p->d_cam0 : nullptr, p->reset_pending ? p->d_pts0 : nullptr);
+      p->reset_pending = false;
       launch_linearise_setup<T>(p, o.jacobi_scaling, /*begun=*/true); }
 
     int term = -1, msg = MSG_NONE;
@@ -522,6 +525,7 @@ int sfmba_problem_create_sharded(int device, int precision, int n_cam, const dou
 }
 
 int sfmba_problem_reset(sfmba_problem* p);
+static int flush_reset(sfmba_problem* p);
 
 // Observations a (re)build starts from: the point-major arrays of the previous structure (device, old arena) and / or new
 // observations on the host (caller indices, mapped through the slot tables of the problem).
@@ -861,6 +865,7 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
                          int64_t n_obs_new, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, double focal) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
     if (p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "a sharded problem cannot grow in place");
+    p->reset_pending = false;           // the parameters are replaced by the caller's below
     if (n_cam < p->n_cam_full || n_pt < p->n_pt_full || n_obs_new < 0 || p->n_obs + n_obs_new >= (int64_t)1 << 31)
         return fail(SFMBA_ERR_INVALID_ARG, "bad sizes: cameras and points can only be added at the end");
     if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs_new > 0 && (!obs_cam || !obs_pt || !obs_xy)))
@@ -898,10 +903,10 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
     return rc;      // `old` releases the previous structure here
 }
 
-int sfmba_problem_reset(sfmba_problem* p) {
-    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
-    p->focal = p->focal0;
-    p->cur = 0;
+// the device side of a reset, for the callers that are not a solve
+static int flush_reset(sfmba_problem* p) {
+    if (!p || !p->reset_pending) return SFMBA_OK;
+    p->reset_pending = false;
     if (p->empty) return SFMBA_OK;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemcpyAsync(p->db.cam[0], p->d_cam0, sizeof(double) * 6 * (size_t)p->ds.ncam, hipMemcpyDeviceToDevice, p->stream));
@@ -913,8 +918,19 @@ int sfmba_problem_reset(sfmba_problem* p) {
     return upload_state(p, st);
 }
 
+int sfmba_problem_reset(sfmba_problem* p) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    p->focal = p->focal0;
+    p->cur = 0;
+    // nothing is enqueued here: the next solve's first kernel copies the initial parameters itself (k_begin); any other entry point
+    // that looks at the parameters flushes the reset first
+    p->reset_pending = !p->empty;
+    return SFMBA_OK;
+}
+
 int sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double* pt3, double focal) {
     if (!p || !cam6 || !pt3) return fail(SFMBA_ERR_INVALID_ARG, "NULL argument");
+    p->reset_pending = false;           // everything a reset would restore is overwritten here
     p->focal = focal;
     p->cur = 0;
     if (p->empty) return SFMBA_OK;
@@ -933,6 +949,7 @@ int sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double*
 }
 
 int sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double* focal) {
+    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
     if (focal) *focal = p->focal;
     if (p->empty) return SFMBA_OK;
@@ -1012,6 +1029,7 @@ int sfmba_problem_get_profile(sfmba_problem* p, sfmba_kernel_time* out, int cap,
 
 // ---- kernel-level entry points ----------------------------------------------------------------
 int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double* cost_out) {
+    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
     if (cost_out) *cost_out = 0.0;
     if (p->empty) return SFMBA_OK;
@@ -1033,6 +1051,7 @@ int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double
 }
 
 int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double* jf) {
+    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
     if (p->empty) return SFMBA_OK;
     HIP_TRY(hipSetDevice(p->device));
@@ -1057,6 +1076,7 @@ int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double
 }
 
 int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, double radius, double* S, double* rhs, double* scale) {
+    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
     sfmba_options o;
     if (opt) o = *opt; else sfmba_options_default(&o);
@@ -1162,10 +1182,12 @@ static int shard_begin_impl(sfmba_problem* p, const sfmba_options* opt, bool fus
     const int f32 = p->precision == SFMBA_PRECISION_F32J;
     if (fused) {
         *p->h_state = st;
-        launch_begin(p->stream, p->ds, p->db, st);
+        launch_begin(p->stream, p->ds, p->db, st, p->reset_pending ? p->d_cam0 : nullptr, p->reset_pending ? p->d_pts0 : nullptr);
+        p->reset_pending = false;
         launch_xnorm(p->stream, p->ds, p->db);
         launch_colnorm_cams_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32, /*clear_udiag=*/false);
     } else {
+        if ((rc = flush_reset(p))) return rc;
         rc = upload_state(p, st);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(p->d_info, 0, sizeof(int), p->stream));
