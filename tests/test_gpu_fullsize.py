@@ -272,3 +272,31 @@ def test_early_linearisation_launch_changes_nothing(capi, sfm, cfg3, monkeypatch
         assert abs(a["final_cost"] - b["final_cost"]) <= 1e-9 * b["final_cost"]
         assert [r["step_is_successful"] for r in tr_a] == [r["step_is_successful"] for r in tr_b]
         assert np.abs(cam_a - cam_b).max() < 1e-6 and np.abs(pt_a - pt_b).max() < 1e-6
+
+
+def test_deferred_reset_is_seen_by_every_entry_point(capi, sfm):
+    """sfmba_problem_reset() enqueues nothing: the next solve's first kernel restores the initial parameters, and every other entry
+    point that looks at the parameters flushes the reset first."""
+    prob = sfm.make_problem("small")
+    opt = capi.default_options(max_seconds=0.0)
+    with capi.Problem(prob) as P:
+        r0, c0 = P.eval_residuals()
+        s1, _ = P.solve(opt)
+        cam1, pt1, f1 = P.get_params()
+        assert s1["termination_name"] == "CONVERGENCE" and np.abs(pt1 - prob.pt3).max() > 0
+        P.reset()
+        cam, pt, f = P.get_params()                               # reset, then a read
+        assert np.array_equal(cam, prob.cam6) and np.array_equal(pt, prob.pt3) and f == prob.focal
+        P.solve(opt); P.reset()
+        r, c = P.eval_residuals()                                 # reset, then an evaluation
+        assert c == c0 and np.array_equal(r, r0)
+        P.solve(opt); P.reset()
+        s2, _ = P.solve(opt)                                      # reset, then a solve (restored inside its first kernel)
+        cam2, pt2, f2 = P.get_params()
+        assert s2["iterations"] == s1["iterations"] and abs(s2["final_cost"] - s1["final_cost"]) <= 1e-12 * s1["final_cost"]
+        assert np.allclose(cam2, cam1, atol=1e-9) and np.allclose(pt2, pt1, atol=1e-9)
+        P.reset(); P.set_params(cam1, pt1, f1)                    # reset, then new parameters: the reset must not come back
+        cam, pt, f = P.get_params()
+        assert np.array_equal(cam, cam1) and np.array_equal(pt, pt1) and f == f1
+        s3, _ = P.solve(opt)
+        assert s3["iterations"] <= 1 or s3["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
