@@ -521,11 +521,61 @@ __global__ __launch_bounds__(256) void k_chol_apply_minv(double* __restrict__ A,
     }
 }
 
+// d < 64 (up to ten cameras: the reference's own data sets start there): the whole solve in ONE launch of one workgroup -- the tile
+// is read together with the right-hand side as its row d, factored with the inverse riding along, and x = L^-T y follows from the
+// rows already in LDS.  Replaces k_augment + k_chol_step + k_chol_backsolve (three launches of a launch-bound LM iteration).
+__global__ __launch_bounds__(256, 1) void k_chol_small(double* __restrict__ A, int ld, int d, double* __restrict__ rhs, double* __restrict__ minv,
+                                                      int* __restrict__ info) {
+    extern __shared__ __align__(16) double cs_lds[];
+    double* U = cs_lds;
+    double* X = U + CS_TILE;
+    double* ED = X + CT_NB * CT_LDP;
+    double* V = ED + (CT_NB / CT_PB + 1) * CT_PB * CT_LDP;
+    __shared__ double yv[NB];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx % NB, c = idx / NB;
+        double v = r >= c ? AT(r, c) : 0.0;
+        if (r == d && c < d) v = rhs[c];             // the augmented row (the padded diagonal is already 1)
+        U[r * CT_LDT + c] = v;
+    }
+    __syncthreads();
+    const int bad = chol_tile_factor(U, X, ED, V, 0, d);
+    if (bad != 0 && tid == 0) atomicCAS(info, 0, bad);
+    // y = scaled row d of the factor; x = L^-T y with L^-T = (s(col) E)(row, col), E from U (block row < block column) and ED (diagonal blocks)
+    if (tid < NB) yv[tid] = tid < d ? X[tid] * U[d * CT_LDT + tid] : 0.0;
+    for (int idx = tid; idx < NB * NB; idx += 256) {          // the factor and its inverse go where the step-by-step path keeps them
+        const int r = idx % NB, c = idx / NB, q = r >> 4, cb = c >> 4;
+        const double sc = X[c];
+        const double u = sc * U[r * CT_LDT + c];
+        if (r >= c) AT(r, c) = u;
+        minv[r + c * NB] = q < cb ? u : q == cb ? sc * ED[(q * CT_PB + (r & 15)) * CT_LDP + (c & 15)] : 0.0;
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const int r = tid, q = r >> 4;
+        double sum = 0.0;
+        for (int c = r; c < d; ++c) {
+            const int cb = c >> 4;
+            const double e = q < cb ? U[r * CT_LDT + c] : ED[(q * CT_PB + (r & 15)) * CT_LDP + (c & 15)];
+            sum = fma(X[c] * e, yv[c], sum);
+        }
+        if (r < ld) rhs[r] = r < d ? sum : 0.0;
+    }
+}
+
 void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof) {
     const int ld = ws->ld, d = ws->d, nblk = ld / NB;
+    static const bool fused_env = [] { const char* e = std::getenv("SFMBA_CHOL_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused_env && nblk == 1) {
+        static bool small_attr_set = false;
+        if (!small_attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CS_LDS_DOUBLES)); small_attr_set = true; }
+        ProfScope ps(prof, KID_CHOL_PANEL, s);
+        hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), sizeof(double) * CS_LDS_DOUBLES, s, S, ld, d, rhs, ws->minv, info_dev);
+        return;
+    }
     { ProfScope ps(prof, KID_CHOL_AUGMENT, s);
       hipLaunchKernelGGL(k_augment, dim3((d + 255) / 256), dim3(256), 0, s, S, ld, d, rhs); }
-    static const bool fused_env = [] { const char* e = std::getenv("SFMBA_CHOL_FUSED"); return !(e && e[0] == '0'); }();
     if (fused_env && nblk <= CHOL_FUSED_MAX_BLOCKS) {
         // one launch per block column (k_chol_step); beyond ~2500 unknowns the redundant panel GEMMs of the fused step cost more than
         // the launch they save and the two-kernel form below takes over

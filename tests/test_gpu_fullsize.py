@@ -289,7 +289,7 @@ def test_deferred_reset_is_seen_by_every_entry_point(capi, sfm):
         assert np.array_equal(cam, prob.cam6) and np.array_equal(pt, prob.pt3) and f == prob.focal
         P.solve(opt); P.reset()
         r, c = P.eval_residuals()                                 # reset, then an evaluation
-        assert c == c0 and np.array_equal(r, r0)
+        assert abs(c - c0) <= 1e-12 * c0 and np.array_equal(r, r0)     # (the cost is a sum of atomics: last bits vary)
         P.solve(opt); P.reset()
         s2, _ = P.solve(opt)                                      # reset, then a solve (restored inside its first kernel)
         cam2, pt2, f2 = P.get_params()

@@ -177,8 +177,8 @@ def test_dense_cholesky_fallback_paths(env):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
-def test_dense_cholesky_flags_indefinite(capi):
-    n = 100
+@pytest.mark.parametrize("n", [40, 100, 700])        # one launch (d < 64) / several block columns
+def test_dense_cholesky_flags_indefinite(capi, n):
     A = np.eye(n) * 4
     A[37, 37] = -1.0
     x, info, _ = capi.dense_spd_solve(A, np.ones(n), method=0)
