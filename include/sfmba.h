@@ -172,7 +172,8 @@ SFMBA_API int  sfmba_problem_create(int device, int precision,
  */
 SFMBA_API int  sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_pt, const double* pt3,
                           int64_t n_obs_new, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, double focal);
-/* Restore the parameters given at create time (device-to-device copy). */
+/* Restore the parameters given at create (or last append) time.  Nothing is enqueued by the call itself: the first kernel of the next
+ * sfmba_problem_solve copies them on the device, and every other entry point that looks at the parameters does so first. */
 SFMBA_API int  sfmba_problem_reset(sfmba_problem* p);
 /* Overwrite the current parameters from host arrays (full-size arrays, as at create). */
 SFMBA_API int  sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double* pt3, double focal);
