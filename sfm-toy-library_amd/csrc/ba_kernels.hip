@@ -830,6 +830,12 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
     int2 pr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int p = pbeg + 16 * u + g; pr[u] = ds.pairs[pbeg < p1 ? (p < p1 ? p : p1 - 1) : 0]; }
+    // Lane-local sums stay in T for at most PAIR_FLUSH rounds (64 pairs each), then the wave sum is taken and carried on in fp64: a block
+    // with tens of thousands of pairs (two cameras sharing most of a large cloud) would otherwise pile thousands of fp32 additions
+    // into one accumulator.  Blocks up to 64 * PAIR_FLUSH pairs -- all of BASELINE config 3 -- never take the branch.
+    constexpr int PAIR_FLUSH = 64;
+    double total = 0.0;            // this lane's entry of the 6x6 block (lanes that own one), over the flushes so far
+    int base = 0, len = 36, rounds = 0;
     for (int p0 = pbeg; p0 < p1; p0 += 64) {
         T qa[4][4], qb[4][4];
 #pragma unroll
@@ -850,14 +856,22 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
             for (int e = 9; e < 15; ++e) ra[e] = (T)0;
         }
         pair_product<T>(ra, rb, MODE == 2, acc);
+        if (sizeof(T) == 4 && ++rounds == PAIR_FLUSH && p0 + 64 < p1) {
+            rounds = 0; base = 0; len = 36;
+            HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
+            total += len >= 1 ? (double)acc[0] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+        }
     }
     // Sum of the 36 entries over the 64 lanes by a halving butterfly (38 shuffles instead of 72 + 96: the epilogue was as long as
     // the pair loop): afterwards lane `base` -- 36 of the 64 lanes -- owns ONE entry of the 6x6 block.
-    int base = 0, len = 36;
+    base = 0; len = 36;
     HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
+    total += len >= 1 ? (double)acc[0] : 0.0;
     const bool owner = len >= 1;
     const int er = owner ? base / 6 : 0, ec = owner ? base - 6 * (base / 6) : 0;
-    const double entry = owner ? -(double)acc[0] * db.cscale[6 * cj.x + er] * db.cscale[6 * cj.y + ec] : 0.0;
+    const double entry = owner ? -total * db.cscale[6 * cj.x + er] * db.cscale[6 * cj.y + ec] : 0.0;
     if (MODE == 0 || MODE == 2) {
         if (owner) {
             double* dst = db.S + (size_t)(6 * cj.x + er) * ds.ld + 6 * cj.y + ec;

@@ -300,3 +300,18 @@ def test_deferred_reset_is_seen_by_every_entry_point(capi, sfm):
         assert np.array_equal(cam, cam1) and np.array_equal(pt, pt1) and f == f1
         s3, _ = P.solve(opt)
         assert s3["iterations"] <= 1 or s3["final_cost"] <= s1["final_cost"] * (1 + 1e-9)
+
+
+def test_pair_pass_carries_long_blocks_in_fp64(capi, sfm):
+    """Three cameras that all see all 30 000 points: every off-diagonal block of the reduced system is the sum of 30 000 pair terms
+    (470 rounds of the wave-per-block pair pass).  In fp32-Jacobian mode the lane-local sums are flushed into fp64 every 64
+    rounds, so the block must agree with the all-fp64 one to fp32 ROUND-OFF of its terms, not to a random walk of 470 of them."""
+    prob = sfm.make_problem("cfg2", n_cam=3, n_pt=30000, views=(3, 3), seed=11)
+    out = {}
+    for prec in (0, 1):
+        with capi.Problem(prob, precision=prec) as P:
+            S, rhs, scale = P.build_reduced(1e4, capi.default_options(precision=prec))
+            out[prec] = S
+    blk64, blk32 = out[0][0:6, 6:12], out[1][0:6, 6:12]
+    assert np.abs(blk64).max() > 0
+    assert np.abs(blk32 - blk64).max() <= 3e-6 * np.abs(blk64).max()
