@@ -262,8 +262,12 @@ SFMBA_API int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);
 
 /*
  * The whole sharded LM loop in one call (the phase functions above remain for callers that drive the choreography themselves).
- * The three all-reduces per LM iteration go through `allreduce(ctx, device_buf, n_doubles, hip_stream)` -- in-place SUM over the
- * ranks, enqueued on hip_stream, return 0 on success -- which may be NULL when world == 1.  sfmba_comm_* is the built-in one:
+ * The all-reduces go through `allreduce(ctx, device_buf, n_doubles, hip_stream)` -- in-place SUM over the ranks, enqueued on
+ * hip_stream, return 0 on success -- which may be NULL when world == 1.  Per LM iteration, exact solver: two (packed upper triangle
+ * of S | rhs | diagonals | scalars, then 80 trial-step scalars).  CG solver: three -- (A) 6x6 diagonal blocks | camera-focal column
+ * | rhs | diagonals | scalars, (B) the off-diagonal blocks of the block-Jacobi-PRECONDITIONED matrix (every rank transforms its
+ * partial blocks with the factors that follow from (A): the transform is linear in S), (C) the 80 trial-step scalars.  Every rank
+ * calls with the same options; what is decided from the reduced sums is then bit-identical on all of them.  sfmba_comm_* is the built-in one:
  * ncclAllReduce (RCCL, xGMI) bound with dlopen at first use; one communicator per rank, created from the 128-byte unique id
  * that rank 0 draws (sfmba_comm_unique_id) and the launcher distributes (bench.py: a torch.distributed broadcast).
  * The host meets the GPU once per LM iteration, at the control kernel's mailbox post; nothing is copied back inside the loop.
