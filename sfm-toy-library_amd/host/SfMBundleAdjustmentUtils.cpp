@@ -623,4 +623,29 @@ void SfMBundleAdjustmentUtils::adjustBundle(
     });
 }
 
+struct WorkerPoolAccess {
+    static int selftest(int batches) {
+        WorkerPool& pool = WorkerPool::instance();
+        int wrong = 0;
+        for (int b = 0; b < batches; ++b) {
+            const unsigned n = 1u + (unsigned)((b * 2654435761u) % 517u);
+            std::atomic<unsigned long long> sum(0);
+            std::atomic<unsigned> calls(0);
+            auto task = [&](unsigned t) { sum.fetch_add(t + 1ull, std::memory_order_relaxed); calls.fetch_add(1, std::memory_order_relaxed); };
+            if (b % 3 == 0) { pool.begin(n, task); volatile unsigned spin = 0; for (unsigned k = 0; k < (unsigned)(b % 7) * 100u; ++k) spin = spin + 1; pool.end(); }
+            else if (b % 3 == 1) pool.run(n, task);
+            else { pool.wake(); pool.run(n, task); }
+            if (sum.load() != (unsigned long long)n * (n + 1) / 2 || calls.load() != n) ++wrong;
+        }
+        return wrong;
+    }
+};
+
 } /* namespace sfmtoylib */
+
+// Self-test of the worker pool (tests/test_shim_pool_cpu.py; no GPU involved): `batches` batches of varying size, run() and the
+// begin() / end() pair alternating, every task adds its index + 1 to a sum.  Returns the number of batches whose sum was wrong.
+extern "C" __attribute__((visibility("default"))) int sfmba_shim_pool_selftest(int batches) {
+    using sfmtoylib::WorkerPoolAccess;
+    return WorkerPoolAccess::selftest(batches);
+}
