@@ -716,11 +716,34 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         HIP_TRY(dev_upload(&p->d_wv_desc, wv_desc));
     }
     bt_mark("upload structure");
-    std::vector<double> cam0((size_t)6 * ncam), pts0((size_t)3 * npt);
-    for (int j = 0; j < ncam; ++j) std::memcpy(&cam0[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
-    for (int i = 0; i < npt; ++i) std::memcpy(&pts0[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
-    HIP_TRY(dev_upload(&p->d_cam0, cam0));
-    HIP_TRY(dev_upload(&p->d_pts0, pts0));
+    {
+        // slot order = order of first observation; when every camera / point of the caller's arrays is observed and the slots came out
+        // in index order (the usual case: point-major observation lists), the arrays go up as they are, without a gathered copy
+        bool cam_identity = (size_t)ncam == p->cam_slot.size(), pt_identity = (size_t)npt == p->pt_slot.size();
+        for (int j = 0; j < ncam && cam_identity; ++j) cam_identity = p->acam_id[j] == j;
+        if (pt_identity) {
+            std::atomic<bool> ok(true);
+            parallel_for(npt, [&](int i0, int i1) { for (int i = i0; i < i1; ++i) if (p->apt_id[i] != i) { ok.store(false, std::memory_order_relaxed); break; } });
+            pt_identity = ok.load();
+        }
+        std::vector<double> cam0, pts0;
+        const double* cam_src = cam6;
+        const double* pts_src = pt3;
+        if (!cam_identity) {
+            cam0.resize((size_t)6 * ncam);
+            for (int j = 0; j < ncam; ++j) std::memcpy(&cam0[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
+            cam_src = cam0.data();
+        }
+        if (!pt_identity) {
+            pts0.resize((size_t)3 * npt);
+            for (int i = 0; i < npt; ++i) std::memcpy(&pts0[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
+            pts_src = pts0.data();
+        }
+        HIP_TRY(dev_alloc(&p->d_cam0, (size_t)6 * ncam));
+        HIP_TRY(dev_alloc(&p->d_pts0, (size_t)3 * npt));
+        if (ncam > 0) HIP_TRY(hipMemcpy(p->d_cam0, cam_src, sizeof(double) * 6 * (size_t)ncam, hipMemcpyHostToDevice));
+        if (npt > 0) HIP_TRY(hipMemcpy(p->d_pts0, pts_src, sizeof(double) * 3 * (size_t)npt, hipMemcpyHostToDevice));
+    }
     p->focal0 = p->focal = focal;
 
     DeviceStructure& ds = p->ds;
