@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--sharded-extras", type=int, default=-1,
                     help="after the headline run also time ONE problem sharded over all ranks (cfg3 and cfg5) with the RCCL all-reduce "
                          "of the reduced camera system: 1 = yes, 0 = no, -1 (default) = only when N > 1")
+    ap.add_argument("--extras-timeout", type=int, default=240, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="LM iterations of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = min(nproc,16))")
@@ -230,11 +231,24 @@ def main():
     sh = None
     if want_sharded:
         sh = {}
+        # The extras must never cost the headline: exceptions are caught below; against a collective that never returns (the N > 1
+        # RCCL path has only ever run on one rank here) a watchdog prints the headline line as it stands and ends the process.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["sharded"] = dict(sh, error="sharded extras did not finish within %d s: abandoned" % args.extras_timeout)
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.extras_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         for wl in (["cfg3", "cfg5"] if args.workload == "cfg3" else [args.workload]):
             try:
                 sh[wl] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)))
             except Exception as e:                       # never lose the headline line to the extras
                 sh[wl] = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
     if rank == 0:
         if sh is not None:
             line["sharded"] = sh
