@@ -196,7 +196,7 @@ struct PointMajor {            // point-major observation list (build_point_majo
     int* pt_ptr = nullptr;     // [npt + 1]
     long long* pair_off = nullptr;   // [npt + 1] pairs of the points before i
 };
-int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int xy_bytes, const int* u_pt, const int* u_cam,
+int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int ncam, int xy_bytes, const int* u_pt, const int* u_cam,
                       const int* u_perm, const void* u_xy, PointMajor* out, long long* npair);
 // camera-pair lists of the Schur pass (d_pair_off: npt + 1 prefix counts on the device)
 int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,

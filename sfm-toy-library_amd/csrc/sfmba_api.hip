@@ -588,7 +588,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             HIP_TRY(hipMemcpyAsync(u_xy + (size_t)xy_bytes * src.n_old, h_xy.data(), h_xy.size(), hipMemcpyHostToDevice, p->stream));
         }
         bt_mark("slots+upload obs");
-        const int brc = build_point_major(p->stream, &p->arena, device, nobs, npt, xy_bytes, u_pt, u_cam, u_perm, u_xy, &pm, &npair_total);
+        const int brc = build_point_major(p->stream, &p->arena, device, nobs, npt, ncam, xy_bytes, u_pt, u_cam, u_perm, u_xy, &pm, &npair_total);
         if (brc) return fail(SFMBA_ERR_HIP, std::string("point-major build: ") + hipGetErrorString((hipError_t)brc));
         // (build_point_major synchronised the stream: the staging arrays and the host vectors may go)
     }

@@ -14,6 +14,7 @@
 #include "device_arena.h"
 
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <vector>
 
@@ -99,18 +100,18 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int
 }
 
 namespace {
-__global__ __launch_bounds__(256) void k_pm_keys(int n, const int* __restrict__ u_pt, const int* __restrict__ u_cam, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+__global__ __launch_bounds__(256) void k_pm_keys(int n, int cshift, const int* __restrict__ u_pt, const int* __restrict__ u_cam, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) { keys[k] = ((unsigned long long)(unsigned)u_pt[k] << 32) | (unsigned)u_cam[k]; vals[k] = k; }
+    if (k < n) { keys[k] = ((unsigned long long)(unsigned)u_pt[k] << cshift) | (unsigned)u_cam[k]; vals[k] = k; }
 }
 template <typename XY>
-__global__ __launch_bounds__(256) void k_pm_gather(int n, const unsigned long long* __restrict__ keys, const int* __restrict__ src, const int* __restrict__ u_perm,
+__global__ __launch_bounds__(256) void k_pm_gather(int n, int cshift, const unsigned long long* __restrict__ keys, const int* __restrict__ src, const int* __restrict__ u_perm,
                                                    const XY* __restrict__ u_xy, int* __restrict__ obs_pt, int* __restrict__ perm, int* __restrict__ obs_cam, XY* __restrict__ obs_xy) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const unsigned long long key = keys[q];
     const int k = src[q];
-    obs_pt[q] = (int)(key >> 32); obs_cam[q] = (int)(key & 0xffffffffull);
+    obs_pt[q] = (int)(key >> cshift); obs_cam[q] = (int)(key & (((unsigned long long)1 << cshift) - 1));
     perm[q] = u_perm[k]; obs_xy[q] = u_xy[k];
 }
 // pt_ptr[i] = first sorted position whose point slot is >= i; cnt[i] = pairs of point i
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(256) void k_pm_paircount(int npt, const int* __rest
 // radix sort on (point, camera) -- the order adjustBundle() adds its residual blocks in (BA.cpp:142-166: points in cloud order,
 // std::map iteration = ascending view inside a point); equal keys keep their input order.  Outputs (from `arena`): the
 // sorted arrays, the CSR pointers and the per-point prefix of the pair counts; *npair = total number of pairs.
-int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int xy_bytes, const int* u_pt, const int* u_cam,
+// rocPRIM's radix sort falls back to a merge sort up to 2^20 items: ten merge passes over the 10^6 observations of BASELINE config 3
+// (~145 us per sort, two sorts per structure build) where a few Onesweep digit passes over the significant bits do (~40 us).
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)1 << 15> OnesweepAbove32k;
+static int bits_for(unsigned long long n) { int b = 1; while (b < 63 && ((unsigned long long)1 << b) < n) ++b; return b; }
+
+int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int ncam, int xy_bytes, const int* u_pt, const int* u_cam,
                       const int* u_perm, const void* u_xy, PointMajor* out, long long* npair) {
     *npair = 0;
     out->obs_pt = arena->alloc_n<int>((size_t)2 * n);
@@ -154,19 +160,20 @@ int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int 
     int* v1 = scratch.alloc_n<int>((size_t)n);
     long long* cnt = scratch.alloc_n<long long>((size_t)npt + 1);
     if (!k0 || !k1 || !v0 || !v1 || !cnt) return (int)hipErrorOutOfMemory;
-    hipLaunchKernelGGL(k_pm_keys, dim3((n + 255) / 256), dim3(256), 0, s, n, u_pt, u_cam, k0, v0);
-    int end_bit = 33;
-    while (end_bit < 64 && ((unsigned long long)1 << (end_bit - 32)) < (unsigned long long)npt) ++end_bit;
+    // key = point slot above the camera slot, packed without a gap: only the significant bits are sorted (25 at 200 cameras / 10^5 points)
+    const int cshift = bits_for((unsigned long long)(ncam > 1 ? ncam : 2));
+    const int end_bit = cshift + bits_for((unsigned long long)(npt > 1 ? npt : 2));
+    hipLaunchKernelGGL(k_pm_keys, dim3((n + 255) / 256), dim3(256), 0, s, n, cshift, u_pt, u_cam, k0, v0);
     size_t tmp_bytes = 0;
-    if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, v1, n, 0, end_bit, s)) != hipSuccess) return (int)e;
+    if ((e = rocprim::radix_sort_pairs<OnesweepAbove32k>(nullptr, tmp_bytes, k0, k1, v0, v1, n, 0u, (unsigned)end_bit, s)) != hipSuccess) return (int)e;
     void* tmp = scratch.alloc(tmp_bytes ? tmp_bytes : 1);
     if (!tmp) return (int)hipErrorOutOfMemory;
-    if ((e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, v1, n, 0, end_bit, s)) != hipSuccess) return (int)e;
+    if ((e = rocprim::radix_sort_pairs<OnesweepAbove32k>(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, (unsigned)end_bit, s)) != hipSuccess) return (int)e;
     if (xy_bytes == 8)
-        hipLaunchKernelGGL(k_pm_gather<float2>, dim3((n + 255) / 256), dim3(256), 0, s, n, k1, v1, u_perm, static_cast<const float2*>(u_xy), out->obs_pt, out->obs_pt + n,
+        hipLaunchKernelGGL(k_pm_gather<float2>, dim3((n + 255) / 256), dim3(256), 0, s, n, cshift, k1, v1, u_perm, static_cast<const float2*>(u_xy), out->obs_pt, out->obs_pt + n,
                            out->obs_cam, static_cast<float2*>(out->obs_xy));
     else
-        hipLaunchKernelGGL(k_pm_gather<double2>, dim3((n + 255) / 256), dim3(256), 0, s, n, k1, v1, u_perm, static_cast<const double2*>(u_xy), out->obs_pt, out->obs_pt + n,
+        hipLaunchKernelGGL(k_pm_gather<double2>, dim3((n + 255) / 256), dim3(256), 0, s, n, cshift, k1, v1, u_perm, static_cast<const double2*>(u_xy), out->obs_pt, out->obs_pt + n,
                            out->obs_cam, static_cast<double2*>(out->obs_xy));
     hipLaunchKernelGGL(k_pm_ptr, dim3((npt + 1 + 255) / 256), dim3(256), 0, s, npt, n, out->obs_pt, out->pt_ptr);
     hipLaunchKernelGGL(k_pm_paircount, dim3((npt + 1 + 255) / 256), dim3(256), 0, s, npt, out->pt_ptr, cnt);
@@ -209,11 +216,11 @@ int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, 
     int end_bit = 1;
     while (end_bit < 32 && ((unsigned long long)1 << end_bit) < (unsigned long long)ncam) ++end_bit;
     size_t tmp_bytes = 0;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0, k1, v0, *d_cam_obs, nobs, 0, end_bit, s);
+    hipError_t e = rocprim::radix_sort_pairs<OnesweepAbove32k>(nullptr, tmp_bytes, k0, k1, v0, *d_cam_obs, nobs, 0u, (unsigned)end_bit, s);
     if (e != hipSuccess) return (int)e;
     void* tmp = scratch.alloc(tmp_bytes ? tmp_bytes : 1);
     if (!tmp) return (int)hipErrorOutOfMemory;
-    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k0, k1, v0, *d_cam_obs, nobs, 0, end_bit, s);
+    e = rocprim::radix_sort_pairs<OnesweepAbove32k>(tmp, tmp_bytes, k0, k1, v0, *d_cam_obs, nobs, 0u, (unsigned)end_bit, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_gather_pt, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, *d_cam_obs, d_obs_pt, *d_cam_obs_pt);
     hipLaunchKernelGGL(k_block_ptr, dim3((ncam + 1 + 255) / 256), dim3(256), 0, s, ncam, nobs, k1, *d_cam_ptr);      // CSR pointers from the sorted keys
