@@ -990,7 +990,12 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;            // [ld] new search direction (p_r)
     double* red = sm + ld;      // [PCG_RED]
-    if (!INIT && flags[PF_DONE]) return;
+    // `in` = (launch number << 1) | parity.  PF_DONE holds the first launch number that has nothing left to do: a launch must not act
+    // on the flag its own workgroup 0 raises (workgroups that start late, e.g. behind another process's kernels, would skip the
+    // converging iteration's x update).
+    const int seq = in >> 1;
+    in &= 1;
+    if (!INIT) { const int dn = flags[PF_DONE]; if (dn != 0 && seq >= dn) return; }
     constexpr int NV = COARSE ? PCG_NPART : 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
     const int row0 = blockIdx.x * rows_per_wg;
@@ -1078,7 +1083,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
         const bool broke = !(pq > 0.0) || !(rrn == rrn);
         if (rrn <= tol2 * scal[PS_RR0] || broke) {
             if (blockIdx.x == 0 && tid == 0) {
-                flags[PF_DONE] = 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
+                flags[PF_DONE] = seq + 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
                 if (broke) atomicCAS(info, 0, d + 1);
                 if (mailbox) pcg_post(mailbox, it, 1);
             }
@@ -1200,7 +1205,12 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
     extern __shared__ __align__(16) double sm[];
     double* pl = sm;
     double* red = sm + ld;
-    if (!INIT && flags[PF_DONE]) return;
+    // `in` = (launch number << 1) | parity.  PF_DONE holds the first launch number that has nothing left to do: a launch must not act
+    // on the flag its own workgroup 0 raises (workgroups that start late, e.g. behind another process's kernels, would skip the
+    // converging iteration's x update).
+    const int seq = in >> 1;
+    in &= 1;
+    if (!INIT) { const int dn = flags[PF_DONE]; if (dn != 0 && seq >= dn) return; }
     constexpr int NV = COARSE ? PCG_NPART : 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
     // first launch of a solve: E^-1 and c_0 from the partials k_pcg_coarse_fast left behind -- formed by EVERY workgroup for
@@ -1335,7 +1345,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         const bool done = rrn <= tol2 * rr0 || broke;
         if (done) {
             if (blockIdx.x == 0 && tid == 0) {
-                flags[PF_DONE] = 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
+                flags[PF_DONE] = seq + 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
                 if (broke) atomicCAS(info, 0, d + 1);
                 if (mailbox) pcg_post(mailbox, it, 1);
             }
@@ -1648,7 +1658,7 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
     const DenseSolver::CgRun& r = ws->run;
     const int d = ws->d, ld = ws->ld;
     double* bt = ws->vec + (size_t)8 * ld;
-    const int in = INIT ? 0 : r.in;
+    const int in = INIT ? 0 : (r.in | ((r.launched + 1) << 1));     // launch number 1.. of this solve, see k_pcg_iter
 #define CG_ARGS(Fptr) d, ld, Fptr, ws->vec, bt, ws->part, ws->scal, ws->flags, r.rows_per_wg, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->AW, ws->coarse
     if (r.fast) {
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
@@ -1671,8 +1681,8 @@ int dense_pcg_more(hipStream_t s, DenseSolver* ws, int n, Profiler* prof) {
     for (int b = 0; b < n; ++b) {
         launch_cg_iteration<false>(s, ws, 0, 1.0);
         r.in ^= 1;
+        ++r.launched;
     }
-    r.launched += n;
     return n;
 }
 

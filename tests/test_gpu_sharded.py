@@ -39,7 +39,14 @@ def _worker(rank, world, port, case, out, native=False):
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw)
     summ = solve_sharded_native(backend, opt, dist=dist) if native else solve_sharded(backend, dist, opt)
     cam, pt, f = backend.get_params()
-    out.put((rank, summ, cam, pt, f, backend._point_range))
+    # native loop: the same solve again and again.  Two processes on one GPU delay each other's workgroups, which is what
+    # exposes a launch acting on a flag raised by its own first workgroup (the CG's early exit once did: replicas drifted apart).
+    repeats = []
+    for _ in range(12 if native else 0):
+        backend.reset()
+        solve_sharded_native(backend, opt, dist=dist)
+        repeats.append(backend.get_params()[0].copy())
+    out.put((rank, summ, cam, pt, f, backend._point_range, repeats))
     dist.barrier()
     backend.close()
     dist.destroy_process_group()
@@ -61,7 +68,10 @@ def test_two_rank_sharded_hip_solve(sfm, oracle, case, native):
         p.join(timeout=60)
         assert p.exitcode == 0
     prob = sfm.make_problem(**kw)
-    (r0, s0, cam0, pt0, f0, rng0), (r1, s1, cam1, pt1, f1, rng1) = results
+    (r0, s0, cam0, pt0, f0, rng0, rep0), (r1, s1, cam1, pt1, f1, rng1, rep1) = results
+    for a, b in zip(rep0, rep1):
+        assert np.array_equal(a, b)                                     # every repeat: replicas bit-identical
+        assert np.abs(a - cam0).max() < 1e-9                            # and the same solve (atomics reorder the last bits)
     pts = np.vstack([pt0, pt1])
     assert rng0 == (0, prob.n_pt // 2) and rng1[1] == prob.n_pt
     assert s0["final_cost"] == s1["final_cost"]
