@@ -196,14 +196,25 @@ struct PointMajor {            // point-major observation list (build_point_majo
     int* pt_ptr = nullptr;     // [npt + 1]
     long long* pair_off = nullptr;   // [npt + 1] pairs of the points before i
 };
-int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int ncam, int xy_bytes, const int* u_pt, const int* u_cam,
-                      const int* u_perm, const void* u_xy, PointMajor* out, long long* npair);
-// camera-pair lists of the Schur pass (d_pair_off: npt + 1 prefix counts on the device)
-int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
+// All three only enqueue (temporaries from `scratch`, which the caller keeps until the stream has drained)
+int build_point_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, int n, int npt, int ncam, int xy_bytes, const int* u_pt, const int* u_cam,
+                      const int* u_perm, const void* u_xy, PointMajor* out);
+// camera-pair lists of the Schur pass (d_pair_off: npt + 1 prefix counts on the device; npair: their total, known to the host)
+int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
                      const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr);
-
-int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
+int build_camera_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
                        int** d_cam_obs, int** d_cam_obs_pt, int** d_cam_ptr);
+// unsorted observation arrays of a build: the old ones (device) followed by the new ones (one uploaded buffer)
+struct StageObs {
+    int n_old = 0, n_new = 0;
+    const int *old_pt = nullptr, *old_cam = nullptr, *old_perm = nullptr; const void* old_xy = nullptr;
+    const int *new_pt = nullptr, *new_cam = nullptr, *new_perm = nullptr; const void* new_xy = nullptr;
+    int *u_pt = nullptr, *u_cam = nullptr, *u_perm = nullptr; void* u_xy = nullptr;
+};
+void launch_stage_obs(hipStream_t s, const StageObs& so, int xy_bytes);
+// pair-pass descriptors and the list of diagonal blocks with pairs, from the block CSR on the device
+void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, int4* desc);
+void launch_dup_blocks(hipStream_t s, int ncam, const int* blk_ptr, const long long* pair_total, int2* dup, int* report);
 
 // triangulate.hip: two-view DLT triangulation + reprojection filter (SfMStereoUtilities::triangulateViews), device pointers
 void launch_triangulate(hipStream_t s, long long n, const float* d_left, const float* d_right, const float K[9], const float Pl[12],

@@ -1841,8 +1841,9 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
     if (!ws->gran) {
         if (ws_alloc(ws, &ws->gran, sizeof(unsigned long long) * 4 * (size_t)ws->ld)) return -1;
         if (ws_alloc(ws, &ws->tmo, 256)) return -1;
-        if (hipMemset(ws->gran, 0, sizeof(unsigned long long) * 4 * (size_t)ws->ld) != hipSuccess) return -1;
-        if (hipMemset(ws->tmo, 0, 256) != hipSuccess) return -1;
+        // (arena memory is handed out zeroed)
+        if (!ws->arena && hipMemset(ws->gran, 0, sizeof(unsigned long long) * 4 * (size_t)ws->ld) != hipSuccess) return -1;
+        if (!ws->arena && hipMemset(ws->tmo, 0, 256) != hipSuccess) return -1;
         ws->epoch = 0;
     }
     if (!ws->Sfull) {
@@ -1863,7 +1864,7 @@ int dense_solver_create(DenseSolver* ws, int d, int ld, DeviceArena* arena, char
     if (ws_alloc(ws, &ws->minv, sizeof(double) * (size_t)nblk * NB * NB)) return -1;
     if (ws_alloc(ws, &ws->y, sizeof(double) * ld)) return -1;
     if (ws_alloc(ws, &ws->back_flags, sizeof(int) * 64)) return -1;
-    if (hipMemset(ws->back_flags, 0, sizeof(int) * 64) != hipSuccess) return -1;
+    if (!ws->arena && hipMemset(ws->back_flags, 0, sizeof(int) * 64) != hipSuccess) return -1;      // (arena memory is handed out zeroed)
     ws->back_epoch = 0;
     if (ws_alloc(ws, &ws->vec, sizeof(double) * 9 * (size_t)ld)) return -1;
     if (ws_alloc(ws, &ws->part, sizeof(double) * 2 * PCG_NPART * PCG_PART)) return -1;

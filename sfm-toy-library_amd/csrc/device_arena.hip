@@ -39,6 +39,7 @@ bool cache_take(int device, size_t need, ArenaChunk* out) {
 }  // namespace
 
 void* DeviceArena::alloc(size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu_);
     bytes = round_up(bytes ? bytes : 1, ALIGN);
     if (!chunks_.empty() && off_ + bytes <= chunks_.back().cap) {
         void* p = chunks_.back().base + off_;
@@ -47,18 +48,28 @@ void* DeviceArena::alloc(size_t bytes) {
     }
     const size_t need = std::max(bytes, MIN_CHUNK);
     ArenaChunk c;
-    if (cache_take(device_, need, &c)) {
-        // recycled memory: hand it out zeroed, like the driver does for fresh allocations
-        if (hipMemsetAsync(c.base, 0, c.cap, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c.base); return nullptr; }
-    } else {
+    if (!cache_take(device_, need, &c)) {
         void* base = nullptr;
         if (hipMalloc(&base, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         c.base = static_cast<char*>(base); c.cap = need; c.device = device_;
+    }
+    if (zero_) {
+        bool ok = hipMemsetAsync(c.base, 0, c.cap, nullptr) == hipSuccess;
+        if (ok && order_stream_) {
+            if (!order_event_) ok = hipEventCreateWithFlags(&order_event_, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventRecord(order_event_, nullptr) == hipSuccess && hipStreamWaitEvent(order_stream_, order_event_, 0) == hipSuccess;
+        } else if (ok) ok = hipStreamSynchronize(nullptr) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); (void)hipFree(c.base); return nullptr; }
     }
     // keep a partially filled small chunk usable: put the new chunk last only if it has more room left
     chunks_.push_back(c);
     off_ = bytes;
     return c.base;
+}
+
+DeviceArena::~DeviceArena() {
+    release();
+    if (order_event_) (void)hipEventDestroy(order_event_);
 }
 
 void DeviceArena::release() {
@@ -93,6 +104,9 @@ bool hostkit_acquire(int device, HostKit* kit) {
     void* hm = nullptr;
     if (hipHostMalloc(&hm, HOSTKIT_PINNED_BYTES, hipHostMallocMapped) != hipSuccess) { (void)hipStreamDestroy(k.stream); return false; }
     k.pinned = static_cast<char*>(hm);
+    void* up = nullptr;
+    if (hipHostMalloc(&up, HOSTKIT_UPLOAD_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipHostFree(hm); (void)hipStreamDestroy(k.stream); return false; }
+    k.upload = static_cast<char*>(up);
     *kit = k;
     return true;
 }
@@ -100,6 +114,7 @@ bool hostkit_acquire(int device, HostKit* kit) {
 static void hostkit_destroy(const HostKit& k) {
     (void)hipSetDevice(k.device);
     if (k.pinned) (void)hipHostFree(k.pinned);
+    if (k.upload) (void)hipHostFree(k.upload);
     if (k.stream) (void)hipStreamDestroy(k.stream);
 }
 

@@ -29,6 +29,9 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <vector>
 
 using namespace sfmba;
@@ -67,7 +70,7 @@ const char* message_text(int id) {
 
 // Device arrays of a problem come from its arena (set for the duration of create_impl); API-call temporaries from HIP.
 thread_local DeviceArena* t_arena = nullptr;
-struct ArenaScope { explicit ArenaScope(DeviceArena* a) { t_arena = a; } ~ArenaScope() { t_arena = nullptr; } };
+struct ArenaScope { DeviceArena* prev; explicit ArenaScope(DeviceArena* a) : prev(t_arena) { t_arena = a; } ~ArenaScope() { t_arena = prev; } };
 
 template <typename T> hipError_t dev_alloc(T** p, size_t n) {
     if (t_arena) { *p = t_arena->alloc_n<T>(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
@@ -82,9 +85,10 @@ template <typename T> hipError_t dev_upload(T** p, const std::vector<T>& v) {
 }
 
 // Host loops over the observation list of a large problem, split over a few threads (structure build of the one-shot call).
+constexpr int PARALLEL_FOR_MIN = 200000;
 template <typename F>
 void parallel_for(int n, F fn) {
-    unsigned nt = n >= 200000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    unsigned nt = n >= PARALLEL_FOR_MIN ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
     if (nt <= 1) { fn(0, n); return; }
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < nt; ++t) pool.emplace_back(fn, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
@@ -127,6 +131,54 @@ __global__ void k_fill(double* p, size_t n, double v) {
 
 }  // namespace
 
+// One resident helper thread per process: the host half of a structure build (descriptor loops, uploads) runs on it while the calling
+// thread enqueues the device half.  A build takes the helper for its duration (Lease); a second build at the same time does both
+// halves itself.  Never destroyed: the thread outlives static destruction.
+class BuildHelper {
+public:
+    static BuildHelper& instance() { static BuildHelper* h = new BuildHelper(); return *h; }
+    class Lease {
+    public:
+        explicit Lease(BuildHelper& h) : h_(h), granted_(h.busy_.try_lock()) {}
+        ~Lease() { if (granted_) { wait(); h_.busy_.unlock(); } }
+        bool granted() const { return granted_; }
+        void post(std::function<void()> fn) {
+            h_.fn_ = std::move(fn);
+            pending_ = true;
+            h_.done_.store(false, std::memory_order_relaxed);
+            h_.ready_.store(true, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(h_.mu_); h_.wake_ = true; }
+            h_.cv_.notify_one();
+        }
+        void wait() {
+            if (!pending_) return;
+            while (!h_.done_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+            pending_ = false;
+        }
+    private:
+        BuildHelper& h_;
+        bool granted_, pending_ = false;
+    };
+private:
+    BuildHelper() { std::thread([this] { loop(); }).detach(); }
+    void loop() {
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return wake_; }); wake_ = false; }
+            if (ready_.load(std::memory_order_acquire)) {
+                ready_.store(false, std::memory_order_relaxed);
+                fn_();
+                fn_ = nullptr;
+                done_.store(true, std::memory_order_release);
+            }
+        }
+    }
+    std::mutex busy_, mu_;
+    std::condition_variable cv_;
+    bool wake_ = false;
+    std::atomic<bool> ready_{ false }, done_{ true };
+    std::function<void()> fn_;
+};
+
 struct sfmba_problem {
     int device = 0;
     int precision = SFMBA_PRECISION_F64;
@@ -134,6 +186,7 @@ struct sfmba_problem {
     int n_cam_full = 0, n_pt_full = 0;
     int64_t n_obs = 0;
     std::vector<int> acam_id, apt_id;     // active slot -> caller index
+    std::vector<int> h_pt_cnt, h_cam_cnt; // observations per point / camera slot (host mirror: CSR pointers without a device round trip)
     std::vector<int> cam_slot, pt_slot;   // caller index -> slot (-1: not observed)
     bool sharded = false;
     DeviceStructure ds = {};
@@ -149,6 +202,7 @@ struct sfmba_problem {
     int* d_blk_ptr = nullptr;
     int* d_cam_chunk_ptr = nullptr;
     bool deterministic = false;             // SFMBA_DETERMINISTIC=1 at build time
+    bool cam_identity = false, pt_identity = false;   // slot == caller index for every camera / point (arrays copied as they are)
     bool reset_pending = false;             // sfmba_problem_reset() was called: the initial parameters are restored by the next solve's first kernel
                                             // (or by flush_reset() if anything else looks at the problem first)
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
@@ -546,7 +600,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     const bool bt_on = std::getenv("SFMBA_BUILD_TIMING") != nullptr;
     auto bt_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double bt_t = bt_now();
-    auto bt_mark = [&](const char* what) { if (bt_on) { const double t = bt_now(); std::fprintf(stderr, "[sfmba build] %-18s %.2f ms\n", what, 1e3 * (t - bt_t)); bt_t = t; } };
+    auto bt_mark = [&](const char* what) { if (bt_on) { const double t = bt_now(); std::fprintf(stderr, "[sfmba build] %-18s %.3f ms\n", what, 1e3 * (t - bt_t)); bt_t = bt_now(); } };
     ArenaScope arena_scope(&p->arena);
     const int ncam = (int)p->acam_id.size(), npt = (int)p->apt_id.size();
     const long long nobs64 = (long long)src.n_old + src.n_new;
@@ -555,178 +609,221 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     const bool f32 = precision == SFMBA_PRECISION_F32J;
     const int xy_bytes = f32 ? 8 : 16;
 
-    // ---- unsorted observations on the device: old ones copied device to device, new ones mapped to slots and uploaded ----
-    PointMajor pm;
-    long long npair_total = 0;
-    {
-        DeviceArena staging(device);
-        int* u_pt = staging.alloc_n<int>((size_t)nobs);
-        int* u_cam = staging.alloc_n<int>((size_t)nobs);
-        int* u_perm = staging.alloc_n<int>((size_t)nobs);
-        char* u_xy = static_cast<char*>(staging.alloc((size_t)xy_bytes * std::max(nobs, 1)));
-        if (!u_pt || !u_cam || !u_perm || !u_xy) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
-        if (src.n_old > 0) {
-            HIP_TRY(hipMemcpyAsync(u_pt, src.d_old_pt, sizeof(int) * (size_t)src.n_old, hipMemcpyDeviceToDevice, p->stream));
-            HIP_TRY(hipMemcpyAsync(u_cam, src.d_old_cam, sizeof(int) * (size_t)src.n_old, hipMemcpyDeviceToDevice, p->stream));
-            HIP_TRY(hipMemcpyAsync(u_perm, src.d_old_perm, sizeof(int) * (size_t)src.n_old, hipMemcpyDeviceToDevice, p->stream));
-            HIP_TRY(hipMemcpyAsync(u_xy, src.d_old_xy, (size_t)xy_bytes * src.n_old, hipMemcpyDeviceToDevice, p->stream));
-        }
-        std::vector<int> h_pt((size_t)src.n_new), h_cam((size_t)src.n_new), h_perm((size_t)src.n_new);
-        std::vector<char> h_xy((size_t)xy_bytes * src.n_new);
-        if (src.n_new > 0) {
-            const int perm0 = (int)p->n_obs - src.n_new;           // caller index of the first new observation
-            parallel_for(src.n_new, [&](int k0, int k1) {
-                for (int k = k0; k < k1; ++k) {
-                    h_pt[(size_t)k] = p->pt_slot[(size_t)src.pt[k]]; h_cam[(size_t)k] = p->cam_slot[(size_t)src.cam[k]]; h_perm[(size_t)k] = perm0 + k;
-                    if (f32) { float* d = reinterpret_cast<float*>(h_xy.data()) + 2 * (size_t)k; d[0] = (float)src.xy[2 * (size_t)k]; d[1] = (float)src.xy[2 * (size_t)k + 1]; }
-                    else { double* d = reinterpret_cast<double*>(h_xy.data()) + 2 * (size_t)k; d[0] = src.xy[2 * (size_t)k]; d[1] = src.xy[2 * (size_t)k + 1]; }
-                }
-            });
-            HIP_TRY(hipMemcpyAsync(u_pt + src.n_old, h_pt.data(), sizeof(int) * h_pt.size(), hipMemcpyHostToDevice, p->stream));
-            HIP_TRY(hipMemcpyAsync(u_cam + src.n_old, h_cam.data(), sizeof(int) * h_cam.size(), hipMemcpyHostToDevice, p->stream));
-            HIP_TRY(hipMemcpyAsync(u_perm + src.n_old, h_perm.data(), sizeof(int) * h_perm.size(), hipMemcpyHostToDevice, p->stream));
-            HIP_TRY(hipMemcpyAsync(u_xy + (size_t)xy_bytes * src.n_old, h_xy.data(), h_xy.size(), hipMemcpyHostToDevice, p->stream));
-        }
-        bt_mark("slots+upload obs");
-        const int brc = build_point_major(p->stream, &p->arena, device, nobs, npt, ncam, xy_bytes, u_pt, u_cam, u_perm, u_xy, &pm, &npair_total);
-        if (brc) return fail(SFMBA_ERR_HIP, std::string("point-major build: ") + hipGetErrorString((hipError_t)brc));
-        // (build_point_major synchronised the stream: the staging arrays and the host vectors may go)
+    // ---- per-point / per-camera observation counts on the HOST (slot order), kept across appends: the CSR pointers, the pair total
+    // and every launch descriptor that depends on them are known without asking the device, so the whole structure build is one
+    // enqueue with a single wait at its end (it used to be sort -> wait -> copy back -> host loop, three times over) ----
+    DeviceArena staging(device);           // unsorted observations + sort temporaries: released once the stream has drained
+    staging.set_zeroing(false);
+    p->h_pt_cnt.resize((size_t)npt, 0); p->h_cam_cnt.resize((size_t)ncam, 0);
+    // new observations as ONE packed host buffer: point slots | camera slots | caller indices | coordinates
+    const size_t nn = (size_t)src.n_new;
+    // (in the kit's pinned block when it fits -- a view's worth does: the upload is then a plain asynchronous copy)
+    const size_t h_new_bytes = (3 * sizeof(int) + (size_t)xy_bytes) * nn + 16;
+    std::vector<char> h_new_heap(h_new_bytes <= HOSTKIT_UPLOAD_BYTES && p->kit.upload ? 0 : h_new_bytes);
+    char* h_new = h_new_heap.empty() ? p->kit.upload : h_new_heap.data();
+    int* h_pt = reinterpret_cast<int*>(h_new);
+    int* h_cam = h_pt + nn;
+    int* h_perm = h_cam + nn;
+    char* h_xy = h_new + (3 * sizeof(int) * nn + 15) / 16 * 16;                  // 16-byte aligned (double2 loads on the device)
+    if (src.n_new > 0) {
+        const int perm0 = (int)p->n_obs - src.n_new;           // caller index of the first new observation
+        std::mutex cam_mu;
+        int* pt_cnt = p->h_pt_cnt.data();
+        // (one thread below PARALLEL_FOR_MIN items: plain increments then -- a locked add is a full fence on x86 and would serialise the
+        // cache misses of the scattered point slots, which are all this loop costs when a view is appended)
+        const bool one_thread = src.n_new < PARALLEL_FOR_MIN;
+        parallel_for(src.n_new, [&](int k0, int k1) {
+            std::vector<int> cam_local((size_t)ncam, 0);
+            for (int k = k0; k < k1; ++k) {
+                if (k + 16 < k1) { const int pf = p->pt_slot[(size_t)src.pt[k + 16]]; __builtin_prefetch(pt_cnt + pf, 1); }
+                const int ps = p->pt_slot[(size_t)src.pt[k]], cs = p->cam_slot[(size_t)src.cam[k]];
+                h_pt[(size_t)k] = ps; h_cam[(size_t)k] = cs; h_perm[(size_t)k] = perm0 + k;
+                if (one_thread) ++pt_cnt[ps]; else __atomic_fetch_add(pt_cnt + ps, 1, __ATOMIC_RELAXED);
+                ++cam_local[(size_t)cs];
+                if (f32) { float* d = reinterpret_cast<float*>(h_xy) + 2 * (size_t)k; d[0] = (float)src.xy[2 * (size_t)k]; d[1] = (float)src.xy[2 * (size_t)k + 1]; }
+                else { double* d = reinterpret_cast<double*>(h_xy) + 2 * (size_t)k; d[0] = src.xy[2 * (size_t)k]; d[1] = src.xy[2 * (size_t)k + 1]; }
+            }
+            std::lock_guard<std::mutex> lk(cam_mu);
+            for (int j = 0; j < ncam; ++j) p->h_cam_cnt[(size_t)j] += cam_local[(size_t)j];
+        });
     }
-    p->d_pt_ptr = pm.pt_ptr; p->d_obs_cam = pm.obs_cam; p->d_obs_pt = pm.obs_pt; p->d_perm = pm.obs_pt + nobs; p->d_obs_xy = pm.obs_xy;
-    if (npair_total >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
-    std::vector<int> pt_ptr((size_t)npt + 1, 0);
-    HIP_TRY(hipMemcpy(pt_ptr.data(), pm.pt_ptr, sizeof(int) * pt_ptr.size(), hipMemcpyDeviceToHost));
-    bt_mark("point-major sort");
-
-    // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the self pairs are folded
-    // into the camera-diagonal pass) goes to block (ja, jb) of the upper triangle of S
+    bt_mark("counts");
+    PointMajor pm;
     const int64_t nblock64 = (int64_t)ncam * (ncam + 1) / 2;
     if (nblock64 >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many cameras");
     const int nblock = (int)nblock64;
     auto block_of = [ncam](int ja, int jb) { return (int)((int64_t)ja * ncam - (int64_t)ja * (ja - 1) / 2 + (jb - ja)); };
-    {
-        const int brc = build_pair_lists(p->stream, &p->arena, device, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pm.pair_off, npair_total,
-                                         &p->d_pairs, &p->d_blk_ptr);
-        if (brc) return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc));
-    }
-    std::vector<int> blk_ptr((size_t)nblock + 1, 0);
-    HIP_TRY(hipMemcpy(blk_ptr.data(), p->d_blk_ptr, sizeof(int) * blk_ptr.size(), hipMemcpyDeviceToHost));
-    bt_mark("pair lists");
-    {
-        const int crc = build_camera_major(p->stream, &p->arena, device, nobs, ncam, p->d_obs_cam, p->d_obs_pt, &p->d_cam_obs, &p->d_cam_obs_pt, &p->d_cam_ptr);
-        if (crc) return fail(SFMBA_ERR_HIP, std::string("camera-major build: ") + hipGetErrorString((hipError_t)crc));
-    }
-    std::vector<int> cam_ptr((size_t)ncam + 1, 0);
-    HIP_TRY(hipMemcpy(cam_ptr.data(), p->d_cam_ptr, sizeof(int) * cam_ptr.size(), hipMemcpyDeviceToHost));
-    bt_mark("camera-major");
 
-    // ---- launch descriptors (host, from the three CSR pointer arrays) ----
-    // chunks of the camera-major list: (camera, entry range)
-    const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
-    // (not in sharded mode: the per-chunk partial sums of the deterministic camera pass are added behind the all-reduce point)
+    // ---- host half of the build: CSR pointers from the counts, launch descriptors, their upload, the parameters.  It runs on the
+    // process's helper thread WHILE this thread enqueues the sorts (some forty launches: the enqueue is what the build costs now);
+    // the two halves meet once, at the pair total (needed to size the pair list), and join before the last two launches. ----
+    std::vector<int> pt_ptr((size_t)npt + 1, 0), cam_ptr((size_t)ncam + 1, 0);
+    long long npair_total = 0;
+    std::atomic<int> counts_state(0);            // 1 = pointers and pair total ready, -1 = counts inconsistent
+    std::vector<int4> chunks, chunks_coarse, wv_desc;
+    std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0), wv_ptr;
+    std::vector<int2> blk_cams, pwg_blocks;
+    std::vector<double> cam0, pts0;
+    std::vector<char> blob;
+    int pair_lpb = 64, blocks_per_wg = 1;
     { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e && e[0] == '1' && !sharded; }
-    const int coarse_len = p->deterministic ? (1 << 30) : 1024;      // deterministic mode: one column-norm workgroup per camera (single writer)
-    std::vector<int4> chunks, chunks_coarse;
-    std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0);
-    for (int j = 0; j < ncam; ++j) {
-        cam_chunk_ptr[(size_t)j] = (int)chunks.size();
-        for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
-            int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = 0;
-            chunks.push_back(c);
-        }
-        for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += coarse_len) {
-            int4 c; c.x = j; c.y = e0; c.z = (int)std::min<long long>((long long)e0 + coarse_len, cam_ptr[(size_t)j + 1]); c.w = 0;
-            chunks_coarse.push_back(c);
-        }
-    }
-    cam_chunk_ptr[(size_t)ncam] = (int)chunks.size();
-    std::vector<int2> blk_cams((size_t)nblock);
-    for (int ja = 0; ja < ncam; ++ja)
-        for (int jb = ja; jb < ncam; ++jb) { int2 c; c.x = ja; c.y = jb; blk_cams[(size_t)block_of(ja, jb)] = c; }
-    // workgroups of the pair pass: consecutive blocks of ONE block-row each; rows are dealt to the 8
-    // XCDs (blockIdx % 8, the observed dispatch order) so a row's records stay in one L2.  Performance
-    // only: any placement gives the same result.
-    // Lanes per block of the pair pass, from the mean number of pairs of an off-diagonal block: a whole wave (64 pairs per
-    // round) or 16 lanes (4 blocks per wave).  Measured on MI355X: 16 lanes win at 56 pairs per block (110 vs 139 us) and
-    // below (280 vs 738 us at 5.6), the whole wave wins at 226 (77 vs 105 us).  SFMBA_PAIR_LPB overrides.
-    const double mean_pairs = (double)npair_total / (double)std::max(1, nblock - ncam);
-    int pair_lpb = mean_pairs >= 128.0 ? 64 : 16;
-    if (const char* e = std::getenv("SFMBA_PAIR_LPB")) { const int v = std::atoi(e); if (v == 64 || v == 16) pair_lpb = v; }
-    const int blocks_per_wg = pair_lpb == 64 ? SFMBA_PAIR_WAVES : 64 / pair_lpb;
-    std::vector<int2> pwg_blocks;
-    {
-        std::vector<std::vector<int2>> per_xcd(8);
-        for (int ja = 0; ja < ncam; ++ja) {
-            const int b0 = block_of(ja, ja), nb = ncam - ja;
-            for (int o = 0; o < nb; o += blocks_per_wg) { int2 w; w.x = b0 + o; w.y = std::min(blocks_per_wg, nb - o); per_xcd[ja % 8].push_back(w); }
-        }
-        size_t longest = 0;
-        for (auto& v : per_xcd) longest = std::max(longest, v.size());
-        for (size_t m = 0; m < longest; ++m)
-            for (int x = 0; x < 8; ++x) {
-                int2 w; w.x = 0; w.y = 0;
-                if (m < per_xcd[x].size()) w = per_xcd[x][m];
-                pwg_blocks.push_back(w);
+    auto host_half = [&]() -> int {
+        for (int i = 0; i < npt; ++i) { const long long m = p->h_pt_cnt[(size_t)i]; pt_ptr[(size_t)i + 1] = pt_ptr[(size_t)i] + (int)m; npair_total += m * (m - 1) / 2; }
+        for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] = cam_ptr[(size_t)j] + p->h_cam_cnt[(size_t)j];
+        const bool counts_ok = pt_ptr[(size_t)npt] == nobs && cam_ptr[(size_t)ncam] == nobs && npair_total < ((long long)1 << 31);
+        counts_state.store(counts_ok ? 1 : -1, std::memory_order_release);
+        if (!counts_ok) return SFMBA_OK;         // (reported by the other half)
+        // ---- launch descriptors (from the CSR pointer arrays) ----
+        // chunks of the camera-major list: (camera, entry range)
+        const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
+        // (not in sharded mode: the per-chunk partial sums of the deterministic camera pass are added behind the all-reduce point)
+        const int coarse_len = p->deterministic ? (1 << 30) : 1024;      // deterministic mode: one column-norm workgroup per camera (single writer)
+        for (int j = 0; j < ncam; ++j) {
+            cam_chunk_ptr[(size_t)j] = (int)chunks.size();
+            for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += chunk_len) {
+                int4 c; c.x = j; c.y = e0; c.z = std::min(e0 + chunk_len, cam_ptr[(size_t)j + 1]); c.w = 0;
+                chunks.push_back(c);
             }
-    }
-    std::vector<int4> pwg_desc(pwg_blocks.size() * (size_t)blocks_per_wg);
-    for (size_t wgi = 0; wgi < pwg_blocks.size(); ++wgi)
-        for (int k = 0; k < blocks_per_wg; ++k) {
-            int4 dsc; dsc.x = -1; dsc.y = 0; dsc.z = 0; dsc.w = 0;
-            if (k < pwg_blocks[wgi].y) {
-                const int b = pwg_blocks[wgi].x + k;
-                dsc.x = b; dsc.y = blk_cams[(size_t)b].x; dsc.z = blk_ptr[(size_t)b]; dsc.w = blk_ptr[(size_t)b + 1];
+            for (int e0 = cam_ptr[j]; e0 < cam_ptr[(size_t)j + 1]; e0 += coarse_len) {
+                int4 c; c.x = j; c.y = e0; c.z = (int)std::min<long long>((long long)e0 + coarse_len, cam_ptr[(size_t)j + 1]); c.w = 0;
+                chunks_coarse.push_back(c);
             }
-            pwg_desc[wgi * (size_t)blocks_per_wg + k] = dsc;
         }
-    // diagonal blocks that contain pairs (the same camera observing a point twice): handled by a separate pass
-    std::vector<int2> dup_blocks;
-    for (int ja = 0; ja < ncam; ++ja) {
-        const int b = block_of(ja, ja);
-        if (blk_ptr[(size_t)b + 1] > blk_ptr[b]) { int2 w; w.x = b; w.y = 1; dup_blocks.push_back(w); }
-    }
-    // waves of the point passes: contiguous ranges of whole points with at most 64 observations (a point
-    // with more observations than that gets a wave of its own and is swept in several rounds)
-    std::vector<int> wv_ptr;
-    wv_ptr.push_back(0);
-    {
-        int cnt = 0, npts_in = 0;
-        for (int i = 0; i < npt; ++i) {
-            const int k = pt_ptr[(size_t)i + 1] - pt_ptr[i];
-            if (npts_in > 0 && (cnt + k > 64 || npts_in >= 64)) { wv_ptr.push_back(i); cnt = 0; npts_in = 0; }
-            cnt += k; ++npts_in;
+        cam_chunk_ptr[(size_t)ncam] = (int)chunks.size();
+        blk_cams.resize((size_t)nblock);
+        for (int ja = 0; ja < ncam; ++ja)
+            for (int jb = ja; jb < ncam; ++jb) { int2 c; c.x = ja; c.y = jb; blk_cams[(size_t)block_of(ja, jb)] = c; }
+        // workgroups of the pair pass: consecutive blocks of ONE block-row each; rows are dealt to the 8
+        // XCDs (blockIdx % 8, the observed dispatch order) so a row's records stay in one L2.  Performance
+        // only: any placement gives the same result.
+        // Lanes per block of the pair pass, from the mean number of pairs of an off-diagonal block: a whole wave (64 pairs per
+        // round) or 16 lanes (4 blocks per wave).  Measured on MI355X: 16 lanes win at 56 pairs per block (110 vs 139 us) and
+        // below (280 vs 738 us at 5.6), the whole wave wins at 226 (77 vs 105 us).  SFMBA_PAIR_LPB overrides.
+        const double mean_pairs = (double)npair_total / (double)std::max(1, nblock - ncam);
+        pair_lpb = mean_pairs >= 128.0 ? 64 : 16;
+        if (const char* e = std::getenv("SFMBA_PAIR_LPB")) { const int v = std::atoi(e); if (v == 64 || v == 16) pair_lpb = v; }
+        blocks_per_wg = pair_lpb == 64 ? SFMBA_PAIR_WAVES : 64 / pair_lpb;
+        {
+            std::vector<std::vector<int2>> per_xcd(8);
+            for (int ja = 0; ja < ncam; ++ja) {
+                const int b0 = block_of(ja, ja), nb = ncam - ja;
+                for (int o = 0; o < nb; o += blocks_per_wg) { int2 w; w.x = b0 + o; w.y = std::min(blocks_per_wg, nb - o); per_xcd[ja % 8].push_back(w); }
+            }
+            size_t longest = 0;
+            for (auto& v : per_xcd) longest = std::max(longest, v.size());
+            for (size_t m = 0; m < longest; ++m)
+                for (int x = 0; x < 8; ++x) {
+                    int2 w; w.x = 0; w.y = 0;
+                    if (m < per_xcd[x].size()) w = per_xcd[x][m];
+                    pwg_blocks.push_back(w);
+                }
         }
-        wv_ptr.push_back(npt);
-    }
-    bt_mark("maps");
-    HIP_TRY(dev_upload(&p->d_chunks, chunks));
-    HIP_TRY(dev_upload(&p->d_chunks_coarse, chunks_coarse));
-    HIP_TRY(dev_upload(&p->d_cam_chunk_ptr, cam_chunk_ptr));
-    HIP_TRY(dev_upload(&p->d_blk_cams, blk_cams));
-    HIP_TRY(dev_upload(&p->d_pwg_blocks, pwg_blocks));
-    HIP_TRY(dev_upload(&p->d_pwg_desc, pwg_desc));
-    HIP_TRY(dev_upload(&p->d_dup_blocks, dup_blocks));
-    HIP_TRY(dev_upload(&p->d_pwg_ptr, wv_ptr));
-    {
-        std::vector<int4> wv_desc(wv_ptr.size() - 1);
+        // waves of the point passes: contiguous ranges of whole points with at most 64 observations (a point
+        // with more observations than that gets a wave of its own and is swept in several rounds)
+        wv_ptr.push_back(0);
+        {
+            int cnt = 0, npts_in = 0;
+            for (int i = 0; i < npt; ++i) {
+                const int k = pt_ptr[(size_t)i + 1] - pt_ptr[i];
+                if (npts_in > 0 && (cnt + k > 64 || npts_in >= 64)) { wv_ptr.push_back(i); cnt = 0; npts_in = 0; }
+                cnt += k; ++npts_in;
+            }
+            wv_ptr.push_back(npt);
+        }
+        wv_desc.resize(wv_ptr.size() - 1);
         for (size_t g = 0; g + 1 < wv_ptr.size(); ++g) {
             int4 wd; wd.x = wv_ptr[g]; wd.y = wv_ptr[g + 1]; wd.z = pt_ptr[(size_t)wv_ptr[g]]; wd.w = pt_ptr[(size_t)wv_ptr[g + 1]];
             wv_desc[g] = wd;
         }
-        HIP_TRY(dev_upload(&p->d_wv_desc, wv_desc));
-    }
-    bt_mark("upload structure");
+        // upload: ONE synchronous copy on the NULL stream (the problem's stream is non-blocking: it runs beside the sorts) of the
+        // seven arrays laid out back to back, 256-byte aligned
+        {
+            size_t off = 0;
+            auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+            const size_t o_chunks = place(sizeof(int4) * chunks.size()), o_coarse = place(sizeof(int4) * chunks_coarse.size()),
+                         o_ccp = place(sizeof(int) * cam_chunk_ptr.size()), o_bc = place(sizeof(int2) * blk_cams.size()),
+                         o_pwg = place(sizeof(int2) * pwg_blocks.size()), o_wvp = place(sizeof(int) * wv_ptr.size()), o_wvd = place(sizeof(int4) * wv_desc.size());
+            blob.resize(off ? off : 1);
+            auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(blob.data() + o, src, bytes); };
+            put(o_chunks, chunks.data(), sizeof(int4) * chunks.size()); put(o_coarse, chunks_coarse.data(), sizeof(int4) * chunks_coarse.size());
+            put(o_ccp, cam_chunk_ptr.data(), sizeof(int) * cam_chunk_ptr.size()); put(o_bc, blk_cams.data(), sizeof(int2) * blk_cams.size());
+            put(o_pwg, pwg_blocks.data(), sizeof(int2) * pwg_blocks.size()); put(o_wvp, wv_ptr.data(), sizeof(int) * wv_ptr.size());
+            put(o_wvd, wv_desc.data(), sizeof(int4) * wv_desc.size());
+            char* d_blob = nullptr;
+            HIP_TRY(dev_alloc(&d_blob, blob.size()));
+            HIP_TRY(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+            p->d_chunks = reinterpret_cast<int4*>(d_blob + o_chunks); p->d_chunks_coarse = reinterpret_cast<int4*>(d_blob + o_coarse);
+            p->d_cam_chunk_ptr = reinterpret_cast<int*>(d_blob + o_ccp); p->d_blk_cams = reinterpret_cast<int2*>(d_blob + o_bc);
+            p->d_pwg_blocks = reinterpret_cast<int2*>(d_blob + o_pwg); p->d_pwg_ptr = reinterpret_cast<int*>(d_blob + o_wvp);
+            p->d_wv_desc = reinterpret_cast<int4*>(d_blob + o_wvd);
+        }
+        HIP_TRY(dev_alloc(&p->d_pwg_desc, pwg_blocks.size() * (size_t)blocks_per_wg));
+        HIP_TRY(dev_alloc(&p->d_dup_blocks, (size_t)ncam));
+        return SFMBA_OK;
+    };
+    int host_rc = SFMBA_OK;
+    std::string host_msg;
+    BuildHelper::Lease helper(BuildHelper::instance());
+    auto host_task = [&] {
+        (void)hipSetDevice(device);
+        ArenaScope helper_scope(&p->arena);
+        host_rc = host_half();
+        if (host_rc != SFMBA_OK) host_msg = g_last_error;
+    };
+    if (helper.granted()) helper.post(host_task); else host_task();        // (another build has the helper: everything on this thread)
+    bt_mark("post");
+    // ---- unsorted observations on the device: one upload of the new ones, one kernel that lays old (device to device) and new
+    // ones out behind each other; then the point-major sort ----
     {
-        // slot order = order of first observation; when every camera / point of the caller's arrays is observed and the slots came out
-        // in index order (the usual case: point-major observation lists), the arrays go up as they are, without a gathered copy
+        int* u_pt = staging.alloc_n<int>((size_t)nobs);
+        int* u_cam = staging.alloc_n<int>((size_t)nobs);
+        int* u_perm = staging.alloc_n<int>((size_t)nobs);
+        char* u_xy = static_cast<char*>(staging.alloc((size_t)xy_bytes * std::max(nobs, 1)));
+        char* d_new = static_cast<char*>(staging.alloc(h_new_bytes));
+        if (!u_pt || !u_cam || !u_perm || !u_xy || !d_new) { helper.wait(); return fail(SFMBA_ERR_ALLOC, "device allocation failed"); }
+        hipError_t ce = hipSuccess;
+        if (src.n_new > 0) ce = hipMemcpyAsync(d_new, h_new, h_new_bytes, hipMemcpyHostToDevice, p->stream);
+        if (ce == hipSuccess) {
+            StageObs so;
+            so.n_old = src.n_old; so.n_new = src.n_new; so.old_pt = src.d_old_pt; so.old_cam = src.d_old_cam; so.old_perm = src.d_old_perm; so.old_xy = src.d_old_xy;
+            so.new_pt = reinterpret_cast<const int*>(d_new); so.new_cam = so.new_pt + nn; so.new_perm = so.new_cam + nn; so.new_xy = d_new + (h_xy - h_new);
+            so.u_pt = u_pt; so.u_cam = u_cam; so.u_perm = u_perm; so.u_xy = u_xy;
+            launch_stage_obs(p->stream, so, xy_bytes);
+            ce = hipGetLastError();
+        }
+        if (ce != hipSuccess) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("staging the observations: ") + hipGetErrorString(ce)); }
+        bt_mark("upload obs");
+        const int brc = build_point_major(p->stream, &p->arena, &staging, nobs, npt, ncam, xy_bytes, u_pt, u_cam, u_perm, u_xy, &pm);
+        if (brc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("point-major build: ") + hipGetErrorString((hipError_t)brc)); }
+    }
+    p->d_pt_ptr = pm.pt_ptr; p->d_obs_cam = pm.obs_cam; p->d_obs_pt = pm.obs_pt; p->d_perm = pm.obs_pt + nobs; p->d_obs_xy = pm.obs_xy;
+    bt_mark("enqueue point-major");
+    while (counts_state.load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
+    if (counts_state.load() < 0) {
+        helper.wait();
+        if (npair_total >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
+        return fail(SFMBA_ERR_HIP, "observation counts out of step with the observation list");
+    }
+    // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the self pairs are folded
+    // into the camera-diagonal pass) goes to block (ja, jb) of the upper triangle of S
+    {
+        const int brc = build_pair_lists(p->stream, &p->arena, &staging, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pm.pair_off, npair_total,
+                                         &p->d_pairs, &p->d_blk_ptr);
+        if (brc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc)); }
+    }
+    {
+        const int crc = build_camera_major(p->stream, &p->arena, &staging, nobs, ncam, p->d_obs_cam, p->d_obs_pt, &p->d_cam_obs, &p->d_cam_obs_pt, &p->d_cam_ptr);
+        if (crc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("camera-major build: ") + hipGetErrorString((hipError_t)crc)); }
+    }
+    bt_mark("enqueue sorts");
+    {
+        // ---- parameters (on this thread: the helper has the longer half).  Slot order = order of first observation; when every
+        // camera / point of the caller's arrays is observed and the slots came out in index order (the usual case: point-major
+        // observation lists), the arrays go up as they are ----
         bool cam_identity = (size_t)ncam == p->cam_slot.size(), pt_identity = (size_t)npt == p->pt_slot.size();
         for (int j = 0; j < ncam && cam_identity; ++j) cam_identity = p->acam_id[j] == j;
-        if (pt_identity) {
-            std::atomic<bool> ok(true);
-            parallel_for(npt, [&](int i0, int i1) { for (int i = i0; i < i1; ++i) if (p->apt_id[i] != i) { ok.store(false, std::memory_order_relaxed); break; } });
-            pt_identity = ok.load();
-        }
-        std::vector<double> cam0, pts0;
+        for (int i = 0; i < npt && pt_identity; ++i) pt_identity = p->apt_id[i] == i;
+        p->cam_identity = cam_identity; p->pt_identity = pt_identity;
         const double* cam_src = cam6;
         const double* pts_src = pt3;
         if (!cam_identity) {
@@ -744,6 +841,19 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         if (ncam > 0) HIP_TRY(hipMemcpy(p->d_cam0, cam_src, sizeof(double) * 6 * (size_t)ncam, hipMemcpyHostToDevice));
         if (npt > 0) HIP_TRY(hipMemcpy(p->d_pts0, pts_src, sizeof(double) * 3 * (size_t)npt, hipMemcpyHostToDevice));
     }
+    bt_mark("upload params");
+    helper.wait();
+    if (host_rc != SFMBA_OK) return fail(host_rc, host_msg);
+    bt_mark("join host half");
+    // what depends on the block CSR is filled in by the device, behind the pair sort: the pair-pass descriptors and the list of
+    // diagonal blocks that contain pairs (the same camera observing a point twice; handled by a separate pass).  The number of
+    // those and the device's own pair total come back through host-mapped memory and are read after the one wait below.
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
+    volatile int* build_report = reinterpret_cast<volatile int*>(p->kit.pinned + 1536);      // [1536, 1552) of the mailbox slice
+    build_report[0] = -1;
+    launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, p->d_pwg_desc);
+    launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, reinterpret_cast<int*>(p->d_pinned + 1536));
+    HIP_TRY(hipGetLastError());
     p->focal0 = p->focal = focal;
 
     DeviceStructure& ds = p->ds;
@@ -759,10 +869,9 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
     ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
-    ds.ndupwg = (int)dup_blocks.size(); ds.dup_blocks = p->d_dup_blocks;
+    ds.ndupwg = 0; ds.dup_blocks = p->d_dup_blocks;          // count: after the wait at the end
     ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr; ds.wv_desc = p->d_wv_desc;
 
-    bt_mark("upload params");
     DeviceBuffers& db = p->db;
     db = DeviceBuffers{};
     for (int b = 0; b < 2; ++b) {
@@ -807,12 +916,12 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         HIP_TRY(dev_alloc(&db.cd_part, (size_t)std::max(ds.nchunk, 1) * 48));
     }
     HIP_TRY(dev_alloc(&p->d_facc, (size_t)db.nslot * SLOT_W));
-    HIP_TRY(hipMemset(p->d_facc, 0, sizeof(double) * (size_t)db.nslot * SLOT_W));
+    HIP_TRY(hipMemsetAsync(p->d_facc, 0, sizeof(double) * (size_t)db.nslot * SLOT_W, p->stream));
     db.slots = p->d_facc;
     // padding of the reduced system (rows/columns >= d) is zero apart from the identity diagonal set by k_finalize
-    HIP_TRY(hipMemset(p->d_sys, 0, sizeof(double) * sys_len));
+    HIP_TRY(hipMemsetAsync(p->d_sys, 0, sizeof(double) * sys_len, p->stream));
     HIP_TRY(dev_alloc(&p->d_info, 2));
-    HIP_TRY(hipMemset(p->d_info, 0, 2 * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(p->d_info, 0, 2 * sizeof(int), p->stream));
     db.lin_info = p->d_info;
     db.fin_counter = p->d_info + 1;
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
@@ -824,9 +933,13 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
     bt_mark("alloc buffers");
-    const int rc = sfmba_problem_reset(p);
-    bt_mark("reset");
-    return rc;
+    // the one wait of the build: sorts, lists and descriptors are in place; the staging arena and the host vectors may go
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (build_report[0] < 0 || (((long long)build_report[3] << 32) | (unsigned)build_report[2]) != npair_total)
+        return fail(SFMBA_ERR_HIP, "structure build: the device's pair count differs from the host's");
+    ds.ndupwg = build_report[0];
+    bt_mark("wait for device");
+    return sfmba_problem_reset(p);
 }
 
 static int create_impl(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
@@ -867,6 +980,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     static_assert(sizeof(LMState) <= 1024, "LMState must fit its slice of the pinned block");
     if (!hostkit_acquire(device, &p->kit)) return fail(SFMBA_ERR_HIP, "stream / pinned memory creation failed");
     p->stream = p->kit.stream;
+    p->arena.set_ordering_stream(p->stream);          // zeroing of its chunks: ordered in front of the stream's work, not waited for
     p->h_state = reinterpret_cast<LMState*>(p->kit.pinned);                        // [0, 1024)
     p->h_lm_mail = reinterpret_cast<volatile int*>(p->kit.pinned + 1024);          // [1024, 1088)
     if (n_obs == 0 && !cam_active) {
@@ -894,17 +1008,23 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
     if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs_new > 0 && (!obs_cam || !obs_pt || !obs_xy)))
         return fail(SFMBA_ERR_INVALID_ARG, "NULL array");
     HIP_TRY(hipSetDevice(p->device));
-    for (int64_t k = 0; k < n_obs_new; ++k)
+    // (the observations of an added view are scattered over the points: the three loops over them cost their cache misses.  The
+    // check pulls the slot entries in, the slot loop the counters of build_structure's loop.)
+    p->cam_slot.resize((size_t)n_cam, -1); p->pt_slot.resize((size_t)n_pt, -1);
+    for (int64_t k = 0; k < n_obs_new; ++k) {
         if (obs_cam[k] < 0 || obs_cam[k] >= n_cam || obs_pt[k] < 0 || obs_pt[k] >= n_pt)
             return fail(SFMBA_ERR_INVALID_ARG, "observation index out of range");
+        __builtin_prefetch(&p->pt_slot[(size_t)obs_pt[k]], 1);
+    }
     HIP_TRY(hipStreamSynchronize(p->stream));
     // cameras / points that become observed get the next free slot (slot order = order of first observation)
-    p->cam_slot.resize((size_t)n_cam, -1); p->pt_slot.resize((size_t)n_pt, -1);
+    p->h_pt_cnt.reserve((size_t)n_pt);
     for (int64_t k = 0; k < n_obs_new; ++k) {
         int& cs = p->cam_slot[(size_t)obs_cam[k]];
         if (cs < 0) { cs = (int)p->acam_id.size(); p->acam_id.push_back(obs_cam[k]); }
         int& ps = p->pt_slot[(size_t)obs_pt[k]];
         if (ps < 0) { ps = (int)p->apt_id.size(); p->apt_id.push_back(obs_pt[k]); }
+        else if ((size_t)ps < p->h_pt_cnt.size()) __builtin_prefetch(&p->h_pt_cnt[(size_t)ps], 1);
     }
     p->n_cam_full = n_cam; p->n_pt_full = n_pt;
     ObsSource src;
@@ -978,15 +1098,22 @@ int sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double
     if (p->empty) return SFMBA_OK;
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    // slot == caller index everywhere (the usual case): straight into the caller's arrays, no gathered copy
     if (cam6) {
-        std::vector<double> cam((size_t)6 * p->ds.ncam);
-        HIP_TRY(hipMemcpy(cam.data(), p->db.cam[p->cur], sizeof(double) * cam.size(), hipMemcpyDeviceToHost));
-        for (int j = 0; j < p->ds.ncam; ++j) std::memcpy(cam6 + 6 * (size_t)p->acam_id[j], &cam[6 * (size_t)j], 6 * sizeof(double));
+        if (p->cam_identity) HIP_TRY(hipMemcpy(cam6, p->db.cam[p->cur], sizeof(double) * 6 * (size_t)p->ds.ncam, hipMemcpyDeviceToHost));
+        else {
+            std::vector<double> cam((size_t)6 * p->ds.ncam);
+            HIP_TRY(hipMemcpy(cam.data(), p->db.cam[p->cur], sizeof(double) * cam.size(), hipMemcpyDeviceToHost));
+            for (int j = 0; j < p->ds.ncam; ++j) std::memcpy(cam6 + 6 * (size_t)p->acam_id[j], &cam[6 * (size_t)j], 6 * sizeof(double));
+        }
     }
     if (pt3) {
-        std::vector<double> pts((size_t)3 * p->ds.npt);
-        HIP_TRY(hipMemcpy(pts.data(), p->db.pts[p->cur], sizeof(double) * pts.size(), hipMemcpyDeviceToHost));
-        for (int i = 0; i < p->ds.npt; ++i) std::memcpy(pt3 + 3 * (size_t)p->apt_id[i], &pts[3 * (size_t)i], 3 * sizeof(double));
+        if (p->pt_identity) HIP_TRY(hipMemcpy(pt3, p->db.pts[p->cur], sizeof(double) * 3 * (size_t)p->ds.npt, hipMemcpyDeviceToHost));
+        else {
+            std::vector<double> pts((size_t)3 * p->ds.npt);
+            HIP_TRY(hipMemcpy(pts.data(), p->db.pts[p->cur], sizeof(double) * pts.size(), hipMemcpyDeviceToHost));
+            for (int i = 0; i < p->ds.npt; ++i) std::memcpy(pt3 + 3 * (size_t)p->apt_id[i], &pts[3 * (size_t)i], 3 * sizeof(double));
+        }
     }
     return SFMBA_OK;
 }

@@ -57,14 +57,16 @@ __global__ void k_block_ptr(int nblock, int npair, const unsigned* __restrict__ 
 
 }  // namespace
 
-// d_pair_off[i] = number of pairs of the points before i (npt + 1 entries, device; build_point_major), npair their total.  On success *d_pairs (npair int2) and
-// *d_blk_ptr (nblock + 1 ints) live in `arena`; the sort's temporaries come from a scratch arena whose chunks go back to
-// the cache on return (the caller's next allocations pick them up).  Returns 0, or a hipError_t value.
-int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
+// d_pair_off[i] = number of pairs of the points before i (npt + 1 entries, device; build_point_major), npair their total (the caller
+// knows it from its per-point observation counts).  On success *d_pairs (npair int2) and *d_blk_ptr (nblock + 1 ints) live in
+// `arena`; the sort's temporaries come from `scratch`, which the caller keeps until the stream has drained: nothing here waits
+// for the device (the whole structure build is ONE enqueue, sfmba_api.hip build_structure).  Returns 0, or a hipError_t value.
+int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_arena, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
                      const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr) {
     *d_pairs = nullptr; *d_blk_ptr = nullptr;
+    (void)npt;
     hipError_t e;
-    DeviceArena scratch(device);
+    DeviceArena& scratch = *scratch_arena;
 #define SB_TRY(expr) do { e = (expr); if (e != hipSuccess) return (int)e; } while (0)
 #define SB_ALLOC(ptr, ar, T, n) do { ptr = (ar)->alloc_n<T>(n); if (!ptr) return (int)hipErrorOutOfMemory; } while (0)
     const size_t np = (size_t)(npair > 0 ? npair : 1);
@@ -74,7 +76,6 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int
     *d_pairs = reinterpret_cast<int2*>(d_v1);
     if (npair == 0) {
         SB_TRY(hipMemsetAsync(*d_blk_ptr, 0, sizeof(int) * ((size_t)nblock + 1), s));
-        SB_TRY(hipStreamSynchronize(s));
         return 0;
     }
     const long long* d_off = d_pair_off;
@@ -93,7 +94,6 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, int device, int npt, int
     SB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
     hipLaunchKernelGGL(k_block_ptr, dim3((nblock + 1 + 255) / 256), dim3(256), 0, s, nblock, (int)npair, d_k1, *d_blk_ptr);
     SB_TRY(hipGetLastError());
-    SB_TRY(hipStreamSynchronize(s));      // the scratch arena must not be recycled before the sort has finished
 #undef SB_TRY
 #undef SB_ALLOC
     return 0;
@@ -133,15 +133,15 @@ __global__ __launch_bounds__(256) void k_pm_paircount(int npt, const int* __rest
 // Point-major order of n observations given as unsorted device arrays of (point slot, camera slot, caller index, xy): stable
 // radix sort on (point, camera) -- the order adjustBundle() adds its residual blocks in (BA.cpp:142-166: points in cloud order,
 // std::map iteration = ascending view inside a point); equal keys keep their input order.  Outputs (from `arena`): the
-// sorted arrays, the CSR pointers and the per-point prefix of the pair counts; *npair = total number of pairs.
+// sorted arrays, the CSR pointers and the per-point prefix of the pair counts (pair_off[npt] = total number of pairs).  Enqueue
+// only: temporaries from the caller's `scratch` arena.
 // rocPRIM's radix sort falls back to a merge sort up to 2^20 items: ten merge passes over the 10^6 observations of BASELINE config 3
 // (~145 us per sort, two sorts per structure build) where a few Onesweep digit passes over the significant bits do (~40 us).
 typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)1 << 15> OnesweepAbove32k;
 static int bits_for(unsigned long long n) { int b = 1; while (b < 63 && ((unsigned long long)1 << b) < n) ++b; return b; }
 
-int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int npt, int ncam, int xy_bytes, const int* u_pt, const int* u_cam,
-                      const int* u_perm, const void* u_xy, PointMajor* out, long long* npair) {
-    *npair = 0;
+int build_point_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_arena, int n, int npt, int ncam, int xy_bytes, const int* u_pt, const int* u_cam,
+                      const int* u_perm, const void* u_xy, PointMajor* out) {
     out->obs_pt = arena->alloc_n<int>((size_t)2 * n);
     out->obs_cam = arena->alloc_n<int>((size_t)n);
     out->obs_xy = arena->alloc((size_t)xy_bytes * (n ? n : 1));
@@ -153,7 +153,7 @@ int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int 
         if ((e = hipMemsetAsync(out->pt_ptr, 0, sizeof(int) * ((size_t)npt + 1), s)) != hipSuccess) return (int)e;
         return (int)hipMemsetAsync(out->pair_off, 0, sizeof(long long) * ((size_t)npt + 1), s);
     }
-    DeviceArena scratch(device);
+    DeviceArena& scratch = *scratch_arena;
     unsigned long long* k0 = scratch.alloc_n<unsigned long long>((size_t)n);
     unsigned long long* k1 = scratch.alloc_n<unsigned long long>((size_t)n);
     int* v0 = scratch.alloc_n<int>((size_t)n);
@@ -182,9 +182,7 @@ int build_point_major(hipStream_t s, DeviceArena* arena, int device, int n, int 
     void* st = scratch.alloc(sb ? sb : 1);
     if (!st) return (int)hipErrorOutOfMemory;
     if ((e = hipcub::DeviceScan::ExclusiveSum(st, sb, cnt, out->pair_off, npt + 1, s)) != hipSuccess) return (int)e;
-    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    if ((e = hipMemcpyAsync(npair, out->pair_off + npt, sizeof(long long), hipMemcpyDeviceToHost, s)) != hipSuccess) return (int)e;
-    return (int)hipStreamSynchronize(s);          // the scratch arena is recycled on return
+    return (int)hipGetLastError();
 }
 
 namespace {
@@ -200,14 +198,14 @@ __global__ void k_gather_pt(int n, const int* __restrict__ cam_obs, const int* _
 
 // Camera-major index of the observations on the device: cam_obs[e] = point-major position q, grouped by camera with a stable
 // radix sort (ascending q, i.e. ascending point, inside a camera -- the order the host loop produced), cam_obs_pt[e] = its point.
-int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
+int build_camera_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_arena, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
                        int** d_cam_obs, int** d_cam_obs_pt, int** d_cam_ptr) {
     *d_cam_obs = arena->alloc_n<int>((size_t)nobs);
     *d_cam_obs_pt = arena->alloc_n<int>((size_t)nobs);
     *d_cam_ptr = arena->alloc_n<int>((size_t)ncam + 1);
     if (!*d_cam_obs || !*d_cam_obs_pt || !*d_cam_ptr) return (int)hipErrorOutOfMemory;
     if (nobs == 0) return (int)hipMemsetAsync(*d_cam_ptr, 0, sizeof(int) * ((size_t)ncam + 1), s);
-    DeviceArena scratch(device);
+    DeviceArena& scratch = *scratch_arena;
     unsigned* k0 = scratch.alloc_n<unsigned>((size_t)nobs);
     unsigned* k1 = scratch.alloc_n<unsigned>((size_t)nobs);
     int* v0 = scratch.alloc_n<int>((size_t)nobs);
@@ -224,10 +222,81 @@ int build_camera_major(hipStream_t s, DeviceArena* arena, int device, int nobs, 
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_gather_pt, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, *d_cam_obs, d_obs_pt, *d_cam_obs_pt);
     hipLaunchKernelGGL(k_block_ptr, dim3((ncam + 1 + 255) / 256), dim3(256), 0, s, ncam, nobs, k1, *d_cam_ptr);      // CSR pointers from the sorted keys
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    e = hipStreamSynchronize(s);          // the scratch arena is recycled on return
-    return (int)e;
+    return (int)hipGetLastError();
+}
+
+namespace {
+// Pair-pass descriptors of every workgroup slot: (block, its row camera, pair range) from the block CSR on the device
+__global__ __launch_bounds__(256) void k_pair_desc(int nslot, int group, const int2* __restrict__ pwg_blocks, const int2* __restrict__ blk_cams,
+                                                   const int* __restrict__ blk_ptr, int4* __restrict__ desc) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslot) return;
+    const int2 w = pwg_blocks[t / group];
+    const int k = t % group;
+    int4 d; d.x = -1; d.y = 0; d.z = 0; d.w = 0;
+    if (k < w.y) { const int b = w.x + k; d.x = b; d.y = blk_cams[b].x; d.z = blk_ptr[b]; d.w = blk_ptr[b + 1]; }
+    desc[t] = d;
+}
+// Diagonal blocks that hold pairs (one camera observing a point twice), ascending camera order; their number and the device's own
+// total pair count go to host-mapped memory (report[0] = blocks, report[2..3] = pairs), read by the host once the stream has drained.
+__global__ __launch_bounds__(256) void k_dup_blocks(int ncam, const int* __restrict__ blk_ptr, const long long* __restrict__ pair_total,
+                                                    int2* __restrict__ dup, int* __restrict__ report) {
+    __shared__ int sc[256];
+    __shared__ int base;
+    const int tid = threadIdx.x;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < ncam; j0 += 256) {
+        const int j = j0 + tid;
+        int b = 0, has = 0;
+        if (j < ncam) { b = (int)block_of(j, j, ncam); has = blk_ptr[b + 1] > blk_ptr[b]; }
+        sc[tid] = has;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int v = tid >= off ? sc[tid - off] : 0;
+            __syncthreads();
+            sc[tid] += v;
+            __syncthreads();
+        }
+        if (has) { int2 w; w.x = b; w.y = 1; dup[base + sc[tid] - 1] = w; }
+        __syncthreads();
+        if (tid == 0) base += sc[255];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        report[0] = base;
+        const long long np = *pair_total;
+        report[2] = (int)(np & 0xffffffffll); report[3] = (int)(np >> 32);
+        __threadfence_system();
+    }
+}
+}  // namespace
+
+namespace {
+template <typename XY>
+__global__ __launch_bounds__(256) void k_stage_obs(StageObs so) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= so.n_old + so.n_new) return;
+    const bool old = k < so.n_old;
+    const int j = old ? k : k - so.n_old;
+    so.u_pt[k] = (old ? so.old_pt : so.new_pt)[j];
+    so.u_cam[k] = (old ? so.old_cam : so.new_cam)[j];
+    so.u_perm[k] = (old ? so.old_perm : so.new_perm)[j];
+    static_cast<XY*>(so.u_xy)[k] = static_cast<const XY*>(old ? so.old_xy : so.new_xy)[j];
+}
+}  // namespace
+void launch_stage_obs(hipStream_t s, const StageObs& so, int xy_bytes) {
+    const int n = so.n_old + so.n_new;
+    if (n <= 0) return;
+    if (xy_bytes == 8) hipLaunchKernelGGL(k_stage_obs<float2>, dim3((n + 255) / 256), dim3(256), 0, s, so);
+    else hipLaunchKernelGGL(k_stage_obs<double2>, dim3((n + 255) / 256), dim3(256), 0, s, so);
+}
+void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, int4* desc) {
+    const int nslot = nwg * group;
+    if (nslot > 0) hipLaunchKernelGGL(k_pair_desc, dim3((nslot + 255) / 256), dim3(256), 0, s, nslot, group, pwg_blocks, blk_cams, blk_ptr, desc);
+}
+void launch_dup_blocks(hipStream_t s, int ncam, const int* blk_ptr, const long long* pair_total, int2* dup, int* report) {
+    hipLaunchKernelGGL(k_dup_blocks, dim3(1), dim3(256), 0, s, ncam, blk_ptr, pair_total, dup, report);
 }
 
 }  // namespace sfmba

@@ -453,10 +453,21 @@ void SfMBundleAdjustmentUtils::adjustBundle(
     std::vector<int>& grown_pts = c.grown_pts;
     grown_pts.clear();
     if (overlap) {
-        for (int i = 0; i < c.n_pt; i++) {
-            const size_t k_new = first[(size_t)i + 1] - first[i], k_old = c.prev.first[(size_t)i + 1] - c.prev.first[i];
-            if (k_new < k_old) { overlap = false; break; }
-            if (k_new != k_old) grown_pts.push_back(i);
+        // pooled over ranges of points; the per-range lists are concatenated in order
+        WorkerPool& cls_pool = WorkerPool::instance();
+        const unsigned n_rng = c.n_pt >= 20000 ? cls_pool.size() : 1u;
+        std::vector<std::vector<int>> grown_rng(n_rng);
+        std::vector<char> shrunk(n_rng, 0);
+        cls_pool.run(n_rng, [&](unsigned t) {
+            for (size_t i = (size_t)c.n_pt * t / n_rng; i < (size_t)c.n_pt * (t + 1) / n_rng; i++) {
+                const size_t k_new = first[i + 1] - first[i], k_old = c.prev.first[i + 1] - c.prev.first[i];
+                if (k_new < k_old) { shrunk[t] = 1; break; }
+                if (k_new != k_old) grown_rng[t].push_back((int)i);
+            }
+        });
+        for (unsigned t = 0; t < n_rng; ++t) {
+            if (shrunk[t]) overlap = false;
+            grown_pts.insert(grown_pts.end(), grown_rng[t].begin(), grown_rng[t].end());
         }
     }
     std::atomic<bool> lists_differ(false);

@@ -87,6 +87,37 @@ def test_concurrent_resident_problems_are_independent(capi, sfm):
             h.close()
 
 
+def test_concurrent_structure_builds(capi, sfm):
+    """Problems CREATED from concurrent host threads: one build at a time gets the process's helper thread for its host half, the
+    others run both halves themselves (sfmba_api.hip build_structure) -- every one must come out like a build made alone."""
+    import threading
+    probs = [sfm.make_problem("cfg4", n_pt=3000, sub=g) for g in range(8)]
+    opt = capi.default_options(max_seconds=0.0, precision=1, linear_solver=1)
+    ref = []
+    for p in probs:
+        h = capi.Problem(p, precision=1)
+        s, _ = h.solve(opt)
+        ref.append((s["iterations"], s["final_cost"], h.get_params()[0].copy()))
+        h.close()
+    for _ in range(3):
+        out = [None] * len(probs)
+
+        def work(k):
+            h = capi.Problem(probs[k], precision=1)
+            try:
+                s, _ = h.solve(opt)
+                out[k] = (s["iterations"], s["final_cost"], h.get_params()[0].copy())
+            finally:
+                h.close()
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(probs))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        for k, got in enumerate(out):
+            assert got is not None and got[0] == ref[k][0]
+            assert abs(got[1] - ref[k][1]) <= 1e-9 * ref[k][1]
+            assert np.abs(got[2] - ref[k][2]).max() < 1e-9
+
+
 def test_invalid_arguments_are_reported_not_crashed(capi, sfm):
     """Error model of the C ABI: integer return code + sfmba_last_error(), nothing is touched, nothing crashes."""
     import ctypes as C
