@@ -293,13 +293,14 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
         nc = prob.n_cam
         ld = (int(L.sfmba_shard_setup_len(be._h)) - 80) // 2
         n_a, n_red = 27 * nc + 3 * ld + 80, 18 * nc * (nc - 1)
+        ex_bytes, b_fp32 = summ.get("exchange_bytes", [8 * n_a, 8 * n_red, 640]), summ.get("exchange_b_fp32", False)
         stream = C.c_void_p(L.sfmba_problem_stream(be._h))
         buf = C.c_void_p(L.sfmba_shard_reduce_buf(be._h))
         reps = 10
         barrier()
         t1 = time.perf_counter()
-        for _ in range(reps):
-            L.sfmba_comm_allreduce(comm._h, buf, C.c_int64(n_red), stream)
+        for _ in range(reps):          # the same call, count and element type as exchange (B) inside the solve
+            (L.sfmba_comm_allreduce_f32 if b_fp32 else L.sfmba_comm_allreduce)(comm._h, buf, C.c_int64(n_red), stream)
         barrier()
         t_ar = (time.perf_counter() - t1) / reps
         tmax = torch.tensor([dt, t_ar], dtype=torch.float64, device="cuda")
@@ -309,11 +310,11 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
         return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
                 "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
                 "ms_per_step": 1e3 * g_dt / steps, "lm_iterations_per_step": iters / steps,
-                "allreduce_bytes_per_lm_iteration": 8 * (n_a + n_red + 80), "allreduce_ms": 1e3 * g_ar,
-                "allreduce_GBps_algorithmic": 8.0 * n_red / g_ar / 1e9,
-                "collective": "three ncclAllReduce(SUM, fp64) per LM iteration on the solver stream: [6x6 diagonal blocks | camera-focal column | rhs | "
-                              "diagonals | scalars] (%d doubles), the off-diagonal blocks of the block-Jacobi-preconditioned reduced matrix (%d doubles: the "
-                              "one timed here), 80 trial-step scalars; every rank runs the CG on the summed matrix redundantly" % (n_a, n_red),
+                "allreduce_bytes_per_lm_iteration": int(sum(ex_bytes)), "allreduce_ms": 1e3 * g_ar,
+                "allreduce_GBps_algorithmic": ex_bytes[1] / g_ar / 1e9, "exchange_b_dtype": "f32" if b_fp32 else "f64",
+                "collective": "three ncclAllReduce(SUM) per LM iteration on the solver stream: [6x6 diagonal blocks | camera-focal column | rhs | "
+                              "diagonals | scalars] (%d doubles), the off-diagonal blocks of the block-Jacobi-preconditioned reduced matrix (%d values, %s: the "
+                              "one timed here), 80 trial-step scalars; every rank runs the CG on the summed matrix redundantly" % (n_a, n_red, "fp32 like the CG's stored matrix" if b_fp32 else "fp64"),
                 "final_rms_px": float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)), "final_cost": summ["final_cost"],
                 "termination": summ["termination_name"], "linear_iters_per_step": summ["linear_iters"]}
     finally:

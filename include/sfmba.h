@@ -281,6 +281,15 @@ SFMBA_API void sfmba_comm_destroy(sfmba_comm* comm);
 SFMBA_API int  sfmba_comm_allreduce(void* comm /* sfmba_comm* */, void* device_buf, int64_t n_doubles, void* hip_stream);   /* an sfmba_allreduce_fn */
 SFMBA_API int  sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx,
                                  sfmba_summary* summary);
+/* Optional single-precision all-reduce (same ctx as the fp64 one).  Where the CG stores the preconditioned matrix in fp32 anyway
+ * (SFMBA_PRECISION_F32J and more than 1280 reduced unknowns: the streaming CG path) exchange (B) -- by far the largest: 18 Nc (Nc - 1)
+ * values, 144 MB in fp64 at 1000 cameras -- is then summed and stored in fp32: half the bytes over xGMI, and the summed buffer is the
+ * CG's matrix without a narrowing pass.  Without it (or with SFMBA_SHARD_F32_EXCHANGE=0) every exchange stays fp64. */
+typedef int (*sfmba_allreduce_f32_fn)(void* ctx, void* device_buf, int64_t n_floats, void* hip_stream);
+SFMBA_API int  sfmba_comm_allreduce_f32(void* comm /* sfmba_comm* */, void* device_buf, int64_t n_floats, void* hip_stream);   /* an sfmba_allreduce_f32_fn */
+SFMBA_API int  sfmba_problem_set_allreduce_f32(sfmba_problem* p, sfmba_allreduce_f32_fn allreduce_f32);                        /* NULL: fp64 only */
+/* what the last sfmba_problem_solve_sharded() exchanged per linearisation: out = { bytes of (A), bytes of (B), bytes of (C), 1 if (B) was fp32 } */
+SFMBA_API int  sfmba_shard_last_exchange(const sfmba_problem* p, int64_t out[4]);
 
 /*
  * The step in front of bundle adjustment: SfMStereoUtilities::triangulateViews

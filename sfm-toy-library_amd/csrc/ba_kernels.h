@@ -143,6 +143,7 @@ struct DeviceBuffers {
                               //         dense_solver.hip), written by k_finalize (PCG mode); null = not wanted
     int* lm_mailbox;          // host-mapped {seq, termination, message, iter}: polled by the host instead of a D2H copy + sync
     double shared_weight;     // 1 normally; 0 on ranks > 0 of a sharded solve (replicated cameras/focal counted once)
+    float* shard_blocks32;    // ... the same in fp32 (exchange (B) in single precision: the streaming CG path stores S~ in fp32 anyway)
     double* shard_blocks;     // sharded CG path: the pair pass (MODE 1) stores the off-diagonal blocks of S~ here (all-reduce layout) instead of pcg_F
     const double* shard_scal; // sharded solve: k_lm_control takes the trial sums from this all-reduced scalar block instead of the slots
 };
@@ -179,6 +180,7 @@ void launch_shard_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuf
 long long shard_offdiag_len(const DeviceStructure& ds);
 void launch_shard_offdiag(hipStream_t s, const DeviceStructure& ds, double* F, double* buf, bool unpack);
 void launch_narrow_matrix(hipStream_t s, const double* src, float* dst, long long n);
+void launch_shard_offdiag_f32(hipStream_t s, const DeviceStructure& ds, float* F32, const float* buf);      // unpack of the fp32 exchange
 void launch_clear_slots(hipStream_t s, const DeviceBuffers& db);
 void launch_shard_xnorm_finish(hipStream_t s, const DeviceBuffers& db);
 void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int precision_f32);

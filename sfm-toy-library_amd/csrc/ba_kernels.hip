@@ -759,6 +759,7 @@ __device__ __forceinline__ void store_F(const DeviceBuffers& db, size_t idx, dou
 // one entry of an off-diagonal block of the preconditioned matrix: both triangles of the CG's matrix, or -- sharded CG path -- the
 // block's slot in the all-reduce buffer (k_shard_offdiag's layout; the matrix is written after the sum over the ranks)
 __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, const DeviceBuffers& db, int b, int2 cj, int r, int c, double v) {
+    if (db.shard_blocks32) { db.shard_blocks32[(size_t)(b - cj.x - 1) * 36 + 6 * r + c] = (float)v; return; }
     if (db.shard_blocks) { db.shard_blocks[(size_t)(b - cj.x - 1) * 36 + 6 * r + c] = v; return; }
     store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
     store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
@@ -1868,6 +1869,22 @@ long long shard_offdiag_len(const DeviceStructure& ds) { return 36ll * (ds.nbloc
 void launch_shard_offdiag(hipStream_t s, const DeviceStructure& ds, double* F, double* buf, bool unpack) {
     const long long n = 36ll * ds.nblock;
     hipLaunchKernelGGL(k_shard_offdiag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, F, buf, unpack ? 1 : 0);
+}
+// the fp32 exchange: the summed blocks ARE the CG's (fp32) matrix entries
+__global__ __launch_bounds__(256) void k_shard_offdiag_f32(DeviceStructure ds, float* __restrict__ F, const float* __restrict__ buf) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(t / 36), e = (int)(t - 36ll * b);
+    if (b >= ds.nblock) return;
+    const int2 cj = ds.blk_cams[b];
+    if (cj.x == cj.y) return;
+    const int r = e / 6, c = e - 6 * r;
+    const float v = buf[(size_t)(b - cj.x - 1) * 36 + e];
+    F[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
+    F[(size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r] = v;
+}
+void launch_shard_offdiag_f32(hipStream_t s, const DeviceStructure& ds, float* F32, const float* buf) {
+    const long long n = 36ll * ds.nblock;
+    hipLaunchKernelGGL(k_shard_offdiag_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, F32, buf);
 }
 __global__ void k_narrow_matrix(const double* __restrict__ src, float* __restrict__ dst, long long n) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dst[e] = (float)src[e];

@@ -228,6 +228,8 @@ struct sfmba_problem {
     int shard_rank = 0, shard_world = 1;
     double* d_scal = nullptr;                     // tail of d_sys: SFMBA_SHARD_SCALARS doubles
     int shard_host_iter = 0;
+    int64_t shard_exchange[4] = { 0, 0, 0, 0 };       // bytes of exchanges (A), (B), (C) per linearisation of the last sharded solve; (B) in fp32?
+    sfmba_allreduce_f32_fn allreduce_f32 = nullptr;   // optional: exchange (B) in fp32 where the CG stores S~ in fp32
     sfmba_summary shard_sum;
     Profiler prof;
 };
@@ -903,7 +905,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.bc = db.udiag + ds.ld;
     p->d_scal = db.bc + ds.ld;
     db.shared_weight = 1.0;
-    db.shard_blocks = nullptr; db.shard_scal = nullptr;
+    db.shard_blocks = nullptr; db.shard_blocks32 = nullptr; db.shard_scal = nullptr;
     HIP_TRY(dev_alloc(&db.st, 1));
     // Opt-in deterministic accumulation (SFMBA_DETERMINISTIC=1 when the problem is built): every workgroup of a launch owns its
     // accumulator slot and the multi-chunk camera sums are added in chunk order, so that no result depends on the order in which
@@ -1495,14 +1497,22 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
         const bool f32 = p->precision == SFMBA_PRECISION_F32J;
         bool first_linear_solve = true;
+        const char* x32_env = std::getenv("SFMBA_SHARD_F32_EXCHANGE");
+        const bool exchange_f32_off = x32_env && x32_env[0] == '0';
         int first_build = o.jacobi_scaling ? 1 : 2;          // the first point pass also forms the point scales
         for (;;) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
             p->db.pcg_W = coarse_cg ? p->solver.W : nullptr;
-            p->db.pcg_F32 = nullptr;             // the partial blocks are summed in fp64; the streaming CG path gets its fp32 copy after the sum
             float* F32 = f32 ? dense_pcg_want_f32(&p->solver) : nullptr;
             p->solver.use_f32 = F32 != nullptr;
+            // the streaming CG path stores S~ in fp32: with a single-precision all-reduce the partial blocks are exchanged in fp32 and
+            // the sum is the CG's matrix (what the camera pass and the pair epilogue write directly -- diagonal blocks, focal column --
+            // goes to the fp32 matrix as on one GPU); otherwise everything is summed in fp64 and narrowed after the sum
+            const bool x32 = F32 != nullptr && p->allreduce_f32 != nullptr && allreduce != nullptr && !exchange_f32_off;
+            p->db.pcg_F32 = x32 ? F32 : nullptr;
+            p->shard_exchange[0] = 8 * shard_diag_len(p->ds); p->shard_exchange[1] = (x32 ? 4 : 8) * shard_offdiag_len(p->ds);
+            p->shard_exchange[2] = 8 * SFMBA_SHARD_SCALARS; p->shard_exchange[3] = x32 ? 1 : 0;
             if (f32) { launch_point_build<float>(p->stream, p->ds, p->db, first_build); launch_cam_diag<float>(p->stream, p->ds, p->db); launch_schur_pairs<float>(p->stream, p->ds, p->db, 2); }
             else { launch_point_build<double>(p->stream, p->ds, p->db, first_build); launch_cam_diag<double>(p->stream, p->ds, p->db); launch_schur_pairs<double>(p->stream, p->ds, p->db, 2); }
             first_build = 0;
@@ -1510,12 +1520,19 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             if ((rc = reduce(p->d_red, shard_diag_len(p->ds)))) return rc;
             launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/true, p->shard_rank, p->shard_world);
             launch_finalize(p->stream, p->ds, p->db, 1);
-            p->db.shard_blocks = p->d_red;         // the pair pass stores its transformed blocks straight into the all-reduce buffer
+            // the pair pass stores its transformed blocks straight into the all-reduce buffer
+            if (x32) p->db.shard_blocks32 = reinterpret_cast<float*>(p->d_red); else p->db.shard_blocks = p->d_red;
             if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 1); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 1);
-            p->db.shard_blocks = nullptr;
-            if ((rc = reduce(p->d_red, shard_offdiag_len(p->ds)))) return rc;
-            launch_shard_offdiag(p->stream, p->ds, p->solver.Sfull, p->d_red, /*unpack=*/true);
-            if (F32) launch_narrow_matrix(p->stream, p->solver.Sfull, F32, (long long)p->ds.d * p->ds.ld);
+            p->db.shard_blocks = nullptr; p->db.shard_blocks32 = nullptr;
+            if (x32) {
+                const int arc = p->allreduce_f32(ctx, p->d_red, shard_offdiag_len(p->ds), (void*)p->stream);
+                if (arc != 0) return fail(SFMBA_ERR_HIP, "all-reduce (fp32) failed (rc " + std::to_string(arc) + ")");
+                launch_shard_offdiag_f32(p->stream, p->ds, F32, reinterpret_cast<const float*>(p->d_red));
+            } else {
+                if ((rc = reduce(p->d_red, shard_offdiag_len(p->ds)))) return rc;
+                launch_shard_offdiag(p->stream, p->ds, p->solver.Sfull, p->d_red, /*unpack=*/true);
+                if (F32) launch_narrow_matrix(p->stream, p->solver.Sfull, F32, (long long)p->ds.d * p->ds.ld);
+            }
             const int anchor = !o.pcg_anchored ? 0 : first_linear_solve ? 1 : 2;
             first_linear_solve = false;
             const int it0 = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
@@ -1660,6 +1677,26 @@ int sfmba_comm_allreduce(void* comm, void* device_buf, int64_t n_doubles, void* 
     if (!c || !a) return -1;
     const ncclResult_t r = a->AllReduce(device_buf, device_buf, (size_t)n_doubles, ncclDouble, ncclSum, c->comm, static_cast<hipStream_t>(hip_stream));
     return r == ncclSuccess ? 0 : (int)r;
+}
+
+int sfmba_comm_allreduce_f32(void* comm, void* device_buf, int64_t n_floats, void* hip_stream) {
+    sfmba_comm* c = static_cast<sfmba_comm*>(comm);
+    RcclApi* a = rccl();
+    if (!c || !a) return -1;
+    const ncclResult_t r = a->AllReduce(device_buf, device_buf, (size_t)n_floats, ncclFloat, ncclSum, c->comm, static_cast<hipStream_t>(hip_stream));
+    return r == ncclSuccess ? 0 : (int)r;
+}
+
+int sfmba_shard_last_exchange(const sfmba_problem* p, int64_t out[4]) {
+    if (!p || !out) return fail(SFMBA_ERR_INVALID_ARG, "NULL argument");
+    for (int k = 0; k < 4; ++k) out[k] = p->shard_exchange[k];
+    return SFMBA_OK;
+}
+
+int sfmba_problem_set_allreduce_f32(sfmba_problem* p, sfmba_allreduce_f32_fn allreduce_f32) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    p->allreduce_f32 = allreduce_f32;
+    return SFMBA_OK;
 }
 
 int sfmba_triangulate(int device, int64_t n, const float* left_xy, const float* right_xy, const float* K, const float* P_left,

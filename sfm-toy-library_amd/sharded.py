@@ -79,8 +79,10 @@ class HipShardBackend:
         capi._check(self.L.sfmba_shard_end(self._h, C.byref(summ)))
         return summ.as_dict()
 
-    def all_reduce(self, dist, which, group=None):
+    def all_reduce(self, dist, which, group=None, n_floats=None):
         t = {"setup": self.setup_t, "reduce": self.reduce_t, "scalars": self.scalars_t}[which]
+        if n_floats is not None:                            # the fp32 exchange: the head of the same buffer, viewed as float32
+            t = t.view(self.torch.float32)[:n_floats]
         with self.torch.cuda.stream(self.stream):           # the collective is ordered on the solver's own stream
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
@@ -136,8 +138,10 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
     L = backend.L
     summ = SfmbaSummary()
     keep = None
+    fn32 = None
     if comm is not None:
         fn, ctx = C.cast(L.sfmba_comm_allreduce, ALLREDUCE_FN), comm._h
+        fn32 = C.cast(L.sfmba_comm_allreduce_f32, ALLREDUCE_FN)
     elif dist is not None and backend.world > 1:
         by_ptr = {int(L.sfmba_shard_setup_buf(backend._h)): "setup", int(L.sfmba_shard_reduce_buf(backend._h)): "reduce",
                   int(L.sfmba_shard_scalars_buf(backend._h)): "scalars"}
@@ -148,13 +152,28 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
                 return 0
             except Exception:                      # never let an exception cross the C boundary
                 return 1
-        keep = fn = ALLREDUCE_FN(_cb)
+        def _cb32(_ctx, buf, n, _stream):
+            try:
+                backend.all_reduce(dist, by_ptr[int(buf)], group, n_floats=int(n))
+                return 0
+            except Exception:
+                return 1
+        fn = ALLREDUCE_FN(_cb)
+        fn32 = ALLREDUCE_FN(_cb32)
+        keep = (fn, fn32)
         ctx = None
     else:
         fn, ctx = C.cast(None, ALLREDUCE_FN), None
+    # the single-precision all-reduce is optional (exchange (B) in fp32 where the CG stores the matrix in fp32, include/sfmba.h)
+    capi._check(L.sfmba_problem_set_allreduce_f32(backend._h, fn32 if fn32 is not None else C.cast(None, ALLREDUCE_FN)))
     capi._check(L.sfmba_problem_solve_sharded(backend._h, C.byref(opt), fn, ctx, C.byref(summ)))
     del keep
-    return summ.as_dict()
+    out = summ.as_dict()
+    ex = (C.c_int64 * 4)()
+    capi._check(L.sfmba_shard_last_exchange(backend._h, ex))
+    out["exchange_bytes"] = [int(ex[0]), int(ex[1]), int(ex[2])]
+    out["exchange_b_fp32"] = bool(ex[3])
+    return out
 
 
 def solve_sharded(backend, dist, opt, group=None):

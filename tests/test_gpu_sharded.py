@@ -52,10 +52,15 @@ def _worker(rank, world, port, case, out, native=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,native", [("small", False), ("cfg2", False), ("wide", False), ("cfg2", True), ("wide", True)])
-def test_two_rank_sharded_hip_solve(sfm, oracle, case, native):
-    """native: the LM loop runs inside the C library (sfmba_problem_solve_sharded), the collectives come back through a callback."""
+@pytest.mark.parametrize("case,native,x32", [("small", False, True), ("cfg2", False, True), ("wide", False, True), ("cfg2", True, True),
+                                             ("wide", True, True), ("wide", True, False)])
+def test_two_rank_sharded_hip_solve(sfm, oracle, monkeypatch, case, native, x32):
+    """native: the LM loop runs inside the C library (sfmba_problem_solve_sharded), the collectives come back through a callback.
+    x32 (only the 'wide' native case has the fp32-stored matrix): the off-diagonal blocks of the preconditioned matrix are exchanged in
+    single precision (sfmba_problem_set_allreduce_f32); False switches that off (every exchange fp64)."""
     from sfm_toy_library_amd import capi
+    if not x32:
+        monkeypatch.setenv("SFMBA_SHARD_F32_EXCHANGE", "0")         # (inherited by the spawned ranks)
     kw, precision, linear, okw = CASES[case]
     world, port = 2, 29711 + (os.getpid() % 500)
     ctx = mp.get_context("spawn")
@@ -75,6 +80,9 @@ def test_two_rank_sharded_hip_solve(sfm, oracle, case, native):
     pts = np.vstack([pt0, pt1])
     assert rng0 == (0, prob.n_pt // 2) and rng1[1] == prob.n_pt
     assert s0["final_cost"] == s1["final_cost"]
+    if native:
+        wide_f32 = case == "wide" and x32           # the only case with the fp32-stored matrix (d = 1381 > 1280, F32J)
+        assert s0["exchange_b_fp32"] == wide_f32 and s0["exchange_bytes"][1] == (4 if wide_f32 else 8) * 18 * prob.n_cam * (prob.n_cam - 1)
     assert np.array_equal(cam0, cam1) and f0 == f1                      # replicas stay bit-identical
     # --- against the oracle's solve of the WHOLE problem (Ceres-equivalent LM + DENSE_SCHUR on one host) ---
     cam_o, pt_o, f_o, s_o, _ = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
