@@ -23,6 +23,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$c.err
 done
 python $REPO/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_pmc_traffic.txt "python bench.py --steps 2 --warmup 1 --no-cpu-baseline   (cfg3, f32j, PCG)" > /dev/null
+# 4. the sharded path on this box's one rank (RCCL communicator of one rank; the exchange is a no-op, its pack / unpack kernels are not)
+for wl in cfg3 cfg5; do
+  $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline 2> $OUT/sharded_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_bench.json
+done
+# 5. the drop-in shim in the reference's call pattern: one view added to 199 (SfM.cpp:464-466)
+SFMBA_BUILD_TIMING=1 python $REPO/tools/time_shim_incremental.py > $OUT/${TAG}_shim_incremental.txt 2>&1
+python $REPO/tools/time_create.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
 # keep the merge-back small
 rm -rf $OUT/stats_pcg $OUT/stats_cholesky $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT
