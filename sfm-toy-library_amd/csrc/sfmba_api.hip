@@ -1497,6 +1497,9 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
         const bool f32 = p->precision == SFMBA_PRECISION_F32J;
         bool first_linear_solve = true;
+        const char* spec_env = std::getenv("SFMBA_EARLY_LINEARISE");
+        const bool speculate = !(spec_env && spec_env[0] == '0');
+        bool build_enqueued = false;
         const char* x32_env = std::getenv("SFMBA_SHARD_F32_EXCHANGE");
         const bool exchange_f32_off = x32_env && x32_env[0] == '0';
         int first_build = o.jacobi_scaling ? 1 : 2;          // the first point pass also forms the point scales
@@ -1513,8 +1516,10 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             p->db.pcg_F32 = x32 ? F32 : nullptr;
             p->shard_exchange[0] = 8 * shard_diag_len(p->ds); p->shard_exchange[1] = (x32 ? 4 : 8) * shard_offdiag_len(p->ds);
             p->shard_exchange[2] = 8 * SFMBA_SHARD_SCALARS; p->shard_exchange[3] = x32 ? 1 : 0;
-            if (f32) { launch_point_build<float>(p->stream, p->ds, p->db, first_build); launch_cam_diag<float>(p->stream, p->ds, p->db); launch_schur_pairs<float>(p->stream, p->ds, p->db, 2); }
-            else { launch_point_build<double>(p->stream, p->ds, p->db, first_build); launch_cam_diag<double>(p->stream, p->ds, p->db); launch_schur_pairs<double>(p->stream, p->ds, p->db, 2); }
+            if (!build_enqueued) { if (f32) launch_point_build<float>(p->stream, p->ds, p->db, first_build); else launch_point_build<double>(p->stream, p->ds, p->db, first_build); }
+            build_enqueued = false;
+            if (f32) { launch_cam_diag<float>(p->stream, p->ds, p->db); launch_schur_pairs<float>(p->stream, p->ds, p->db, 2); }
+            else { launch_cam_diag<double>(p->stream, p->ds, p->db); launch_schur_pairs<double>(p->stream, p->ds, p->db, 2); }
             first_build = 0;
             launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/false, p->shard_rank, p->shard_world);
             if ((rc = reduce(p->d_red, shard_diag_len(p->ds)))) return rc;
@@ -1551,12 +1556,20 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                 launch_control(p->stream, p->ds, dbu);
                 if (hipError_t le = hipGetLastError(); le != hipSuccess) return fail(SFMBA_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(le));
                 ++controls;
+                // the next linearisation's first kernel before the host waits for the verdict, as in the one-GPU loop (run_solve): it
+                // looks at the LM state itself and returns at once if the solve ended or the iteration wants more CG first
+                if (speculate && p->shard_host_iter + 2 <= o.max_iters) {
+                    if (f32) launch_point_build<float>(p->stream, p->ds, p->db, 4); else launch_point_build<double>(p->stream, p->ds, p->db, 4);
+                    build_enqueued = true;
+                }
                 if (wait_mailbox(mb, controls, p->stream) != 0) {
                     const hipError_t se = hipStreamSynchronize(p->stream);
                     return fail(SFMBA_ERR_HIP, std::string("sharded LM iteration did not complete: ") + (se != hipSuccess ? hipGetErrorString(se) : "no control post"));
                 }
                 if (mb[1] != -2) break;
                 // the CG batch was too short (identically on every rank: same matrix, same arithmetic): more iterations, then the trio again
+                // (the early linearisation kernel behind that control kernel has returned without doing anything)
+                build_enqueued = false;
                 if (dense_pcg_more(p->stream, &p->solver, 8, nullptr) == 0) dbu.cg_force = 1;
             }
             dense_pcg_note(&p->solver, p->shard_host_iter, mb[4]);
