@@ -139,7 +139,7 @@ public:
     static BuildHelper& instance() { static BuildHelper* h = new BuildHelper(); return *h; }
     class Lease {
     public:
-        explicit Lease(BuildHelper& h) : h_(h), granted_(h.busy_.try_lock()) {}
+        explicit Lease(BuildHelper& h) : h_(h), granted_(h.alive_ && h.busy_.try_lock()) {}
         ~Lease() { if (granted_) { wait(); h_.busy_.unlock(); } }
         bool granted() const { return granted_; }
         void post(std::function<void()> fn) {
@@ -160,7 +160,10 @@ public:
         bool granted_, pending_ = false;
     };
 private:
-    BuildHelper() { std::thread([this] { loop(); }).detach(); }
+    BuildHelper() {
+        try { std::thread([this] { loop(); }).detach(); alive_ = true; }
+        catch (...) { alive_ = false; }          // no thread to be had: every build does both halves itself
+    }
     void loop() {
         for (;;) {
             { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return wake_; }); wake_ = false; }
@@ -174,7 +177,7 @@ private:
     }
     std::mutex busy_, mu_;
     std::condition_variable cv_;
-    bool wake_ = false;
+    bool wake_ = false, alive_ = false;
     std::atomic<bool> ready_{ false }, done_{ true };
     std::function<void()> fn_;
 };
@@ -594,8 +597,8 @@ struct ObsSource {
 
 // Builds everything that depends on the observation list into p->arena (which must be empty of structure): point-major order,
 // camera-major index, pair lists, launch descriptors, parameter / record / reduced-system buffers, dense-solver workspace;
-// uploads the parameters.  All sorting and list building runs on the device (structure_build.hip); the host only derives
-// the launch descriptors from three small CSR pointer arrays.  The counterpart of the reference's AddResidualBlock loop
+// uploads the parameters.  All sorting and list building runs on the device (structure_build.hip); the host derives the
+// launch descriptors from its own per-point / per-camera observation counts (no device round trip).  The counterpart of the reference's AddResidualBlock loop
 // (BA.cpp:142-166) -- and, for sfmba_problem_append, of re-running it after a view was added (SfM.cpp:464-466).
 static int build_structure(sfmba_problem* p, const ObsSource& src, const double* cam6, const double* pt3, double focal, bool sharded) {
     const int device = p->device, precision = p->precision;
