@@ -60,10 +60,15 @@ struct HostKit {
     int device = 0;
     hipStream_t stream = nullptr;
     char* pinned = nullptr;            // HOSTKIT_PINNED_BYTES, hipHostMallocMapped
-    char* upload = nullptr;            // HOSTKIT_UPLOAD_BYTES of pinned memory: small uploads that must not wait for a staging copy
+    char* upload = nullptr;            // pinned memory for uploads (no staging copy, no page faults): upload_bytes, grown on demand by hostkit_upload
+    size_t upload_bytes = 0;
 };
 constexpr size_t HOSTKIT_PINNED_BYTES = 65536;    // [0,1024) LM state mirror, [1024,2048) LM mailbox, [2048,4096) solver, [4096,..) trace rows
-constexpr size_t HOSTKIT_UPLOAD_BYTES = (size_t)1 << 20;
+constexpr size_t HOSTKIT_UPLOAD_BYTES = (size_t)1 << 20;          // initial size
+constexpr size_t HOSTKIT_UPLOAD_MAX = (size_t)256 << 20;         // larger uploads go through pageable memory
+// Pinned upload buffer of at least `bytes` (the kit's, grown if need be; contents are not kept); nullptr if bytes > HOSTKIT_UPLOAD_MAX or
+// the allocation fails.  Nothing enqueued from the old buffer may still be in flight.
+char* hostkit_upload(HostKit* kit, size_t bytes);
 bool hostkit_acquire(int device, HostKit* kit);     // false on HIP failure
 void hostkit_release(const HostKit& kit);           // the stream must be idle
 

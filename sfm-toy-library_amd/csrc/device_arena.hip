@@ -107,8 +107,21 @@ bool hostkit_acquire(int device, HostKit* kit) {
     void* up = nullptr;
     if (hipHostMalloc(&up, HOSTKIT_UPLOAD_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipHostFree(hm); (void)hipStreamDestroy(k.stream); return false; }
     k.upload = static_cast<char*>(up);
+    k.upload_bytes = HOSTKIT_UPLOAD_BYTES;
     *kit = k;
     return true;
+}
+
+char* hostkit_upload(HostKit* kit, size_t bytes) {
+    if (bytes <= kit->upload_bytes && kit->upload) return kit->upload;
+    if (bytes > HOSTKIT_UPLOAD_MAX) return nullptr;
+    const size_t want = std::min(HOSTKIT_UPLOAD_MAX, std::max(bytes + bytes / 4, HOSTKIT_UPLOAD_BYTES));
+    void* up = nullptr;
+    if (hipHostMalloc(&up, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (kit->upload) (void)hipHostFree(kit->upload);
+    kit->upload = static_cast<char*>(up);
+    kit->upload_bytes = want;
+    return kit->upload;
 }
 
 static void hostkit_destroy(const HostKit& k) {
