@@ -1,11 +1,12 @@
-"""Throughput of sfmba_triangulate (host arrays in, host arrays out) vs the numpy oracle, n matches."""
+"""Throughput of sfmba_triangulate (host arrays in, host arrays out) vs the numpy oracle, n matches.  Lives under tests/ because it
+runs the oracle (test infrastructure); not collected by pytest."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sfm_toy_library_amd as sfm
 from sfm_toy_library_amd import capi
 from oracle import triangulate_oracle as tri
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_gpu_triangulate import _random_scene
 for n in (5000, 1000000):
     K, Pl, Pr, l, r, _ = _random_scene(n, 3)
