@@ -1471,7 +1471,6 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double step2 = 0.0, xn2 = 0.0;
     if (j < ds.ncam) {
-        const CamRow ct = { db.camtab[cur] + 4 * (size_t)(j), ds.ncam };
         double dlt[6], cn[6], z[6];
         if (db.pcg_vec) {          // z_j = Linv_j^T x~_j  (block-Jacobi transformed unknowns)
             const double* x = db.pcg_vec + (size_t)db.pcg_flags[2] * ds.ld + 6 * j;

@@ -15,8 +15,6 @@ struct DenseSolver {
     int d = 0;                // true dimension
     double* minv = nullptr;   // [ld/NB][NB*NB] inverse-transposed diagonal blocks (L_kk^-T)
     double* y = nullptr;      // [ld] work vector of the back substitution
-    int* back_flags = nullptr; // [64] one-launch back substitution: flags[j] == back_epoch <=> x_j of the running solve is in memory
-    int back_epoch = 0;
     // PCG
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
     float* Sfull32 = nullptr; // fp32 copy for the streaming path (allocated by dense_pcg_want_f32)

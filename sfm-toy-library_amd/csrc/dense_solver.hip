@@ -373,9 +373,14 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, in
 }
 
 // rhs -> augmented row d (row-major column d); padded diagonal is already 1
-__global__ void k_augment(double* __restrict__ A, int ld, int d, const double* __restrict__ rhs) {
+// "not computed yet" marker of the one-launch back substitution (k_chol_backsolve): a signalling-NaN bit pattern no computation produces
+constexpr unsigned long long CHOL_X_PENDING = 0x7FF4C0DEC0DE0001ull;
+// rhs becomes row d of the matrix (the forward substitution rides along with the factorisation); its first `pending` entries are then
+// marked "not computed yet" for the back substitution, which overwrites rhs with the solution
+__global__ void k_augment(double* __restrict__ A, int ld, int d, double* __restrict__ rhs, int pending) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < d) AT(d, c) = rhs[c];
+    if (c < pending) reinterpret_cast<unsigned long long*>(rhs)[c] = CHOL_X_PENDING;
 }
 
 // y = L(d, 0:d) (forward-substituted rhs), zero in the padding
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(256) void k_chol_backstep(const double* __restrict_
 // products -> flag instead of a kernel boundary plus the same products.  flags[j] == epoch means x_j of THIS solve is in memory
 // (the epoch changes with every call: no reset pass).
 __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ A, int ld, int d, const double* __restrict__ minv,
-                                                        double* __restrict__ x, int* __restrict__ flags, int epoch, int nblk) {
+                                                        double* __restrict__ x, int nblk) {
     __shared__ double xi[NB];
     __shared__ double part[4][NB];
     __shared__ double v[NB];
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 #pragma unroll
         for (int m = 0; m < 16; ++m) t[m] = AT((nblk - 1) * NB + seg * 16 + m, jb + c);  // column c of A_ij, this thread's 16 rows
     }
+    const double aj = (tid < NB && jb + tid < d) ? AT(d, jb + tid) : 0.0;      // (before the chain starts, not on it)
     double acc = 0.0;
     for (int i = nblk - 1; i > j; --i) {
         double tn[16];
@@ -455,9 +461,14 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 #pragma unroll
             for (int m = 0; m < 16; ++m) tn[m] = AT((i - 1) * NB + seg * 16 + m, jb + c);
         }
-        if (tid == 0) { while (__hip_atomic_load(&flags[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1); }
-        __syncthreads();
-        if (tid < NB) xi[tid] = __hip_atomic_load(&x[i * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // x_i: every entry carries its own "ready" (k_augment marked the vector; the producer's stores and these loads are agent-scope
+        // atomics): one round trip per step instead of flag, then data, and no release / acquire (L2 write-back / invalidate) pair
+        if (tid < NB) {
+            const unsigned long long* xp = reinterpret_cast<const unsigned long long*>(x) + i * NB + tid;
+            unsigned long long b = __hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (b == CHOL_X_PENDING) { __builtin_amdgcn_s_sleep(1); b = __hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            xi[tid] = __longlong_as_double((long long)b);
+        }
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < 16; ++m) acc = fma(t[m], xi[seg * 16 + m], acc);
@@ -465,11 +476,12 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
 #pragma unroll
             for (int m = 0; m < 16; ++m) t[m] = tn[m];
         }
+        __syncthreads();          // xi is rewritten by the next step
     }
     part[seg][c] = acc;
     __syncthreads();
     // w = a_j - sum (raw row d of the panel tile; in the last block column row d of the stored factor, which is y itself)
-    if (tid < NB) v[tid] = (jb + tid < d ? AT(d, jb + tid) : 0.0) - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+    if (tid < NB) v[tid] = aj - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
     __syncthreads();
     if (!last) {
         // y-part: v <- M_j^T w
@@ -492,9 +504,6 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict
         const double xr = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
         __hip_atomic_store(&x[jb + tid], jb + tid < d ? xr : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&flags[j], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The fused factorisation followed by the step-by-step back substitution (SFMBA_CHOL_BACKSOLVE=0, or more than 64 block columns):
@@ -574,8 +583,11 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
         hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), sizeof(double) * CS_LDS_DOUBLES, s, S, ld, d, rhs, ws->minv, info_dev);
         return;
     }
+    static const bool backsolve_env = [] { const char* e = std::getenv("SFMBA_CHOL_BACKSOLVE"); return !(e && e[0] == '0'); }();
+    const bool one_launch_back = fused_env && backsolve_env && nblk <= CHOL_FUSED_MAX_BLOCKS && nblk <= 64;
     { ProfScope ps(prof, KID_CHOL_AUGMENT, s);
-      hipLaunchKernelGGL(k_augment, dim3((d + 255) / 256), dim3(256), 0, s, S, ld, d, rhs); }
+      const int pending = one_launch_back ? nblk * NB : 0;
+      hipLaunchKernelGGL(k_augment, dim3((std::max(d, pending) + 255) / 256), dim3(256), 0, s, S, ld, d, rhs, pending); }
     if (fused_env && nblk <= CHOL_FUSED_MAX_BLOCKS) {
         // one launch per block column (k_chol_step); beyond ~2500 unknowns the redundant panel GEMMs of the fused step cost more than
         // the launch they save and the two-kernel form below takes over
@@ -595,11 +607,9 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
         if (m > 0) { ProfScope ps(prof, KID_CHOL_UPDATE, s);
           hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k); }
     }
-    static const bool backsolve_env = [] { const char* e = std::getenv("SFMBA_CHOL_BACKSOLVE"); return !(e && e[0] == '0'); }();
-    if (fused_env && backsolve_env && nblk <= CHOL_FUSED_MAX_BLOCKS && nblk <= 64) {
+    if (one_launch_back) {
         ProfScope ps(prof, KID_CHOL_BACKSTEP, s);
-        ws->back_epoch = ws->back_epoch == 0x7fffffff ? 1 : ws->back_epoch + 1;
-        hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, s, S, ld, d, ws->minv, rhs, ws->back_flags, ws->back_epoch, nblk);
+        hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, s, S, ld, d, ws->minv, rhs, nblk);
         return;
     }
     if (fused_env && nblk <= CHOL_FUSED_MAX_BLOCKS && nblk > 1)
@@ -1725,7 +1735,6 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     const int ld = ws->ld, d = ws->d;
     if (dense_pcg_ensure_workspace(ws)) return -1;
     if (max_iters <= 0) max_iters = 4 * d;
-    const int nb6 = (d - 1) / 6, nB = nb6 + (d - 6 * nb6);
     int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
     const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
     if (!fast) rows_per_wg = std::max(8, ((d + PCG_MAXWG_BIG - 1) / PCG_MAXWG_BIG + 7) / 8 * 8);   // two rows per wave at a time
@@ -1863,9 +1872,6 @@ int dense_solver_create(DenseSolver* ws, int d, int ld, DeviceArena* arena, char
     const int nblk = ld / NB;
     if (ws_alloc(ws, &ws->minv, sizeof(double) * (size_t)nblk * NB * NB)) return -1;
     if (ws_alloc(ws, &ws->y, sizeof(double) * ld)) return -1;
-    if (ws_alloc(ws, &ws->back_flags, sizeof(int) * 64)) return -1;
-    if (!ws->arena && hipMemset(ws->back_flags, 0, sizeof(int) * 64) != hipSuccess) return -1;      // (arena memory is handed out zeroed)
-    ws->back_epoch = 0;
     if (ws_alloc(ws, &ws->vec, sizeof(double) * 9 * (size_t)ld)) return -1;
     if (ws_alloc(ws, &ws->part, sizeof(double) * 2 * PCG_NPART * PCG_PART)) return -1;
     if (ws_alloc(ws, &ws->binv, sizeof(double) * 36 * (size_t)(ld / 6 + 2))) return -1;
@@ -1890,7 +1896,6 @@ void dense_solver_destroy(DenseSolver* ws) {
     if (!ws->arena) {
         if (ws->minv) (void)hipFree(ws->minv);
         if (ws->y) (void)hipFree(ws->y);
-        if (ws->back_flags) (void)hipFree(ws->back_flags);
         if (ws->vec) (void)hipFree(ws->vec);
         if (ws->part) (void)hipFree(ws->part);
         if (ws->binv) (void)hipFree(ws->binv);
