@@ -28,7 +28,11 @@ for wl in cfg3 cfg5; do
   $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline 2> $OUT/sharded_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_bench.json
 done
 # 5. the drop-in shim in the reference's call pattern: one view added to 199 (SfM.cpp:464-466)
-SFMBA_BUILD_TIMING=1 python $REPO/tools/time_shim_incremental.py > $OUT/${TAG}_shim_incremental.txt 2>&1
+echo "== SFMBA_LINEAR=pcg (block-Jacobi + gauge coarse space CG) ==" > $OUT/${TAG}_shim_incremental.txt
+SFMBA_BUILD_TIMING=1 python $REPO/tools/time_shim_incremental.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
+echo "== SFMBA_LINEAR=cholesky (the shim's default: exact DENSE_SCHUR-equivalent solve) ==" >> $OUT/${TAG}_shim_incremental.txt
+SFMBA_LINEAR=cholesky python $REPO/tools/time_shim_incremental.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
+echo "== structure build on its own ==" >> $OUT/${TAG}_shim_incremental.txt
 python $REPO/tools/time_create.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
 # keep the merge-back small
 rm -rf $OUT/stats_pcg $OUT/stats_cholesky $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
