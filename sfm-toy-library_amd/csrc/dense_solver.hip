@@ -428,11 +428,13 @@ __global__ __launch_bounds__(256) void k_chol_backstep(const double* __restrict_
 // off-diagonal tiles of block column j as the RAW (fully updated) A_ij with L_ij = A_ij M_j implied, and the right-hand side as row d
 // of the last block row, so   y_j = M_j^T a_j (a_j = A(d, column block j)),   sum_{i>j} L_ij^T x_i = M_j^T sum_{i>j} A_ij^T x_i   and
 //   x_j = M_j M_j^T (a_j - sum_{i>j} A_ij^T x_i)                  (last block column: x = M y with y = row d of the stored factor).
-// Workgroup j prefetches its tiles A_ij and M_j, then consumes the x_i in the order they appear (i = nblk-1 ... j+1), each announced
-// by a flag of the workgroup that produced it.  Workgroup j waits only for workgroups dispatched BEFORE it (block index nblk-1-j),
-// so the chain cannot deadlock however few of them are resident.  Per block column the chain is flag -> 64x64 product -> two M_j
-// products -> flag instead of a kernel boundary plus the same products.  flags[j] == epoch means x_j of THIS solve is in memory
-// (the epoch changes with every call: no reset pass).
+// Workgroup j prefetches its tiles A_ij and M_j, then consumes the x_i in the order they appear (i = nblk-1 ... j+1).  The data
+// announce themselves: k_augment marked every entry of x "not computed yet" (CHOL_X_PENDING), the producer writes its 64 values with
+// agent-scope atomic stores and the consumer's 64 lanes poll them with agent-scope atomic loads -- one round trip per step, no flag,
+// no release / acquire fence (an L2 write-back and an invalidate on the chain of every step with the flag version: 51 -> 26 us).
+// Workgroup j waits only for workgroups dispatched BEFORE it (block index nblk-1-j), so the chain cannot deadlock however few of
+// them are resident.  Per block column the chain is  x_{j+1} arrives -> 64x64 product -> two M_j products -> x_j leaves  instead of a
+// kernel boundary plus the same products.
 __global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ A, int ld, int d, const double* __restrict__ minv,
                                                         double* __restrict__ x, int nblk) {
     __shared__ double xi[NB];
