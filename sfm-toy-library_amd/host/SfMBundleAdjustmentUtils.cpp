@@ -190,7 +190,13 @@ private:
             const uint64_t v = ticket_.fetch_add(1, std::memory_order_acq_rel);
             const uint64_t g = v >> 32;
             const unsigned idx = (unsigned)(v & 0xffffffffu);
-            if (g != generation_.load(std::memory_order_acquire)) return;
+            // begin() publishes the ticket word (g << 32) BEFORE generation_ = g: a worker still in this loop from batch g - 1 can
+            // draw index 0 of batch g between the two stores.  Returning then would lose that task for good (pending_ never
+            // reaches 0, end() spins forever -- ADVICE r2, reproduced under CPU contention): wait for generation_ to catch up
+            // with the ticket, and give up only if it has moved PAST it.
+            uint64_t cur = generation_.load(std::memory_order_acquire);
+            while (cur < g) { __builtin_ia32_pause(); cur = generation_.load(std::memory_order_acquire); }
+            if (cur != g) return;
             const unsigned n = slot_n_[g & 1].load(std::memory_order_relaxed);
             if (idx >= n || g != generation_.load(std::memory_order_acquire)) return;
             slot_fn_[g & 1](idx);
@@ -650,6 +656,19 @@ struct WorkerPoolAccess {
         }
         return wrong;
     }
+    // many SMALL batches back to back (the regime where a worker of batch g - 1 is still drawing tickets when batch g is published)
+    static int stress(int batches, int max_tasks) {
+        WorkerPool& pool = WorkerPool::instance();
+        int wrong = 0;
+        std::atomic<unsigned> calls(0);
+        for (int b = 0; b < batches; ++b) {
+            const unsigned n = 2u + (unsigned)((b * 2654435761u) % (unsigned)(max_tasks > 1 ? max_tasks - 1 : 1));
+            calls.store(0, std::memory_order_relaxed);
+            pool.run(n, [&](unsigned) { calls.fetch_add(1, std::memory_order_relaxed); });
+            if (calls.load() != n) ++wrong;
+        }
+        return wrong;
+    }
 };
 
 } /* namespace sfmtoylib */
@@ -659,4 +678,8 @@ struct WorkerPoolAccess {
 extern "C" __attribute__((visibility("default"))) int sfmba_shim_pool_selftest(int batches) {
     using sfmtoylib::WorkerPoolAccess;
     return WorkerPoolAccess::selftest(batches);
+}
+// Contended variant (tests/test_shim_pool_cpu.py runs several PROCESSES of it at once under a watchdog): small batches only.
+extern "C" __attribute__((visibility("default"))) int sfmba_shim_pool_stress(int batches, int max_tasks) {
+    return sfmtoylib::WorkerPoolAccess::stress(batches, max_tasks);
 }
