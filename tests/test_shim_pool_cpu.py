@@ -19,7 +19,7 @@ def test_every_task_of_every_batch_runs_exactly_once():
 def test_callers_on_different_threads_take_turns():
     lib = _lib()
     out = []
-    ths = [threading.Thread(target=lambda: out.append(lib.sfmba_shim_pool_selftest(C.c_int(600)))) for _ in range(6)]
+    ths = [threading.Thread(target=lambda: out.append(lib.sfmba_shim_pool_selftest(C.c_int(600)))) for _ in range(4)]
     for t in ths:
         t.start()
     for t in ths:
