@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SFMBA_ABI_VERSION 3
+#define SFMBA_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define SFMBA_API __attribute__((visibility("default")))
@@ -51,11 +51,16 @@ enum {
     SFMBA_FAILURE        = 2
 };
 
-enum { SFMBA_LINEAR_CHOLESKY = 0,   /* exact Schur + dense LLT == DENSE_SCHUR (BA.cpp:172) */
-       SFMBA_LINEAR_PCG      = 1,   /* exact Schur + block-Jacobi PCG on the dense reduced system */
-       SFMBA_LINEAR_AUTO     = 2 }; /* CHOLESKY while the reduced system is small (<= 256 unknowns: a handful of panels, exact),
-                                       PCG above (parameters agree with the exact solve to ~2e-7, cost to 1e-12).  The drop-in shim
-                                       uses CHOLESKY like the reference; PCG / AUTO are opt-in there (SFMBA_LINEAR) */
+enum { SFMBA_LINEAR_CHOLESKY = 0,   /* exact Schur + dense LLT == DENSE_SCHUR (BA.cpp:172), always factorised */
+       SFMBA_LINEAR_PCG      = 1,   /* exact Schur + two-level block-Jacobi PCG on the dense reduced system, stopped at pcg_tolerance
+                                       (inexact Newton: parameters agree with the exact solve to ~1e-8, cost to 1e-12) */
+       SFMBA_LINEAR_AUTO     = 2 }; /* THE DEFAULT (library and drop-in shim): the reference's DENSE_SCHUR result at the cost of the
+                                       cheapest solver that delivers it.  Up to 256 reduced unknowns (the reference's own data sets):
+                                       CHOLESKY.  Above: the same PCG run to a plain relative residual of min(pcg_tolerance, 1e-12)
+                                       -- the step then agrees with the factorised solve to ~1e-10 relative, below what the float
+                                       containers of adjustBundle() resolve -- and, if the CG has not converged after
+                                       pcg_max_iters (0 = min(4 dim, 200)) iterations or breaks down, the SAME linearisation is solved
+                                       by CHOLESKY instead (the matrix is re-formed unpreconditioned; nothing is skipped). */
 
 enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
        SFMBA_PRECISION_F32J = 1 };  /* fp32 Jacobian blocks AND fp32 observation coordinates (BASELINE config 3; the reference's
@@ -95,7 +100,24 @@ typedef struct sfmba_options {
     int    pcg_anchored;              /* 1: inside an LM solve the CG tolerance is anchored to the FIRST iteration's right-hand side,
                                          |r| <= tol * max(|b_k|, |b_first|), never looser than 1e-4 |b_k| -- every LM step is then solved
                                          to the same ABSOLUTE accuracy (dense_solver.hip).  0: plain relative residual. */
+    /* ---- ABI v4: behaviour switches that were environment variables only (a C caller could not set them per problem or
+       thread-safely).  0 = library default, 1 = on, -1 = off.  The environment variable named beside each switch, when set,
+       still OVERRIDES the field (process-wide debugging aid; "0" = off, anything else = on). ---- */
+    int    pcg_coarse_space;          /* SFMBA_PCG_COARSE         default on : two-level CG preconditioner (8 gauge vectors) */
+    int    pcg_persistent;            /* SFMBA_PCG_PERSISTENT     default off: whole CG solve in one cooperative launch (d <= 1280) */
+    int    pcg_f32_matrix;            /* SFMBA_PCG_F32_MATRIX     default on : F32J + streaming CG (d > 1280) store S~ in fp32 */
+    int    early_linearise;           /* SFMBA_EARLY_LINEARISE    default on : next linearisation enqueued before the host reads the verdict */
+    int    shard_two_phase;           /* SFMBA_SHARD_TWO_PHASE    default on : sharded CG path exchanges (A) diagonal data, (B) preconditioned blocks */
+    int    shard_f32_exchange;        /* SFMBA_SHARD_F32_EXCHANGE default on : exchange (B) in fp32 where the CG stores S~ in fp32 anyway */
+    int    shard_distributed_cg;      /* SFMBA_SHARD_DIST_CG      default off: sharded CG path WITHOUT the redundant solve -- exchange (B) is a
+                                         reduce-scatter into row slabs of S~, every rank multiplies its slab, one small all-gather per CG
+                                         iteration (needs the reduce-scatter / all-gather callbacks, sfmba_problem_set_collectives) */
 } sfmba_options;
+
+/* Flags of sfmba_problem_create_ex (ABI v4; were environment variables read at create time). */
+enum { SFMBA_CREATE_DETERMINISTIC = 1 };  /* SFMBA_DETERMINISTIC=1 forces it on: every workgroup owns its accumulator slot and multi-chunk
+                                             sums are added in a fixed order, so results do not depend on the order fp64 atomics arrive in
+                                             (bitwise reproducible run to run; ~30 % slower).  Sharded problems included (ABI v4). */
 
 typedef struct sfmba_summary {
     int    termination;               /* SFMBA_CONVERGENCE / NO_CONVERGENCE / FAILURE */
@@ -110,6 +132,7 @@ typedef struct sfmba_summary {
     double seconds;                   /* solve wall time, excludes H2D/D2H and structure build */
     double setup_seconds;             /* structure build + H2D (sfmba_solve only) */
     char   message[128];
+    int    cholesky_fallbacks;        /* ABI v4: LM iterations of an AUTO solve whose CG did not reach 1e-12 and were factorised instead */
 } sfmba_summary;
 
 /* One row per LM iteration (row 0 = the initial evaluation), mirrors ceres::IterationSummary. */
@@ -159,6 +182,12 @@ SFMBA_API int  sfmba_problem_create(int device, int precision,
                           int n_cam, const double* cam6, int n_pt, const double* pt3,
                           int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                           double focal, sfmba_problem** out);
+/* The same with create flags (SFMBA_CREATE_*); cam_active != NULL makes it a sharded problem exactly like
+ * sfmba_problem_create_sharded (rank / world then matter; pass 0 / 1 otherwise). */
+SFMBA_API int  sfmba_problem_create_ex(int device, int precision, int flags,
+                          int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
+                          int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                          double focal, int rank, int world, sfmba_problem** out);
 /*
  * Grows a resident problem in place -- the incremental caller re-runs BA after every added view (SfM.cpp:464-466) with a
  * cloud that only ever GROWS (new points, new views of existing points, SfM.cpp:530-629): n_cam >= the previous n_cam and
@@ -167,8 +196,15 @@ SFMBA_API int  sfmba_problem_create(int device, int precision,
  * and the focal are replaced from cam6 / pt3 / focal (full arrays, as at create time): the caller's containers hold the
  * float-rounded result of the previous solve plus the new entries (BA.cpp:187-221).  The observation list never leaves the
  * device: the new observations are uploaded, merged into the point-major order by a device sort, and the dependent lists
- * (camera-major index, camera-pair lists, launch descriptors) are rebuilt on the device.  Result identical to
- * sfmba_problem_create on the concatenated observation list (old observations first, then the new ones).
+ * (camera-major index, camera-pair lists, launch descriptors) are rebuilt on the device.  The problem solved afterwards is
+ * the one sfmba_problem_create would build from the concatenated observation list (old observations first, then the new ones);
+ * results agree with that up to floating-point reordering, NOT bit for bit: newly observed cameras / points take the next free
+ * slot in order of first observation (create assigns slots in ascending caller index), so the reduced system is a symmetric
+ * permutation of create's and sums are taken in a different order.
+ * Failure contract: if the call fails after it has begun replacing the device structure (allocation or HIP error), the problem
+ * is POISONED -- every later entry point on it returns SFMBA_ERR_INVALID_ARG ("poisoned") without touching the device and the
+ * only valid call is sfmba_problem_destroy.  Argument errors (bad sizes, indices out of range) are detected first and leave the
+ * problem as it was.
  */
 SFMBA_API int  sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_pt, const double* pt3,
                           int64_t n_obs_new, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, double focal);
@@ -271,6 +307,12 @@ SFMBA_API int     sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary);
  * ncclAllReduce (RCCL, xGMI) bound with dlopen at first use; one communicator per rank, created from the 128-byte unique id
  * that rank 0 draws (sfmba_comm_unique_id) and the launcher distributes (bench.py: a torch.distributed broadcast).
  * The host meets the GPU once per LM iteration, at the control kernel's mailbox post; nothing is copied back inside the loop.
+ * options.max_seconds is NOT applied in sharded solves (ranks would disagree on a wall clock); max_iters is.
+ * Error behaviour is fail-stop, as with RCCL itself: every allocation the loop needs is made BEFORE the rank issues its first
+ * collective, so a rank that cannot take part returns an error without having entered one; inside the loop only HIP / collective
+ * errors remain.  A rank that returns an error leaves its peers blocked in their next collective: the caller must then tear the
+ * job down -- sfmba_comm_abort (ncclCommAbort) on the built-in communicator makes the peers' pending collectives fail so that
+ * they return SFMBA_ERR_HIP too.
  */
 #define SFMBA_COMM_ID_BYTES 128
 typedef struct sfmba_comm sfmba_comm;
@@ -278,6 +320,7 @@ typedef int (*sfmba_allreduce_fn)(void* ctx, void* device_buf, int64_t n_doubles
 SFMBA_API int  sfmba_comm_unique_id(unsigned char id[SFMBA_COMM_ID_BYTES]);
 SFMBA_API int  sfmba_comm_create(const unsigned char id[SFMBA_COMM_ID_BYTES], int rank, int world, int device, sfmba_comm** out);
 SFMBA_API void sfmba_comm_destroy(sfmba_comm* comm);
+SFMBA_API int  sfmba_comm_abort(sfmba_comm* comm);      /* ncclCommAbort: call on the ranks that failed; the communicator is unusable afterwards */
 SFMBA_API int  sfmba_comm_allreduce(void* comm /* sfmba_comm* */, void* device_buf, int64_t n_doubles, void* hip_stream);   /* an sfmba_allreduce_fn */
 SFMBA_API int  sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx,
                                  sfmba_summary* summary);

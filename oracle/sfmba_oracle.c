@@ -1061,7 +1061,7 @@ ORACLE_API void sfmba_oracle_options_default(sfmba_options* o) {
     o->max_lm_diagonal = 1e32;
     o->jacobi_scaling = 1;
     o->max_consecutive_invalid_steps = 5;
-    o->linear_solver = SFMBA_LINEAR_CHOLESKY;
+    o->linear_solver = SFMBA_LINEAR_AUTO;   /* (the oracle itself always factorises: the field only mirrors the product's default) */
     o->precision = SFMBA_PRECISION_F64;
     o->pcg_tolerance = 1e-8;
     o->pcg_max_iters = 0;

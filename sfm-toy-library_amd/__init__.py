@@ -11,14 +11,14 @@ Nothing in this package imports oracle/: the product path fails loudly when the 
 or a GPU is missing, it never falls back to a CPU implementation.
 """
 from .structs import (SfmbaOptions, SfmbaSummary, SfmbaIteration, TERMINATION_NAMES,
-                      CONVERGENCE, NO_CONVERGENCE, FAILURE, LINEAR_CHOLESKY, LINEAR_PCG,
-                      PRECISION_F64, PRECISION_F32J)
+                      CONVERGENCE, NO_CONVERGENCE, FAILURE, LINEAR_CHOLESKY, LINEAR_PCG, LINEAR_AUTO,
+                      PRECISION_F64, PRECISION_F32J, CREATE_DETERMINISTIC)
 from .synthetic import make_problem, BAProblem, CONFIGS
 from .problem_io import save_problem, load_problem, save_bal, load_bal
 
 __all__ = [
     "SfmbaOptions", "SfmbaSummary", "SfmbaIteration", "TERMINATION_NAMES",
-    "CONVERGENCE", "NO_CONVERGENCE", "FAILURE", "LINEAR_CHOLESKY", "LINEAR_PCG",
-    "PRECISION_F64", "PRECISION_F32J",
+    "CONVERGENCE", "NO_CONVERGENCE", "FAILURE", "LINEAR_CHOLESKY", "LINEAR_PCG", "LINEAR_AUTO",
+    "PRECISION_F64", "PRECISION_F32J", "CREATE_DETERMINISTIC",
     "make_problem", "BAProblem", "CONFIGS", "save_problem", "load_problem", "save_bal", "load_bal",
 ]

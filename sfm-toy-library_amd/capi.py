@@ -30,6 +30,7 @@ SYMBOLS = [
     "sfmba_find_2d3d_matches", "sfmba_merge_candidates", "sfmba_problem_append",
     "sfmba_comm_unique_id", "sfmba_comm_create", "sfmba_comm_destroy", "sfmba_comm_allreduce", "sfmba_problem_solve_sharded",
     "sfmba_comm_allreduce_f32", "sfmba_problem_set_allreduce_f32", "sfmba_shard_last_exchange",
+    "sfmba_problem_create_ex", "sfmba_comm_abort",
 ]
 
 
@@ -223,15 +224,21 @@ def dense_spd_solve(A, b, method=0, tol=1e-12, max_iters=0, device=0):
 class Problem:
     """Device-resident problem (sfmba_problem_*)."""
 
-    def __init__(self, prob, precision=0, device=0):
+    def __init__(self, prob, precision=0, device=0, flags=0):
+        """flags: SFMBA_CREATE_* (structs.CREATE_DETERMINISTIC); 0 goes through plain sfmba_problem_create."""
         self.n_cam, self.n_pt, self.n_obs = prob.n_cam, prob.n_pt, prob.n_obs
         cam6, pt3 = _d(prob.cam6), _d(prob.pt3)
         oc, op, oxy = _i(prob.obs_cam), _i(prob.obs_pt), _d(prob.obs_xy)
         self._h = C.c_void_p()
         self._template = (cam6.copy(), pt3.copy())
-        _check(lib().sfmba_problem_create(C.c_int(device), C.c_int(precision), C.c_int(prob.n_cam), _p(cam6, _dp),
-                                          C.c_int(prob.n_pt), _p(pt3, _dp), C.c_int64(prob.n_obs), _p(oc, _ip), _p(op, _ip),
-                                          _p(oxy, _dp), C.c_double(prob.focal), C.byref(self._h)))
+        if flags:
+            _check(lib().sfmba_problem_create_ex(C.c_int(device), C.c_int(precision), C.c_int(flags), C.c_int(prob.n_cam), _p(cam6, _dp),
+                                                 None, C.c_int(prob.n_pt), _p(pt3, _dp), C.c_int64(prob.n_obs), _p(oc, _ip), _p(op, _ip),
+                                                 _p(oxy, _dp), C.c_double(prob.focal), C.c_int(0), C.c_int(1), C.byref(self._h)))
+        else:
+            _check(lib().sfmba_problem_create(C.c_int(device), C.c_int(precision), C.c_int(prob.n_cam), _p(cam6, _dp),
+                                              C.c_int(prob.n_pt), _p(pt3, _dp), C.c_int64(prob.n_obs), _p(oc, _ip), _p(op, _ip),
+                                              _p(oxy, _dp), C.c_double(prob.focal), C.byref(self._h)))
 
     def close(self):
         if self._h:

@@ -243,6 +243,9 @@ int assoc_find_2d3d(hipStream_t s, int device, int n_views, const unsigned char*
         int& slot = tab[(size_t)l * n_views + r];
         if (slot < 0) { slot = p; pair_ok[p] = 1; }
     }
+    // the probe sequence works on a 32-bit slot index (mask = 2^bits - 1, bits <= 31): more than 2^29 matches would need
+    // bits >= 32, where `1u << bits` is undefined -- refuse instead
+    if (4 * n_match > (1ll << 31)) return ASSOC_ERR_TOO_LARGE;
     unsigned bits = 4;
     while ((1ull << bits) < (u64)(4 * std::max(n_match, 1ll))) ++bits;
     const unsigned mask = (1u << bits) - 1u;

@@ -161,6 +161,7 @@ template <typename T> void launch_point_build(hipStream_t s, const DeviceStructu
 template <typename T> void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode);
 template <typename T> void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int pcg);
+void launch_cd_fold(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // deterministic + sharded: chunk sums into the partial system (before the exchange)
 void launch_gauge(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // gauge vectors from db.pcg_binv (see k_gauge)
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);

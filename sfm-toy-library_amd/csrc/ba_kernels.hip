@@ -1442,6 +1442,37 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
     if (is_last && threadIdx.x < 64) post_linearisation(ds, db);
 }
 
+// Deterministic mode, sharded solve: the per-chunk sums of k_cam_diag are folded into the reduced system (in chunk order, one thread
+// per camera) BEFORE the partial system is packed for the exchange; k_finalize, which does this on one GPU, runs behind the all-reduce
+// there and is then called with cd_part = null.
+__global__ __launch_bounds__(64) void k_cd_fold(DeviceStructure ds, DeviceBuffers db) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ds.ncam || !db.cd_part) return;
+    const int row0 = 6 * g, fo = ds.d - 1;
+    double acc[45];
+#pragma unroll
+    for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+    for (int c = ds.cam_chunk_ptr[g]; c < ds.cam_chunk_ptr[g + 1]; ++c) {
+#pragma unroll
+        for (int k = 0; k < 45; ++k) acc[k] += db.cd_part[(size_t)c * 48 + k];
+    }
+    int u = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) db.S[(size_t)(row0 + a) * ds.ld + row0 + b] += acc[u++];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        db.udiag[row0 + a] += acc[21 + a];
+        db.S[(size_t)(row0 + a) * ds.ld + fo] += acc[27 + a];
+        db.bc[row0 + a] += acc[33 + a];
+        db.rhs[row0 + a] += acc[39 + a];
+    }
+}
+void launch_cd_fold(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+    if (db.cd_part) hipLaunchKernelGGL(k_cd_fold, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);
+}
+
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int pcg) {
     const int work = ds.ncam + (ds.ld - ds.d) + 64;     // cameras, padding rows, room for the focal wave
     hipLaunchKernelGGL(k_finalize, dim3((work + 255) / 256), dim3(256), 0, s, ds, db, pcg);

@@ -124,6 +124,13 @@ int wait_mailbox(volatile int* word, int want, hipStream_t stream) {
     }
 }
 
+// A behaviour switch of sfmba_options (ABI v4): the environment variable, when set, overrides the field ("0" = off, else on);
+// otherwise the field (1 on, -1 off), otherwise the library default.
+bool option_switch(int field, const char* env_name, bool dflt) {
+    if (const char* e = std::getenv(env_name)) return e[0] != '0';
+    return field > 0 ? true : field < 0 ? false : dflt;
+}
+
 __global__ void k_fill(double* p, size_t n, double v) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) p[e] = v;
@@ -223,6 +230,7 @@ struct sfmba_problem {
     int cur = 0;                                  // which buffer holds the current parameters
     double focal = 0.0;
     bool empty = false;                           // no observations
+    bool poisoned = false;                        // an append failed half way: only sfmba_problem_destroy is valid (include/sfmba.h)
     // sharded-mode state
     sfmba_options shard_opt;
     bool shard_active = false;
@@ -347,31 +355,34 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     bool first_linearisation = true;
     bool first_linear_solve = true;
     const char* gate_env = std::getenv("SFMBA_PCG_GATED");
-    const bool gated_cg = !(gate_env && gate_env[0] == '0');
-    const char* f32m_env = std::getenv("SFMBA_PCG_F32_MATRIX");
-    const bool f32_matrix = !(f32m_env && f32m_env[0] == '0');
+    const bool gated_env = !(gate_env && gate_env[0] == '0');
+    const bool f32_matrix = option_switch(o.pcg_f32_matrix, "SFMBA_PCG_F32_MATRIX", true);
     const char* anchor_env = std::getenv("SFMBA_PCG_ANCHOR");
-    const bool anchored_cg = o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
-    // two-level preconditioner (8 gauge vectors as a coarse space, dense_solver.hip): on unless SFMBA_PCG_COARSE=0
-    const char* coarse_env = std::getenv("SFMBA_PCG_COARSE");
-    const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
-    const char* pcg_env = std::getenv("SFMBA_PCG_PERSISTENT");
-    // One persistent (cooperative) launch per CG solve: opt-in only (SFMBA_PCG_PERSISTENT=1).  It used to win below d = 640 where the
+    // two-level preconditioner (8 gauge vectors as a coarse space, dense_solver.hip)
+    const bool coarse_cg = option_switch(o.pcg_coarse_space, "SFMBA_PCG_COARSE", true);
+    // One persistent (cooperative) launch per CG solve: opt-in only.  It used to win below d = 640 where the
     // solve is launch-bound; with the gauge coarse space the launch-per-iteration path needs half the iterations and is as fast or
     // faster at every size measured (cfg 4, d = 151: 4990 vs 4820 LM it/s; cfg 2: 6300 vs 6220; 7 views: 6170 vs 6380), and it has
     // no device-wide spin barrier in it.
-    const bool persistent_cg = pcg_env && pcg_env[0] == '1';
+    const bool pcg = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
+    // AUTO above 256 unknowns = the DENSE_SCHUR result through the CG: plain relative residual <= 1e-12, bounded iteration count,
+    // Cholesky on the same linearisation if the CG does not get there (include/sfmba.h)
+    const bool exact_pcg = pcg && o.linear_solver == SFMBA_LINEAR_AUTO;
+    const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
+    const int cg_max_iters = exact_pcg ? (o.pcg_max_iters > 0 ? o.pcg_max_iters : std::min(4 * p->ds.d, 200)) : o.pcg_max_iters;
+    const bool anchored_cg = !exact_pcg && o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
+    const bool gated_cg = gated_env || exact_pcg;        // (the fallback is decided where the gated loop learns that the batch was too short)
+    const bool persistent_cg = !exact_pcg && option_switch(o.pcg_persistent, "SFMBA_PCG_PERSISTENT", false);
     int launched_controls = 0;
-    const char* spec_env = std::getenv("SFMBA_EARLY_LINEARISE");
-    const bool speculate = !(spec_env && spec_env[0] == '0') && !p->prof.on;
+    const bool speculate = option_switch(o.early_linearise, "SFMBA_EARLY_LINEARISE", true) && !p->prof.on;
     bool build_enqueued = false;
     std::vector<int> lin_hist;
+    int cholesky_fallbacks = 0;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
-        const bool pcg = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
         if (pcg) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
@@ -404,13 +415,13 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             // count is read from the solver's mailbox after this LM iteration's control post
             const int anchor = anchored_cg ? (first_linear_solve ? 1 : 2) : 0;
             first_linear_solve = false;
-            pcg_async = persistent_cg && dense_pcg_solve_persistent(p->stream, &p->solver, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof, anchor);
+            pcg_async = persistent_cg && dense_pcg_solve_persistent(p->stream, &p->solver, cg_tol, cg_max_iters, p->d_info, prof, anchor);
             if (!pcg_async) {
                 // Launch-per-iteration CG: a batch of the length the previous solve needed (+2) goes into the queue together
                 // with the three kernels that consume the solution; those are GATED on the CG's done flag, so the host does
                 // not wait for the linear solve.  If the batch was too short k_lm_control says so and more is enqueued.
                 pcg_gated = gated_cg;
-                const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, prof,
+                const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, cg_tol, cg_max_iters, p->d_info, prof,
                                                /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/pcg_gated, /*coarse=*/coarse_cg);
                 if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
                 if (!pcg_gated) { sum.linear_iters += it; lin_hist.push_back(it); }
@@ -451,7 +462,20 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             if (mb[1] == -2) {
                 // the CG batch was too short: enqueue more iterations (or force the step once max_iters are spent), then the trio again
                 // (the early linearisation kernel behind that control kernel has returned without doing anything)
-                if (dense_pcg_more(p->stream, &p->solver, 8, prof) == 0) dbu.cg_force = 1;
+                if (dense_pcg_more(p->stream, &p->solver, 8, prof) == 0) {
+                    if (exact_pcg) {
+                        // AUTO: the CG has spent its iterations without reaching 1e-12 -- solve THIS linearisation exactly instead.  The
+                        // damped diagonal blocks, the focal column and the right-hand side are in db.S / db.rhs already (camera pass +
+                        // k_finalize); the pair pass writes the off-diagonal blocks again, unpreconditioned, and the Cholesky takes over.
+                        { ProfScope ps(prof, KID_SCHUR_PAIRS, p->stream); launch_schur_pairs<T>(p->stream, p->ds, p->db, 0); }
+                        dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, prof);
+                        dbu.pcg_vec = nullptr; dbu.pcg_linv = nullptr; dbu.pcg_flags = nullptr; dbu.cg_gate = nullptr;
+                        pcg_gated = false;
+                        ++cholesky_fallbacks;
+                    } else {
+                        dbu.cg_force = 1;
+                    }
+                }
                 build_enqueued = false;
                 continue;
             }
@@ -463,8 +487,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 const int it = p->solver.h_mailbox[1] != 0 ? p->solver.h_mailbox[0] : 0;
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
-            } else if (pcg_gated) {
-                const int it = mb[4];
+            } else if (pcg_gated || (pcg && exact_pcg && dbu.cg_gate == nullptr)) {
+                const int it = (pcg_gated || dbu.pcg_vec) ? mb[4] : p->solver.run.launched;      // after a fallback: the launches that were spent
                 dense_pcg_note(&p->solver, (int)lin_hist.size(), it);
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
@@ -497,6 +521,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     sum.jacobian_evals = hs.jacobian_evals;
     sum.final_cost = hs.cost;
     sum.seconds = now_seconds() - t0;
+    sum.cholesky_fallbacks = cholesky_fallbacks;
     std::snprintf(sum.message, sizeof(sum.message), "%s", message_text(msg));
     // trace rows
     const int rows = std::min(hs.iter + 1, p->db.trace_cap);
@@ -534,7 +559,7 @@ void sfmba_options_default(sfmba_options* o) {
     o->max_lm_diagonal = 1e32;
     o->jacobi_scaling = 1;
     o->max_consecutive_invalid_steps = 5;
-    o->linear_solver = SFMBA_LINEAR_CHOLESKY;
+    o->linear_solver = SFMBA_LINEAR_AUTO;       // DENSE_SCHUR-equivalent result (BA.cpp:172), cheapest solver that delivers it
     o->precision = SFMBA_PRECISION_F64;
     o->pcg_tolerance = 1e-8;
     o->pcg_max_iters = 0;
@@ -566,21 +591,30 @@ void sfmba_problem_destroy(sfmba_problem* p) {
     delete p;
 }
 
-static int create_impl(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
+static int create_impl(int device, int precision, int flags, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
                        int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                        double focal, int rank, int world, sfmba_problem** out);
 
 int sfmba_problem_create(int device, int precision, int n_cam, const double* cam6, int n_pt, const double* pt3,
                          int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                          double focal, sfmba_problem** out) {
-    return create_impl(device, precision, n_cam, cam6, nullptr, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal, 0, 1, out);
+    return create_impl(device, precision, 0, n_cam, cam6, nullptr, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal, 0, 1, out);
+}
+
+int sfmba_problem_create_ex(int device, int precision, int flags, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt,
+                            const double* pt3, int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                            double focal, int rank, int world, sfmba_problem** out) {
+    if (flags & ~SFMBA_CREATE_DETERMINISTIC) return fail(SFMBA_ERR_INVALID_ARG, "unknown create flag");
+    if (cam_active && (world < 1 || rank < 0 || rank >= world || world > SFMBA_SHARD_SCALARS - 16)) return fail(SFMBA_ERR_INVALID_ARG, "bad rank/world");
+    return create_impl(device, precision, flags, n_cam, cam6, cam_active, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal,
+                       cam_active ? rank : 0, cam_active ? world : 1, out);
 }
 
 int sfmba_problem_create_sharded(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active,
                                  int n_pt, const double* pt3, int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt,
                                  const double* obs_xy, double focal, int rank, int world, sfmba_problem** out) {
     if (world < 1 || rank < 0 || rank >= world || world > SFMBA_SHARD_SCALARS - 16) return fail(SFMBA_ERR_INVALID_ARG, "bad rank/world");
-    return create_impl(device, precision, n_cam, cam6, cam_active, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal, rank, world, out);
+    return create_impl(device, precision, 0, n_cam, cam6, cam_active, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal, rank, world, out);
 }
 
 int sfmba_problem_reset(sfmba_problem* p);
@@ -673,7 +707,6 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     std::vector<double> cam0, pts0;
     std::vector<char> blob;
     int pair_lpb = 64, blocks_per_wg = 1;
-    { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e && e[0] == '1' && !sharded; }
     auto host_half = [&]() -> int {
         for (int i = 0; i < npt; ++i) { const long long m = p->h_pt_cnt[(size_t)i]; pt_ptr[(size_t)i + 1] = pt_ptr[(size_t)i] + (int)m; npair_total += m * (m - 1) / 2; }
         for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] = cam_ptr[(size_t)j] + p->h_cam_cnt[(size_t)j];
@@ -683,7 +716,6 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         // ---- launch descriptors (from the CSR pointer arrays) ----
         // chunks of the camera-major list: (camera, entry range)
         const int chunk_len = SFMBA_CAM_CHUNK;   // k_cam_diag: one lane per entry, one workgroup per chunk
-        // (not in sharded mode: the per-chunk partial sums of the deterministic camera pass are added behind the all-reduce point)
         const int coarse_len = p->deterministic ? (1 << 30) : 1024;      // deterministic mode: one column-norm workgroup per camera (single writer)
         for (int j = 0; j < ncam; ++j) {
             cam_chunk_ptr[(size_t)j] = (int)chunks.size();
@@ -949,7 +981,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     return sfmba_problem_reset(p);
 }
 
-static int create_impl(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
+static int create_impl(int device, int precision, int flags, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt, const double* pt3,
                        int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                        double focal, int rank, int world, sfmba_problem** out) {
     if (!out) return fail(SFMBA_ERR_INVALID_ARG, "out is NULL");
@@ -970,6 +1002,8 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
     p->focal0 = p->focal = focal;
     p->shard_rank = rank; p->shard_world = world;
     p->sharded = cam_active != nullptr;
+    // create flag, or the environment override (kept across appends: the structure is rebuilt in the same mode)
+    { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e ? e[0] == '1' : (flags & SFMBA_CREATE_DETERMINISTIC) != 0; }
     struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
 
     // active (observed) cameras / points -> slots, ascending caller index
@@ -1017,6 +1051,7 @@ static int create_impl(int device, int precision, int n_cam, const double* cam6,
 int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_pt, const double* pt3,
                          int64_t n_obs_new, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy, double focal) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     if (p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "a sharded problem cannot grow in place");
     p->reset_pending = false;           // the parameters are replaced by the caller's below
     if (n_cam < p->n_cam_full || n_pt < p->n_pt_full || n_obs_new < 0 || p->n_obs + n_obs_new >= (int64_t)1 << 31)
@@ -1058,7 +1093,10 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
     p->db.trace = nullptr; p->db.trace_cap = 0; p->trace_mapped = false;
     p->cur = 0;
     const int rc = build_structure(p, src, cam6, pt3, focal, false);
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    // not failure-atomic (the old structure is gone, counts and slot tables are already the new ones): a failed build leaves the
+    // handle POISONED -- every entry point refuses it from here on, only sfmba_problem_destroy is valid (include/sfmba.h)
+    if (rc != SFMBA_OK) { p->poisoned = true; (void)hipStreamSynchronize(p->stream); return rc; }
+    if (hipStreamSynchronize(p->stream) != hipSuccess) { p->poisoned = true; return fail(SFMBA_ERR_HIP, "structure build did not complete"); }
     return rc;      // `old` releases the previous structure here
 }
 
@@ -1079,6 +1117,7 @@ static int flush_reset(sfmba_problem* p) {
 
 int sfmba_problem_reset(sfmba_problem* p) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     p->focal = p->focal0;
     p->cur = 0;
     // nothing is enqueued here: the next solve's first kernel copies the initial parameters itself (k_begin); any other entry point
@@ -1089,6 +1128,7 @@ int sfmba_problem_reset(sfmba_problem* p) {
 
 int sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double* pt3, double focal) {
     if (!p || !cam6 || !pt3) return fail(SFMBA_ERR_INVALID_ARG, "NULL argument");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     p->reset_pending = false;           // everything a reset would restore is overwritten here
     p->focal = focal;
     p->cur = 0;
@@ -1108,8 +1148,9 @@ int sfmba_problem_set_params(sfmba_problem* p, const double* cam6, const double*
 }
 
 int sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double* focal) {
-    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
+    if (p && !p->poisoned) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     if (focal) *focal = p->focal;
     if (p->empty) return SFMBA_OK;
     HIP_TRY(hipSetDevice(p->device));
@@ -1137,6 +1178,7 @@ int sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double
 int sfmba_problem_solve(sfmba_problem* p, const sfmba_options* opt, sfmba_summary* summary,
                         sfmba_iteration* trace, int trace_cap, int* trace_len) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     sfmba_options o;
     if (opt) o = *opt; else sfmba_options_default(&o);
     if (p->precision == SFMBA_PRECISION_F32J) return run_solve<float>(p, o, summary, trace, trace_cap, trace_len);
@@ -1172,6 +1214,7 @@ int sfmba_solve(int n_cam, double* cam6, int n_pt, double* pt3, int64_t n_obs, c
 
 int sfmba_problem_set_profiling(sfmba_problem* p, int enable) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     p->prof.reset();
     p->prof.on = enable != 0;
     return SFMBA_OK;
@@ -1195,8 +1238,9 @@ int sfmba_problem_get_profile(sfmba_problem* p, sfmba_kernel_time* out, int cap,
 
 // ---- kernel-level entry points ----------------------------------------------------------------
 int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double* cost_out) {
-    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
+    if (p && !p->poisoned) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     if (cost_out) *cost_out = 0.0;
     if (p->empty) return SFMBA_OK;
     HIP_TRY(hipSetDevice(p->device));
@@ -1217,8 +1261,9 @@ int sfmba_problem_eval_residuals(sfmba_problem* p, double* residuals_out, double
 }
 
 int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double* jf) {
-    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
+    if (p && !p->poisoned) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     if (p->empty) return SFMBA_OK;
     HIP_TRY(hipSetDevice(p->device));
     const size_t n = (size_t)p->ds.nobs;
@@ -1242,8 +1287,8 @@ int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double
 }
 
 int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, double radius, double* S, double* rhs, double* scale) {
-    if (p) { const int frc = flush_reset(p); if (frc) return frc; }
-    if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
+    if (p && !p->poisoned) { const int frc = flush_reset(p); if (frc) return frc; }
+    if (!p || p->empty || p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, p && p->poisoned ? "poisoned problem (a failed sfmba_problem_append): destroy it" : "NULL or empty problem");
     sfmba_options o;
     if (opt) o = *opt; else sfmba_options_default(&o);
     HIP_TRY(hipSetDevice(p->device));
@@ -1332,7 +1377,7 @@ void* sfmba_shard_scalars_buf(sfmba_problem* p) { return p ? (void*)p->d_scal : 
 // fused = true (the C loop of sfmba_problem_solve_sharded, CG path): one k_begin launch carries the LM state and clears / builds what
 // five launches and two copies do otherwise, and the point scales are left to the first k_point_build, as in run_solve
 static int shard_begin_impl(sfmba_problem* p, const sfmba_options* opt, bool fused) {
-    if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
+    if (!p || p->empty || p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, p && p->poisoned ? "poisoned problem (a failed sfmba_problem_append): destroy it" : "NULL or empty problem");
     if (opt) p->shard_opt = *opt; else sfmba_options_default(&p->shard_opt);
     HIP_TRY(hipSetDevice(p->device));
     int rc = ensure_trace(p, std::min(std::max(p->shard_opt.max_iters, 0) + 2, 1 << 16));
@@ -1395,6 +1440,7 @@ int sfmba_shard_partial_build(sfmba_problem* p) {
         launch_schur_pairs<double>(p->stream, p->ds, p->db, 2);
         launch_schur_pairs<double>(p->stream, p->ds, p->db, 0);
     }
+    launch_cd_fold(p->stream, p->ds, p->db);       // deterministic mode: chunk sums in chunk order, before the exchange
     launch_shard_pack(p->stream, p->db, p->d_scal, 1, p->shard_rank);
     launch_shard_tri(p->stream, p->d_sys, p->d_red, p->ds.ld, 3 * (long long)p->ds.ld + SFMBA_SHARD_SCALARS, /*unpack=*/false);
     return SFMBA_OK;
@@ -1406,18 +1452,19 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     const sfmba_options& o = p->shard_opt;
     launch_shard_tri(p->stream, p->d_sys, p->d_red, p->ds.ld, 3 * (long long)p->ds.ld + SFMBA_SHARD_SCALARS, /*unpack=*/true);
     launch_shard_unpack(p->stream, p->db, p->d_scal, 1, p->shard_world);
-    launch_finalize(p->stream, p->ds, p->db, 0);
+    { DeviceBuffers dbf = p->db; dbf.cd_part = nullptr; launch_finalize(p->stream, p->ds, dbf, 0); }     // (chunk sums: folded before the exchange)
     DeviceBuffers dbu = p->db;
     if (o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) {
         // fp32 Jacobian mode: the streaming CG path keeps the preconditioned matrix in fp32 (k_pcg_transform writes it)
         p->solver.use_f32 = p->precision == SFMBA_PRECISION_F32J && dense_pcg_want_f32(&p->solver) != nullptr;
         // block factors and S~ from the all-reduced system, then the gauge vectors from those factors (two-level preconditioner)
         if (dense_pcg_transform(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, nullptr)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
-        const char* coarse_env = std::getenv("SFMBA_PCG_COARSE");
-        const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
+        const bool coarse_cg = option_switch(o.pcg_coarse_space, "SFMBA_PCG_COARSE", true);
         if (coarse_cg) { p->db.pcg_W = p->solver.W; launch_gauge(p->stream, p->ds, p->db); }
-        const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
-                                       false, p->shard_host_iter, /*pretransformed=*/true, /*anchor=*/!o.pcg_anchored ? 0 : p->shard_host_iter == 0 ? 1 : 2,
+        const bool exact_pcg = o.linear_solver == SFMBA_LINEAR_AUTO;
+        const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
+        const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, cg_tol, o.pcg_max_iters, p->d_info, nullptr,
+                                       false, p->shard_host_iter, /*pretransformed=*/true, /*anchor=*/(!o.pcg_anchored || exact_pcg) ? 0 : p->shard_host_iter == 0 ? 1 : 2,
                                        /*no_wait=*/false, /*coarse=*/coarse_cg);
         if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
         p->shard_sum.linear_iters += it;
@@ -1483,7 +1530,7 @@ int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) {
 
 // ---- the sharded LM loop in one call: collectives through a callback (RCCL below, or the caller's) ----
 int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx, sfmba_summary* summary) {
-    if (!p || p->empty) return fail(SFMBA_ERR_INVALID_ARG, "NULL or empty problem");
+    if (!p || p->empty || p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, p && p->poisoned ? "poisoned problem (a failed sfmba_problem_append): destroy it" : "NULL or empty problem");
     if (!p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "not a sharded problem (sfmba_problem_create_sharded)");
     if (p->shard_world > 1 && !allreduce) return fail(SFMBA_ERR_INVALID_ARG, "world > 1 needs an all-reduce");
     auto reduce = [&](void* buf, int64_t n) -> int {
@@ -1493,9 +1540,13 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
     };
     sfmba_options o_in;
     if (opt) o_in = *opt; else sfmba_options_default(&o_in);
-    const char* twophase_env = std::getenv("SFMBA_SHARD_TWO_PHASE");
     const bool two_phase = (o_in.linear_solver == SFMBA_LINEAR_PCG || (o_in.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) &&
-                           !(twophase_env && twophase_env[0] == '0');
+                           option_switch(o_in.shard_two_phase, "SFMBA_SHARD_TWO_PHASE", true);
+    // fail-stop rule (include/sfmba.h): everything the loop allocates is allocated before this rank's first collective
+    if (two_phase) {
+        if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+        if (p->precision == SFMBA_PRECISION_F32J) (void)dense_pcg_want_f32(&p->solver);     // (null = not applicable at this size)
+    }
     int rc = shard_begin_impl(p, opt, /*fused=*/two_phase);
     if (rc) return rc;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
@@ -1507,15 +1558,16 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         // CG solver: two all-reduces per linearisation (diagonal blocks + vectors, then the off-diagonal blocks of the preconditioned
         // matrix, ba_kernels.hip k_shard_diag / k_shard_offdiag) and the same fused kernels as the one-GPU loop in run_solve:
         // block factors and gauge vectors in k_finalize, transform in the pair pass, gated CG batches (no host wait on the solve).
-        const char* coarse_env = std::getenv("SFMBA_PCG_COARSE");
-        const bool coarse_cg = !(coarse_env && coarse_env[0] == '0');
+        const bool coarse_cg = option_switch(o.pcg_coarse_space, "SFMBA_PCG_COARSE", true);
         const bool f32 = p->precision == SFMBA_PRECISION_F32J;
         bool first_linear_solve = true;
-        const char* spec_env = std::getenv("SFMBA_EARLY_LINEARISE");
-        const bool speculate = !(spec_env && spec_env[0] == '0');
+        const bool speculate = option_switch(o.early_linearise, "SFMBA_EARLY_LINEARISE", true);
         bool build_enqueued = false;
-        const char* x32_env = std::getenv("SFMBA_SHARD_F32_EXCHANGE");
-        const bool exchange_f32_off = x32_env && x32_env[0] == '0';
+        const bool exchange_f32_off = !option_switch(o.shard_f32_exchange, "SFMBA_SHARD_F32_EXCHANGE", true);
+        // AUTO here = the CG run to a plain relative 1e-12 (no Cholesky fallback in the sharded loop: the factorisation would need the
+        // unpreconditioned matrix exchanged as well; at max_iters the step is forced, as with PCG)
+        const bool exact_pcg = o.linear_solver == SFMBA_LINEAR_AUTO;
+        const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
         int first_build = o.jacobi_scaling ? 1 : 2;          // the first point pass also forms the point scales
         for (;;) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
@@ -1535,10 +1587,11 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             if (f32) { launch_cam_diag<float>(p->stream, p->ds, p->db); launch_schur_pairs<float>(p->stream, p->ds, p->db, 2); }
             else { launch_cam_diag<double>(p->stream, p->ds, p->db); launch_schur_pairs<double>(p->stream, p->ds, p->db, 2); }
             first_build = 0;
+            launch_cd_fold(p->stream, p->ds, p->db);       // deterministic mode: chunk sums in chunk order, before the exchange
             launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/false, p->shard_rank, p->shard_world);
             if ((rc = reduce(p->d_red, shard_diag_len(p->ds)))) return rc;
             launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/true, p->shard_rank, p->shard_world);
-            launch_finalize(p->stream, p->ds, p->db, 1);
+            { DeviceBuffers dbf = p->db; dbf.cd_part = nullptr; launch_finalize(p->stream, p->ds, dbf, 1); }
             // the pair pass stores its transformed blocks straight into the all-reduce buffer
             if (x32) p->db.shard_blocks32 = reinterpret_cast<float*>(p->d_red); else p->db.shard_blocks = p->d_red;
             if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 1); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 1);
@@ -1552,9 +1605,9 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                 launch_shard_offdiag(p->stream, p->ds, p->solver.Sfull, p->d_red, /*unpack=*/true);
                 if (F32) launch_narrow_matrix(p->stream, p->solver.Sfull, F32, (long long)p->ds.d * p->ds.ld);
             }
-            const int anchor = !o.pcg_anchored ? 0 : first_linear_solve ? 1 : 2;
+            const int anchor = (!o.pcg_anchored || exact_pcg) ? 0 : first_linear_solve ? 1 : 2;
             first_linear_solve = false;
-            const int it0 = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, o.pcg_tolerance, o.pcg_max_iters, p->d_info, nullptr,
+            const int it0 = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, cg_tol, o.pcg_max_iters, p->d_info, nullptr,
                                             /*finish=*/false, /*hist_key=*/p->shard_host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/true, coarse_cg);
             if (it0 < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             DeviceBuffers dbu = p->db;
@@ -1641,6 +1694,9 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi* rccl() {
@@ -1655,6 +1711,9 @@ RcclApi* rccl() {
             api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
             api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
             api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+            api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
+            api.ReduceScatter = reinterpret_cast<decltype(api.ReduceScatter)>(dlsym(api.handle, "ncclReduceScatter"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
             if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.handle = nullptr;
         }
     }
@@ -1698,6 +1757,13 @@ void sfmba_comm_destroy(sfmba_comm* c) {
     delete c;
 }
 
+int sfmba_comm_abort(sfmba_comm* c) {
+    RcclApi* a = rccl();
+    if (!c || !a || !a->CommAbort) return fail(SFMBA_ERR_HIP, "ncclCommAbort is not available");
+    if (c->comm) { (void)a->CommAbort(c->comm); c->comm = nullptr; }
+    return SFMBA_OK;
+}
+
 int sfmba_comm_allreduce(void* comm, void* device_buf, int64_t n_doubles, void* hip_stream) {
     sfmba_comm* c = static_cast<sfmba_comm*>(comm);
     RcclApi* a = rccl();
@@ -1722,6 +1788,7 @@ int sfmba_shard_last_exchange(const sfmba_problem* p, int64_t out[4]) {
 
 int sfmba_problem_set_allreduce_f32(sfmba_problem* p, sfmba_allreduce_f32_fn allreduce_f32) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     p->allreduce_f32 = allreduce_f32;
     return SFMBA_OK;
 }

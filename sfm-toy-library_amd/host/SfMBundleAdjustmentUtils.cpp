@@ -7,13 +7,13 @@
 //   BA.cpp:123-134          R (float) -> angle-axis computed IN FLOAT, then widened; t widened from float
 //   BA.cpp:138              focal = K(0,0);  BA.cpp:149-153  obs = feature - (K(0,2), K(1,2)) in float
 //   BA.cpp:142-166          residual blocks in point-major order, ascending view (std::map order)
-//   BA.cpp:171-177          500 iterations, 10 s; linear solver = exact Schur + dense Cholesky (== DENSE_SCHUR) unless
-//                           SFMBA_LINEAR opts into the inexact block-Jacobi PCG
+//   BA.cpp:171-177          500 iterations, 10 s; linear solver = the DENSE_SCHUR result (exact Schur complement; dense Cholesky, or
+//                           above 256 reduced unknowns the CG run to 1e-12 with the Cholesky as fallback) unless SFMBA_LINEAR says otherwise
 //   BA.cpp:180              one-line report on stdout
 //   BA.cpp:182-185          anything but CONVERGENCE: "Bundle adjustment failed." on stderr, outputs untouched
 //   BA.cpp:187-221          K(0,0)=K(1,1)=focal; angle-axis -> R; t; points; all narrowed to float
 // Environment overrides (reference options are hard-coded, BA.cpp:171-177):
-//   SFMBA_LINEAR=cholesky|pcg|auto (default cholesky; auto = cholesky up to 256 reduced unknowns, PCG above)
+//   SFMBA_LINEAR=cholesky|pcg|auto (default auto, see sfmba.h SFMBA_LINEAR_AUTO)
 //   SFMBA_PRECISION=f64|f32j  SFMBA_MAX_SECONDS=<s>  SFMBA_VERBOSE=1
 //   SFMBA_DUMP=<path>  writes the marshalled problem (format: sfm-toy-library_amd/problem_io.py)
 //   SFMBA_SHIM_CACHE=0  disables the resident-problem cache described below;  SFMBA_SHIM_OVERLAP=0  its overlapped comparison
@@ -369,10 +369,11 @@ void SfMBundleAdjustmentUtils::adjustBundle(
     // ---- options (BA.cpp:171-177) ----
     sfmba_options opt;
     sfmba_options_default(&opt);
-    // The reference solves the reduced camera system exactly (DENSE_SCHUR, BA.cpp:172): so does the drop-in by default.
-    // The block-Jacobi PCG (faster above a few dozen views; poses and points agree with the exact solve to ~2e-7, the cost
-    // to 1e-12) is an explicit opt-in: SFMBA_LINEAR=pcg, or =auto for Cholesky up to 256 reduced unknowns and PCG above.
-    opt.linear_solver = SFMBA_LINEAR_CHOLESKY;
+    // The reference solves the reduced camera system exactly (DENSE_SCHUR, BA.cpp:172).  The library default (SFMBA_LINEAR_AUTO)
+    // delivers that result with the cheapest solver: Cholesky up to 256 reduced unknowns; above, the two-level CG run to a relative
+    // residual of 1e-12 (step within ~1e-10 of the factorised one: far below the float containers this function writes back to),
+    // with the Cholesky as fallback on the same linearisation if the CG does not get there.  SFMBA_LINEAR=cholesky forces the
+    // factorisation, =pcg the inexact CG (tolerance 1e-8: poses and points agree with the exact solve to ~1e-8, the cost to 1e-12).
     if (const char* e = std::getenv("SFMBA_LINEAR"))
         opt.linear_solver = std::strcmp(e, "pcg") == 0 ? SFMBA_LINEAR_PCG : std::strcmp(e, "auto") == 0 ? SFMBA_LINEAR_AUTO : SFMBA_LINEAR_CHOLESKY;
     if (const char* e = std::getenv("SFMBA_PRECISION")) opt.precision = std::strcmp(e, "f32j") == 0 ? SFMBA_PRECISION_F32J : SFMBA_PRECISION_F64;

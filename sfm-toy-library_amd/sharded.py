@@ -27,7 +27,7 @@ class _DevicePtr:
 class HipShardBackend:
     """Rank-local half of the sharded solve on one MI355X."""
 
-    def __init__(self, full_prob, rank, world, device=0, precision=1):
+    def __init__(self, full_prob, rank, world, device=0, precision=1, flags=0):
         import torch
         self.torch = torch
         self.rank, self.world, self.device = rank, world, device
@@ -43,8 +43,8 @@ class HipShardBackend:
         self._h = C.c_void_p()
         L = capi.lib()
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
-        capi._check(L.sfmba_problem_create_sharded(
-            C.c_int(device), C.c_int(precision), C.c_int(shard.n_cam), cam6.ctypes.data_as(dp),
+        capi._check(L.sfmba_problem_create_ex(
+            C.c_int(device), C.c_int(precision), C.c_int(flags), C.c_int(shard.n_cam), cam6.ctypes.data_as(dp),
             active.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_int(shard.n_pt), pt3.ctypes.data_as(dp), C.c_int64(shard.n_obs),
             oc.ctypes.data_as(ip), op.ctypes.data_as(ip), oxy.ctypes.data_as(dp), C.c_double(shard.focal),
             C.c_int(rank), C.c_int(world), C.byref(self._h)))

@@ -5,6 +5,7 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 TERMINATION_NAMES = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
 LINEAR_CHOLESKY, LINEAR_PCG, LINEAR_AUTO = 0, 1, 2
 PRECISION_F64, PRECISION_F32J = 0, 1
+CREATE_DETERMINISTIC = 1
 
 
 class SfmbaOptions(C.Structure):
@@ -28,6 +29,14 @@ class SfmbaOptions(C.Structure):
         ("pcg_max_iters", C.c_int),
         ("verbose", C.c_int),
         ("pcg_anchored", C.c_int),
+        # ABI v4: behaviour switches (0 = library default, 1 = on, -1 = off; the SFMBA_* environment variable overrides)
+        ("pcg_coarse_space", C.c_int),
+        ("pcg_persistent", C.c_int),
+        ("pcg_f32_matrix", C.c_int),
+        ("early_linearise", C.c_int),
+        ("shard_two_phase", C.c_int),
+        ("shard_f32_exchange", C.c_int),
+        ("shard_distributed_cg", C.c_int),
     ]
 
     @classmethod
@@ -36,7 +45,7 @@ class SfmbaOptions(C.Structure):
         o = cls(max_iters=500, max_seconds=10.0, function_tolerance=1e-6, gradient_tolerance=1e-10,
                 parameter_tolerance=1e-8, initial_radius=1e4, max_radius=1e16, min_radius=1e-32,
                 min_relative_decrease=1e-3, min_lm_diagonal=1e-6, max_lm_diagonal=1e32,
-                jacobi_scaling=1, max_consecutive_invalid_steps=5, linear_solver=LINEAR_CHOLESKY,
+                jacobi_scaling=1, max_consecutive_invalid_steps=5, linear_solver=LINEAR_AUTO,
                 precision=PRECISION_F64, pcg_tolerance=1e-8, pcg_max_iters=0, verbose=0, pcg_anchored=1)
         for k, v in overrides.items():
             if not hasattr(o, k):
@@ -59,6 +68,7 @@ class SfmbaSummary(C.Structure):
         ("seconds", C.c_double),
         ("setup_seconds", C.c_double),
         ("message", C.c_char * 128),
+        ("cholesky_fallbacks", C.c_int),
     ]
 
     def as_dict(self):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sfmba_abi_version() == 3
+    assert L.sfmba_abi_version() == 4
 
 
 def test_default_options_match_reference_values(capi, sfm, oracle):
@@ -42,8 +42,16 @@ def test_default_options_match_reference_values(capi, sfm, oracle):
 def test_struct_sizes_match_header(capi, sfm):
     # natural C layout of the header structs on x86-64
     assert C.sizeof(sfm.SfmbaIteration) == 4 * 4 + 6 * 8
-    assert C.sizeof(sfm.SfmbaSummary) == 7 * 4 + 4 + 4 * 8 + 128
-    assert C.sizeof(sfm.SfmbaOptions) == 8 + 10 * 8 + 4 * 4 + 8 + 3 * 4 + 4     # ... pcg_max_iters, verbose, pcg_anchored + tail padding
+    assert C.sizeof(sfm.SfmbaSummary) == 7 * 4 + 4 + 4 * 8 + 128 + 4 + 4      # ... message, cholesky_fallbacks (ABI v4) + tail padding
+    assert C.sizeof(sfm.SfmbaOptions) == 8 + 10 * 8 + 4 * 4 + 8 + 3 * 4 + 7 * 4     # ... pcg_max_iters, verbose, pcg_anchored, 7 switches (ABI v4)
+    # the header and the mirror agree on the field lists (names, in order)
+    header = open(os.path.join(ROOT, "include", "sfmba.h")).read()
+    body = header[header.index("typedef struct sfmba_options {"):header.index("} sfmba_options;")]
+    names = re.findall(r"^\s+(?:int|double)\s+(\w+);", body, flags=re.M)
+    assert names == [n for n, _ in sfm.SfmbaOptions._fields_]
+    body = header[header.index("typedef struct sfmba_summary {"):header.index("} sfmba_summary;")]
+    names = re.findall(r"^\s+(?:int|double|char)\s+(\w+)(?:\[\d+\])?;", body, flags=re.M)
+    assert names == [n for n, _ in sfm.SfmbaSummary._fields_]
 
 
 def test_no_cpu_fallback_without_device(capi, sfm):
