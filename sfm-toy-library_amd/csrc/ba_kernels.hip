@@ -15,6 +15,7 @@
 #include "ba_kernels.h"
 #include "sfmba_device.h"
 #include "../../include/sfmba.h"
+#include <cstdlib>
 
 namespace sfmba {
 
@@ -571,6 +572,20 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
             sl[w][lane][3] = (T)(Li[3] * sp[0]); sl[w][lane][4] = (T)(Li[4] * sp[1]); sl[w][lane][5] = (T)(Li[5] * sp[2]);
             st_yf[w][lane][0] = (T)t0; st_yf[w][lane][1] = (T)t1; st_yf[w][lane][2] = (T)t2;
             st_yf[w][lane][3] = (T)y0; st_yf[w][lane][4] = (T)y1; st_yf[w][lane][5] = (T)y2;
+            // the per-point table of the re-evaluating reduced-system passes (sfmba_device.h): the point itself, the SAME L values the
+            // record sweep below uses, and t, y_f as the side record sees them
+            if (db.PA) {
+                PtRecA<T> ra;
+                ra.X[0] = pts[3 * i]; ra.X[1] = pts[3 * i + 1]; ra.X[2] = pts[3 * i + 2];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ra.L[c] = sl[w][lane][c];
+                if (sizeof(T) == 8) reinterpret_cast<double*>(&ra)[9] = 0.0;
+                reinterpret_cast<PtRecA<T>*>(db.PA)[i] = ra;
+                PtRecB<T> rb;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { rb.t[c] = st_yf[w][lane][c]; rb.yf[c] = st_yf[w][lane][3 + c]; }
+                reinterpret_cast<PtRecB<T>*>(db.PB)[i] = rb;
+            }
         }
         wave_lds_fence();
         // record sweep: one packed 64-byte (fp32) record per observation
@@ -608,6 +623,11 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
             z[2] = rec[9] * ty[3] + rec[10] * ty[4] + rec[11] * ty[5];
             z[3] = rec[12] * ty[3] + rec[13] * ty[4] + rec[14] * ty[5];
             z[4] = rk0; z[5] = rk1; z[6] = (T)0; z[7] = (T)0;
+            if (db.res) {       // the residual alone: 8 bytes instead of the 32-byte side record (the rest is re-evaluated from the point table)
+                typename ObsXY<T>::type rr; rr.x = z[4]; rr.y = z[5];
+                reinterpret_cast<typename ObsXY<T>::type*>(db.res)[q] = rr;
+            }
+            if (db.Z) {
             T* zd = reinterpret_cast<T*>(db.Z) + (size_t)q * 8;
             if (sizeof(T) == 4) {
                 float4* z4 = reinterpret_cast<float4*>(zd);
@@ -617,6 +637,7 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
                 double2* z2 = reinterpret_cast<double2*>(zd);
                 z2[0] = make_double2((double)z[0], (double)z[1]); z2[1] = make_double2((double)z[2], (double)z[3]);
                 z2[2] = make_double2((double)z[4], (double)z[5]); z2[3] = make_double2(0.0, 0.0);
+            }
             }
         }
     }
@@ -765,8 +786,14 @@ __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, con
     store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
 }
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+// RECOMP (modes 0 / 1): nothing is gathered per observation.  Both cameras of a block are fixed for the wave, so their table rows sit
+// in scalar registers; per pair a lane loads ONE point-table entry (48 bytes in fp32 mode, from a table that stays in L2) and
+// re-evaluates both observations with the expressions of the point pass (obs_record): the same values, pair for pair and in the
+// same lane, as the record-gathering form -- minus the two random 64-byte gathers per pair from the 64 MB of records.
+// RECOMP = 0: gathering form; 3 / 4: re-evaluating form compiled for that many waves per SIMD (register budget 512 / RECOMP: 3 fits
+// without scratch, 4 spills ~40 registers per lane; SFMBA_PAIR_RC_WAVES picks at launch, default below)
+template <typename T, int MODE, int RECOMP>
+__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? RECOMP : 4) : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int b, pbeg, pend;
@@ -818,25 +845,58 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
     const T* Y = reinterpret_cast<const T*>(db.Y);
     const int s = lane & 3, g = lane >> 2;
     const bool b0 = (s & 1) != 0, b1 = (s & 2) != 0;
-    // A quad LOADS four pairs cooperatively (each 64-byte record is one request of four adjacent lanes: the vector-memory
-    // pipe walks lines, not bytes) and then transposes them with DPP so that every lane COMPUTES one pair on its own:
-    // the first version had all four lanes form the same 2x2 core and the same T block (75 % VALU-busy, 7.1 wave
-    // instructions per pair); this one needs 3.8.
     T acc[36];
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = (T)0;
     const int p1 = pend;
-    // the pair indices of a round are fetched one round ahead: a round then costs ONE dependent memory level (the record
-    // gathers) instead of two (indices, then records)
-    int2 pr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int p = pbeg + 16 * u + g; pr[u] = ds.pairs[pbeg < p1 ? (p < p1 ? p : p1 - 1) : 0]; }
     // Lane-local sums stay in T for at most PAIR_FLUSH rounds (64 pairs each), then the wave sum is taken and carried on in fp64: a block
     // with tens of thousands of pairs (two cameras sharing most of a large cloud) would otherwise pile thousands of fp32 additions
     // into one accumulator.  Blocks up to 64 * PAIR_FLUSH pairs -- all of BASELINE config 3 -- never take the branch.
     constexpr int PAIR_FLUSH = 64;
     double total = 0.0;            // this lane's entry of the 6x6 block (lanes that own one), over the flushes so far
     int base = 0, len = 36, rounds = 0;
+    if (RECOMP) {
+        const LMState* st = db.st;
+        const int cur = st->cur;
+        const double focal = st->focal[cur];
+        CamU<T> ca, cb;
+        load_cam_u<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.x), ds.ncam, ca);
+        load_cam_u<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.y), ds.ncam, cb);
+        const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
+        // lane (s, g) owns pair p0 + 16 s + g of a round -- the pair the DPP transpose of the gathering form hands it -- so the
+        // lane-local sums (and every bit of the block) come out the same in both forms.  The point index of the NEXT round's pair
+        // is fetched one round ahead (one dependent memory level per round: the point-table entry).
+        const int mine = 16 * s + g;
+        int pt_next = ds.pair_pt[pbeg < p1 ? (pbeg + mine < p1 ? pbeg + mine : p1 - 1) : 0];
+        for (int p0 = pbeg; p0 < p1; p0 += 64) {
+            const PtRecA<T> pa = PA[pt_next];
+            { const int p = p0 + 64 + mine; pt_next = ds.pair_pt[p < p1 ? p : p1 - 1]; }
+            T ra[YREC], rb[YREC];
+            obs_record<T>(ca, focal, pa.X, pa.L, ra);
+            obs_record<T>(cb, focal, pa.X, pa.L, rb);
+            if (p0 + mine >= p1) {              // this lane's pair lies beyond the block: contribute nothing
+#pragma unroll
+                for (int e = 9; e < 15; ++e) ra[e] = (T)0;
+            }
+            pair_product<T>(ra, rb, false, acc);
+            if (sizeof(T) == 4 && ++rounds == PAIR_FLUSH && p0 + 64 < p1) {
+                rounds = 0; base = 0; len = 36;
+                HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
+                total += len >= 1 ? (double)acc[0] : 0.0;
+#pragma unroll
+                for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+            }
+        }
+    } else {
+    // A quad LOADS four pairs cooperatively (each 64-byte record is one request of four adjacent lanes: the vector-memory
+    // pipe walks lines, not bytes) and then transposes them with DPP so that every lane COMPUTES one pair on its own:
+    // the first version had all four lanes form the same 2x2 core and the same T block (75 % VALU-busy, 7.1 wave
+    // instructions per pair); this one needs 3.8.
+    // the pair indices of a round are fetched one round ahead: a round then costs ONE dependent memory level (the record
+    // gathers) instead of two (indices, then records)
+    int2 pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int p = pbeg + 16 * u + g; pr[u] = ds.pairs[pbeg < p1 ? (p < p1 ? p : p1 - 1) : 0]; }
     for (int p0 = pbeg; p0 < p1; p0 += 64) {
         T qa[4][4], qb[4][4];
 #pragma unroll
@@ -864,6 +924,7 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
 #pragma unroll
             for (int e = 0; e < 36; ++e) acc[e] = (T)0;
         }
+    }
     }
     // Sum of the 36 entries over the 64 lanes by a halving butterfly (38 shuffles instead of 72 + 96: the epilogue was as long as
     // the pair loop): afterwards lane `base` -- 36 of the 64 lanes -- owns ONE entry of the 6x6 block.
@@ -1046,38 +1107,14 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
 #define CD_N 48      // Sjj(21) udiag(6) Sjf(6) bc(6) rhs(6) uff bf + pad
 #define CD_BLK SFMBA_CAM_CHUNK
 
+// the 47 terms one observation contributes to its camera's diagonal block, focal column, gradient and right-hand side, from its packed
+// record and side values z = {C t (2), C y_f (2), residual (2)} -- shared by the record-gathering and the re-evaluating camera pass
 template <typename T>
-__global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double red[CD_BLK / 64][CD_N];
-    const int4 ch = ds.chunks[blockIdx.x];
-    const int j = ch.x;
-    const LMState* st = db.st;
-    const T fscale = (T)st->fscale;
-    const T* Y = reinterpret_cast<const T*>(db.Y);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int e = ch.y + threadIdx.x;
-
-    T v[CD_N];
-#pragma unroll
-    for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
-    if (e < ch.z) {
-        const int q = ds.cam_obs[e];
-        T rec[YREC], A[12];
-        load_rec<T>(Y, q, rec);
-        T z[8];
-        {
-            const T* zs = reinterpret_cast<const T*>(db.Z) + (size_t)q * 8;
-            if (sizeof(T) == 4) {
-                const float4 a = reinterpret_cast<const float4*>(zs)[0], b = reinterpret_cast<const float4*>(zs)[1];
-                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)a.z; z[3] = (T)a.w; z[4] = (T)b.x; z[5] = (T)b.y;
-            } else {
-                const double2 a = reinterpret_cast<const double2*>(zs)[0], b = reinterpret_cast<const double2*>(zs)[1], c = reinterpret_cast<const double2*>(zs)[2];
-                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)b.x; z[3] = (T)b.y; z[4] = (T)c.x; z[5] = (T)c.y;
-            }
-        }
+__device__ __forceinline__ void cam_diag_terms(const T (&rec)[YREC], const T (&z)[8], const double* __restrict__ cscale6, T fscale, T (&v)[CD_N]) {
+        T A[12];
         rec_camera_block<T>(rec, A);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { const T s = (T)db.cscale[6 * j + c]; A[c] *= s; A[6 + c] *= s; }
+        for (int c = 0; c < 6; ++c) { const T s = (T)cscale6[c]; A[c] *= s; A[6 + c] *= s; }
         const T r0 = z[4], r1 = z[5];
         const T g0 = rec[7] * fscale, g1 = rec[8] * fscale;
         // N = I - C C^T
@@ -1103,7 +1140,13 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
         }
         v[45] = g0 * g0 + g1 * g1;
         v[46] = g0 * r0 + g1 * r1;
-    }
+}
+
+// sums of the 47 terms over the workgroup (fp64: halving butterfly inside the wave, LDS across the waves) and one atomic per value
+// per workgroup -- or, deterministic mode, the per-chunk slot that k_finalize / k_cd_fold add in chunk order
+template <typename T>
+__device__ __forceinline__ void cam_diag_finish(const DeviceStructure& ds, const DeviceBuffers& db, int j, T (&v)[CD_N], double (*red)[CD_N]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // first halving step on the T values (one 32-bit shuffle each), the rest in fp64
     double acc[CD_N / 2];
     {
@@ -1148,6 +1191,75 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double red[CD_BLK / 64][CD_N];
+    const int4 ch = ds.chunks[blockIdx.x];
+    const int j = ch.x;
+    const LMState* st = db.st;
+    const T fscale = (T)st->fscale;
+    const T* Y = reinterpret_cast<const T*>(db.Y);
+    const int e = ch.y + threadIdx.x;
+
+    T v[CD_N];
+#pragma unroll
+    for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
+    if (e < ch.z) {
+        const int q = ds.cam_obs[e];
+        T rec[YREC];
+        load_rec<T>(Y, q, rec);
+        T z[8];
+        {
+            const T* zs = reinterpret_cast<const T*>(db.Z) + (size_t)q * 8;
+            if (sizeof(T) == 4) {
+                const float4 a = reinterpret_cast<const float4*>(zs)[0], b = reinterpret_cast<const float4*>(zs)[1];
+                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)a.z; z[3] = (T)a.w; z[4] = (T)b.x; z[5] = (T)b.y;
+            } else {
+                const double2 a = reinterpret_cast<const double2*>(zs)[0], b = reinterpret_cast<const double2*>(zs)[1], c = reinterpret_cast<const double2*>(zs)[2];
+                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)b.x; z[3] = (T)b.y; z[4] = (T)c.x; z[5] = (T)c.y;
+            }
+        }
+        cam_diag_terms<T>(rec, z, db.cscale + 6 * j, fscale, v);
+    }
+    cam_diag_finish<T>(ds, db, j, v, red);
+}
+
+// The same pass WITHOUT the per-observation records: the camera's table row sits in scalar registers (one camera per workgroup), a lane
+// gathers its observation's point-table entries (72 bytes from a table that stays in L2) and the stored residual (8 bytes), and
+// re-evaluates the record with the expressions of the point pass (obs_record): bit for bit the values k_cam_diag reads.
+template <typename T>
+__global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double red[CD_BLK / 64][CD_N];
+    const int4 ch = ds.chunks[blockIdx.x];
+    const int j = ch.x;
+    const LMState* st = db.st;
+    const int cur = st->cur;
+    const double focal = st->focal[cur];
+    const T fscale = (T)st->fscale;
+    CamRegs ct;
+    load_cam_regs(db.camtab[cur], j, ds.ncam, ct);
+    const int e = ch.y + threadIdx.x;
+    T v[CD_N];
+#pragma unroll
+    for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
+    if (e < ch.z) {
+        const int q = ds.cam_obs[e], i = ds.cam_obs_pt[e];
+        const PtRecA<T> pa = reinterpret_cast<const PtRecA<T>*>(db.PA)[i];
+        const PtRecB<T> pb = reinterpret_cast<const PtRecB<T>*>(db.PB)[i];
+        const typename ObsXY<T>::type rr = reinterpret_cast<const typename ObsXY<T>::type*>(db.res)[q];
+        T rec[YREC], z[8];
+        obs_record<T>(ct, focal, pa.X, pa.L, rec);
+        // side values exactly as the record sweep of k_point_build forms them: C t, C y_f, residual
+        z[0] = rec[9] * pb.t[0] + rec[10] * pb.t[1] + rec[11] * pb.t[2];
+        z[1] = rec[12] * pb.t[0] + rec[13] * pb.t[1] + rec[14] * pb.t[2];
+        z[2] = rec[9] * pb.yf[0] + rec[10] * pb.yf[1] + rec[11] * pb.yf[2];
+        z[3] = rec[12] * pb.yf[0] + rec[13] * pb.yf[1] + rec[14] * pb.yf[2];
+        z[4] = rr.x; z[5] = rr.y; z[6] = (T)0; z[7] = (T)0;
+        cam_diag_terms<T>(rec, z, db.cscale + 6 * j, fscale, v);
+    }
+    cam_diag_finish<T>(ds, db, j, v, red);
+}
+
 
 
 template <typename T>
@@ -1157,17 +1269,31 @@ void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBu
 template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 
+// the re-evaluating pair pass: one wave per block (pair_lpb == 64), off-diagonal modes, the point table and the pair-point list present
+// (a problem built with SFMBA_SCHUR_RECORDS=1 has no point table: the record-gathering forms run -- A/B measurements and the
+// bit-for-bit comparison test)
+bool schur_recompute_applies(const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
+    return db.PA != nullptr && ds.pair_pt != nullptr && ds.pair_lpb == 64 && mode != 2;
+}
+
 template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
+    const bool rc = schur_recompute_applies(ds, db, mode);
+    static const int rc_waves = [] { const char* e = std::getenv("SFMBA_PAIR_RC_WAVES"); return e && std::atoi(e) == 4 ? 4 : 3; }();
+    const dim3 grid(ds.npairwg), block(64 * SFMBA_PAIR_WAVES);
     if (mode == 2) {
-        if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2>), dim3(ds.ndupwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
+        if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2, 0>), dim3(ds.ndupwg), block, 0, s, ds, db);
     } else if (ds.pair_lpb == 16) {
-        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), dim3(ds.npairwg), dim3(64), 0, s, ds, db);
-        else hipLaunchKernelGGL((k_schur_pairs_sub<T, 0, 16>), dim3(ds.npairwg), dim3(64), 0, s, ds, db);
+        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
+        else hipLaunchKernelGGL((k_schur_pairs_sub<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
     } else if (mode == 1) {
-        hipLaunchKernelGGL((k_schur_pairs<T, 1>), dim3(ds.npairwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
+        if (rc && rc_waves == 4) hipLaunchKernelGGL((k_schur_pairs<T, 1, 4>), grid, block, 0, s, ds, db);
+        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 1, 3>), grid, block, 0, s, ds, db);
+        else hipLaunchKernelGGL((k_schur_pairs<T, 1, 0>), grid, block, 0, s, ds, db);
     } else {
-        hipLaunchKernelGGL((k_schur_pairs<T, 0>), dim3(ds.npairwg), dim3(64 * SFMBA_PAIR_WAVES), 0, s, ds, db);
+        if (rc && rc_waves == 4) hipLaunchKernelGGL((k_schur_pairs<T, 0, 4>), grid, block, 0, s, ds, db);
+        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 0, 3>), grid, block, 0, s, ds, db);
+        else hipLaunchKernelGGL((k_schur_pairs<T, 0, 0>), grid, block, 0, s, ds, db);
     }
 }
 template void launch_schur_pairs<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
@@ -1175,7 +1301,8 @@ template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, co
 
 template <typename T>
 void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_cam_diag<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
+    if (db.PA && db.res) hipLaunchKernelGGL(k_cam_diag_f<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
+    else hipLaunchKernelGGL(k_cam_diag<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
 }
 template void launch_cam_diag<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);

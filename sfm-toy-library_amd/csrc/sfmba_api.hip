@@ -216,6 +216,7 @@ struct sfmba_problem {
     bool reset_pending = false;             // sfmba_problem_reset() was called: the initial parameters are restored by the next solve's first kernel
                                             // (or by flush_reset() if anything else looks at the problem first)
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
+    int* d_pair_pt = nullptr;
     int* d_pwg_ptr = nullptr;
     double* d_facc = nullptr;
     double *d_cam0 = nullptr, *d_pts0 = nullptr;  // parameters given at create time
@@ -847,7 +848,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     // into the camera-diagonal pass) goes to block (ja, jb) of the upper triangle of S
     {
         const int brc = build_pair_lists(p->stream, &p->arena, &staging, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pm.pair_off, npair_total,
-                                         &p->d_pairs, &p->d_blk_ptr);
+                                         &p->d_pairs, &p->d_blk_ptr, &p->d_pair_pt);
         if (brc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc)); }
     }
     {
@@ -905,7 +906,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
     ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
     ds.obs_pt = p->d_obs_pt;
-    ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs;
+    ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs; ds.pair_pt = p->d_pair_pt;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
     ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
     ds.ndupwg = 0; ds.dup_blocks = p->d_dup_blocks;          // count: after the wait at the end
@@ -923,8 +924,20 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     HIP_TRY(dev_alloc(&db.pscale, (size_t)3 * npt));
     const size_t ybytes = (size_t)std::max(nobs, 1) * YREC * (f32 ? sizeof(float) : sizeof(double));
     db.Y = p->arena.alloc(ybytes);
-    db.Z = p->arena.alloc(ybytes / 2);
-    if (!db.Y || !db.Z) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+    if (!db.Y) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+    // The reduced-system passes re-evaluate every observation from the camera row and a per-point table (PA / PB, 72 bytes per point)
+    // plus the stored residual (8 bytes per observation) -- no 32-byte side record, and the 64-byte records are only read by the
+    // back-substitution.  SFMBA_SCHUR_RECORDS=1 at build time keeps the record-gathering passes of rounds 1 / 2 instead (A/B).
+    { const char* e = std::getenv("SFMBA_SCHUR_RECORDS");
+      if (e && e[0] == '1') {
+          db.Z = p->arena.alloc(ybytes / 2);
+          if (!db.Z) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+      } else {
+          db.PA = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecA<float>) : sizeof(PtRecA<double>)));
+          db.PB = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecB<float>) : sizeof(PtRecB<double>)));
+          db.res = p->arena.alloc((size_t)std::max(nobs, 1) * (f32 ? sizeof(float2) : sizeof(double2)));
+          if (!db.PA || !db.PB || !db.res) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+      } }
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_M, (size_t)6 * npt));

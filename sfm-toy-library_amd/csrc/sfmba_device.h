@@ -37,6 +37,20 @@ constexpr int ST_STRIDE = 20;
 // (layout in ba_kernels.hip): 16 values = 64 B in fp32 (one sector), 128 B in fp64 (one line).
 constexpr int YREC = 16;
 
+// ---- per-point table (round 3): what the reduced-system passes need about a POINT to RE-EVALUATE the blocks of one of its
+// observations instead of gathering a 64-byte record per observation (the records of BASELINE config 3 are 64 MB gathered ~10 times
+// at random; this table is 4.8 MB and stays in every XCD's L2).  Written by k_point_build once per linearisation.
+//   PtRecA: X (3 doubles: the projection is evaluated in fp64, exactly as the point pass does) | L = L^-1 diag(s_p) (6 values T:
+//           l00 l10 l11 l20 l21 l22 -- C = B L^T row by row)                    48 B in fp32 mode, 80 B (72 + pad) in fp64 mode
+//   PtRecB: t = L^-1 b_p (3 T) | y_f = L^-1 E_f (3 T)                           (camera-diagonal pass only)
+template <typename T> struct PtRecA;
+template <> struct alignas(16) PtRecA<float>  { double X[3]; float L[6]; };
+template <> struct alignas(16) PtRecA<double> { double X[3]; double L[6]; double pad; };
+template <typename T> struct PtRecB;
+template <> struct alignas(8)  PtRecB<float>  { float t[3]; float yf[3]; };
+template <> struct alignas(16) PtRecB<double> { double t[3]; double yf[3]; };
+static_assert(sizeof(PtRecA<float>) == 48 && sizeof(PtRecA<double>) == 80 && sizeof(PtRecB<float>) == 24 && sizeof(PtRecB<double>) == 48, "point table layout");
+
 // Camera tables are stored in component quads (AoSoA): values 4c .. 4c+3 of camera j are the 32 contiguous bytes at
 // tab[(c * ncam + j) * 4].  A wave whose lanes need the same components of 64 different cameras then issues ONE 32-byte
 // load per lane and quad instead of four 8-byte loads (the vector-memory pipe counts lines per 16-lane group per
@@ -49,6 +63,41 @@ struct CamRow {
     int stride;           // ncam
     __device__ __forceinline__ double operator[](int k) const { return base[(size_t)(k >> 2) * stride * 4 + (k & 3)]; }
 };
+
+// The table row of ONE camera held in registers: the block passes work on one camera (pair pass: two) per wave, so the row is
+// loaded with a wave-uniform index -- scalar loads into SGPRs, no per-lane gather.
+struct CamRegs {
+    double v[CT_SCALE];     // R, t, K', small-angle flag (the Jacobi scales are applied by the consumers themselves)
+    __device__ __forceinline__ double operator[](int k) const { return v[k]; }
+};
+__device__ __forceinline__ void load_cam_regs(const double* __restrict__ tab, int j_uniform, int ncam, CamRegs& c) {
+#pragma unroll
+    for (int k = 0; k < CT_SCALE; ++k) c.v[k] = tab[cam_tab_index(k, j_uniform, ncam)];
+}
+
+// The same for the pair pass, which holds TWO rows for the whole block: R and t in fp64 (projection) plus R and K' converted to T
+// ONCE and moved to scalar registers -- left to itself the compiler hoists the conversions out of the pair loop into 36 vector
+// registers of wave-uniform values, which is what pushed the kernel over its register budget.
+__device__ __forceinline__ float to_uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ double to_uniform(double x) { return x; }       // (already scalar: loaded with a uniform index)
+template <typename T>
+struct CamU {
+    double v[CT_K];          // R (9), t (3)
+    T vt[CT_SMALL];          // (T)R at 0..8, (T)K' at 12..20
+    double small;
+    __device__ __forceinline__ double operator[](int k) const { return k == CT_SMALL ? small : v[k]; }
+};
+template <typename T>
+__device__ __forceinline__ void load_cam_u(const double* __restrict__ tab, int j_uniform, int ncam, CamU<T>& c) {
+#pragma unroll
+    for (int k = 0; k < CT_K; ++k) c.v[k] = tab[cam_tab_index(k, j_uniform, ncam)];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { c.vt[k] = to_uniform((T)c.v[k]); c.vt[CT_K + k] = to_uniform((T)tab[cam_tab_index(CT_K + k, j_uniform, ncam)]); }
+    c.small = tab[cam_tab_index(CT_SMALL, j_uniform, ncam)];
+}
+// table entry k as T: converted on the spot, or taken from the pre-converted copy
+template <typename T, typename CamPtr> __device__ __forceinline__ T cam_val(const CamPtr& cam, int k) { return (T)cam[k]; }
+template <typename T> __device__ __forceinline__ T cam_val(const CamU<T>& cam, int k) { return cam.vt[k]; }
 
 template <typename T> struct ObsXY;
 template <> struct ObsXY<float>  { typedef float2 type; };
@@ -123,7 +172,7 @@ __device__ __forceinline__ void point_block(CamPtr cam, const Proj& pr, double f
     const T fz = (T)(focal * pr.iz), xp = (T)pr.xp, yp = (T)pr.yp;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const T r0 = (T)cam[CT_R + c], r1 = (T)cam[CT_R + 3 + c], r2 = (T)cam[CT_R + 6 + c];
+        const T r0 = cam_val<T>(cam, CT_R + c), r1 = cam_val<T>(cam, CT_R + 3 + c), r2 = cam_val<T>(cam, CT_R + 6 + c);
         B[c] = fz * (r0 - xp * r2);
         B[3 + c] = fz * (r1 - yp * r2);
     }
@@ -149,7 +198,7 @@ __device__ __forceinline__ void camera_block(CamPtr cam, const Proj& pr, double 
         T M[9];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const T k0 = (T)cam[CT_K + c], k1 = (T)cam[CT_K + 3 + c], k2 = (T)cam[CT_K + 6 + c];
+            const T k0 = cam_val<T>(cam, CT_K + c), k1 = cam_val<T>(cam, CT_K + 3 + c), k2 = cam_val<T>(cam, CT_K + 6 + c);
             M[c] = X1 * k2 - X2 * k1;
             M[3 + c] = X2 * k0 - X0 * k2;
             M[6 + c] = X0 * k1 - X1 * k0;
@@ -162,6 +211,28 @@ __device__ __forceinline__ void camera_block(CamPtr cam, const Proj& pr, double 
     }
     A[3] = fz;   A[4] = (T)0; A[5] = -fz * xp;
     A[9] = (T)0; A[10] = fz;  A[11] = -fz * yp;
+}
+
+// The packed record of one observation (layout: ba_kernels.hip, "Packed per-observation record") from the camera's table row, the
+// point and the point's L -- the SAME expressions, in the same order, as the record sweep of k_point_build, so that a pass which
+// re-evaluates an observation sees bit for bit what a pass reading the stored record sees.  rec[15] (camera slot) is not set.
+template <typename T, typename CamPtr>
+__device__ __forceinline__ void obs_record(CamPtr cam, double focal, const double X[3], const T L[6], T rec[YREC]) {
+    const Proj pr = project_point(cam, CT_R, CT_T, X);
+    T B[6], A[12];
+    point_block<T>(cam, pr, focal, B);
+    camera_block<T>(cam, pr, focal, X, B, A);
+    rec[0] = A[0]; rec[1] = A[1]; rec[2] = A[2]; rec[3] = A[6]; rec[4] = A[7]; rec[5] = A[8];
+    rec[6] = (T)(focal * pr.iz); rec[7] = (T)pr.xp; rec[8] = (T)pr.yp;
+    const T l00 = L[0], l10 = L[1], l11 = L[2], l20 = L[3], l21 = L[4], l22 = L[5];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {   // C = B~ L^-T
+        const T b0 = B[3 * r], b1 = B[3 * r + 1], b2 = B[3 * r + 2];
+        rec[9 + 3 * r + 0] = b0 * l00;
+        rec[9 + 3 * r + 1] = b0 * l10 + b1 * l11;
+        rec[9 + 3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
+    }
+    rec[15] = (T)0;
 }
 
 }  // namespace sfmba

@@ -55,6 +55,11 @@ __global__ void k_block_ptr(int nblock, int npair, const unsigned* __restrict__ 
     blk_ptr[b] = lo;
 }
 
+__global__ __launch_bounds__(256) void k_pair_points(int npair, const int2* __restrict__ pairs, const int* __restrict__ obs_pt, int* __restrict__ pair_pt) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npair) pair_pt[p] = obs_pt[pairs[p].x];
+}
+
 }  // namespace
 
 // d_pair_off[i] = number of pairs of the points before i (npt + 1 entries, device; build_point_major), npair their total (the caller
@@ -62,8 +67,9 @@ __global__ void k_block_ptr(int nblock, int npair, const unsigned* __restrict__ 
 // `arena`; the sort's temporaries come from `scratch`, which the caller keeps until the stream has drained: nothing here waits
 // for the device (the whole structure build is ONE enqueue, sfmba_api.hip build_structure).  Returns 0, or a hipError_t value.
 int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_arena, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
-                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr) {
+                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr, int** d_pair_pt) {
     *d_pairs = nullptr; *d_blk_ptr = nullptr;
+    if (d_pair_pt) *d_pair_pt = nullptr;
     (void)npt;
     hipError_t e;
     DeviceArena& scratch = *scratch_arena;
@@ -74,6 +80,7 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_are
     SB_ALLOC(*d_blk_ptr, arena, int, (size_t)nblock + 1);
     SB_ALLOC(d_v1, arena, unsigned long long, np);
     *d_pairs = reinterpret_cast<int2*>(d_v1);
+    if (d_pair_pt) SB_ALLOC(*d_pair_pt, arena, int, np);
     if (npair == 0) {
         SB_TRY(hipMemsetAsync(*d_blk_ptr, 0, sizeof(int) * ((size_t)nblock + 1), s));
         return 0;
@@ -93,6 +100,8 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_are
     if (!d_tmp) return (int)hipErrorOutOfMemory;
     SB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
     hipLaunchKernelGGL(k_block_ptr, dim3((nblock + 1 + 255) / 256), dim3(256), 0, s, nblock, (int)npair, d_k1, *d_blk_ptr);
+    // the point of every pair, in list order: all the re-evaluating pair pass reads per pair
+    if (d_pair_pt) hipLaunchKernelGGL(k_pair_points, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, (int)npair, *d_pairs, d_obs_pt, *d_pair_pt);
     SB_TRY(hipGetLastError());
 #undef SB_TRY
 #undef SB_ALLOC

@@ -31,6 +31,11 @@ CONFIGS = {
     "cfg3": dict(n_cam=200, n_pt=100000, views=10, seed=1003),                   # 1 000 000 obs, headline
     "cfg4": dict(n_cam=25, n_pt=12500, views=10, seed=1004),                     # one of 8 replicas (sub=g)
     "cfg5": dict(n_cam=1000, n_pt=500000, views=10, seed=1005),                  # 5 000 000 obs (10/pt assumed)
+    # realistic co-visibility (reference shape: the incremental loop SfM.cpp:366-469 -- every new view sees its
+    # neighbours): 200 cameras on a closed path around the scene, every point seen by a RUN of 2..30 NEIGHBOURING cameras
+    # (power-law track length, mean ~10 => ~1M observations) => banded reduced system with a few very heavy blocks
+    "cfg3_banded": dict(n_cam=200, n_pt=100000, views="banded", seed=1013),
+    "banded_small": dict(n_cam=40, n_pt=3000, views="banded", seed=1014),        # the same shape at a size the CPU tests afford
     "tiny": dict(n_cam=4, n_pt=40, views=(2, 4), seed=999),                      # unit-test size
     "small": dict(n_cam=8, n_pt=400, views=(2, 6), seed=998),
 }
@@ -131,6 +136,33 @@ def _choose_views(rng, n_pt, n_cam, views):
     return obs_pt, obs_cam.astype(np.int32)
 
 
+def _banded_views(rng, n_pt, n_cam, target_mean=10.0, lo=2, hi=30):
+    """Per point: a run of `m` CONSECUTIVE cameras of the (closed) camera path, m in [lo, hi] drawn from a truncated power law
+    P(m) ~ m^-a whose exponent is chosen so that the mean track length is `target_mean` (real SfM tracks: many short, few
+    long).  Returns (obs_pt, obs_cam) point-major, ascending camera inside a point."""
+    hi = min(hi, n_cam)
+    ms = np.arange(lo, hi + 1, dtype=np.float64)
+    a_lo, a_hi = -3.0, 6.0
+    for _ in range(60):                                   # bisection on the exponent (mean is monotone decreasing in a)
+        a = 0.5 * (a_lo + a_hi)
+        w = ms ** (-a)
+        mean = float((w * ms).sum() / w.sum())
+        if mean > target_mean:
+            a_lo = a
+        else:
+            a_hi = a
+    w = ms ** (-0.5 * (a_lo + a_hi))
+    m = rng.choice(ms.astype(np.int64), size=n_pt, p=w / w.sum())
+    start = rng.integers(0, n_cam, size=n_pt)
+    mmax = int(m.max())
+    cams = (start[:, None] + np.arange(mmax)[None, :]) % n_cam
+    keep = np.arange(mmax)[None, :] < m[:, None]
+    big = np.where(keep, cams, 2**30).astype(np.int64)
+    big.sort(axis=1)
+    obs_pt = np.repeat(np.arange(n_pt, dtype=np.int32), m)
+    return obs_pt, big[keep].astype(np.int32)
+
+
 def make_problem(name="cfg2", sub=None, n_cam=None, n_pt=None, views=None, seed=None,
                  noise_px=0.5, perturb=True):
     """Build one of CONFIGS (optionally overriding sizes).  `sub` selects one of the independent
@@ -143,9 +175,14 @@ def make_problem(name="cfg2", sub=None, n_cam=None, n_pt=None, views=None, seed=
     rng = np.random.default_rng([seed, int(sub)] if sub is not None else seed)
 
     pt_true = rng.uniform(-1.0, 1.0, size=(n_pt, 3))
+    banded = isinstance(views, str) and views == "banded"
 
     # camera centres on a shell, looking at the origin with jitter and random roll
     d = rng.normal(size=(n_cam, 3))
+    if banded:
+        # cameras along a closed, gently undulating path around the scene (consecutive cameras are neighbours in space too)
+        ang = 2.0 * np.pi * (np.arange(n_cam) + rng.uniform(-0.2, 0.2, size=n_cam)) / n_cam
+        d = np.stack([np.cos(ang), np.sin(ang), 0.25 * np.sin(3.0 * ang) + rng.normal(0.0, 0.03, size=n_cam)], axis=1)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     centre = d * rng.uniform(4.0, 6.0, size=(n_cam, 1))
     z = -centre / np.linalg.norm(centre, axis=1, keepdims=True)
@@ -165,7 +202,7 @@ def make_problem(name="cfg2", sub=None, n_cam=None, n_pt=None, views=None, seed=
     w_true[0] = 0.0
     cam_true = np.concatenate([w_true, t], axis=1)
 
-    obs_pt, obs_cam = _choose_views(rng, n_pt, n_cam, views)
+    obs_pt, obs_cam = _banded_views(rng, n_pt, n_cam) if banded else _choose_views(rng, n_pt, n_cam, views)
     uv, pz = project(cam_true, pt_true, F_TRUE, obs_cam, obs_pt)
     good = pz > 0.1
     if not np.all(good):                                       # never happens for this geometry; keep the rule

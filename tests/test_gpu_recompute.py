@@ -1,0 +1,71 @@
+"""Round 3: the reduced-system passes RE-EVALUATE every observation from the camera's table row and a 72-byte per-point table instead of
+gathering a 64-byte record per observation (k_cam_diag_f, k_schur_pairs<.., RECOMP>).  The re-evaluation uses the
+expressions of the point pass, pair for pair in the same lane, so the two forms must agree BIT FOR BIT wherever no atomic decides
+the order of a sum -- asserted here on the reduced system itself and, in deterministic mode, on whole solves.  A problem built with
+SFMBA_SCHUR_RECORDS=1 runs the record-gathering passes of rounds 1 / 2."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from sfm_toy_library_amd import capi as c
+    assert c.device_count() >= 1
+    return c
+
+
+def _both(monkeypatch, fn):
+    out = {}
+    for records in ("1", "0"):
+        monkeypatch.setenv("SFMBA_SCHUR_RECORDS", records)
+        out[records] = fn()
+    monkeypatch.delenv("SFMBA_SCHUR_RECORDS")
+    return out["1"], out["0"]
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("name,kw", [("cfg3", dict(n_cam=60, n_pt=20000, seed=11)),        # ~110 pairs per block... forced to the wave-per-block pass below
+                                      ("cfg3", dict(n_cam=24, n_pt=30000, views=8, seed=12)),   # ~3000 pairs per block
+                                      ("small", dict())])
+def test_reduced_system_is_bitwise_the_same(capi, sfm, monkeypatch, precision, name, kw):
+    prob = sfm.make_problem(name, **kw)
+    monkeypatch.setenv("SFMBA_PAIR_LPB", "64")                  # one wave per block (the form with a re-evaluating variant) at every density
+    monkeypatch.setenv("SFMBA_DETERMINISTIC", "1")              # the camera pass adds its chunks in a fixed order
+
+    def build():
+        with capi.Problem(prob, precision=precision) as P:
+            return P.build_reduced(1e4)
+    (S1, r1, s1), (S0, r0, s0) = _both(monkeypatch, build)
+    assert np.array_equal(s1, s0)
+    off = ~np.kron(np.eye(prob.n_cam + 1, dtype=bool), np.ones((6, 6), dtype=bool))[:S1.shape[0], :S1.shape[0]]
+    assert np.array_equal(S1[off], S0[off]), np.abs(S1 - S0).max()                      # pair pass: every off-diagonal entry, every bit
+    assert np.array_equal(S1, S0) and np.array_equal(r1, r0)                            # camera pass (deterministic chunk order)
+
+
+def test_whole_solve_is_bitwise_the_same_in_deterministic_mode(capi, sfm, monkeypatch):
+    prob = sfm.make_problem("cfg3", n_cam=40, n_pt=30000, seed=13)
+    monkeypatch.setenv("SFMBA_PAIR_LPB", "64")
+
+    def solve():
+        res = []
+        for linear in (0, 1, 2):
+            with capi.Problem(prob, precision=1, flags=sfm.CREATE_DETERMINISTIC) as P:
+                s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=1, linear_solver=linear))
+                res.append((P.get_params(), s["final_cost"], s["iterations"], [r["cost"] for r in tr]))
+        return res
+    a, b = _both(monkeypatch, solve)
+    for (pa, ca, ia, ta), (pb, cb, ib, tb) in zip(a, b):
+        assert ia == ib and ca == cb and ta == tb
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]) and pa[2] == pb[2]
+
+
+def test_recompute_form_is_the_default_and_matches_oracle(capi, sfm, oracle, monkeypatch):
+    monkeypatch.delenv("SFMBA_SCHUR_RECORDS", raising=False)
+    prob = sfm.make_problem("cfg3", n_cam=24, n_pt=30000, views=8, seed=12)
+    want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    got = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=0))
+    assert got[3]["termination_name"] == want[3]["termination_name"] == "CONVERGENCE" and got[3]["iterations"] == want[3]["iterations"]
+    assert abs(got[3]["final_cost"] - want[3]["final_cost"]) <= 1e-9 * want[3]["final_cost"]
+    assert np.abs(got[0] - want[0]).max() < 1e-8 and np.abs(got[1] - want[1]).max() < 1e-8

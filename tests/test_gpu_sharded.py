@@ -20,10 +20,16 @@ CASES = {
     # 230 cameras: reduced dimension 1381 > 1280 -> streaming CG (fp32-stored matrix in F32J mode); ~10 pairs per 6x6
     # block -> the sixteen-lane pair pass k_schur_pairs_sub; sharded ranks transform the all-reduced system (k_pcg_transform)
     "wide": (dict(name="cfg3", n_cam=230, n_pt=6000, seed=77), 1, 1, dict()),
+    # point counts that no world size of 2, 3 or 4 divides (5003 is prime, 6001 = 17 * 353): ranks hold shards of different sizes
+    "cfg2_uneven": (dict(name="cfg2", n_pt=5003), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
+    "wide_uneven": (dict(name="cfg3", n_cam=230, n_pt=6001, seed=78), 1, 1, dict()),
+    # the library default (AUTO: CG to 1e-12; d = 361 > 256) and the exact solver on an uneven split
+    "auto_uneven": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 0, 2, dict()),
+    "chol_uneven": (dict(name="cfg2", n_pt=5003), 0, 0, dict()),
 }
 
 
-def _worker(rank, world, port, case, out, native=False):
+def _worker(rank, world, port, case, out, native=False, n_repeats=12):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -42,7 +48,7 @@ def _worker(rank, world, port, case, out, native=False):
     # native loop: the same solve again and again.  Two processes on one GPU delay each other's workgroups, which is what
     # exposes a launch acting on a flag raised by its own first workgroup (the CG's early exit once did: replicas drifted apart).
     repeats = []
-    for _ in range(12 if native else 0):
+    for _ in range(n_repeats if native else 0):
         backend.reset()
         solve_sharded_native(backend, opt, dist=dist)
         repeats.append(backend.get_params()[0].copy())
@@ -149,3 +155,42 @@ def test_sharded_exchange_variants_agree(sfm, monkeypatch, linear):
         assert np.abs(got["1"][1][0] - got["0"][1][0]).max() < 2e-6
     finally:
         be.close()
+
+
+@pytest.mark.parametrize("world,case", [(2, "cfg2_uneven"), (3, "cfg2_uneven"), (4, "cfg2_uneven"), (3, "wide_uneven"), (4, "wide_uneven"),
+                                        (3, "auto_uneven"), (4, "chol_uneven")])
+def test_multi_rank_uneven_sharded_hip_solve(sfm, oracle, world, case):
+    """2, 3 and 4 ranks (processes) on the one MI355X of the box, point counts the world size does not divide
+    (shards of different sizes), native C loop with the collectives through the callback -- against the ORACLE's solve of the whole
+    problem; replicas must stay bit-identical."""
+    from sfm_toy_library_amd import capi
+    kw, precision, linear, okw = CASES[case]
+    port = 29311 + (os.getpid() % 300) + 7 * world
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, True, 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([out.get(timeout=420) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prob = sfm.make_problem(**kw)
+    assert prob.n_pt % world != 0
+    ranges = [r[5] for r in results]
+    assert ranges[0][0] == 0 and ranges[-1][1] == prob.n_pt and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    assert len({hi - lo for lo, hi in ranges}) > 1                       # genuinely uneven
+    cam0, f0, s0 = results[0][2], results[0][4], results[0][1]
+    for r in results[1:]:
+        assert np.array_equal(r[2], cam0) and r[4] == f0 and r[1]["final_cost"] == s0["final_cost"]     # replicas bit-identical
+        for a, b in zip(results[0][6], r[6]):
+            assert np.array_equal(a, b)
+    pts = np.vstack([r[3] for r in results])
+    cam_o, pt_o, f_o, s_o, _ = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    exact = precision == 0
+    assert s0["termination_name"] == s_o["termination_name"] == "CONVERGENCE" and s0["iterations"] == s_o["iterations"]
+    assert abs(s0["final_cost"] - s_o["final_cost"]) <= (1e-9 if exact else 1e-6) * s_o["final_cost"]
+    assert abs(np.sqrt(2 * s0["final_cost"] / prob.n_obs) - np.sqrt(2 * s_o["final_cost"] / prob.n_obs)) < 1e-4
+    atol = 1e-7 if exact else 5e-6
+    assert np.abs(cam0 - cam_o).max() <= atol and np.isclose(f0, f_o, rtol=1e-9 if exact else 1e-7)
+    assert np.abs(pts - pt_o).max() <= atol
