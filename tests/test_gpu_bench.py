@@ -30,7 +30,7 @@ def test_bench_line_has_the_contract_keys():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1
+    assert r["bound"] in ("hbm", "mfma", "l2_mall_latency") and 0 < r["frac"] < 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
