@@ -4,9 +4,10 @@
 #include <vector>
 #include <stdint.h>
 
-// observations of one camera handled by one workgroup of k_cam_diag (one lane each); the host cuts the camera-major list accordingly
+// observations of one camera handled by one workgroup of k_cam_diag (256 threads, SFMBA_CAM_CHUNK / 256 observations per lane); the host
+// cuts the camera-major list accordingly
 #ifndef SFMBA_CAM_CHUNK
-#define SFMBA_CAM_CHUNK 256
+#define SFMBA_CAM_CHUNK 1024
 #endif
 
 // 6x6 blocks (one wave each) handled by one workgroup of k_schur_pairs; the host groups consecutive blocks of a block row

@@ -21,10 +21,6 @@ namespace sfmba {
 
 #define BLK 256
 
-// address-space-qualified pointers of the global -> LDS DMA builtin
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
@@ -794,15 +790,11 @@ __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, con
 // in scalar registers; per pair a lane loads ONE point-table entry (48 bytes in fp32 mode, from a table that stays in L2) and
 // re-evaluates both observations with the expressions of the point pass (obs_record): the same values, pair for pair and in the
 // same lane, as the record-gathering form -- minus the two random 64-byte gathers per pair from the 64 MB of records.
-// RECOMP = 0: gathering form; 3 / 4: re-evaluating form compiled for that many waves per SIMD (register budget 512 / RECOMP: 3 fits
-// without scratch, 4 spills ~40 registers per lane; SFMBA_PAIR_RC_WAVES picks at launch, default below)
+// RECOMP = 0: gathering form; 3: re-evaluating form, compiled for three waves per SIMD (162 registers; at four it spills ~40 of them
+// and runs 2.3x slower: measured 163 vs 71 us at BASELINE config 3)
 template <typename T, int MODE, int RECOMP>
 __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? RECOMP : 4) : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
-    // re-evaluating form: DMA landing area (two buffers x two rounds x NP pieces x 64 lanes x 16 bytes) and the epilogue constants
-    __shared__ __align__(16) char rc_stage[SFMBA_PAIR_WAVES][RECOMP ? 4 * (sizeof(PtRecA<T>) / 16) * 1024 : 16];
-    __shared__ __align__(16) double rc_const[SFMBA_PAIR_WAVES][RECOMP ? 84 : 2];
-    __shared__ T rc_camt[SFMBA_PAIR_WAVES][2][RECOMP ? CT_SMALL : 1];          // R and K' of the block's two cameras as T
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int b, pbeg, pend;
     int2 cj;
@@ -864,104 +856,37 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? 
     double total = 0.0;            // this lane's entry of the 6x6 block (lanes that own one), over the flushes so far
     int base = 0, len = 36, rounds = 0;
     if (RECOMP) {
-        // ---- the re-evaluating form.  A wave's life is a chain of dependent memory levels (each ~1 us on the loaded chip) around a few
-        // hundred instructions per round, so everything is asked for as early as it can be and parked in LDS by the DMA path
-        // (global_load_lds: no vector registers while in flight):
-        //   * what the epilogue needs (Jacobi scales of both cameras, Linv of both blocks) right away;
-        //   * the point-table entries of TWO rounds per buffer, two buffers: a block of up to four rounds (all of BASELINE config 3)
-        //     has all of its entries in flight before the first one is used; longer blocks refill a buffer while the other is worked on.
-        constexpr int NP = (int)(sizeof(PtRecA<T>) / 16);
         const LMState* st = db.st;
         const int cur = st->cur;
         const double focal = st->focal[cur];
-        const int ja = __builtin_amdgcn_readfirstlane(cj.x), jb = __builtin_amdgcn_readfirstlane(cj.y);
-        char* const my_stage = &rc_stage[w][0];
-        double* const my_const = &rc_const[w][0];                    // [0..36) Linv_a  [36..72) Linv_b  [72..78) s_a  [78..84) s_b
-        if (MODE == 1) {
-            if (lane < 18) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(db.pcg_binv + (size_t)ja * 36 + 2 * lane), (lptr_t)(my_const), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(db.pcg_binv + (size_t)jb * 36 + 2 * lane), (lptr_t)(my_const + 36), 16, 0, 0);
-            }
-        }
-        if (lane < 3) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(db.cscale + 6 * ja + 2 * lane), (lptr_t)(my_const + 72), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(db.cscale + 6 * jb + 2 * lane), (lptr_t)(my_const + 78), 16, 0, 0);
-        }
+        CamU<T> ca, cb;
+        load_cam_u<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.x), ds.ncam, ca);
+        load_cam_u<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.y), ds.ncam, cb);
         const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
         // lane (s, g) owns pair p0 + 16 s + g of a round -- the pair the DPP transpose of the gathering form hands it -- so the
-        // lane-local sums (and every bit of the block) come out the same in both forms
+        // lane-local sums (and every bit of the block) come out the same in both forms.  The point index of the NEXT round's pair
+        // is fetched one round ahead (one dependent memory level per round: the point-table entry).
         const int mine = 16 * s + g;
-        const int nrounds = (p1 - pbeg + 63) >> 6, niter = (nrounds + 1) >> 1;
-        auto pair_point = [&](int round) { const int p = pbeg + 64 * round + mine; return ds.pair_pt[p < p1 ? p : p1 - 1]; };
-        auto issue = [&](int buf, int pt0, int pt1) {       // the entries of two rounds -> buffer `buf`, NP pieces of 16 bytes per lane each
+        int pt_next = ds.pair_pt[pbeg < p1 ? (pbeg + mine < p1 ? pbeg + mine : p1 - 1) : 0];
+        for (int p0 = pbeg; p0 < p1; p0 += 64) {
+            const PtRecA<T> pa = PA[pt_next];
+            { const int p = p0 + 64 + mine; pt_next = ds.pair_pt[p < p1 ? p : p1 - 1]; }
+            T ra[YREC], rb[YREC];
+            obs_record<T>(ca, focal, pa.X, pa.L, ra);
+            obs_record<T>(cb, focal, pa.X, pa.L, rb);
+            if (p0 + mine >= p1) {              // this lane's pair lies beyond the block: contribute nothing
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const char* src = reinterpret_cast<const char*>(PA + (r == 0 ? pt0 : pt1));
-#pragma unroll
-                for (int k = 0; k < NP; ++k)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src + 16 * k), (lptr_t)(my_stage + ((buf * 2 + r) * NP + k) * 1024), 16, 0, 0);
+                for (int e = 9; e < 15; ++e) ra[e] = (T)0;
             }
-        };
-        if (pbeg < p1) {
-            int q0 = pair_point(0), q1 = pair_point(1), q2 = 0, q3 = 0, qn0 = 0, qn1 = 0;
-            if (niter > 1) { q2 = pair_point(2); q3 = pair_point(3); }
-            if (niter > 2) { qn0 = pair_point(4); qn1 = pair_point(5); }
-            issue(0, q0, q1);
-            if (niter > 1) issue(1, q2, q3);
-            CamU<T> ca, cb;
-            load_cam_u<T>(db.camtab[cur], ja, ds.ncam, &rc_camt[w][0][0], lane, ca);
-            load_cam_u<T>(db.camtab[cur], jb, ds.ncam, &rc_camt[w][1][0], lane, cb);
-            wave_lds_fence();
-            // (segments of PAIR_FLUSH rounds: the fp32 lane-local sums are folded into the fp64 total between them, OUTSIDE the round
-            // loop -- inside it the reduction's temporaries cost the whole loop ~10 registers, i.e. the third wave per SIMD)
-            for (int seg0 = 0; seg0 < niter; seg0 += PAIR_FLUSH / 2) {
-            const int seg1 = seg0 + PAIR_FLUSH / 2 < niter ? seg0 + PAIR_FLUSH / 2 : niter;
-            for (int it = seg0; it < seg1; ++it) {
-                const int buf = it & 1;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // everything asked for so far has landed (LDS writes of the DMA path included)
-#pragma unroll 1
-                for (int r = 0; r < 2; ++r) {
-                    const int p0 = pbeg + 64 * (2 * it + r);
-                    PtRecA<T> pa;
-                    {
-                        float4* dst = reinterpret_cast<float4*>(&pa);
-#pragma unroll
-                        for (int k = 0; k < NP; ++k) dst[k] = *reinterpret_cast<const float4*>(my_stage + ((buf * 2 + r) * NP + k) * 1024 + 16 * lane);
-                    }
-                    if (r == 1) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // both rounds of the buffer have been read: it may be refilled
-                        if (it + 2 < niter) {
-                            issue(buf, qn0, qn1);
-                            if (it + 3 < niter) { qn0 = pair_point(2 * it + 6); qn1 = pair_point(2 * it + 7); }
-                        }
-                    }
-                    if (p0 < p1) {                                         // (uniform: the block's last iteration may hold one round only)
-                        // the two evaluations one after the other, not interleaved: interleaving them is what the scheduler does by itself,
-                        // and it costs ~40 live registers (the kernel then no longer fits its budget)
-                        T ra[YREC], rb[YREC];
-                        obs_record<T>(ca, focal, pa.X, pa.L, ra);
-                        __builtin_amdgcn_sched_barrier(0);
-                        obs_record<T>(cb, focal, pa.X, pa.L, rb);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (p0 + mine >= p1) {              // this lane's pair lies beyond the block: contribute nothing
-#pragma unroll
-                            for (int e = 9; e < 15; ++e) ra[e] = (T)0;
-                        }
-                        pair_product<T>(ra, rb, false, acc);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            if (sizeof(T) == 4 && __builtin_expect(seg1 < niter, 0)) {
-                base = 0; len = 36;
+            pair_product<T>(ra, rb, false, acc);
+            if (sizeof(T) == 4 && ++rounds == PAIR_FLUSH && p0 + 64 < p1) {
+                rounds = 0; base = 0; len = 36;
                 HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
                 total += len >= 1 ? (double)acc[0] : 0.0;
 #pragma unroll
                 for (int e = 0; e < 36; ++e) acc[e] = (T)0;
             }
-            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (empty block: the epilogue constants)
     } else {
     // A quad LOADS four pairs cooperatively (each 64-byte record is one request of four adjacent lanes: the vector-memory
     // pipe walks lines, not bytes) and then transposes them with DPP so that every lane COMPUTES one pair on its own:
@@ -1008,8 +933,7 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? 
     total += len >= 1 ? (double)acc[0] : 0.0;
     const bool owner = len >= 1;
     const int er = owner ? base / 6 : 0, ec = owner ? base - 6 * (base / 6) : 0;
-    const double entry = !owner ? 0.0 : RECOMP ? -total * rc_const[w][72 + er] * rc_const[w][78 + ec]
-                                               : -total * db.cscale[6 * cj.x + er] * db.cscale[6 * cj.y + ec];
+    const double entry = owner ? -total * db.cscale[6 * cj.x + er] * db.cscale[6 * cj.y + ec] : 0.0;
     if (MODE == 0 || MODE == 2) {
         if (owner) {
             double* dst = db.S + (size_t)(6 * cj.x + er) * ds.ld + 6 * cj.y + ec;
@@ -1021,8 +945,8 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? 
         wave_lds_fence();
         if (lane < 36) {
             const int r = lane / 6, c = lane - 6 * r;
-            const double* Li = RECOMP ? &rc_const[w][r * 6] : db.pcg_binv + (size_t)cj.x * 36 + r * 6;            // row r of Linv_I (lower triangular)
-            const double* Lj = RECOMP ? &rc_const[w][36 + c * 6] : db.pcg_binv + (size_t)cj.y * 36 + c * 6;       // row c of Linv_J
+            const double* Li = db.pcg_binv + (size_t)cj.x * 36 + r * 6;     // row r of Linv_I (lower triangular)
+            const double* Lj = db.pcg_binv + (size_t)cj.y * 36 + c * 6;     // row c of Linv_J
             double v = 0.0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -1181,7 +1105,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
 //   S_jj += A~^T (I - C C^T) A~   (U_jj minus the self term Y_a Y_a^T), undamped diagonal, S_jf, b_c, rhs
 // ------------------------------------------------------------------------------------------
 #define CD_N 48      // Sjj(21) udiag(6) Sjf(6) bc(6) rhs(6) uff bf + pad
-#define CD_BLK SFMBA_CAM_CHUNK
+#define CD_BLK 256   // threads of a workgroup; a lane takes SFMBA_CAM_CHUNK / CD_BLK observations of the chunk, one after the other
+#define CD_OBS (SFMBA_CAM_CHUNK / CD_BLK)
+static_assert(SFMBA_CAM_CHUNK % CD_BLK == 0, "camera chunk length");
 
 // the 47 terms one observation contributes to its camera's diagonal block, focal column, gradient and right-hand side, from its packed
 // record and side values z = {C t (2), C y_f (2), residual (2)} -- shared by the record-gathering and the re-evaluating camera pass
@@ -1204,18 +1130,18 @@ __device__ __forceinline__ void cam_diag_terms(const T (&rec)[YREC], const T (&z
         for (int a = 0; a < 6; ++a) {
             const T p0 = n00 * A[a] + n01 * A[6 + a], p1 = n01 * A[a] + n11 * A[6 + a];
 #pragma unroll
-            for (int b = a; b < 6; ++b) v[u++] = p0 * A[b] + p1 * A[6 + b];
+            for (int b = a; b < 6; ++b) v[u++] += p0 * A[b] + p1 * A[6 + b];
         }
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             const T ar = A[a] * r0 + A[6 + a] * r1;
-            v[21 + a] = A[a] * A[a] + A[6 + a] * A[6 + a];                               // undamped diagonal
-            v[27 + a] = (A[a] * g0 + A[6 + a] * g1) - (A[a] * cy0 + A[6 + a] * cy1);     // S[j,f]
-            v[33 + a] = ar;                                                              // b_c (scaled gradient)
-            v[39 + a] = ar - (A[a] * ct0 + A[6 + a] * ct1);                              // reduced rhs
+            v[21 + a] += A[a] * A[a] + A[6 + a] * A[6 + a];                               // undamped diagonal
+            v[27 + a] += (A[a] * g0 + A[6 + a] * g1) - (A[a] * cy0 + A[6 + a] * cy1);     // S[j,f]
+            v[33 + a] += ar;                                                              // b_c (scaled gradient)
+            v[39 + a] += ar - (A[a] * ct0 + A[6 + a] * ct1);                              // reduced rhs
         }
-        v[45] = g0 * g0 + g1 * g1;
-        v[46] = g0 * r0 + g1 * r1;
+        v[45] += g0 * g0 + g1 * g1;
+        v[46] += g0 * r0 + g1 * r1;
 }
 
 // sums of the 47 terms over the workgroup (fp64: halving butterfly inside the wave, LDS across the waves) and one atomic per value
@@ -1275,12 +1201,13 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
     const LMState* st = db.st;
     const T fscale = (T)st->fscale;
     const T* Y = reinterpret_cast<const T*>(db.Y);
-    const int e = ch.y + threadIdx.x;
-
     T v[CD_N];
 #pragma unroll
     for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
-    if (e < ch.z) {
+    // CD_OBS observations per lane, summed in the lane (T) before the ONE reduction of the workgroup: with one observation per lane
+    // the reduction (halving butterfly, LDS, atomics) was more than half of the pass's instructions, and the pass is instruction-bound
+#pragma unroll 1
+    for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {
         const int q = ds.cam_obs[e];
         T rec[YREC];
         load_rec<T>(Y, q, rec);
@@ -1314,11 +1241,11 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
     const T fscale = (T)st->fscale;
     CamRegs ct;
     load_cam_regs(db.camtab[cur], j, ds.ncam, ct);
-    const int e = ch.y + threadIdx.x;
     T v[CD_N];
 #pragma unroll
     for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
-    if (e < ch.z) {
+#pragma unroll 1
+    for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {      // (see k_cam_diag)
         const int q = ds.cam_obs[e], i = ds.cam_obs_pt[e];
         const PtRecA<T> pa = reinterpret_cast<const PtRecA<T>*>(db.PA)[i];
         const PtRecB<T> pb = reinterpret_cast<const PtRecB<T>*>(db.PB)[i];
@@ -1355,7 +1282,6 @@ bool schur_recompute_applies(const DeviceStructure& ds, const DeviceBuffers& db,
 template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
     const bool rc = schur_recompute_applies(ds, db, mode);
-    static const int rc_waves = [] { const char* e = std::getenv("SFMBA_PAIR_RC_WAVES"); return e && std::atoi(e) == 4 ? 4 : 3; }();
     const dim3 grid(ds.npairwg), block(64 * SFMBA_PAIR_WAVES);
     if (mode == 2) {
         if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2, 0>), dim3(ds.ndupwg), block, 0, s, ds, db);
@@ -1363,12 +1289,10 @@ void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBu
         if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs_sub<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
     } else if (mode == 1) {
-        if (rc && rc_waves == 4) hipLaunchKernelGGL((k_schur_pairs<T, 1, 4>), grid, block, 0, s, ds, db);
-        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 1, 3>), grid, block, 0, s, ds, db);
+        if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 1, 3>), grid, block, 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs<T, 1, 0>), grid, block, 0, s, ds, db);
     } else {
-        if (rc && rc_waves == 4) hipLaunchKernelGGL((k_schur_pairs<T, 0, 4>), grid, block, 0, s, ds, db);
-        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 0, 3>), grid, block, 0, s, ds, db);
+        if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 0, 3>), grid, block, 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs<T, 0, 0>), grid, block, 0, s, ds, db);
     }
 }

@@ -78,22 +78,21 @@ __device__ __forceinline__ void load_cam_regs(const double* __restrict__ tab, in
 // The same for the pair pass, which holds TWO rows for the whole block: R and t in fp64 (projection) plus R and K' converted to T
 // ONCE and moved to scalar registers -- left to itself the compiler hoists the conversions out of the pair loop into 36 vector
 // registers of wave-uniform values, which is what pushed the kernel over its register budget.
+__device__ __forceinline__ float to_uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ double to_uniform(double x) { return x; }       // (already scalar: loaded with a uniform index)
 template <typename T>
 struct CamU {
-    double v[CT_K];          // R (9), t (3): scalar registers (every fp64 FMA of the projection takes one of them as its constant operand)
-    const T* vt;             // LDS: (T)R at 0..8, (T)K' at 12..20 -- read where used (a VALU instruction takes ONE scalar operand, so keeping
-                             // these 18 values per camera in scalar registers makes the compiler copy them into vector registers for good)
+    double v[CT_K];          // R (9), t (3)
+    T vt[CT_SMALL];          // (T)R at 0..8, (T)K' at 12..20
     double small;
     __device__ __forceinline__ double operator[](int k) const { return k == CT_SMALL ? small : v[k]; }
 };
-// `lds_t`: CT_SMALL values of T in LDS owned by the calling wave; filled here by lanes 0..17 (the caller fences before the first use)
 template <typename T>
-__device__ __forceinline__ void load_cam_u(const double* __restrict__ tab, int j_uniform, int ncam, T* lds_t, int lane, CamU<T>& c) {
+__device__ __forceinline__ void load_cam_u(const double* __restrict__ tab, int j_uniform, int ncam, CamU<T>& c) {
 #pragma unroll
     for (int k = 0; k < CT_K; ++k) c.v[k] = tab[cam_tab_index(k, j_uniform, ncam)];
-    if (lane < 9) lds_t[lane] = (T)tab[cam_tab_index(lane, j_uniform, ncam)];
-    else if (lane < 18) lds_t[CT_K + lane - 9] = (T)tab[cam_tab_index(CT_K + lane - 9, j_uniform, ncam)];
-    c.vt = lds_t;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { c.vt[k] = to_uniform((T)c.v[k]); c.vt[CT_K + k] = to_uniform((T)tab[cam_tab_index(CT_K + k, j_uniform, ncam)]); }
     c.small = tab[cam_tab_index(CT_SMALL, j_uniform, ncam)];
 }
 // table entry k as T: converted on the spot, or taken from the pre-converted copy
