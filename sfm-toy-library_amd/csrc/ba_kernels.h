@@ -5,9 +5,11 @@
 #include <stdint.h>
 
 // observations of one camera handled by one workgroup of k_cam_diag (256 threads, SFMBA_CAM_CHUNK / 256 observations per lane); the host
-// cuts the camera-major list accordingly
+// cuts the camera-major list accordingly.  One per lane: with four (1024-entry chunks, one reduction per four observations) the pass
+// ran 46 instead of 40 us at BASELINE config 3 -- it is bound by its dependent loads and the number of waves in flight, not by the
+// reduction's instructions
 #ifndef SFMBA_CAM_CHUNK
-#define SFMBA_CAM_CHUNK 1024
+#define SFMBA_CAM_CHUNK 256
 #endif
 
 // 6x6 blocks (one wave each) handled by one workgroup of k_schur_pairs; the host groups consecutive blocks of a block row
@@ -78,6 +80,7 @@ struct DeviceStructure {
     const int* cam_ptr;       // [ncam+1] camera-major CSR
     const int* cam_obs;       // [nobs] point-major position q of each camera-major entry
     const int* cam_obs_pt;    // [nobs] point slot of that entry
+    const void* cam_obs_xy;   // [nobs] float2 / double2: the observation coordinates in camera-major order (re-evaluating camera pass)
     const int* obs_pt;        // [nobs] point slot, point-major order
     int nchunk;
     const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), 0}: SFMBA_CAM_CHUNK entries each (k_cam_diag)
@@ -115,7 +118,6 @@ struct DeviceBuffers {
     void* Z;                  // [nobs][8] float or double: C t, C y_f, residual (side record of the record-gathering camera pass); null = not wanted
     void* PA;                 // [npt] PtRecA<T>: X, L^-1 diag(s_p) -- the per-point table of the re-evaluating passes (sfmba_device.h); null = not wanted
     void* PB;                 // [npt] PtRecB<T>: t = L^-1 b_p, y_f = L^-1 E_f
-    void* res;                // [nobs] float2 / double2: the residual of every observation at the linearisation point (point-major order)
     double* pt_t;             // [npt][3] L^-1 b_p
     double* pt_yf;            // [npt][3] L^-1 E_f
     double* pt_M;             // [npt][6] diag(s_p) L^-T (upper triangle, row-major): dX = M z maps the reduced point right-hand side to the unscaled step
@@ -216,6 +218,7 @@ int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, in
                      const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr, int** d_pair_pt = nullptr);
 int build_camera_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
                        int** d_cam_obs, int** d_cam_obs_pt, int** d_cam_ptr);
+int build_camera_major_xy(hipStream_t s, DeviceArena* arena, int nobs, int xy_bytes, const int* d_cam_obs, const void* d_obs_xy, void** d_cam_obs_xy);
 // unsorted observation arrays of a build: the old ones (device) followed by the new ones (one uploaded buffer)
 struct StageObs {
     int n_old = 0, n_new = 0;

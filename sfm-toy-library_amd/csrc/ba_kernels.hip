@@ -623,10 +623,6 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
             z[2] = rec[9] * ty[3] + rec[10] * ty[4] + rec[11] * ty[5];
             z[3] = rec[12] * ty[3] + rec[13] * ty[4] + rec[14] * ty[5];
             z[4] = rk0; z[5] = rk1; z[6] = (T)0; z[7] = (T)0;
-            if (db.res) {       // the residual alone: 8 bytes instead of the 32-byte side record (the rest is re-evaluated from the point table)
-                typename ObsXY<T>::type rr; rr.x = z[4]; rr.y = z[5];
-                reinterpret_cast<typename ObsXY<T>::type*>(db.res)[q] = rr;
-            }
             if (db.Z) {
             T* zd = reinterpret_cast<T*>(db.Z) + (size_t)q * 8;
             if (sizeof(T) == 4) {
@@ -1204,8 +1200,7 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
     T v[CD_N];
 #pragma unroll
     for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
-    // CD_OBS observations per lane, summed in the lane (T) before the ONE reduction of the workgroup: with one observation per lane
-    // the reduction (halving butterfly, LDS, atomics) was more than half of the pass's instructions, and the pass is instruction-bound
+    // (SFMBA_CAM_CHUNK / CD_BLK observations per lane, summed in the lane before the one reduction of the workgroup; 1 by default)
 #pragma unroll 1
     for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {
         const int q = ds.cam_obs[e];
@@ -1228,8 +1223,8 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
 }
 
 // The same pass WITHOUT the per-observation records: the camera's table row sits in scalar registers (one camera per workgroup), a lane
-// gathers its observation's point-table entries (72 bytes from a table that stays in L2) and the stored residual (8 bytes), and
-// re-evaluates the record with the expressions of the point pass (obs_record): bit for bit the values k_cam_diag reads.
+// gathers its observation's point-table entries (72 bytes from a table that stays in L2), reads the observation's coordinates from
+// the camera-major copy (coalesced), and re-evaluates record and residual with the expressions of the point pass (obs_record).
 template <typename T>
 __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double red[CD_BLK / 64][CD_N];
@@ -1246,12 +1241,16 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
     for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
 #pragma unroll 1
     for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {      // (see k_cam_diag)
-        const int q = ds.cam_obs[e], i = ds.cam_obs_pt[e];
+        // two coalesced streams (point slot, observation coordinates in camera-major order) and two gathers from the L2-resident point table
+        const int i = ds.cam_obs_pt[e];
+        const typename ObsXY<T>::type oxy = reinterpret_cast<const typename ObsXY<T>::type*>(ds.cam_obs_xy)[e];
         const PtRecA<T> pa = reinterpret_cast<const PtRecA<T>*>(db.PA)[i];
         const PtRecB<T> pb = reinterpret_cast<const PtRecB<T>*>(db.PB)[i];
-        const typename ObsXY<T>::type rr = reinterpret_cast<const typename ObsXY<T>::type*>(db.res)[q];
         T rec[YREC], z[8];
         obs_record<T>(ct, focal, pa.X, pa.L, rec);
+        // the residual as the point pass forms it: fp64 projection, fp64 subtraction, then rounded to T
+        typename ObsXY<T>::type rr;
+        { const Proj pr = project_point(ct, CT_R, CT_T, pa.X); rr.x = (T)(focal * pr.xp - (double)oxy.x); rr.y = (T)(focal * pr.yp - (double)oxy.y); }
         // side values exactly as the record sweep of k_point_build forms them: C t, C y_f, residual
         z[0] = rec[9] * pb.t[0] + rec[10] * pb.t[1] + rec[11] * pb.t[2];
         z[1] = rec[12] * pb.t[0] + rec[13] * pb.t[1] + rec[14] * pb.t[2];
@@ -1301,7 +1300,7 @@ template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, co
 
 template <typename T>
 void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    if (db.PA && db.res) hipLaunchKernelGGL(k_cam_diag_f<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
+    if (db.PA && ds.cam_obs_xy) hipLaunchKernelGGL(k_cam_diag_f<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
     else hipLaunchKernelGGL(k_cam_diag<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
 }
 template void launch_cam_diag<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);

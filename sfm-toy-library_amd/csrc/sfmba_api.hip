@@ -217,6 +217,7 @@ struct sfmba_problem {
                                             // (or by flush_reset() if anything else looks at the problem first)
     int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pair_pt = nullptr;
+    void* d_cam_obs_xy = nullptr;
     int* d_pwg_ptr = nullptr;
     double* d_facc = nullptr;
     double *d_cam0 = nullptr, *d_pts0 = nullptr;  // parameters given at create time
@@ -855,6 +856,12 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         const int crc = build_camera_major(p->stream, &p->arena, &staging, nobs, ncam, p->d_obs_cam, p->d_obs_pt, &p->d_cam_obs, &p->d_cam_obs_pt, &p->d_cam_ptr);
         if (crc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("camera-major build: ") + hipGetErrorString((hipError_t)crc)); }
     }
+    {
+        void* cxy = nullptr;
+        const int xrc = build_camera_major_xy(p->stream, &p->arena, nobs, xy_bytes, p->d_cam_obs, p->d_obs_xy, &cxy);
+        if (xrc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("camera-major coordinates: ") + hipGetErrorString((hipError_t)xrc)); }
+        p->d_cam_obs_xy = cxy;
+    }
     bt_mark("enqueue sorts");
     {
         // ---- parameters (on this thread: the helper has the longer half).  Slot order = order of first observation; when every
@@ -902,7 +909,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.d = 6 * ncam + 1;
     ds.ld = dense_padded_dim(ds.d);
     ds.pt_ptr = p->d_pt_ptr; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
-    ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt;
+    ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt; ds.cam_obs_xy = p->d_cam_obs_xy;
     ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
     ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
     ds.obs_pt = p->d_obs_pt;
@@ -926,7 +933,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.Y = p->arena.alloc(ybytes);
     if (!db.Y) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
     // The reduced-system passes re-evaluate every observation from the camera row and a per-point table (PA / PB, 72 bytes per point)
-    // plus the stored residual (8 bytes per observation) -- no 32-byte side record, and the 64-byte records are only read by the
+    // plus a camera-major copy of the observation coordinates -- no 32-byte side record, and the 64-byte records are only read by the
     // back-substitution.  SFMBA_SCHUR_RECORDS=1 at build time keeps the record-gathering passes of rounds 1 / 2 instead (A/B).
     { const char* e = std::getenv("SFMBA_SCHUR_RECORDS");
       if (e && e[0] == '1') {
@@ -935,8 +942,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
       } else {
           db.PA = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecA<float>) : sizeof(PtRecA<double>)));
           db.PB = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecB<float>) : sizeof(PtRecB<double>)));
-          db.res = p->arena.alloc((size_t)std::max(nobs, 1) * (f32 ? sizeof(float2) : sizeof(double2)));
-          if (!db.PA || !db.PB || !db.res) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+          if (!db.PA || !db.PB) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
       } }
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
@@ -1066,7 +1072,6 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
     if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     if (p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "a sharded problem cannot grow in place");
-    p->reset_pending = false;           // the parameters are replaced by the caller's below
     if (n_cam < p->n_cam_full || n_pt < p->n_pt_full || n_obs_new < 0 || p->n_obs + n_obs_new >= (int64_t)1 << 31)
         return fail(SFMBA_ERR_INVALID_ARG, "bad sizes: cameras and points can only be added at the end");
     if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs_new > 0 && (!obs_cam || !obs_pt || !obs_xy)))
@@ -1081,6 +1086,8 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
         __builtin_prefetch(&p->pt_slot[(size_t)obs_pt[k]], 1);
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
+    // (argument errors are behind us: from here on the problem is being replaced)
+    p->reset_pending = false;           // the parameters are replaced by the caller's below
     // cameras / points that become observed get the next free slot (slot order = order of first observation)
     p->h_pt_cnt.reserve((size_t)n_pt);
     for (int64_t k = 0; k < n_obs_new; ++k) {

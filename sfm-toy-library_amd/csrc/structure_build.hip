@@ -205,6 +205,24 @@ __global__ void k_gather_pt(int n, const int* __restrict__ cam_obs, const int* _
 }
 }  // namespace
 
+namespace {
+template <typename XY>
+__global__ __launch_bounds__(256) void k_gather_xy(int n, const int* __restrict__ cam_obs, const XY* __restrict__ obs_xy, XY* __restrict__ cam_obs_xy) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) cam_obs_xy[e] = obs_xy[cam_obs[e]];
+}
+}  // namespace
+// The observation coordinates once more in camera-major order (static: built with the structure): the re-evaluating camera pass reads
+// them coalesced and forms the residual itself instead of gathering a stored one by point-major position.
+int build_camera_major_xy(hipStream_t s, DeviceArena* arena, int nobs, int xy_bytes, const int* d_cam_obs, const void* d_obs_xy, void** d_cam_obs_xy) {
+    *d_cam_obs_xy = arena->alloc((size_t)xy_bytes * (nobs ? nobs : 1));
+    if (!*d_cam_obs_xy) return (int)hipErrorOutOfMemory;
+    if (nobs == 0) return 0;
+    if (xy_bytes == 8) hipLaunchKernelGGL(k_gather_xy<float2>, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, d_cam_obs, static_cast<const float2*>(d_obs_xy), static_cast<float2*>(*d_cam_obs_xy));
+    else hipLaunchKernelGGL(k_gather_xy<double2>, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, d_cam_obs, static_cast<const double2*>(d_obs_xy), static_cast<double2*>(*d_cam_obs_xy));
+    return (int)hipGetLastError();
+}
+
 // Camera-major index of the observations on the device: cam_obs[e] = point-major position q, grouped by camera with a stable
 // radix sort (ascending q, i.e. ascending point, inside a camera -- the order the host loop produced), cam_obs_pt[e] = its point.
 int build_camera_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_arena, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,

@@ -71,7 +71,7 @@ def test_whole_solve_agrees_in_deterministic_mode(capi, sfm, monkeypatch):
     (p1, c1, t1), (p0, c0, t0) = _both(monkeypatch, solve64)
     assert c1 == c0 and t1 == t0 and np.array_equal(p1[0], p0[0]) and np.array_equal(p1[1], p0[1]) and p1[2] == p0[2]
     for (pa, ca, ia, ta), (pb, cb, ib, tb) in zip(a, b):
-        assert ia == ib and abs(ca - cb) <= 1e-9 * cb and np.allclose(ta, tb, rtol=1e-6)
+        assert ia == ib and abs(ca - cb) <= 1e-8 * cb and np.allclose(ta, tb, rtol=5e-5)      # (intermediate iterates: as in the F32J parity tests)
         assert np.abs(pa[0] - pb[0]).max() < 2e-6 and np.abs(pa[1] - pb[1]).max() < 2e-6 and abs(pa[2] - pb[2]) < 1e-3
 
 
