@@ -410,8 +410,9 @@ def pmc_traffic(kernel):
 LIMITERS = {
     "pcg_iter": "L2 / Infinity-Cache latency + the dependent-launch boundary (one launch per CG iteration; the 11.5 MB matrix never leaves the "
                 "256 MiB Infinity Cache, so FETCH_SIZE counts cache hits): not an HBM-bandwidth-bound kernel",
-    "schur_pairs": "random 64-byte record gathers from L2 / MALL (measured ceiling ~80 G lines/s) + VALU",
-    "cam_diag": "L2 misses on the camera-major record gather (latency)",
+    "schur_pairs": "VALU issue: ~33 M wave instructions per launch at 4-5 cycles each = ~72 % of the SIMD time (rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU, "
+                   "tools/micro/pk_bench.hip); the gathers of rounds 1 / 2 are gone (re-evaluation from an L2-resident point table) and the time did not move",
+    "cam_diag": "dependent loads x waves in flight (40 % VALU-busy): index -> point-table gather -> ~700 instructions -> butterfly -> 47 atomics per workgroup",
     "point_build": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
     "point_update": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
     "chol_panel": "the serial chain of 64 pivots in the diagonal tile (one workgroup: ~250 cycles per pivot) + one launch boundary per block column",
@@ -492,19 +493,21 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
     nb = 64
     nblk = (d + 1 + nb - 1) // nb
     b_res = n_obs * (8 + 2 * t) + 24 * n_pt + 48 * n_cam          # one residual evaluation (B_res)
+    pa = 48 if t == 4 else 80          # PtRecA / PtRecB of the per-point table (sfmba_device.h)
+    pb = 24 if t == 4 else 48
     return {
         "point_build": {"bound": "hbm", "bytes": b_res,
-                        "moved": n_obs * (4 + 2 * t) + n_obs * (yrec + yrec // 2) + n_pt * (24 + 24 + 48 + 4),
-                        "note": "algorithmic: one pass over observations, points and cameras (B_res); moved: + one packed record (16 values) "
-                                "and one side record (8 values) written per observation + per-point t, y_f (materialised Jacobian data)"},
+                        "moved": n_obs * (4 + 2 * t) + n_obs * yrec + n_pt * (24 + 24 + 48 + 4 + pa + pb),
+                        "note": "algorithmic: one pass over observations, points and cameras (B_res); moved: + one packed record (16 values) per observation "
+                                "(read back by the back-substitution only) + per point t, y_f, M and the 72-byte table entry of the re-evaluating passes"},
         "schur_pairs": {"bound": "hbm", "bytes": 8 * d * d,
-                        "moved": n_obs * yrec + 8 * npair + 8 * d * d,
-                        "note": "algorithmic: the reduced matrix written once (8 d^2); moved: + every record read once and the pair list once "
-                                "(each record is in fact gathered ~k-1 times from L2 / MALL)"},
+                        "moved": 4 * npair + n_pt * pa + 8 * d * d,
+                        "note": "algorithmic: the reduced matrix written once (8 d^2); moved: + the pair-point list (4 bytes per pair) and the point table once "
+                                "(it stays in L2: every pair re-reads its entry from there); no per-observation record is gathered any more (round 3)"},
         "cam_diag": {"bound": "hbm", "bytes": 96 * n_cam + 8 * d,
-                     "moved": n_obs * (4 + yrec + yrec // 2),
+                     "moved": n_obs * (4 + 2 * t) + n_pt * (pa + pb),
                      "note": "algorithmic: the camera-diagonal blocks and right-hand side written once -- in a fused design this pass would "
-                             "not exist; moved: the camera-major index list and, per observation, its packed record and side record"},
+                             "not exist; moved: the camera-major point index and observation coordinates (coalesced) and the point table once (L2-resident gathers)"},
         "point_update": {"bound": "hbm", "bytes": b_res + 24 * n_pt,
                          "note": "one residual evaluation (B_res) + the trial points written"},
         "pcg_iter": {"bound": "hbm", "label": "l2_mall_latency", "bytes": 8 * d * d + 9 * 8 * d,

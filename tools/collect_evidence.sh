@@ -23,6 +23,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$c.err
 done
 python $REPO/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_pmc_traffic.txt "python bench.py --steps 2 --warmup 1 --no-cpu-baseline   (cfg3, f32j, PCG)" > /dev/null
+# 3b. round 3: the library default (AUTO), the realistic-visibility workload, and the record-gathering passes of rounds 1 / 2 as A/B
+$BENCH --linear auto --no-cpu-baseline > $OUT/${TAG}_cfg3_auto_bench.json 2> $OUT/bench_auto.err
+$BENCH --workload cfg3_banded --no-cpu-baseline > $OUT/${TAG}_cfg3_banded_pcg_bench.json 2> $OUT/bench_banded.err
+SFMBA_SCHUR_RECORDS=1 $BENCH --no-cpu-baseline > $OUT/${TAG}_cfg3_pcg_records_form_bench.json 2> $OUT/bench_rec.err
+SFMBA_SCHUR_RECORDS=1 $BENCH --workload cfg3_banded --no-cpu-baseline > $OUT/${TAG}_cfg3_banded_pcg_records_form_bench.json 2> $OUT/bench_banded_rec.err
+rm -rf $OUT/stats_banded
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_banded -- $BENCH --workload cfg3_banded --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/stats_banded.err
+python $REPO/tools/rocprof_summary.py $OUT/stats_banded $OUT/${TAG}_cfg3_banded_pcg_kernel_stats.txt "$TAG: bench.py --workload cfg3_banded --steps 10 --warmup 2 (f32j, PCG) under rocprofv3 --kernel-trace --stats" > /dev/null
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/pmcr_$c
+  SFMBA_SCHUR_RECORDS=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcr_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmcr_$c.err
+done
+python $REPO/tools/pmc_summary.py $OUT/pmcr_FETCH_SIZE $OUT/pmcr_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_records_form_pmc_traffic.txt.ab "SFMBA_SCHUR_RECORDS=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline   (cfg3, f32j, PCG, record-gathering passes of rounds 1 / 2)" > /dev/null
+rm -rf $OUT/stats_banded $OUT/pmcr_FETCH_SIZE $OUT/pmcr_WRITE_SIZE
+$REPO/tools/micro/pk_bench > $OUT/${TAG}_valu_issue_microbench.txt 2>&1
 # 4. the sharded path on this box's one rank (RCCL communicator of one rank; the exchange is a no-op, its pack / unpack kernels are not)
 for wl in cfg3 cfg5; do
   $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline 2> $OUT/sharded_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_bench.json
@@ -30,7 +45,9 @@ done
 # 5. the drop-in shim in the reference's call pattern: one view added to 199 (SfM.cpp:464-466)
 echo "== SFMBA_LINEAR=pcg (block-Jacobi + gauge coarse space CG) ==" > $OUT/${TAG}_shim_incremental.txt
 SFMBA_BUILD_TIMING=1 python $REPO/tools/time_shim_incremental.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
-echo "== SFMBA_LINEAR=cholesky (the shim's default: exact DENSE_SCHUR-equivalent solve) ==" >> $OUT/${TAG}_shim_incremental.txt
+echo "== SFMBA_LINEAR=auto (the shim's default since round 3: DENSE_SCHUR result through the CG at 1e-12, Cholesky fallback) ==" >> $OUT/${TAG}_shim_incremental.txt
+SFMBA_LINEAR=auto python $REPO/tools/time_shim_incremental.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
+echo "== SFMBA_LINEAR=cholesky (always factorise: the reference's literal configuration) ==" >> $OUT/${TAG}_shim_incremental.txt
 SFMBA_LINEAR=cholesky python $REPO/tools/time_shim_incremental.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
 echo "== structure build on its own ==" >> $OUT/${TAG}_shim_incremental.txt
 python $REPO/tools/time_create.py >> $OUT/${TAG}_shim_incremental.txt 2>&1

@@ -11,6 +11,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     const float m = 1.0000001f, c = 1e-9f;
     const v2f pm = {m, m}, pc = {c, c};
     const double dm = 1.0000001, dc = 1e-9;
+    const unsigned long long mask = 0x5555aaaa3333ccccull ^ (unsigned long long)iters;
     for (int i = 0; i < iters; ++i) {
         if (KIND == 0) {
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -28,6 +29,30 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
             asm volatile("v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %1, %2, %1, vcc\n v_cndmask_b32 %2, %3, %2, vcc\n v_cndmask_b32 %3, %4, %3, vcc\n"
                          "v_cndmask_b32 %4, %5, %4, vcc\n v_cndmask_b32 %5, %6, %5, vcc\n v_cndmask_b32 %6, %7, %6, vcc\n v_cndmask_b32 %7, %0, %7, vcc"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :: "vcc");
+        } else if (KIND == 5) {
+            asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                         "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+        } else if (KIND == 6) {
+            asm volatile("v_cndmask_b32_e64 %0, %1, %0, %8\n v_cndmask_b32_e64 %1, %2, %1, %8\n v_cndmask_b32_e64 %2, %3, %2, %8\n v_cndmask_b32_e64 %3, %4, %3, %8\n"
+                         "v_cndmask_b32_e64 %4, %5, %4, %8\n v_cndmask_b32_e64 %5, %6, %5, %8\n v_cndmask_b32_e64 %6, %7, %6, %8\n v_cndmask_b32_e64 %7, %0, %7, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(mask));
+        } else if (KIND == 7) {
+            asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %8"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+        } else if (KIND == 8) {
+            asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                         "v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                         "v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                         "v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+        } else if (KIND == 9) {
+            a0 = __shfl_xor(a0, 32, 64); a1 = __shfl_xor(a1, 16, 64); a2 = __shfl_xor(a2, 32, 64); a3 = __shfl_xor(a3, 16, 64);
+            a4 = __shfl_xor(a4, 32, 64); a5 = __shfl_xor(a5, 16, 64); a6 = __shfl_xor(a6, 32, 64); a7 = __shfl_xor(a7, 16, 64);
+        } else if (KIND == 10) {
+            asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                         "v_pk_add_f32 %4, %4, %9\n v_pk_add_f32 %5, %5, %9\n v_pk_add_f32 %6, %6, %9\n v_pk_add_f32 %7, %7, %9"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm), "v"(pc));
         } else if (KIND == 4) {
             asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
                          "v_add_f32 %4, %4, %9\n v_add_f32 %5, %5, %9\n v_add_f32 %6, %6, %9\n v_add_f32 %7, %7, %9"
@@ -51,11 +76,9 @@ template <int KIND> int run(const char* name, float* d, int wg_per_cu) {
 }
 int main() {
     float* d; CK(hipMalloc(&d, 256 * 8 * 256 * sizeof(float)));
-    for (int w : {1, 2, 4, 8}) {
-        if (w == 1) { run<0>("v_fma_f32", d, 1); run<1>("v_pk_fma_f32", d, 1); run<2>("v_fma_f64", d, 1); run<3>("v_cndmask_b32", d, 1); run<4>("v_mul/add_f32", d, 1); }
-        if (w == 2) { run<0>("v_fma_f32", d, 2); run<1>("v_pk_fma_f32", d, 2); run<2>("v_fma_f64", d, 2); run<3>("v_cndmask_b32", d, 2); run<4>("v_mul/add_f32", d, 2); }
-        if (w == 4) { run<0>("v_fma_f32", d, 4); run<1>("v_pk_fma_f32", d, 4); run<2>("v_fma_f64", d, 4); run<3>("v_cndmask_b32", d, 4); run<4>("v_mul/add_f32", d, 4); }
-        if (w == 8) { run<0>("v_fma_f32", d, 8); run<1>("v_pk_fma_f32", d, 8); run<2>("v_fma_f64", d, 8); run<3>("v_cndmask_b32", d, 8); run<4>("v_mul/add_f32", d, 8); }
+    for (int w : {1, 4, 8}) {
+        run<0>("v_fma_f32", d, w); run<5>("v_fmac_f32", d, w); run<1>("v_pk_fma_f32", d, w); run<10>("v_pk_mul/add", d, w); run<2>("v_fma_f64", d, w);
+        run<4>("v_mul/add_f32", d, w); run<3>("cndmask vcc", d, w); run<6>("cndmask sgpr", d, w); run<7>("v_mov_b32", d, w); run<8>("v_mov_dpp", d, w); run<9>("shfl_xor", d, w);
     }
     return 0;
 }
