@@ -110,8 +110,9 @@ typedef struct sfmba_options {
     int    shard_two_phase;           /* SFMBA_SHARD_TWO_PHASE    default on : sharded CG path exchanges (A) diagonal data, (B) preconditioned blocks */
     int    shard_f32_exchange;        /* SFMBA_SHARD_F32_EXCHANGE default on : exchange (B) in fp32 where the CG stores S~ in fp32 anyway */
     int    shard_distributed_cg;      /* SFMBA_SHARD_DIST_CG      default off: sharded CG path WITHOUT the redundant solve -- exchange (B) is a
-                                         reduce-scatter into row slabs of S~, every rank multiplies its slab, one small all-gather per CG
-                                         iteration (needs the reduce-scatter / all-gather callbacks, sfmba_problem_set_collectives) */
+                                         reduce-scatter of the upper-triangle blocks of S~ into ranges of block rows (half the bytes of the
+                                         all-reduce), every rank multiplies the blocks it owns, one all-reduce of ld doubles per CG
+                                         iteration's partial product (needs sfmba_problem_set_reduce_scatter when world > 1) */
 } sfmba_options;
 
 /* Flags of sfmba_problem_create_ex (ABI v4; were environment variables read at create time). */
@@ -331,7 +332,16 @@ SFMBA_API int  sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options
 typedef int (*sfmba_allreduce_f32_fn)(void* ctx, void* device_buf, int64_t n_floats, void* hip_stream);
 SFMBA_API int  sfmba_comm_allreduce_f32(void* comm /* sfmba_comm* */, void* device_buf, int64_t n_floats, void* hip_stream);   /* an sfmba_allreduce_f32_fn */
 SFMBA_API int  sfmba_problem_set_allreduce_f32(sfmba_problem* p, sfmba_allreduce_f32_fn allreduce_f32);                        /* NULL: fp64 only */
-/* what the last sfmba_problem_solve_sharded() exchanged per linearisation: out = { bytes of (A), bytes of (B), bytes of (C), 1 if (B) was fp32 } */
+/* Collectives of the DISTRIBUTED CG (options.shard_distributed_cg, include above): exchange (B) becomes a reduce-scatter of the
+ * upper-triangle blocks of S~ in a layout of `world` equal chunks (contiguous ranges of block rows, padded): after the call, stream-ordered,
+ * recv_buf (= send_buf + rank * n_values elements: in place) holds the SUM over the ranks of chunk `rank`.  is_f32 != 0: the elements are
+ * floats.  Every CG iteration then all-reduces ONE vector of ld doubles through the sfmba_allreduce_fn given to sfmba_problem_solve_sharded
+ * (eight of them, in one call, at the coarse-space setup).  Without a reduce-scatter callback the option is ignored when world > 1. */
+typedef int (*sfmba_reduce_scatter_fn)(void* ctx, void* send_buf, void* recv_buf, int64_t n_values, int is_f32, void* hip_stream);
+SFMBA_API int  sfmba_comm_reduce_scatter(void* comm /* sfmba_comm* */, void* send_buf, void* recv_buf, int64_t n_values, int is_f32, void* hip_stream);   /* an sfmba_reduce_scatter_fn: ncclReduceScatter */
+SFMBA_API int  sfmba_problem_set_reduce_scatter(sfmba_problem* p, sfmba_reduce_scatter_fn reduce_scatter);     /* NULL: none */
+/* what the last sfmba_problem_solve_sharded() exchanged per linearisation: out = { bytes of (A), bytes of (B), bytes of (C), flags: bit 0 = (B) was fp32, bit 1 = distributed CG (then (B) = the bytes of the whole
+ * reduce-scatter buffer, of which a rank receives 1 / world, and every CG iteration adds 8 ld bytes of all-reduce) } */
 SFMBA_API int  sfmba_shard_last_exchange(const sfmba_problem* p, int64_t out[4]);
 
 /*

@@ -153,6 +153,7 @@ struct DeviceBuffers {
     float* shard_blocks32;    // ... the same in fp32 (exchange (B) in single precision: the streaming CG path stores S~ in fp32 anyway)
     double* shard_blocks;     // sharded CG path: the pair pass (MODE 1) stores the off-diagonal blocks of S~ here (all-reduce layout) instead of pcg_F
     const double* shard_scal; // sharded solve: k_lm_control takes the trial sums from this all-reduced scalar block instead of the slots
+    const int* shard_row_shift; // distributed CG: blocks to ADD to a block's list position, per block row (reduce-scatter layout: dist_cg.h); null = none
 };
 
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);

@@ -776,8 +776,11 @@ __device__ __forceinline__ void store_F(const DeviceBuffers& db, size_t idx, dou
 // one entry of an off-diagonal block of the preconditioned matrix: both triangles of the CG's matrix, or -- sharded CG path -- the
 // block's slot in the all-reduce buffer (k_shard_offdiag's layout; the matrix is written after the sum over the ranks)
 __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, const DeviceBuffers& db, int b, int2 cj, int r, int c, double v) {
-    if (db.shard_blocks32) { db.shard_blocks32[(size_t)(b - cj.x - 1) * 36 + 6 * r + c] = (float)v; return; }
-    if (db.shard_blocks) { db.shard_blocks[(size_t)(b - cj.x - 1) * 36 + 6 * r + c] = v; return; }
+    if (db.shard_blocks32 || db.shard_blocks) {
+        const size_t o = (size_t)((long long)(b - cj.x - 1) + (db.shard_row_shift ? db.shard_row_shift[cj.x] : 0)) * 36 + 6 * r + c;
+        if (db.shard_blocks32) db.shard_blocks32[o] = (float)v; else db.shard_blocks[o] = v;
+        return;
+    }
     store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
     store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
 }

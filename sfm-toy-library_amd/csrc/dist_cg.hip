@@ -1,0 +1,346 @@
+// dist_cg.hip -- distributed CG of the sharded solve (see dist_cg.h).  Everything here is small and simple on purpose: the matrix product
+// streams 1/N of the matrix per rank, the rest is O(d) work in one workgroup; what a CG iteration costs at N > 1 is its collective.
+#include "dist_cg.h"
+#include "sfmba_device.h"
+
+namespace sfmba {
+
+namespace {
+
+enum { PF_DONE = 0, PF_ITERS = 1, PF_XBUF = 2 };                       // DenseSolver::flags (dense_solver.hip)
+enum { DS_RZ = 0, DS_RR0 = 1, DS_RRF = 2, DS_EINV = 8, DS_NV = 80 };  // scal: rz, threshold base, |b~|^2 of the first solve of an anchored run, E^-1 (64), live vectors
+constexpr int NW = 8;
+constexpr int STEP_T = 1024;
+
+__device__ __forceinline__ long long first_of_row(int I, int ncam) { return (long long)I * ncam - (long long)I * (I + 1) / 2; }   // off-diagonal upper blocks before row I
+
+template <typename FT> __device__ __forceinline__ double ld_val(const FT* p, size_t i) { return (double)p[i]; }
+
+// N block-wide sums (every thread returns all of them); sh: >= 16 * N doubles
+template <int N>
+__device__ __forceinline__ void block_sums_all(double (&v)[N], double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] += __shfl_xor(v[k], off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) sh[w * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) { double s = 0.0; for (int i = 0; i < nw; ++i) s += sh[i * N + k]; v[k] = s; }
+}
+
+// Partial product from the OWNED blocks (rows [row0, row1) of the upper triangle, in list order behind `owned`):
+//   role A, one workgroup per owned row I:      qa[6 I + r]  = sum_{J > I} sum_c B_IJ[r][c] p[6 J + c]
+//   role B, one workgroup per column J > row0:  qb[6 J + c]  = sum_{I in [row0, min(row1, J))} sum_r B_IJ[r][c] p[6 I + r]
+template <typename FT>
+__global__ __launch_bounds__(256) void k_dcg_spmv(int ncam, int row0, int row1, const FT* __restrict__ owned, const double* __restrict__ p,
+                                                  double* __restrict__ qa, double* __restrict__ qb, const int* __restrict__ flags) {
+    if (flags && flags[PF_DONE]) return;
+    __shared__ double sh[4 * 6];
+    const int nA = row1 - row0;
+    const bool roleA = (int)blockIdx.x < nA;
+    const long long base = first_of_row(row0, ncam);
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    if (roleA) {
+        const int I = row0 + blockIdx.x;
+        const long long rowpos = first_of_row(I, ncam) - base;
+        for (int J = I + 1 + threadIdx.x; J < ncam; J += blockDim.x) {
+            const FT* B = owned + (size_t)(rowpos + (J - I - 1)) * 36;
+            double pj[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pj[c] = p[6 * J + c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[r] = fma(ld_val(B, 6 * r + c), pj[c], acc[r]);
+        }
+    } else {
+        const int J = row0 + 1 + ((int)blockIdx.x - nA);
+        const int iend = row1 < J ? row1 : J;
+        for (int I = row0 + threadIdx.x; I < iend; I += blockDim.x) {
+            const FT* B = owned + (size_t)(first_of_row(I, ncam) - base + (J - I - 1)) * 36;
+            double pi[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) pi[r] = p[6 * I + r];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc[c] = fma(ld_val(B, 6 * r + c), pi[r], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sh[w * 6 + k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double s = sh[threadIdx.x] + sh[6 + threadIdx.x] + sh[12 + threadIdx.x] + sh[18 + threadIdx.x];
+        if (roleA) qa[6 * (row0 + blockIdx.x) + threadIdx.x] = s;
+        else qb[6 * (row0 + 1 + ((int)blockIdx.x - nA)) + threadIdx.x] = s;
+    }
+}
+
+// the rank's partial product as it goes into the all-reduce: owned-block parts + (rank 0 only) what is known everywhere: the identity
+// diagonal blocks and the focal row / column of S~
+template <typename FF>
+__global__ __launch_bounds__(STEP_T) void k_dcg_comb(int d, int ncam, int row0, int row1, int rank, const double* __restrict__ qa, const double* __restrict__ qb,
+                                                      const double* __restrict__ p, const FF* __restrict__ focal_row, double* __restrict__ out,
+                                                      const int* __restrict__ flags) {
+    if (flags && flags[PF_DONE]) return;
+    __shared__ double sh[16];
+    const int fo = d - 1;
+    double fdot[1] = { 0.0 };
+    if (rank == 0) { for (int i = threadIdx.x; i < fo; i += blockDim.x) fdot[0] += (double)focal_row[i] * p[i]; }
+    block_sums_all<1>(fdot, sh);
+    const double pf = p[fo];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        const int cam = i / 6;
+        double v = 0.0;
+        if (i < fo) {
+            if (cam >= row0 && cam < row1) v += qa[i];
+            if (cam > row0) v += qb[i];
+            if (rank == 0) v += p[i] + (double)focal_row[i] * pf;
+        } else if (rank == 0) {
+            v = pf + fdot[0];
+        }
+        out[i] = v;
+    }
+}
+
+// 8 x 8 symmetric E -> E^-1 by Gauss-Jordan with a pivot test (dependent gauge vectors -- fewer cameras than gauge freedoms -- drop out)
+__device__ void invert8(const double* E, double* Einv) {
+    double a[NW][2 * NW];
+    double scale = 0.0;
+    for (int i = 0; i < NW; ++i) scale = fmax(scale, fabs(E[i * NW + i]));
+    for (int i = 0; i < NW; ++i)
+        for (int j = 0; j < NW; ++j) { a[i][j] = E[i * NW + j]; a[i][NW + j] = i == j ? 1.0 : 0.0; }
+    bool dead[NW];
+    for (int k = 0; k < NW; ++k) {
+        const double piv = a[k][k];
+        dead[k] = !(piv > 1e-12 * scale);
+        if (dead[k]) continue;
+        const double ip = 1.0 / piv;
+        for (int j = 0; j < 2 * NW; ++j) a[k][j] *= ip;
+        for (int i = 0; i < NW; ++i) {
+            if (i == k) continue;
+            const double f = a[i][k];
+            for (int j = 0; j < 2 * NW; ++j) a[i][j] -= f * a[k][j];
+        }
+    }
+    for (int i = 0; i < NW; ++i)
+        for (int j = 0; j < NW; ++j) Einv[i * NW + j] = (dead[i] || dead[j]) ? 0.0 : a[i][NW + j];
+}
+
+// start of a solve: E^-1 from AW (all-reduced), x = 0, r = b~, z = r + W E^-1 W^T r, p = z, thresholds, flags
+__global__ __launch_bounds__(STEP_T) void k_dcg_init(int d, int ld, const double* __restrict__ bt, const double* __restrict__ W, const double* __restrict__ AW,
+                                                      double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ scal,
+                                                      int* __restrict__ flags, int anchor, double cap) {
+    __shared__ double sh[16 * 9];
+    __shared__ double E[NW * NW], Einv[NW * NW];
+    const int tid = threadIdx.x;
+    if (W) {
+        // E[k][l] = sum_i W[k][i] AW[l][i]: 64 sums, eight at a time
+        for (int k = 0; k < NW; ++k) {
+            double v[NW];
+#pragma unroll
+            for (int l = 0; l < NW; ++l) v[l] = 0.0;
+            for (int i = tid; i < d; i += blockDim.x) {
+                const double w = W[(size_t)k * ld + i];
+#pragma unroll
+                for (int l = 0; l < NW; ++l) v[l] = fma(w, AW[(size_t)l * ld + i], v[l]);
+            }
+            block_sums_all<NW>(v, sh);
+            if (tid < NW) E[k * NW + tid] = v[tid];
+        }
+        __syncthreads();
+        if (tid == 0) invert8(E, Einv);
+        __syncthreads();
+        if (tid < NW * NW) scal[DS_EINV + tid] = Einv[tid];
+    }
+    double v[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; ++k) v[k] = 0.0;
+    for (int i = tid; i < d; i += blockDim.x) {
+        const double b = bt[i];
+        v[NW] = fma(b, b, v[NW]);
+        if (W) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) v[k] = fma(W[(size_t)k * ld + i], b, v[k]);
+        }
+    }
+    block_sums_all<NW + 1>(v, sh);
+    double mu[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { mu[k] = 0.0; if (W) { for (int l = 0; l < NW; ++l) mu[k] = fma(Einv[k * NW + l], v[l], mu[k]); } }
+    const double rr = v[NW];
+    double rz[1] = { 0.0 };
+    for (int i = tid; i < d; i += blockDim.x) {
+        const double b = bt[i];
+        double z = b;
+        if (W) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) z = fma(W[(size_t)k * ld + i], mu[k], z);
+        }
+        x[i] = 0.0; r[i] = b; p[i] = z;
+        rz[0] = fma(b, z, rz[0]);
+    }
+    block_sums_all<1>(rz, sh);
+    if (tid == 0) {
+        double base = rr;
+        if (anchor == 1) scal[DS_RRF] = rr;
+        else if (anchor == 2) base = fmin(fmax(rr, scal[DS_RRF]), cap * rr);
+        scal[DS_RR0] = base; scal[DS_RZ] = rz[0];
+        flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = 0;
+    }
+}
+
+// one CG iteration behind the all-reduced product q = S~ p
+__global__ __launch_bounds__(STEP_T) void k_dcg_step(int d, int ld, const double* __restrict__ q, const double* __restrict__ W, double* __restrict__ x,
+                                                      double* __restrict__ r, double* __restrict__ p, double* __restrict__ scal, int* __restrict__ flags,
+                                                      double tol2, int* info) {
+    if (flags[PF_DONE]) return;
+    __shared__ double sh[16 * 9];
+    const int tid = threadIdx.x;
+    double pq[1] = { 0.0 };
+    for (int i = tid; i < d; i += blockDim.x) pq[0] = fma(p[i], q[i], pq[0]);
+    block_sums_all<1>(pq, sh);
+    const double rz = scal[DS_RZ];
+    const bool broke = !(pq[0] > 0.0);
+    const double alpha = broke ? 0.0 : rz / pq[0];
+    double v[NW + 1];
+#pragma unroll
+    for (int k = 0; k <= NW; ++k) v[k] = 0.0;
+    for (int i = tid; i < d; i += blockDim.x) {
+        const double rn = fma(-alpha, q[i], r[i]);
+        x[i] = fma(alpha, p[i], x[i]);
+        r[i] = rn;
+        v[NW] = fma(rn, rn, v[NW]);
+        if (W) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) v[k] = fma(W[(size_t)k * ld + i], rn, v[k]);
+        }
+    }
+    block_sums_all<NW + 1>(v, sh);
+    const double rr = v[NW];
+    const bool done = broke || !(rr == rr) || rr <= tol2 * scal[DS_RR0];
+    if (done) {
+        __syncthreads();
+        if (tid == 0) { flags[PF_ITERS] = flags[PF_ITERS] + 1; flags[PF_DONE] = 1; if (broke || !(rr == rr)) atomicCAS(info, 0, d + 1); }
+        return;
+    }
+    double mu[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { mu[k] = 0.0; if (W) { for (int l = 0; l < NW; ++l) mu[k] = fma(scal[DS_EINV + k * NW + l], v[l], mu[k]); } }
+    double rzn[1] = { 0.0 };
+    double zl[8];                                     // this thread's entries of z (d <= 8 * STEP_T; larger systems recompute below)
+    int m = 0;
+    for (int i = tid; i < d; i += blockDim.x, ++m) {
+        double z = r[i];
+        if (W) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) z = fma(W[(size_t)k * ld + i], mu[k], z);
+        }
+        if (m < 8) zl[m] = z;
+        rzn[0] = fma(r[i], z, rzn[0]);
+    }
+    block_sums_all<1>(rzn, sh);
+    const double beta = rzn[0] / rz;
+    m = 0;
+    for (int i = tid; i < d; i += blockDim.x, ++m) {
+        double z;
+        if (m < 8) z = zl[m];
+        else {
+            z = r[i];
+            if (W) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) z = fma(W[(size_t)k * ld + i], mu[k], z);
+            }
+        }
+        p[i] = fma(beta, p[i], z);
+    }
+    if (tid == 0) { scal[DS_RZ] = rzn[0]; flags[PF_ITERS] = flags[PF_ITERS] + 1; }
+}
+
+}  // namespace
+
+void dcg_partition(int ncam, int world, std::vector<int>* rows, long long* chunk_blocks) {
+    const long long total = (long long)ncam * (ncam - 1) / 2;
+    rows->assign((size_t)world + 1, ncam);
+    (*rows)[0] = 0;
+    long long acc = 0;
+    int r = 1;
+    for (int I = 0; I < ncam && r < world; ++I) {
+        acc += ncam - 1 - I;
+        // row I closes rank r - 1 once its share is reached (the remaining ranks get the remaining rows)
+        while (r < world && acc * world >= total * r) { (*rows)[(size_t)r] = I + 1; ++r; }
+    }
+    long long big = 0;
+    for (int k = 0; k < world; ++k) {
+        const long long a = (long long)(*rows)[(size_t)k] * ncam - (long long)(*rows)[(size_t)k] * ((*rows)[(size_t)k] + 1) / 2;
+        const long long b = (long long)(*rows)[(size_t)k + 1] * ncam - (long long)(*rows)[(size_t)k + 1] * ((*rows)[(size_t)k + 1] + 1) / 2;
+        big = std::max(big, b - a);
+    }
+    *chunk_blocks = std::max<long long>(big, 1);
+}
+
+int dcg_create(DistCg* g, int d, int ld, int ncam, int rank, int world, DeviceArena* arena) {
+    g->d = d; g->ld = ld; g->ncam = ncam; g->rank = rank; g->world = world;
+    dcg_partition(ncam, world, &g->rows, &g->chunk_blocks);
+    g->row0 = g->rows[(size_t)rank]; g->row1 = g->rows[(size_t)rank + 1];
+    std::vector<int> shift((size_t)std::max(ncam, 1), 0);
+    for (int k = 0; k < world; ++k) {
+        const long long first = (long long)g->rows[(size_t)k] * ncam - (long long)g->rows[(size_t)k] * (g->rows[(size_t)k] + 1) / 2;
+        for (int I = g->rows[(size_t)k]; I < g->rows[(size_t)k + 1]; ++I) shift[(size_t)I] = (int)(k * g->chunk_blocks - first);
+    }
+    g->d_row_shift = arena->alloc_n<int>(shift.size());
+    g->qa = arena->alloc_n<double>((size_t)ld); g->qb = arena->alloc_n<double>((size_t)ld);
+    g->qred = arena->alloc_n<double>((size_t)9 * ld);
+    g->r = arena->alloc_n<double>((size_t)ld); g->p = arena->alloc_n<double>((size_t)ld); g->z = arena->alloc_n<double>((size_t)ld);
+    g->scal = arena->alloc_n<double>(128);
+    if (!g->d_row_shift || !g->qa || !g->qb || !g->qred || !g->r || !g->p || !g->z || !g->scal) return -1;
+    if (hipMemcpy(g->d_row_shift, shift.data(), sizeof(int) * shift.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    g->AW = g->qred;                  // slots 0..7 of the all-reduce buffer ARE S~ W~ after the setup; slot 8 carries the iterations' products
+    g->ready = true;
+    return 0;
+}
+
+static void launch_product(hipStream_t s, const DistCg* g, const DcgSolveArgs& a, const double* p, double* out, const int* flags) {
+    const int nA = g->row1 - g->row0, nB = std::max(0, g->ncam - g->row0 - 1);
+    if (nA + nB > 0) {
+        if (a.owned_f32) hipLaunchKernelGGL(k_dcg_spmv<float>, dim3(nA + nB), dim3(256), 0, s, g->ncam, g->row0, g->row1, static_cast<const float*>(a.owned), p, g->qa, g->qb, flags);
+        else hipLaunchKernelGGL(k_dcg_spmv<double>, dim3(nA + nB), dim3(256), 0, s, g->ncam, g->row0, g->row1, static_cast<const double*>(a.owned), p, g->qa, g->qb, flags);
+    }
+    if (a.focal_row32) hipLaunchKernelGGL(k_dcg_comb<float>, dim3(1), dim3(STEP_T), 0, s, g->d, g->ncam, g->row0, g->row1, g->rank, g->qa, g->qb, p, a.focal_row32, out, flags);
+    else hipLaunchKernelGGL(k_dcg_comb<double>, dim3(1), dim3(STEP_T), 0, s, g->d, g->ncam, g->row0, g->row1, g->rank, g->qa, g->qb, p, a.focal_row, out, flags);
+}
+
+int dcg_begin(hipStream_t s, DistCg* g, const DcgSolveArgs& a, dcg_allreduce_fn ar, void* ctx) {
+    if (a.W) {
+        for (int k = 0; k < NW; ++k) launch_product(s, g, a, a.W + (size_t)k * g->ld, g->qred + (size_t)k * g->ld, nullptr);
+        if (ar) { const int rc = ar(ctx, g->qred, (long long)NW * g->ld, s); if (rc) return rc; }
+    }
+    hipLaunchKernelGGL(k_dcg_init, dim3(1), dim3(STEP_T), 0, s, g->d, g->ld, a.bt, a.W, g->AW, g->x, g->r, g->p, g->scal, a.flags, a.anchor, a.cap);
+    return 0;
+}
+
+int dcg_iterate(hipStream_t s, DistCg* g, const DcgSolveArgs& a, int n, dcg_allreduce_fn ar, void* ctx) {
+    double* q = g->qred + (size_t)NW * g->ld;
+    for (int it = 0; it < n; ++it) {
+        launch_product(s, g, a, g->p, q, a.flags);
+        if (ar) { const int rc = ar(ctx, q, (long long)g->ld, s); if (rc) return rc; }
+        hipLaunchKernelGGL(k_dcg_step, dim3(1), dim3(STEP_T), 0, s, g->d, g->ld, q, a.W, g->x, g->r, g->p, g->scal, a.flags, a.tol * a.tol, a.info);
+    }
+    return 0;
+}
+
+}  // namespace sfmba

@@ -13,6 +13,7 @@
 #include "association.h"
 #include "ba_kernels.h"
 #include "dense_solver.h"
+#include "dist_cg.h"
 #include "device_arena.h"
 #include "profiler.h"
 #include "sfmba_device.h"
@@ -243,6 +244,10 @@ struct sfmba_problem {
     int shard_host_iter = 0;
     int64_t shard_exchange[4] = { 0, 0, 0, 0 };       // bytes of exchanges (A), (B), (C) per linearisation of the last sharded solve; (B) in fp32?
     sfmba_allreduce_f32_fn allreduce_f32 = nullptr;   // optional: exchange (B) in fp32 where the CG stores S~ in fp32
+    sfmba_reduce_scatter_fn reduce_scatter = nullptr; // optional: the distributed CG's exchange (B)
+    DistCg dcg;                                       // distributed CG workspace (created by the first solve that asks for it)
+    long long shard_blocks_off = 0;                   // doubles: where the block region of d_red starts (behind the region of exchange (A))
+    int dcg_last_f32 = -1;
     sfmba_summary shard_sum;
     Profiler prof;
 };
@@ -953,7 +958,13 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     if (sharded) {
         // the all-reduce buffer: packed triangle of S + tail (exact solver), or the two blocks of the CG path (ba_kernels.hip, k_shard_diag)
         const size_t tri = (size_t)ds.ld * (ds.ld + 1) / 2 + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
-        HIP_TRY(dev_alloc(&p->d_red, std::max(tri, (size_t)std::max(shard_diag_len(ds), shard_offdiag_len(ds)))));
+        // distributed CG: the blocks go behind the region of exchange (A), in `world` equal chunks (the padding stays zero)
+        std::vector<int> rows; long long chunk = 0;
+        dcg_partition(ncam, p->shard_world, &rows, &chunk);
+        p->shard_blocks_off = (shard_diag_len(ds) + 63) / 64 * 64;
+        const size_t dist = (size_t)p->shard_blocks_off + (size_t)p->shard_world * (size_t)chunk * 36;
+        HIP_TRY(dev_alloc(&p->d_red, std::max(std::max(tri, dist), (size_t)std::max(shard_diag_len(ds), shard_offdiag_len(ds)))));
+        p->dcg = DistCg(); p->dcg_last_f32 = -1;
     }
     db.S = p->d_sys;
     db.rhs = db.S + (size_t)ds.ld * ds.ld;
@@ -1588,6 +1599,16 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         // unpreconditioned matrix exchanged as well; at max_iters the step is forced, as with PCG)
         const bool exact_pcg = o.linear_solver == SFMBA_LINEAR_AUTO;
         const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
+        // the CG without the redundant solve (dist_cg.h): reduce-scatter of the blocks, products from the owned blocks, one small
+        // all-reduce per CG iteration
+        const bool dist_cg = option_switch(o.shard_distributed_cg, "SFMBA_SHARD_DIST_CG", false) && (p->shard_world == 1 || p->reduce_scatter != nullptr);
+        struct ArCtx { sfmba_allreduce_fn fn; void* ctx; } arctx{ allreduce, ctx };
+        auto ar_thunk = [](void* c, void* buf, long long n, hipStream_t st) -> int { ArCtx* a = static_cast<ArCtx*>(c); return a->fn ? a->fn(a->ctx, buf, (int64_t)n, (void*)st) : 0; };
+        int dcg_launched = 0, dcg_max = o.pcg_max_iters > 0 ? o.pcg_max_iters : 4 * p->ds.d;
+        if (dist_cg && !p->dcg.ready) {
+            ArenaScope as(&p->arena);
+            if (dcg_create(&p->dcg, p->ds.d, p->ds.ld, p->ds.ncam, p->shard_rank, p->shard_world, &p->arena)) return fail(SFMBA_ERR_ALLOC, "distributed CG workspace allocation failed");
+        }
         int first_build = o.jacobi_scaling ? 1 : 2;          // the first point pass also forms the point scales
         for (;;) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
@@ -1613,6 +1634,39 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/true, p->shard_rank, p->shard_world);
             { DeviceBuffers dbf = p->db; dbf.cd_part = nullptr; launch_finalize(p->stream, p->ds, dbf, 1); }
             // the pair pass stores its transformed blocks straight into the all-reduce buffer
+            DcgSolveArgs da;
+            if (dist_cg) {
+                // ... in the reduce-scatter layout (`world` equal chunks of whole block rows behind the region of exchange (A); padding zero)
+                double* blocks = p->d_red + p->shard_blocks_off;
+                const long long cv = dcg_chunk_values(p->dcg), total = cv * p->shard_world;
+                if (p->dcg_last_f32 != (x32 ? 1 : 0)) { HIP_TRY(hipMemsetAsync(blocks, 0, (size_t)total * (x32 ? 4 : 8), p->stream)); p->dcg_last_f32 = x32 ? 1 : 0; }
+                p->db.shard_row_shift = p->dcg.d_row_shift;
+                if (x32) p->db.shard_blocks32 = reinterpret_cast<float*>(blocks); else p->db.shard_blocks = blocks;
+                if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 1); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 1);
+                p->db.shard_blocks = nullptr; p->db.shard_blocks32 = nullptr; p->db.shard_row_shift = nullptr;
+                char* mine = reinterpret_cast<char*>(blocks) + (size_t)p->shard_rank * (size_t)cv * (x32 ? 4 : 8);
+                if (p->shard_world > 1) {
+                    const int rrc = p->reduce_scatter(ctx, blocks, mine, (int64_t)cv, x32 ? 1 : 0, (void*)p->stream);
+                    if (rrc != 0) return fail(SFMBA_ERR_HIP, "reduce-scatter failed (rc " + std::to_string(rrc) + ")");
+                }
+                p->shard_exchange[1] = (x32 ? 4 : 8) * total; p->shard_exchange[3] = (x32 ? 1 : 0) | 2;
+                const int fo = p->ds.d - 1;
+                da.owned = mine; da.owned_f32 = x32;
+                if (p->db.pcg_F32) da.focal_row32 = p->db.pcg_F32 + (size_t)fo * p->ds.ld; else da.focal_row = p->solver.Sfull + (size_t)fo * p->ds.ld;
+                da.bt = p->solver.vec + (size_t)8 * p->ds.ld; da.W = coarse_cg ? p->solver.W : nullptr;
+                da.flags = p->solver.flags; da.info = p->d_info; da.tol = cg_tol;
+                da.anchor = (!o.pcg_anchored || exact_pcg) ? 0 : first_linear_solve ? 1 : 2;
+                { const double t2 = cg_tol * cg_tol; da.cap = t2 > 0.0 ? std::max(t2, 1e-8) / t2 : 1.0; }
+                first_linear_solve = false;
+                p->dcg.x = p->solver.vec;
+                int drc = dcg_begin(p->stream, &p->dcg, da, ar_thunk, &arctx);
+                int batch = 24;
+                if (p->shard_host_iter < (int)p->solver.hist.size() && p->solver.hist[(size_t)p->shard_host_iter] > 0) batch = p->solver.hist[(size_t)p->shard_host_iter] + 2;
+                batch = std::min(batch, dcg_max);
+                if (!drc) drc = dcg_iterate(p->stream, &p->dcg, da, batch, ar_thunk, &arctx);
+                if (drc) return fail(SFMBA_ERR_HIP, "distributed CG: collective failed (rc " + std::to_string(drc) + ")");
+                dcg_launched = batch;
+            } else {
             if (x32) p->db.shard_blocks32 = reinterpret_cast<float*>(p->d_red); else p->db.shard_blocks = p->d_red;
             if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 1); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 1);
             p->db.shard_blocks = nullptr; p->db.shard_blocks32 = nullptr;
@@ -1630,6 +1684,7 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             const int it0 = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, cg_tol, o.pcg_max_iters, p->d_info, nullptr,
                                             /*finish=*/false, /*hist_key=*/p->shard_host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/true, coarse_cg);
             if (it0 < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
+            }
             DeviceBuffers dbu = p->db;
             dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
             dbu.cg_gate = p->solver.flags; dbu.cg_force = 0;
@@ -1657,7 +1712,15 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                 // the CG batch was too short (identically on every rank: same matrix, same arithmetic): more iterations, then the trio again
                 // (the early linearisation kernel behind that control kernel has returned without doing anything)
                 build_enqueued = false;
-                if (dense_pcg_more(p->stream, &p->solver, 8, nullptr) == 0) dbu.cg_force = 1;
+                if (dist_cg) {
+                    const int more = std::min(8, dcg_max - dcg_launched);
+                    if (more <= 0) dbu.cg_force = 1;
+                    else {
+                        const int drc = dcg_iterate(p->stream, &p->dcg, da, more, ar_thunk, &arctx);
+                        if (drc) return fail(SFMBA_ERR_HIP, "distributed CG: collective failed (rc " + std::to_string(drc) + ")");
+                        dcg_launched += more;
+                    }
+                } else if (dense_pcg_more(p->stream, &p->solver, 8, nullptr) == 0) dbu.cg_force = 1;
             }
             dense_pcg_note(&p->solver, p->shard_host_iter, mb[4]);
             p->shard_sum.linear_iters += mb[4];
@@ -1798,6 +1861,20 @@ int sfmba_comm_allreduce_f32(void* comm, void* device_buf, int64_t n_floats, voi
     if (!c || !a) return -1;
     const ncclResult_t r = a->AllReduce(device_buf, device_buf, (size_t)n_floats, ncclFloat, ncclSum, c->comm, static_cast<hipStream_t>(hip_stream));
     return r == ncclSuccess ? 0 : (int)r;
+}
+
+int sfmba_comm_reduce_scatter(void* comm, void* send_buf, void* recv_buf, int64_t n_values, int is_f32, void* hip_stream) {
+    sfmba_comm* c = static_cast<sfmba_comm*>(comm);
+    RcclApi* a = rccl();
+    if (!c || !a || !a->ReduceScatter) return -1;
+    const ncclResult_t r = a->ReduceScatter(send_buf, recv_buf, (size_t)n_values, is_f32 ? ncclFloat : ncclDouble, ncclSum, c->comm, static_cast<hipStream_t>(hip_stream));
+    return r == ncclSuccess ? 0 : (int)r;
+}
+
+int sfmba_problem_set_reduce_scatter(sfmba_problem* p, sfmba_reduce_scatter_fn reduce_scatter) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    p->reduce_scatter = reduce_scatter;
+    return SFMBA_OK;
 }
 
 int sfmba_shard_last_exchange(const sfmba_problem* p, int64_t out[4]) {

@@ -24,6 +24,13 @@ class _DevicePtr:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
+class _DevicePtrT:
+    """The same for any element type (typestr '<f8' / '<f4')."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 class HipShardBackend:
     """Rank-local half of the sharded solve on one MI355X."""
 
@@ -104,6 +111,7 @@ class HipShardBackend:
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+REDUCE_SCATTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 
 class RcclComm:
@@ -139,9 +147,11 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
     summ = SfmbaSummary()
     keep = None
     fn32 = None
+    rs = None
     if comm is not None:
         fn, ctx = C.cast(L.sfmba_comm_allreduce, ALLREDUCE_FN), comm._h
         fn32 = C.cast(L.sfmba_comm_allreduce_f32, ALLREDUCE_FN)
+        rs = C.cast(L.sfmba_comm_reduce_scatter, REDUCE_SCATTER_FN)
     elif dist is not None and backend.world > 1:
         by_ptr = {int(L.sfmba_shard_setup_buf(backend._h)): "setup", int(L.sfmba_shard_reduce_buf(backend._h)): "reduce",
                   int(L.sfmba_shard_scalars_buf(backend._h)): "scalars"}
@@ -158,21 +168,47 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
                 return 0
             except Exception:
                 return 1
-        fn = ALLREDUCE_FN(_cb)
+        def _any(buf, n, typestr):
+            t = backend.torch.as_tensor(_DevicePtrT(buf, n, typestr), device="cuda:%d" % backend.device)
+            with backend.torch.cuda.stream(backend.stream):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+        def _cb_generic(_ctx, buf, n, _stream):
+            try:
+                key = int(buf)
+                if key in by_ptr:
+                    backend.all_reduce(dist, by_ptr[key], group)
+                else:                              # the distributed CG's vectors: any device buffer of n doubles
+                    _any(buf, int(n), "<f8")
+                return 0
+            except Exception:
+                return 1
+
+        def _rs(_ctx, send, recv, n, is_f32, _stream):
+            # gloo has no reduce-scatter: all-reduce the whole send buffer (world chunks of n values); chunk `rank` is then in place
+            try:
+                _any(send, int(n) * backend.world, "<f4" if is_f32 else "<f8")
+                return 0
+            except Exception:
+                return 1
+        fn = ALLREDUCE_FN(_cb_generic)
         fn32 = ALLREDUCE_FN(_cb32)
-        keep = (fn, fn32)
+        rs = REDUCE_SCATTER_FN(_rs)
+        keep = (fn, fn32, rs)
         ctx = None
     else:
         fn, ctx = C.cast(None, ALLREDUCE_FN), None
     # the single-precision all-reduce is optional (exchange (B) in fp32 where the CG stores the matrix in fp32, include/sfmba.h)
     capi._check(L.sfmba_problem_set_allreduce_f32(backend._h, fn32 if fn32 is not None else C.cast(None, ALLREDUCE_FN)))
+    capi._check(L.sfmba_problem_set_reduce_scatter(backend._h, rs if rs is not None else C.cast(None, REDUCE_SCATTER_FN)))
     capi._check(L.sfmba_problem_solve_sharded(backend._h, C.byref(opt), fn, ctx, C.byref(summ)))
     del keep
     out = summ.as_dict()
     ex = (C.c_int64 * 4)()
     capi._check(L.sfmba_shard_last_exchange(backend._h, ex))
     out["exchange_bytes"] = [int(ex[0]), int(ex[1]), int(ex[2])]
-    out["exchange_b_fp32"] = bool(ex[3])
+    out["exchange_b_fp32"] = bool(ex[3] & 1)
+    out["distributed_cg"] = bool(ex[3] & 2)
     return out
 
 

@@ -26,6 +26,12 @@ CASES = {
     # the library default (AUTO: CG to 1e-12; d = 361 > 256) and the exact solver on an uneven split
     "auto_uneven": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 0, 2, dict()),
     "chol_uneven": (dict(name="cfg2", n_pt=5003), 0, 0, dict()),
+    # the CG without the redundant solve: reduce-scatter of the blocks, products from the owned blocks, one small
+    # all-reduce per CG iteration -- fp64 blocks, fp32 blocks (d = 1381 > 1280, F32J), the library default, plain block-Jacobi
+    "dist_cfg2": (dict(name="cfg2", n_pt=5003), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0, shard_distributed_cg=1)),
+    "dist_wide": (dict(name="cfg3", n_cam=230, n_pt=6001, seed=78), 1, 1, dict(shard_distributed_cg=1)),
+    "dist_auto": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 0, 2, dict(shard_distributed_cg=1)),
+    "dist_plain": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 1, 1, dict(shard_distributed_cg=1, pcg_coarse_space=-1)),
 }
 
 
@@ -158,7 +164,8 @@ def test_sharded_exchange_variants_agree(sfm, monkeypatch, linear):
 
 
 @pytest.mark.parametrize("world,case", [(2, "cfg2_uneven"), (3, "cfg2_uneven"), (4, "cfg2_uneven"), (3, "wide_uneven"), (4, "wide_uneven"),
-                                        (3, "auto_uneven"), (4, "chol_uneven")])
+                                        (3, "auto_uneven"), (4, "chol_uneven"),
+                                        (2, "dist_cfg2"), (3, "dist_cfg2"), (4, "dist_wide"), (3, "dist_auto"), (2, "dist_plain")])
 def test_multi_rank_uneven_sharded_hip_solve(sfm, oracle, world, case):
     """2, 3 and 4 ranks (processes) on the one MI355X of the box, point counts the world size does not divide
     (shards of different sizes), native C loop with the collectives through the callback -- against the ORACLE's solve of the whole
@@ -181,6 +188,7 @@ def test_multi_rank_uneven_sharded_hip_solve(sfm, oracle, world, case):
     assert ranges[0][0] == 0 and ranges[-1][1] == prob.n_pt and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
     assert len({hi - lo for lo, hi in ranges}) > 1                       # genuinely uneven
     cam0, f0, s0 = results[0][2], results[0][4], results[0][1]
+    assert s0["distributed_cg"] == case.startswith("dist_")
     for r in results[1:]:
         assert np.array_equal(r[2], cam0) and r[4] == f0 and r[1]["final_cost"] == s0["final_cost"]     # replicas bit-identical
         for a, b in zip(results[0][6], r[6]):
