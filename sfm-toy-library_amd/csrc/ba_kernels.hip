@@ -22,8 +22,8 @@ namespace sfmba {
 #define BLK 256
 
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    v = fmax(v, xlane_get<32>(v)); v = fmax(v, xlane_get<16>(v)); v = fmax(v, xlane_get<8>(v));
+    v = fmax(v, xlane_get<4>(v)); v = fmax(v, xlane_get<2>(v)); v = fmax(v, xlane_get<1>(v));
     return v;
 }
 
@@ -35,9 +35,7 @@ __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; 
 template <int N>
 __device__ __forceinline__ double block_sums(double (&v)[N], double* scratch) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int k = 0; k < N; ++k) v[k] += __shfl_xor(v[k], off, 64);
+    for (int k = 0; k < N; ++k) v[k] = wave_allsum(v[k]);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) {
 #pragma unroll
@@ -68,8 +66,9 @@ __device__ double slots_take(const DeviceBuffers& db, int which) {
             *p = 0.0;
             v = (o > v || o != o) ? o : v;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = (o > v || o != o) ? o : v; }
+#define SFMBA_MAXSTEP(OFF) { const double o = xlane_get<OFF>(v); v = (o > v || o != o) ? o : v; }
+        SFMBA_MAXSTEP(32) SFMBA_MAXSTEP(16) SFMBA_MAXSTEP(8) SFMBA_MAXSTEP(4) SFMBA_MAXSTEP(2) SFMBA_MAXSTEP(1)
+#undef SFMBA_MAXSTEP
         return v;
     }
     double v = 0.0;
@@ -109,14 +108,12 @@ __device__ __forceinline__ void slots_take_n(const DeviceBuffers& db, const int 
                 }
             }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double o = __shfl_xor(v[k], off, 64);
-            if (which[k] == ACC_GMAX) v[k] = (o > v[k] || o != o) ? o : v[k]; else v[k] += o;
-        }
-    }
+#define SFMBA_TAKE_STEP(OFF) \
+    _Pragma("unroll") for (int k = 0; k < N; ++k) { \
+        const double o = xlane_get<OFF>(v[k]); \
+        if (which[k] == ACC_GMAX) v[k] = (o > v[k] || o != o) ? o : v[k]; else v[k] += o; }
+    SFMBA_TAKE_STEP(32) SFMBA_TAKE_STEP(16) SFMBA_TAKE_STEP(8) SFMBA_TAKE_STEP(4) SFMBA_TAKE_STEP(2) SFMBA_TAKE_STEP(1)
+#undef SFMBA_TAKE_STEP
 #pragma unroll
     for (int k = 0; k < N; ++k) out[k] = v[k];
 }
@@ -670,9 +667,19 @@ struct HalvingReduceT {
         for (int k = 0; k < H; ++k) {
             const V lo = v[k];
             const V hi = (H + k < N) ? v[H + k] : (V)0;
-            const V send = up ? lo : hi;
-            const V keep = up ? hi : lo;
-            v[k] = keep + __shfl_xor(send, OFF, 64);
+            if constexpr (sizeof(V) == 8) {
+                // fp64 (camera pass: 24 doubles): through the LDS pipe as before.  The permlane / DPP forms cost that pass its occupancy
+                // (62 -> 144 registers: two registers in and two out per swapped word), and it is bound by loads in flight, not by issue.
+                const V send = up ? lo : hi;
+                const V keep = up ? hi : lo;
+                v[k] = keep + __shfl_xor(send, OFF, 64);
+            } else if constexpr (OFF >= 16) {
+                v[k] = xlane_pairsum<OFF>(lo, hi);                           // the swap does the selects (sfmba_device.h)
+            } else {
+                const V send = up ? lo : hi;
+                const V keep = up ? hi : lo;
+                v[k] = keep + xlane_get<OFF>(send);                          // partner: lane ^ OFF (lane ^ 7 at OFF = 4)
+            }
         }
         base += up ? H : 0;
         len = up ? len - H : (len < H ? len : H);
@@ -1050,8 +1057,10 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
         const T r0 = s == 0 ? acc[c] : s == 1 ? acc[6 + c] : s == 2 ? acc[12 + c] : acc[18 + c];
         const T r1 = s == 0 ? acc[24 + c] : s == 1 ? acc[30 + c] : (T)0;
         double v = (double)r0, w2 = (double)r1;
-#pragma unroll
-        for (int off = 4; off < LPB; off <<= 1) { v += __shfl_xor(v, off, 64); w2 += __shfl_xor(w2, off, 64); }
+        // (the quad sums are replicated over the quad: any lane of the partner quad will do -- lane ^ 7 at the first level, sfmba_device.h)
+        if (LPB > 4) { v = xlane_add<4>(v); w2 = xlane_add<4>(w2); }
+        if (LPB > 8) { v = xlane_add<8>(v); w2 = xlane_add<8>(w2); }
+        static_assert(LPB <= 16, "lane group of the small-block pair pass");
         accd[c] = v; accd[6 + c] = w2;
     }
     const double* sa = db.cscale + 6 * cj.x;
@@ -1108,9 +1117,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
 #define CD_OBS (SFMBA_CAM_CHUNK / CD_BLK)
 static_assert(SFMBA_CAM_CHUNK % CD_BLK == 0, "camera chunk length");
 
-// the 47 terms one observation contributes to its camera's diagonal block, focal column, gradient and right-hand side, from its packed
+// the 47 terms (ACCUM: added to v, else stored) one observation contributes to its camera's diagonal block, focal column, gradient and right-hand side, from its packed
 // record and side values z = {C t (2), C y_f (2), residual (2)} -- shared by the record-gathering and the re-evaluating camera pass
-template <typename T>
+template <typename T, bool ACCUM>
 __device__ __forceinline__ void cam_diag_terms(const T (&rec)[YREC], const T (&z)[8], const double* __restrict__ cscale6, T fscale, T (&v)[CD_N]) {
         T A[12];
         rec_camera_block<T>(rec, A);
@@ -1129,18 +1138,18 @@ __device__ __forceinline__ void cam_diag_terms(const T (&rec)[YREC], const T (&z
         for (int a = 0; a < 6; ++a) {
             const T p0 = n00 * A[a] + n01 * A[6 + a], p1 = n01 * A[a] + n11 * A[6 + a];
 #pragma unroll
-            for (int b = a; b < 6; ++b) v[u++] += p0 * A[b] + p1 * A[6 + b];
+            for (int b = a; b < 6; ++b) { const T t_ = p0 * A[b] + p1 * A[6 + b]; if (ACCUM) v[u] += t_; else v[u] = t_; ++u; }
         }
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             const T ar = A[a] * r0 + A[6 + a] * r1;
-            v[21 + a] += A[a] * A[a] + A[6 + a] * A[6 + a];                               // undamped diagonal
-            v[27 + a] += (A[a] * g0 + A[6 + a] * g1) - (A[a] * cy0 + A[6 + a] * cy1);     // S[j,f]
-            v[33 + a] += ar;                                                              // b_c (scaled gradient)
-            v[39 + a] += ar - (A[a] * ct0 + A[6 + a] * ct1);                              // reduced rhs
+            { const T t_ = A[a] * A[a] + A[6 + a] * A[6 + a]; if (ACCUM) v[21 + a] += t_; else v[21 + a] = t_; }                               // undamped diagonal
+            { const T t_ = (A[a] * g0 + A[6 + a] * g1) - (A[a] * cy0 + A[6 + a] * cy1); if (ACCUM) v[27 + a] += t_; else v[27 + a] = t_; }     // S[j,f]
+            { const T t_ = ar; if (ACCUM) v[33 + a] += t_; else v[33 + a] = t_; }                                                              // b_c (scaled gradient)
+            { const T t_ = ar - (A[a] * ct0 + A[6 + a] * ct1); if (ACCUM) v[39 + a] += t_; else v[39 + a] = t_; }                              // reduced rhs
         }
-        v[45] += g0 * g0 + g1 * g1;
-        v[46] += g0 * r0 + g1 * r1;
+        { const T t_ = g0 * g0 + g1 * g1; if (ACCUM) v[45] += t_; else v[45] = t_; }
+        { const T t_ = g0 * r0 + g1 * r1; if (ACCUM) v[46] += t_; else v[46] = t_; }
 }
 
 // sums of the 47 terms over the workgroup (fp64: halving butterfly inside the wave, LDS across the waves) and one atomic per value
@@ -1156,7 +1165,7 @@ __device__ __forceinline__ void cam_diag_finish(const DeviceStructure& ds, const
         for (int k = 0; k < CD_N / 2; ++k) {
             const T lo = v[k], hi = v[CD_N / 2 + k];
             const T send = up ? lo : hi, keep = up ? hi : lo;
-            acc[k] = (double)keep + (double)__shfl_xor(send, 32, 64);
+            acc[k] = (double)keep + (double)__shfl_xor(send, 32, 64);        // (LDS pipe: see HalvingReduceT, fp64)
         }
     }
     int base = (lane & 32) ? CD_N / 2 : 0, len = CD_N / 2;
@@ -1220,7 +1229,7 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
                 z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)b.x; z[3] = (T)b.y; z[4] = (T)c.x; z[5] = (T)c.y;
             }
         }
-        cam_diag_terms<T>(rec, z, db.cscale + 6 * j, fscale, v);
+        cam_diag_terms<T, (CD_OBS > 1)>(rec, z, db.cscale + 6 * j, fscale, v);
     }
     cam_diag_finish<T>(ds, db, j, v, red);
 }
@@ -1260,7 +1269,7 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
         z[2] = rec[9] * pb.yf[0] + rec[10] * pb.yf[1] + rec[11] * pb.yf[2];
         z[3] = rec[12] * pb.yf[0] + rec[13] * pb.yf[1] + rec[14] * pb.yf[2];
         z[4] = rr.x; z[5] = rr.y; z[6] = (T)0; z[7] = (T)0;
-        cam_diag_terms<T>(rec, z, db.cscale + 6 * j, fscale, v);
+        cam_diag_terms<T, (CD_OBS > 1)>(rec, z, db.cscale + 6 * j, fscale, v);
     }
     cam_diag_finish<T>(ds, db, j, v, red);
 }

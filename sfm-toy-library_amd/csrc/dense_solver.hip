@@ -762,8 +762,7 @@ __global__ __launch_bounds__(64) void k_pcg_transform(const double* __restrict__
 }
 
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    { a = wave_allsum(a); b = wave_allsum(b); }
     const int w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
@@ -853,8 +852,7 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(int d, int ld, const FT* __r
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) {
             double v = acc[r][k];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            v = wave_allsum(v);
             if (lane == k) { AW[(size_t)row * PCG_NW + k] = v; awrow[w][k] = v; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -889,9 +887,7 @@ __device__ __forceinline__ void coarse_sum_partials(int nwg, const double* __res
             for (int i = 0; i < 2; ++i) part[m] += (i0 + lane + 64 * i < nwg) ? t[m][i] : 0.0;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int m = 0; m < 18; ++m) part[m] += __shfl_xor(part[m], off, 64);
+    for (int m = 0; m < 18; ++m) part[m] = wave_allsum(part[m]);
     if (lane == 0) {
 #pragma unroll
         for (int m = 0; m < 18; ++m) tot[w + 4 * m] = part[m];
@@ -953,9 +949,7 @@ template <int NV>
 __device__ __forceinline__ void reduce_partials(double (&mine)[3], double* red) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) if (4 * j < NV) mine[j] += __shfl_xor(mine[j], off, 64);
+    for (int j = 0; j < 3; ++j) if (4 * j < NV) mine[j] = wave_allsum(mine[j]);
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) if (w + 4 * j < NV) red[w + 4 * j] = mine[j];
@@ -1025,8 +1019,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
     if (INIT) {
         double rr = 0.0;
         for (int e = tid; e < d; e += 256) { const double v = bt[e]; pl[e] = v; rr += v * v; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
+        rr = wave_allsum(rr);
         if (lane == 0) red[16 + w] = rr;
         __syncthreads();
         rr = red[16] + red[17] + red[18] + red[19];
@@ -1077,8 +1070,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
         const double cmu = COARSE ? dot8(c_new, mu_new) : 0.0;
         double rrn = 0.0;
         for (int e = tid; e < d; e += 256) { const double v = r_in[e] - alpha * q_in[e]; pl[e] = v; rrn += v * v; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rrn += __shfl_xor(rrn, off, 64);
+        rrn = wave_allsum(rrn);
         if (lane == 0) red[16 + w] = rrn;
         // x += alpha p  with p = p_r + W~ p_mu, own rows
         for (int e = row0 + tid; e < row1; e += 256) {
@@ -1182,8 +1174,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
+        { sa = wave_allsum(sa); sb = wave_allsum(sb); }
         if (lane == 0) {
             q_out[row] = sa; pqp += pl[row] * sa;
             if (rowb != row) { q_out[rowb] = sb; pqp += pl[rowb] * sb; }
@@ -1311,8 +1302,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         double rr = 0.0;
 #pragma unroll
         for (int m = 0; m < PCG_EPT; ++m) rr += rv[m] * rv[m];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rr += __shfl_xor(rr, off, 64);
+        rr = wave_allsum(rr);
         if (lane == 0) red[16 + w] = rr;
         __syncthreads();
         rr = red[16] + red[17] + red[18] + red[19];
@@ -1343,8 +1333,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         double rrn = 0.0;
 #pragma unroll
         for (int m = 0; m < PCG_EPT; ++m) { rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) rrn += __shfl_xor(rrn, off, 64);
+        rrn = wave_allsum(rrn);
         if (lane == 0) red[16 + w] = rrn;
         const double cmu = COARSE ? dot8(c_new, mu_new) : 0.0;
         if (own) {                                       // x += alpha (p_r + W~ p_mu)
@@ -1393,8 +1382,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             sacc2 = fma(fv[k][m].y, pv2.y, sacc2);
         }
         sacc += sacc2;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+        sacc = wave_allsum(sacc);
         if (lane == 0 && row < row1) { q_out[row] = sacc; pqp += pl[row] * sacc; }
         if (COARSE && lane >= PCG_NW && lane < 2 * PCG_NW && row < row1) gacc = fma(awv[k], sacc, gacc);
     }
@@ -1458,11 +1446,9 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_fast(int d, int ld, const do
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+    for (int r = 0; r < PCG_RPW; ++r)
 #pragma unroll
-        for (int r = 0; r < PCG_RPW; ++r)
-#pragma unroll
-            for (int k = 0; k < PCG_NW; ++k) acc[r][k] += __shfl_xor(acc[r][k], off, 64);
+        for (int k = 0; k < PCG_NW; ++k) acc[r][k] = wave_allsum(acc[r][k]);
     double e_acc = 0.0, c_acc = 0.0;
 #pragma unroll
     for (int r = 0; r < PCG_RPW; ++r) {
@@ -1570,8 +1556,7 @@ __global__ __launch_bounds__(256) void k_pcg_persistent(int d, int ld, const dou
                     sacc2 = fma(fv[k][m].y, pv2.y, sacc2);
                 }
                 sacc += sacc2;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off, 64);
+                sacc = wave_allsum(sacc);
                 if (lane < 2 && row < row1) {                  // lane 0: low half, lane 1: high half -- one aligned 8-byte store each
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
                     const unsigned half = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);

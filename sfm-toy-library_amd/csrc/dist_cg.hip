@@ -20,9 +20,7 @@ template <typename FT> __device__ __forceinline__ double ld_val(const FT* p, siz
 template <int N>
 __device__ __forceinline__ void block_sums_all(double (&v)[N], double* sh) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int k = 0; k < N; ++k) v[k] += __shfl_xor(v[k], off, 64);
+    for (int k = 0; k < N; ++k) v[k] = wave_allsum(v[k]);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     __syncthreads();
     if (lane == 0) {
@@ -74,9 +72,7 @@ __global__ __launch_bounds__(256) void k_dcg_spmv(int ncam, int row0, int row1, 
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+    for (int k = 0; k < 6; ++k) acc[k] = wave_allsum(acc[k]);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) {
 #pragma unroll

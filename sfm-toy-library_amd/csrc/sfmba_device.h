@@ -103,11 +103,76 @@ template <typename T> struct ObsXY;
 template <> struct ObsXY<float>  { typedef float2 type; };
 template <> struct ObsXY<double> { typedef double2 type; };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// ---- cross-lane exchange without the LDS pipe ----
+// __shfl_xor compiles to ds_bpermute_b32: measured 24 cycles of SIMD time per shuffle with every wave shuffling (tools/micro/pk_bench.hip;
+// a plain VALU instruction: 4-5), i.e. the 38 shuffles of a 36-value halving butterfly were ~10 % of a pair-pass wave and the 94 of the
+// camera pass's 24 doubles more than a third of it.  gfx950 has everything needed in the VALU: DPP quad permutes (lane ^ 1, lane ^ 2),
+// row_half_mirror (lane ^ 7: a partner across bit 2, which is all a butterfly needs), row_ror:8 (lane ^ 8 inside a row of 16) and the
+// v_permlane16_swap / v_permlane32_swap pair for the two top levels (verified on the hardware: tools/micro/permtest).
+// "partner(OFF)" below: lane ^ OFF for OFF = 1, 2, 8, 16, 32 and lane ^ 7 for OFF = 4.
+template <int OFF> __device__ __forceinline__ int xlane_get_i(int v) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "butterfly level");
+    if (OFF == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);       // quad_perm [1,0,3,2]
+    if (OFF == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);       // quad_perm [2,3,0,1]
+    if (OFF == 4) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);      // row_half_mirror
+    if (OFF == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);      // row_ror:8
+    const bool up = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & OFF) != 0;
+    if (OFF == 16) { const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); return (int)(up ? r[0] : r[1]); }
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(up ? r[0] : r[1]);
+}
+template <int OFF> __device__ __forceinline__ float xlane_get(float v) { return __int_as_float(xlane_get_i<OFF>(__float_as_int(v))); }
+template <int OFF> __device__ __forceinline__ double xlane_get(double v) {
+    return __hiloint2double(xlane_get_i<OFF>(__double2hiint(v)), xlane_get_i<OFF>(__double2loint(v)));
+}
+// v[lane] + v[partner(OFF)].  The two top levels need no select at all: after swap(A, B) the two registers hold, lane by lane, the
+// lane's own value and its partner's (in one order or the other) -- their sum is the same either way.
+template <int OFF> __device__ __forceinline__ float xlane_add(float v) {
+    if (OFF >= 16) {
+        const unsigned b = (unsigned)__float_as_int(v);
+        if (OFF == 16) { const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false); return __int_as_float((int)r[0]) + __int_as_float((int)r[1]); }
+        const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+        return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+    }
+    return v + xlane_get<OFF>(v);
+}
+template <int OFF> __device__ __forceinline__ double xlane_add(double v) {
+    if (OFF >= 16) {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        if (OFF == 16) {
+            const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+        }
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v + xlane_get<OFF>(v);
+}
+// Halving step of the two top levels: lanes with bit OFF clear end up with lo[lane] + lo[partner], the others with hi[lane] + hi[partner]
+// -- ONE swap and one add per value pair (the selects of the generic step are done by the swap itself).
+template <int OFF> __device__ __forceinline__ float xlane_pairsum(float lo, float hi) {
+    static_assert(OFF == 16 || OFF == 32, "swap levels");
+    const unsigned a = (unsigned)__float_as_int(lo), b = (unsigned)__float_as_int(hi);
+    if (OFF == 16) { const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); return __int_as_float((int)r[0]) + __int_as_float((int)r[1]); }
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+}
+template <int OFF> __device__ __forceinline__ double xlane_pairsum(double lo, double hi) {
+    static_assert(OFF == 16 || OFF == 32, "swap levels");
+    const unsigned al = (unsigned)__double2loint(lo), ah = (unsigned)__double2hiint(lo), bl = (unsigned)__double2loint(hi), bh = (unsigned)__double2hiint(hi);
+    if (OFF == 16) {
+        const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false), h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false), h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+// the sum over the wave, in every lane
+template <typename V> __device__ __forceinline__ V wave_allsum(V v) {
+    v = xlane_add<32>(v); v = xlane_add<16>(v); v = xlane_add<8>(v); v = xlane_add<4>(v); v = xlane_add<2>(v); v = xlane_add<1>(v);
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) { return wave_allsum(v); }
 
 // Block-wide sum of `v`; result valid in thread 0.  `scratch` holds >= blockDim.x/64 doubles.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
