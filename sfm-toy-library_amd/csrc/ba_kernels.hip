@@ -1057,10 +1057,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
         const T r0 = s == 0 ? acc[c] : s == 1 ? acc[6 + c] : s == 2 ? acc[12 + c] : acc[18 + c];
         const T r1 = s == 0 ? acc[24 + c] : s == 1 ? acc[30 + c] : (T)0;
         double v = (double)r0, w2 = (double)r1;
-        // (the quad sums are replicated over the quad: any lane of the partner quad will do -- lane ^ 7 at the first level, sfmba_device.h)
-        if (LPB > 4) { v = xlane_add<4>(v); w2 = xlane_add<4>(w2); }
-        if (LPB > 8) { v = xlane_add<8>(v); w2 = xlane_add<8>(w2); }
-        static_assert(LPB <= 16, "lane group of the small-block pair pass");
+        // (a true lane ^ off exchange: lane s of every quad carries row s -- the lane ^ 7 partner of the VALU butterfly would mix the rows)
+#pragma unroll
+        for (int off = 4; off < LPB; off <<= 1) { v += __shfl_xor(v, off, 64); w2 += __shfl_xor(w2, off, 64); }
         accd[c] = v; accd[6 + c] = w2;
     }
     const double* sa = db.cscale + 6 * cj.x;
