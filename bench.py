@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--sharded-extras", type=int, default=-1,
                     help="after the headline run also time ONE problem sharded over all ranks (cfg3 and cfg5) with the RCCL all-reduce "
                          "of the reduced camera system: 1 = yes, 0 = no, -1 (default) = only when N > 1")
-    ap.add_argument("--extras-timeout", type=int, default=240, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
+    ap.add_argument("--distributed-cg", action="store_true", help="--mode sharded: the CG without the redundant solve (reduce-scatter + one small all-reduce per CG iteration)")
+    ap.add_argument("--extras-timeout", type=int, default=300, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=0, help="LM iterations of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = swept upwards from 16 while it still gets faster; "
@@ -305,10 +306,13 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         for wl in (["cfg3", "cfg5"] if args.workload == "cfg3" else [args.workload]):
-            try:
-                sh[wl] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)))
-            except Exception as e:                       # never lose the headline line to the extras
-                sh[wl] = {"error": "%s: %s" % (type(e).__name__, e)}
+            for variant in ("replicated_cg", "distributed_cg"):          # both forms of the reduced-system solve
+                key = wl if variant == "replicated_cg" else wl + "_distributed_cg"
+                try:
+                    sh[key] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)),
+                                          distributed=(variant == "distributed_cg"))
+                except Exception as e:                       # never lose the headline line to the extras
+                    sh[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         watchdog.cancel()
     if rank == 0:
         if sh is not None:
@@ -319,14 +323,15 @@ def main():
         dist.destroy_process_group()
 
 
-def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps):
+def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps, distributed=False):
     """ONE problem, points sharded over the ranks; the LM loop runs inside the C library (sfmba_problem_solve_sharded) with
     ncclAllReduce on the solver's stream (sharded.RcclComm); every rank times the same K solves.  Returns the result dict."""
     from sfm_toy_library_amd import sharded
     import ctypes as C
     prob = sfm.make_problem(workload)
     be = sharded.HipShardBackend(prob, rank, world, device=local_rank, precision=precision)
-    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol)
+    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol,
+                               shard_distributed_cg=1 if distributed else 0)
     comm = sharded.RcclComm(dist, rank, world, device=local_rank)
 
     def barrier():
@@ -368,7 +373,14 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
         if dist is not None and world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         g_dt, g_ar = [float(v) for v in tmax.tolist()]
+        dist_note = None
+        if summ.get("distributed_cg"):
+            dist_note = ("reduce-scatter of the upper-triangle blocks of the preconditioned matrix into ranges of block rows (%d bytes in the buffer, a rank "
+                         "receives 1 / %d of it), then per CG iteration ONE all-reduce of %d doubles (the partial product from the owned blocks); "
+                         "vector updates replicated" % (ex_bytes[1], world, ld))
         return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
+                "reduced_system_solve": "distributed CG (no redundant solve)" if summ.get("distributed_cg") else "every rank runs the CG on the summed matrix (redundant)",
+                "distributed_cg_exchange": dist_note,
                 "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
                 "ms_per_step": 1e3 * g_dt / steps, "lm_iterations_per_step": iters / steps,
                 "allreduce_bytes_per_lm_iteration": int(sum(ex_bytes)),
@@ -387,7 +399,7 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
 
 def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear):
     """--mode sharded: the sharded run IS the headline line (strong scaling)."""
-    r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps)
+    r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps, distributed=args.distributed_cg)
     if rank == 0:
         print(json.dumps({
             "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
