@@ -60,7 +60,9 @@ enum { SFMBA_LINEAR_CHOLESKY = 0,   /* exact Schur + dense LLT == DENSE_SCHUR (B
                                        -- the step then agrees with the factorised solve to ~1e-10 relative, below what the float
                                        containers of adjustBundle() resolve -- and, if the CG has not converged after
                                        pcg_max_iters (0 = min(4 dim, 200)) iterations or breaks down, the SAME linearisation is solved
-                                       by CHOLESKY instead (the matrix is re-formed unpreconditioned; nothing is skipped). */
+                                       by CHOLESKY instead (the matrix is re-formed unpreconditioned; nothing is skipped).  A linearisation
+                                       that needed more CG iterations than a factorisation costs (~3.3 per block column of 64) makes the
+                                       following ones go straight to CHOLESKY, for as long as the problem's structure stays. */
 
 enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
        SFMBA_PRECISION_F32J = 1 };  /* fp32 Jacobian blocks AND fp32 observation coordinates (BASELINE config 3; the reference's

@@ -233,6 +233,7 @@ struct sfmba_problem {
     int cur = 0;                                  // which buffer holds the current parameters
     double focal = 0.0;
     bool empty = false;                           // no observations
+    bool auto_prefers_cholesky = false;           // AUTO: the CG of the last linearisation cost more than a factorisation would have (sticky until the structure changes)
     bool poisoned = false;                        // an append failed half way: only sfmba_problem_destroy is valid (include/sfmba.h)
     // sharded-mode state
     sfmba_options shard_opt;
@@ -371,14 +372,19 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // solve is launch-bound; with the gauge coarse space the launch-per-iteration path needs half the iterations and is as fast or
     // faster at every size measured (cfg 4, d = 151: 4990 vs 4820 LM it/s; cfg 2: 6300 vs 6220; 7 views: 6170 vs 6380), and it has
     // no device-wide spin barrier in it.
-    const bool pcg = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
+    const bool pcg_mode = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
     // AUTO above 256 unknowns = the DENSE_SCHUR result through the CG: plain relative residual <= 1e-12, bounded iteration count,
     // Cholesky on the same linearisation if the CG does not get there (include/sfmba.h)
-    const bool exact_pcg = pcg && o.linear_solver == SFMBA_LINEAR_AUTO;
+    const bool exact_pcg = pcg_mode && o.linear_solver == SFMBA_LINEAR_AUTO;
     const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
     const int cg_max_iters = exact_pcg ? (o.pcg_max_iters > 0 ? o.pcg_max_iters : std::min(4 * p->ds.d, 200)) : o.pcg_max_iters;
     const bool anchored_cg = !exact_pcg && o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
     const bool gated_cg = gated_env || exact_pcg;        // (the fallback is decided where the gated loop learns that the batch was too short)
+    // AUTO picks per LM iteration: the CG while it is the cheaper way to the DENSE_SCHUR result, the factorisation once a linearisation
+    // has needed more CG iterations than a factorisation costs (measured at d = 1201: 0.41 ms against 6.4 us per iteration = ~64
+    // iterations; uniform co-visibility needs 14 per LM iteration, a banded reduced system ~160 -- profiles/r03_*_banded_*).
+    const int nblk64 = p->ds.ld / 64;
+    const int cg_break_even = std::max(30, (nblk64 <= 40 ? 33 : 20) * nblk64 / 10);
     const bool persistent_cg = !exact_pcg && option_switch(o.pcg_persistent, "SFMBA_PCG_PERSISTENT", false);
     int launched_controls = 0;
     const bool speculate = option_switch(o.early_linearise, "SFMBA_EARLY_LINEARISE", true) && !p->prof.on;
@@ -390,6 +396,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
+        const bool pcg = pcg_mode && !(exact_pcg && p->auto_prefers_cholesky);
         if (pcg) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
@@ -496,6 +503,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 lin_hist.push_back(it);
             } else if (pcg_gated || (pcg && exact_pcg && dbu.cg_gate == nullptr)) {
                 const int it = (pcg_gated || dbu.pcg_vec) ? mb[4] : p->solver.run.launched;      // after a fallback: the launches that were spent
+                if (exact_pcg && it > cg_break_even) p->auto_prefers_cholesky = true;              // the next linearisations are factorised
                 dense_pcg_note(&p->solver, (int)lin_hist.size(), it);
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
@@ -1007,6 +1015,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     if (build_report[0] < 0 || (((long long)build_report[3] << 32) | (unsigned)build_report[2]) != npair_total)
         return fail(SFMBA_ERR_HIP, "structure build: the device's pair count differs from the host's");
     ds.ndupwg = build_report[0];
+    p->auto_prefers_cholesky = false;
     bt_mark("wait for device");
     return sfmba_problem_reset(p);
 }

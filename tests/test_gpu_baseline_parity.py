@@ -190,3 +190,40 @@ def test_cfg5_real_one_rank_sharded_matches_oracle(capi, sfm, cfg5, cfg5_oracle,
     assert abs(s["final_cost"] - want[3]["final_cost"]) <= 1e-6 * want[3]["final_cost"]
     assert abs(rms(s["final_cost"], cfg5.n_obs) - rms(want[3]["final_cost"], cfg5.n_obs)) < 1e-4
     assert np.abs(cam - want[0]).max() <= 2e-5 and np.abs(pt - want[1]).max() <= 2e-5 and np.isclose(f, want[2], rtol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# realistic co-visibility: cameras on a path, every point seen by a run of 2..30 neighbouring cameras
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def banded(sfm):
+    return sfm.make_problem("cfg3_banded")
+
+
+@pytest.fixture(scope="module")
+def banded_oracle(sfm, oracle, banded):
+    return oracle.solve(banded, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+
+
+def test_banded_visibility_bench_mode_and_default_match_oracle(capi, sfm, banded, banded_oracle):
+    """cfg3_banded: 200 cameras / 100k points / ~1M observations, banded reduced system with a few very heavy blocks (up to ~10^4 pairs:
+    the fp64 flush of the pair pass) and ~90 CG iterations per LM iteration.  Bench mode (F32J, two-level PCG 1e-8 anchored), the library
+    default (AUTO: starts on the CG, sees that a linearisation costs more CG iterations than a factorisation and factorises from there on)
+    and the exact fp64 configuration."""
+    assert banded.n_cam == 200 and 950000 < banded.n_obs < 1050000
+    k = np.bincount(banded.obs_pt)
+    assert k.min() >= 2 and k.max() <= 30 and abs(k.mean() - 10.0) < 0.2
+    with capi.Problem(banded, precision=1) as P:
+        s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=1, linear_solver=1))
+        cam, pt, f = P.get_params()
+        assert_same_solve(banded, (cam, pt, f, s, tr), banded_oracle, param_atol=5e-5, trace_rtol=5e-5)
+        P.reset()
+        s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=1))                    # AUTO
+        cam, pt, f = P.get_params()
+        assert_same_solve(banded, (cam, pt, f, s, tr), banded_oracle, param_atol=5e-5, trace_rtol=5e-5)
+        assert tr[1]["linear_iters"] > 60 and all(r["linear_iters"] == 0 for r in tr[2:])      # one linearisation on the CG, the rest factorised
+        P.reset()
+        s2, tr2 = P.solve(capi.default_options(max_seconds=0.0, precision=1))                  # the preference is remembered with the structure
+        assert s2["linear_iters"] == 0 and abs(s2["final_cost"] - s["final_cost"]) <= 1e-9 * s["final_cost"]
+    got = capi.solve(banded, capi.default_options(max_seconds=0.0, precision=0, linear_solver=0))
+    assert_same_solve(banded, got, banded_oracle, param_atol=1e-7, cost_rtol=1e-9)
