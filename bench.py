@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--distributed-cg", action="store_true", help="--mode sharded: the CG without the redundant solve (reduce-scatter + one small all-reduce per CG iteration)")
     ap.add_argument("--extras-timeout", type=int, default=300, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not spawn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic live; the committed "
+                         "profiles/*_pmc_traffic.txt summary is used instead")
     ap.add_argument("--cpu-iters", type=int, default=0, help="LM iterations of the CPU sample (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = swept upwards from 16 while it still gets faster; "
                                                                "nproc itself is 650x SLOWER than 16 threads on the 256-thread box, see cpu_baseline())")
@@ -262,6 +265,8 @@ def main():
         line["whole_iteration_hbm"] = {"algorithmic_bytes_per_iteration": b_iter,
                                        "achieved_GBps": b_iter * (g_iters / world) / g_dt / 1e9,
                                        "frac_of_8TBps": b_iter * (g_iters / world) / g_dt / 8.0e12}
+        if world == 1 and not args.no_live_traffic:
+            globals()["LIVE_PMC"] = live_pmc_passes(args)
         line["roofline"] = roofline_entry(profile, prob, precision)
         line["roofline_all_kernels"] = roofline_entry(profile, prob, precision, all_kernels=True)
         line["ms_per_step_with_event_bracketing"] = 1e3 * dt_prof / args.steps
@@ -418,25 +423,80 @@ PMC_KERNEL_NAMES = {"pcg_iter": "k_pcg_iter_fast", "schur_pairs": "k_schur_pairs
                     "chol_update": "k_chol_update"}
 
 
+LIVE_PMC = None      # {kernel name as rocprofv3 prints it: (FETCH_SIZE KB, WRITE_SIZE KB) per launch}, filled by live_pmc_passes()
+
+
+def live_pmc_passes(args):
+    """roofline.traffic measured by THIS run: two child runs of this script (2 steps, 1 warm-up, same workload and solver) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- separate passes, counters only, as
+    MI355X_MICROARCH.md's HBM section prescribes.  Returns None (and the committed summary is used) when rocprofv3 is missing,
+    a pass fails or takes longer than 150 s."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if os.environ.get("SFMBA_BENCH_PMC_CHILD") or shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):      # this run is itself being profiled: no nested profiler
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_summary import per_kernel
+    out = {}
+    env = dict(os.environ, SFMBA_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="sfmba_pmc_", dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic",
+                   "--workload", args.workload, "--linear", args.linear, "--precision", args.precision, "--pcg-tol", repr(args.pcg_tol)]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)      # the process group started here, nothing else
+                proc.wait()
+                return None
+            if rc != 0:
+                return None
+            vals = per_kernel(d, counter)
+            if not vals:
+                return None
+            out[counter] = vals
+    names = set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"])
+    return {"kernels": {k: (out["FETCH_SIZE"].get(k, 0.0), out["WRITE_SIZE"].get(k, 0.0)) for k in names},
+            "seconds": time.perf_counter() - t0}
+
+
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc summary of the same
-    command (profiles/; PMC passes cannot be collected from inside bench.py).  FETCH_SIZE is doubled for the
+    """HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE): from the two rocprofv3 --pmc passes this run spawned
+    (live_pmc_passes), else from the committed summary of the same command under profiles/.  FETCH_SIZE is doubled for the
     streaming kernels as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")))
     want = PMC_KERNEL_NAMES.get(kernel)
-    if not files or not want:
+    if not want:
+        return None
+    wide = kernel in ("pcg_iter", "point_build", "point_update")     # 16-byte-per-lane coalesced streams
+
+    def entry(fetch_kb, write_kb, source, live):
+        return {"bytes": (fetch_kb * (2.0 if wide else 1.0) + write_kb) * 1024.0, "fetch_kb": fetch_kb, "write_kb": write_kb,
+                "fetch_x2_correction": wide, "source": source, "live": live}
+    if LIVE_PMC is not None:
+        hits = [v for k, v in LIVE_PMC["kernels"].items() if want in k]
+        if hits:
+            # several instantiations of one kernel (k_schur_pairs<..., MODE, ...>): the one that moves the most is the per-iteration pass
+            f, w = max(hits, key=lambda v: v[0] + v[1])
+            return entry(f, w, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run (%.0f s)" % LIVE_PMC["seconds"], True)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")))
+    if not files:
         return None
     for line in open(files[-1]):
         if want in line and not line.startswith("#"):
             parts = line.split()
             try:
-                fetch_kb, write_kb = float(parts[-2]), float(parts[-1])
+                return entry(float(parts[-2]), float(parts[-1]), os.path.basename(files[-1]), False)
             except ValueError:
                 return None
-            wide = kernel in ("pcg_iter", "point_build", "point_update")     # 16-byte-per-lane coalesced streams
-            return {"bytes": (fetch_kb * (2.0 if wide else 1.0) + write_kb) * 1024.0, "fetch_kb": fetch_kb, "write_kb": write_kb,
-                    "fetch_x2_correction": wide, "source": os.path.basename(files[-1])}
     return None
 
 
@@ -459,7 +519,7 @@ def roofline_one(name, profile, model, overhead_us):
     tr = pmc_traffic(name)
     base = {"kernel": name, "avg_launch_us": avg_us, "empty_event_bracket_us": overhead_us,
             "launches": profile[name]["launches"], "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr,
-            "traffic_is_static": True,          # PMC passes cannot run inside bench.py: builder-committed rocprofv3 --pmc summary of this command
+            "traffic_is_static": not (tr or {}).get("live", False),   # False: measured by this run's own rocprofv3 --pmc passes; True: committed summary
             "limiter": LIMITERS.get(name),
             "timing": ("HIP events on the solver stream around batches of back-to-back launches (per-launch average includes the "
                        "~1.5-2.6 us launch boundary and the early-exit surplus launches of a batch)" if name == "pcg_iter" else

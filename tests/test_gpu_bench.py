@@ -31,6 +31,10 @@ def test_bench_line_has_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma", "l2_mall_latency") and 0 < r["frac"] < 1
+    import shutil
+    if shutil.which("rocprofv3") and not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        # roofline.traffic is measured by the run itself: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same command
+        assert r["traffic_is_static"] is False and r["traffic"] > 0 and r["traffic_detail"]["live"] is True, r
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -40,5 +44,5 @@ def test_bench_line_has_the_contract_keys():
 
 
 def test_bench_cholesky_and_f64_modes_run():
-    d = _run("--linear", "cholesky", "--precision", "f64", "--no-cpu-baseline")
+    d = _run("--linear", "cholesky", "--precision", "f64", "--no-cpu-baseline", "--no-live-traffic")
     assert d["termination"] == "CONVERGENCE" and "cpu_baseline" not in d

@@ -5,7 +5,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/ab
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 3"
+B="python $REPO/bench.py --no-cpu-baseline --no-live-traffic --steps 20 --warmup 3"
 pick='import json,sys; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(sys.argv[1], "it/s %.1f" % d["value"], "ms/step %.4f" % d["ms_per_step"], {k: v for k, v in d["kernel_profile_us"].items()}, "auto:", d.get("default_solver_auto", {}).get("value"), d.get("default_solver_auto", {}).get("ms_per_step"), d.get("default_solver_auto", {}).get("cg_iterations_per_step"))'
 SFMBA_SCHUR_RECORDS=1 $B 2>$OUT/rec.err | python -c "$pick" records | tee $OUT/ab.txt
 $B 2>$OUT/rc3.err | python -c "$pick" recompute_w3 | tee -a $OUT/ab.txt

@@ -10,37 +10,37 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py"
 # 1. the bench line itself (with cpu_baseline), PCG (default) and the exact Cholesky path
 $BENCH > $OUT/${TAG}_cfg3_pcg_bench.json 2> $OUT/bench_pcg.err
-$BENCH --linear cholesky --no-cpu-baseline > $OUT/${TAG}_cfg3_cholesky_bench.json 2> $OUT/bench_chol.err
+$BENCH --linear cholesky --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_cholesky_bench.json 2> $OUT/bench_chol.err
 # 2. rocprofv3 kernel statistics of the same command
 for lin in pcg cholesky; do
   rm -rf $OUT/stats_$lin
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$lin -- $BENCH --linear $lin --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/stats_$lin.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$lin -- $BENCH --linear $lin --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/stats_$lin.err
   python $REPO/tools/rocprof_summary.py $OUT/stats_$lin $OUT/${TAG}_cfg3_${lin}_kernel_stats.txt "$TAG: bench.py --linear $lin --steps 10 --warmup 2 (cfg3, f32j) under rocprofv3 --kernel-trace --stats" > /dev/null
 done
 # 3. HBM-side traffic: separate PMC passes, no trace domains besides --kernel-trace
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/pmc_$c.err
 done
-python $REPO/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_pmc_traffic.txt "python bench.py --steps 2 --warmup 1 --no-cpu-baseline   (cfg3, f32j, PCG)" > /dev/null
+python $REPO/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_pmc_traffic.txt "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic   (cfg3, f32j, PCG)" > /dev/null
 # 3b. round 3: the library default (AUTO), the realistic-visibility workload, and the record-gathering passes of rounds 1 / 2 as A/B
-$BENCH --linear auto --no-cpu-baseline > $OUT/${TAG}_cfg3_auto_bench.json 2> $OUT/bench_auto.err
-$BENCH --workload cfg3_banded --no-cpu-baseline > $OUT/${TAG}_cfg3_banded_pcg_bench.json 2> $OUT/bench_banded.err
-SFMBA_SCHUR_RECORDS=1 $BENCH --no-cpu-baseline > $OUT/${TAG}_cfg3_pcg_records_form_bench.json 2> $OUT/bench_rec.err
-SFMBA_SCHUR_RECORDS=1 $BENCH --workload cfg3_banded --no-cpu-baseline > $OUT/${TAG}_cfg3_banded_pcg_records_form_bench.json 2> $OUT/bench_banded_rec.err
+$BENCH --linear auto --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_auto_bench.json 2> $OUT/bench_auto.err
+$BENCH --workload cfg3_banded --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_banded_pcg_bench.json 2> $OUT/bench_banded.err
+SFMBA_SCHUR_RECORDS=1 $BENCH --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_pcg_records_form_bench.json 2> $OUT/bench_rec.err
+SFMBA_SCHUR_RECORDS=1 $BENCH --workload cfg3_banded --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_banded_pcg_records_form_bench.json 2> $OUT/bench_banded_rec.err
 rm -rf $OUT/stats_banded
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_banded -- $BENCH --workload cfg3_banded --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/stats_banded.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_banded -- $BENCH --workload cfg3_banded --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/stats_banded.err
 python $REPO/tools/rocprof_summary.py $OUT/stats_banded $OUT/${TAG}_cfg3_banded_pcg_kernel_stats.txt "$TAG: bench.py --workload cfg3_banded --steps 10 --warmup 2 (f32j, PCG) under rocprofv3 --kernel-trace --stats" > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmcr_$c
-  SFMBA_SCHUR_RECORDS=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcr_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmcr_$c.err
+  SFMBA_SCHUR_RECORDS=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcr_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/pmcr_$c.err
 done
-python $REPO/tools/pmc_summary.py $OUT/pmcr_FETCH_SIZE $OUT/pmcr_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_records_form_pmc_traffic.txt.ab "SFMBA_SCHUR_RECORDS=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline   (cfg3, f32j, PCG, record-gathering passes of rounds 1 / 2)" > /dev/null
+python $REPO/tools/pmc_summary.py $OUT/pmcr_FETCH_SIZE $OUT/pmcr_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_records_form_pmc_traffic.txt.ab "SFMBA_SCHUR_RECORDS=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic   (cfg3, f32j, PCG, record-gathering passes of rounds 1 / 2)" > /dev/null
 rm -rf $OUT/stats_banded $OUT/pmcr_FETCH_SIZE $OUT/pmcr_WRITE_SIZE
 $REPO/tools/micro/pk_bench > $OUT/${TAG}_valu_issue_microbench.txt 2>&1
 # 4. the sharded path on this box's one rank (RCCL communicator of one rank; the exchange is a no-op, its pack / unpack kernels are not)
 for wl in cfg3 cfg5; do
-  $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline 2> $OUT/sharded_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_bench.json
+  $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline --no-live-traffic 2> $OUT/sharded_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_bench.json
 done
 # 5. the drop-in shim in the reference's call pattern: one view added to 199 (SfM.cpp:464-466)
 echo "== SFMBA_LINEAR=pcg (block-Jacobi + gauge coarse space CG) ==" > $OUT/${TAG}_shim_incremental.txt

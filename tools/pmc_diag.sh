@@ -9,7 +9,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_IN
            "TA_TA_BUSY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/p$i.err
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic "$@" > /dev/null 2> $OUT/p$i.err
 done
 python - <<PY
 import csv, glob, collections
