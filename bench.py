@@ -292,6 +292,29 @@ def main():
         line["default_solver_auto"] = {"value": it2 / da, "unit": "LM iterations/s", "ms_per_step": 1e3 * da / args.steps,
                                        "cg_iterations_per_step": li2 / args.steps, "cholesky_fallbacks": fb2,
                                        "final_cost": s2["final_cost"], "note": "same problem, sfmba_options_default (SFMBA_LINEAR_AUTO)"}
+    if rank == 0 and linear == 1 and world == 1 and args.pcg_tol < 1e-3:
+        # Inexact Newton: the same solver with the CG stopped at 1e-3 relative (Ceres' own default for its iterative Schur solvers is
+        # eta = 1e-1, the reference sets eta = 1e-2, BA.cpp:173) -- NOT the headline: the headline keeps the 1e-8 of rounds 1 / 2, which
+        # reproduces the exact solve's PARAMETERS to 1e-8.  Reported because it is the time-to-solution optimum at the north_star's bar:
+        # same number of LM iterations, final RMS within 1e-4 px (measured: 4e-8) of the exact solve.
+        o3 = capi.default_options(max_seconds=0.0, linear_solver=1, precision=precision, pcg_tolerance=1e-3)
+        for _ in range(3):
+            P.reset(); P.solve(o3)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        it3 = li3 = 0
+        for _ in range(args.steps):
+            P.reset()
+            s3, _ = P.solve(o3)
+            it3 += s3["iterations"]; li3 += s3["linear_iters"]
+        torch.cuda.synchronize()
+        da = time.perf_counter() - ta
+        rms3 = float(np.sqrt(2.0 * s3["final_cost"] / n_obs))
+        line["inexact_newton_pcg_tol_1e-3"] = {"value": it3 / da, "unit": "LM iterations/s", "ms_per_step": 1e3 * da / args.steps,
+                                               "lm_iterations_per_step": it3 / args.steps, "cg_iterations_per_step": li3 / args.steps,
+                                               "final_rms_px": rms3, "final_rms_minus_headline_px": rms3 - line["final_rms_px"],
+                                               "termination": s3["termination_name"],
+                                               "note": "same resident problem and solver, CG tolerance 1e-3 instead of 1e-8; not the headline"}
     P.close()
     # ---- the path with a real exchange step: one problem, points sharded over the ranks (all ranks take part) ----
     want_sharded = args.sharded_extras == 1 or (args.sharded_extras == -1 and world > 1)

@@ -14,6 +14,8 @@
 //   BA.cpp:187-221          K(0,0)=K(1,1)=focal; angle-axis -> R; t; points; all narrowed to float
 // Environment overrides (reference options are hard-coded, BA.cpp:171-177):
 //   SFMBA_LINEAR=cholesky|pcg|auto (default auto, see sfmba.h SFMBA_LINEAR_AUTO)
+//   SFMBA_PCG_TOL=<t>           CG tolerance with SFMBA_LINEAR=pcg (library default 1e-8; 1e-3 is the measured time-to-solution optimum
+//                               with the LM trajectory length and the final RMS of the exact solve)
 //   SFMBA_PRECISION=f64|f32j  SFMBA_MAX_SECONDS=<s>  SFMBA_VERBOSE=1
 //   SFMBA_DUMP=<path>  writes the marshalled problem (format: sfm-toy-library_amd/problem_io.py)
 //   SFMBA_SHIM_CACHE=0  disables the resident-problem cache described below;  SFMBA_SHIM_OVERLAP=0  its overlapped comparison
@@ -376,6 +378,7 @@ void SfMBundleAdjustmentUtils::adjustBundle(
     // factorisation, =pcg the inexact CG (tolerance 1e-8: poses and points agree with the exact solve to ~1e-8, the cost to 1e-12).
     if (const char* e = std::getenv("SFMBA_LINEAR"))
         opt.linear_solver = std::strcmp(e, "pcg") == 0 ? SFMBA_LINEAR_PCG : std::strcmp(e, "auto") == 0 ? SFMBA_LINEAR_AUTO : SFMBA_LINEAR_CHOLESKY;
+    if (const char* e = std::getenv("SFMBA_PCG_TOL")) { const double t = std::atof(e); if (t > 0.0 && t < 1.0) opt.pcg_tolerance = t; }   // SFMBA_LINEAR=pcg only
     if (const char* e = std::getenv("SFMBA_PRECISION")) opt.precision = std::strcmp(e, "f32j") == 0 ? SFMBA_PRECISION_F32J : SFMBA_PRECISION_F64;
     if (const char* e = std::getenv("SFMBA_MAX_SECONDS")) opt.max_seconds = std::atof(e);
     if (const char* e = std::getenv("SFMBA_VERBOSE")) opt.verbose = std::atoi(e);

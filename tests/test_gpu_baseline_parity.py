@@ -102,6 +102,23 @@ def test_cfg3_default_options_match_oracle(capi, sfm, cfg3, cfg3_oracle):
     assert_same_solve(cfg3, (cam, pt, f, s, tr), cfg3_oracle, param_atol=2e-5, trace_rtol=5e-5)
 
 
+def test_cfg3_inexact_newton_meets_the_baseline_bar(capi, sfm, cfg3, cfg3_oracle):
+    """CG stopped at 1e-3 relative (bench.py's `inexact_newton_pcg_tol_1e-3` extra; the shim's SFMBA_PCG_TOL): the LM trajectory has the
+    oracle's length and accept / reject sequence, the final cost agrees to 1e-6 relative (BASELINE config 2's bar) and the final RMS
+    to 1e-6 px (bar: 1e-4 px); the parameters are NOT held to the 2e-5 of the 1e-8 headline mode (measured 3e-5 / 1e-3 on the focal)."""
+    opt = capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_tolerance=1e-3)
+    cam_o, pt_o, f_o, s_o, tr_o = cfg3_oracle
+    with capi.Problem(cfg3, precision=1) as P:
+        s, tr = P.solve(opt)
+        cam, pt, f = P.get_params()
+    assert s["termination_name"] == "CONVERGENCE" and s["iterations"] == s_o["iterations"]
+    assert [r["step_is_successful"] for r in tr] == [r["step_is_successful"] for r in tr_o]
+    assert abs(s["final_cost"] - s_o["final_cost"]) <= 1e-6 * s_o["final_cost"]
+    assert abs(rms(s["final_cost"], cfg3.n_obs) - rms(s_o["final_cost"], cfg3.n_obs)) < 1e-6
+    assert np.abs(cam - cam_o).max() < 5e-4 and np.abs(pt - pt_o).max() < 5e-4 and abs(f - f_o) < 2e-2
+    assert 0 < s["linear_iters"] <= 6 * s["iterations"]          # ~4 CG iterations per LM iteration instead of 8
+
+
 def test_cfg3_one_shot_pcg_f64_matches_oracle(capi, sfm, cfg3, cfg3_oracle):
     got = capi.solve(cfg3, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1))
     assert_same_solve(cfg3, got, cfg3_oracle, param_atol=1e-6, cost_rtol=1e-9)
