@@ -609,7 +609,7 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
     nb = 64
     nblk = (d + 1 + nb - 1) // nb
     b_res = n_obs * (8 + 2 * t) + 24 * n_pt + 48 * n_cam          # one residual evaluation (B_res)
-    pa = 48 if t == 4 else 80          # PtRecA / PtRecB of the per-point table (sfmba_device.h)
+    pa = 64 if t == 4 else 80          # PtRecA / PtRecB of the per-point table (sfmba_device.h)
     pb = 24 if t == 4 else 48
     return {
         "point_build": {"bound": "hbm", "bytes": b_res,

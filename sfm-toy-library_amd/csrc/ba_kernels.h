@@ -146,6 +146,8 @@ struct DeviceBuffers {
     float* pcg_F32;           // the same in fp32 instead (streaming CG path, d > 1280: the matvec is HBM-bound); else null
     double* pcg_bt;           // [ld]    Lb^-1 rhs
     double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
+    double* pair_G;           // [ncam*36] per-camera factor the factored pair pass applies from both sides of a block (row-major 6 x 6):
+                              // Linv D E^T (PCG: k_finalize) or D E^T (exact solver: k_pair_factors), E = diag(R K', I) -- sfmba_device.h
     double* pcg_W;            // [8][ld] gauge vectors in the transformed unknowns (coarse space of the two-level CG preconditioner,
                               //         dense_solver.hip), written by k_finalize (PCG mode); null = not wanted
     int* lm_mailbox;          // host-mapped {seq, termination, message, iter}: polled by the host instead of a D2H copy + sync

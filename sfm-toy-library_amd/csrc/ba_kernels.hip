@@ -797,9 +797,11 @@ __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, con
 // re-evaluates both observations with the expressions of the point pass (obs_record): the same values, pair for pair and in the
 // same lane, as the record-gathering form -- minus the two random 64-byte gathers per pair from the 64 MB of records.
 // RECOMP = 0: gathering form; 3: re-evaluating form, compiled for three waves per SIMD (162 registers; at four it spills ~40 of them
-// and runs 2.3x slower: measured 163 vs 71 us at BASELINE config 3)
+// and runs 2.3x slower: measured 163 vs 71 us at BASELINE config 3); 4: re-evaluating FACTORED form (fp32-Jacobian mode): the per-camera
+// factor diag(R K', I) of the camera blocks is taken out of the pair loop (sfmba_device.h, obs_factored) -- 295 instead of 363 wave
+// instructions per round, 128 registers (four waves per SIMD): 60 vs 68 us.
 template <typename T, int MODE, int RECOMP>
-__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? RECOMP : 4) : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP == 3 ? 3 : 4) : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int b, pbeg, pend;
@@ -861,7 +863,35 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? 
     constexpr int PAIR_FLUSH = 64;
     double total = 0.0;            // this lane's entry of the 6x6 block (lanes that own one), over the flushes so far
     int base = 0, len = 36, rounds = 0;
-    if (RECOMP) {
+    if (RECOMP == 4) {
+        // Factored form (sfmba_device.h, obs_factored): the per-camera factor diag(R K', I) of the camera blocks is applied once per
+        // block in the epilogue, the pair loop works on [ -[R X]x | I ], the projection Jacobian and C.
+        const LMState* st = db.st;
+        const int cur = st->cur;
+        const double focal = st->focal[cur];
+        CamG<T> ca, cb;
+        load_cam_g<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.x), ds.ncam, ca);
+        load_cam_g<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.y), ds.ncam, cb);
+        const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
+        const int mine = 16 * s + g;
+        int pt_next = ds.pair_pt[pbeg < p1 ? (pbeg + mine < p1 ? pbeg + mine : p1 - 1) : 0];
+        for (int p0 = pbeg; p0 < p1; p0 += 64) {
+            const PtRecA<T> pa = load_ptrec(PA + pt_next);
+            { const int p = p0 + 64 + mine; pt_next = ds.pair_pt[p < p1 ? p : p1 - 1]; }
+            T ga[GREC], gb[GREC];
+            obs_factored<T>(ca, focal, pa.X, pa.L, ga);
+            obs_factored<T>(cb, focal, pa.X, pa.L, gb);
+            if (p0 + mine >= p1) ga[3] = (T)0;      // this lane's pair lies beyond the block: contribute nothing (N carries f_a / p_z)
+            pair_product_factored<T>(ga, gb, acc);
+            if (sizeof(T) == 4 && ++rounds == PAIR_FLUSH && p0 + 64 < p1) {
+                rounds = 0; base = 0; len = 36;
+                HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
+                total += len >= 1 ? (double)acc[0] : 0.0;
+#pragma unroll
+                for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+            }
+        }
+    } else if (RECOMP) {
         const LMState* st = db.st;
         const int cur = st->cur;
         const double focal = st->focal[cur];
@@ -875,7 +905,7 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? 
         const int mine = 16 * s + g;
         int pt_next = ds.pair_pt[pbeg < p1 ? (pbeg + mine < p1 ? pbeg + mine : p1 - 1) : 0];
         for (int p0 = pbeg; p0 < p1; p0 += 64) {
-            const PtRecA<T> pa = PA[pt_next];
+            const PtRecA<T> pa = load_ptrec(PA + pt_next);
             { const int p = p0 + 64 + mine; pt_next = ds.pair_pt[p < p1 ? p : p1 - 1]; }
             T ra[YREC], rb[YREC];
             obs_record<T>(ca, focal, pa.X, pa.L, ra);
@@ -939,6 +969,29 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ? 
     total += len >= 1 ? (double)acc[0] : 0.0;
     const bool owner = len >= 1;
     const int er = owner ? base / 6 : 0, ec = owner ? base - 6 * (base / 6) : 0;
+    if (RECOMP == 4) {
+        // the sums are in the factored coordinates (sfmba_device.h): S_IJ = G_I [sum] G_J^T with the per-camera G = Lw D E^T that
+        // k_finalize (PCG: Lw = Linv, so this IS the preconditioned block) or k_pair_factors (exact solver: Lw = I) left in pair_G --
+        // the same two-sided 6 x 6 transform, and the same loads, as the Linv transform of the unfactored forms below
+        if (owner) tile[w][base] = -total;
+        wave_lds_fence();
+        if (lane < 36) {
+            const int r = lane / 6, c = lane - 6 * r;
+            const double* Gi = db.pair_G + (size_t)cj.x * 36 + r * 6;
+            const double* Gj = db.pair_G + (size_t)cj.y * 36 + c * 6;
+            double v = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double u = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Gj[bb];
+                v += Gi[a] * u;
+            }
+            if (MODE == 0) db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
+            else store_block_entry(ds, db, b, cj, r, c, v);
+        }
+        return;
+    }
     const double entry = owner ? -total * db.cscale[6 * cj.x + er] * db.cscale[6 * cj.y + ec] : 0.0;
     if (MODE == 0 || MODE == 2) {
         if (owner) {
@@ -1282,6 +1335,46 @@ void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBu
 template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 
+// Per-camera factor of the factored pair pass (sfmba_device.h, obs_factored): G = Lw D E^T, E = diag(Q, I), Q = R K' (I for a camera on
+// the first-order branch), D the Jacobi scales, Lw = Linv (PCG: the block-Jacobi transform) or I.  Row-major 6 x 6 at out[36].
+template <bool HAVE_L>
+__device__ __forceinline__ void pair_factor(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Lw)[6][6], double* out) {
+    const double* tab = db.camtab[db.st->cur];
+    double Q[3][3];
+    const bool first_order = tab[cam_tab_index(CT_SMALL, j, ds.ncam)] != 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) v += tab[cam_tab_index(CT_R + 3 * a + m, j, ds.ncam)] * tab[cam_tab_index(CT_K + 3 * m + c, j, ds.ncam)];
+            Q[a][c] = first_order ? (a == c ? 1.0 : 0.0) : v;
+        }
+    double cs[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) cs[a] = db.cscale[6 * j + a];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double v;
+            if (c < 3) {            // sum_{a < 3} Lw[r][a] cs[a] E^T[a][c],  E^T[a][c] = Q[c][a]
+                v = 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) v += (HAVE_L ? Lw[r][a] : (r == a ? 1.0 : 0.0)) * cs[a] * Q[c][a];
+            } else {
+                v = (HAVE_L ? Lw[r][c] : (r == c ? 1.0 : 0.0)) * cs[c];
+            }
+            out[6 * r + c] = v;
+        }
+}
+__global__ void k_pair_factors(DeviceStructure ds, DeviceBuffers db) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const double none[6][6] = {};
+    if (j < ds.ncam) pair_factor<false>(ds, db, j, none, db.pair_G + (size_t)j * 36);
+}
+
 // the re-evaluating pair pass: one wave per block (pair_lpb == 64), off-diagonal modes, the point table and the pair-point list present
 // (a problem built with SFMBA_SCHUR_RECORDS=1 has no point table: the record-gathering forms run -- A/B measurements and the
 // bit-for-bit comparison test)
@@ -1292,6 +1385,10 @@ bool schur_recompute_applies(const DeviceStructure& ds, const DeviceBuffers& db,
 template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
     const bool rc = schur_recompute_applies(ds, db, mode);
+    // fp32-Jacobian mode: the factored form (RECOMP = 4); fp64 mode keeps the unfactored one, whose sums are bit for bit those of the
+    // record-gathering passes (tests/test_gpu_recompute.py).  SFMBA_PAIR_FORM=3 forces the unfactored form (A/B).
+    static const bool unfactored = [] { const char* e = std::getenv("SFMBA_PAIR_FORM"); return e && e[0] == '3'; }();
+    const bool factored = rc && sizeof(T) == 4 && !unfactored && db.pair_G != nullptr;
     const dim3 grid(ds.npairwg), block(64 * SFMBA_PAIR_WAVES);
     if (mode == 2) {
         if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2, 0>), dim3(ds.ndupwg), block, 0, s, ds, db);
@@ -1299,10 +1396,15 @@ void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBu
         if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs_sub<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
     } else if (mode == 1) {
-        if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 1, 3>), grid, block, 0, s, ds, db);
+        if (factored) hipLaunchKernelGGL((k_schur_pairs<T, 1, 4>), grid, block, 0, s, ds, db);
+        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 1, 3>), grid, block, 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs<T, 1, 0>), grid, block, 0, s, ds, db);
     } else {
-        if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 0, 3>), grid, block, 0, s, ds, db);
+        if (factored) {
+            hipLaunchKernelGGL(k_pair_factors, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);      // D E^T per camera (PCG: k_finalize wrote Linv D E^T)
+            hipLaunchKernelGGL((k_schur_pairs<T, 0, 4>), grid, block, 0, s, ds, db);
+        }
+        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 0, 3>), grid, block, 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs<T, 0, 0>), grid, block, 0, s, ds, db);
     }
 }
@@ -1552,6 +1654,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             for (int r = 0; r < 6; ++r)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) db.pcg_binv[(size_t)g * 36 + r * 6 + c] = Li[r][c];
+            if (db.pair_G) pair_factor<true>(ds, db, g, Li, db.pair_G + (size_t)g * 36);
             if (db.pcg_W) gauge_vectors(ds, db, g, Li);
         }
     } else if (g - ds.ncam < ds.ld - ds.d) {

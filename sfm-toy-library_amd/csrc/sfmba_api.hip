@@ -1009,6 +1009,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
+    HIP_TRY(dev_alloc(&db.pair_G, (size_t)36 * std::max(ncam, 1)));
     bt_mark("alloc buffers");
     // the one wait of the build: sorts, lists and descriptors are in place; the staging arena and the host vectors may go
     HIP_TRY(hipStreamSynchronize(p->stream));

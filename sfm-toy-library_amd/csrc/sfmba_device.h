@@ -41,15 +41,28 @@ constexpr int YREC = 16;
 // observations instead of gathering a 64-byte record per observation (the records of BASELINE config 3 are 64 MB gathered ~10 times
 // at random; this table is 4.8 MB and stays in every XCD's L2).  Written by k_point_build once per linearisation.
 //   PtRecA: X (3 doubles: the projection is evaluated in fp64, exactly as the point pass does) | L = L^-1 diag(s_p) (6 values T:
-//           l00 l10 l11 l20 l21 l22 -- C = B L^T row by row)                    48 B in fp32 mode, 80 B (72 + pad) in fp64 mode
+//           l00 l10 l11 l20 l21 l22 -- C = B L^T row by row)                    64 B (48 + pad: one sector, so that the four lanes of
+//           a quad can fetch it with ONE request) in fp32 mode, 80 B (72 + pad) in fp64 mode
 //   PtRecB: t = L^-1 b_p (3 T) | y_f = L^-1 E_f (3 T)                           (camera-diagonal pass only)
 template <typename T> struct PtRecA;
-template <> struct alignas(16) PtRecA<float>  { double X[3]; float L[6]; };
+template <> struct alignas(64) PtRecA<float>  { double X[3]; float L[6]; float pad[4]; };      // one 64-byte sector per point
 template <> struct alignas(16) PtRecA<double> { double X[3]; double L[6]; double pad; };
 template <typename T> struct PtRecB;
 template <> struct alignas(8)  PtRecB<float>  { float t[3]; float yf[3]; };
 template <> struct alignas(16) PtRecB<double> { double t[3]; double yf[3]; };
-static_assert(sizeof(PtRecA<float>) == 48 && sizeof(PtRecA<double>) == 80 && sizeof(PtRecB<float>) == 24 && sizeof(PtRecB<double>) == 48, "point table layout");
+// One entry in three (fp32 mode) 16-byte loads: left to itself the compiler loads the two member arrays separately (16 + 8 and, at an
+// 8-byte-aligned offset, 16 + 8 bytes: four requests per lane, and the vector-memory pipe walks one line per lane and request).
+__device__ __forceinline__ PtRecA<float> load_ptrec(const PtRecA<float>* p) {
+    const int4* q = reinterpret_cast<const int4*>(p);
+    const int4 c0 = q[0], c1 = q[1], c2 = q[2];
+    PtRecA<float> r;
+    r.X[0] = __hiloint2double(c0.y, c0.x); r.X[1] = __hiloint2double(c0.w, c0.z); r.X[2] = __hiloint2double(c1.y, c1.x);
+    r.L[0] = __int_as_float(c1.z); r.L[1] = __int_as_float(c1.w);
+    r.L[2] = __int_as_float(c2.x); r.L[3] = __int_as_float(c2.y); r.L[4] = __int_as_float(c2.z); r.L[5] = __int_as_float(c2.w);
+    return r;
+}
+__device__ __forceinline__ PtRecA<double> load_ptrec(const PtRecA<double>* p) { return *p; }
+static_assert(sizeof(PtRecA<float>) == 64 && sizeof(PtRecA<double>) == 80 && sizeof(PtRecB<float>) == 24 && sizeof(PtRecB<double>) == 48, "point table layout");
 
 // Camera tables are stored in component quads (AoSoA): values 4c .. 4c+3 of camera j are the 32 contiguous bytes at
 // tab[(c * ncam + j) * 4].  A wave whose lanes need the same components of 64 different cameras then issues ONE 32-byte
@@ -298,6 +311,93 @@ __device__ __forceinline__ void obs_record(CamPtr cam, double focal, const doubl
         rec[9 + 3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
     }
     rec[15] = (T)0;
+}
+
+// ---- factored form of an observation for the pair pass -------------------------------------------------------------------------
+// The camera block of an observation factors as  A = P [ -[X_g]x | I ] diag(Q, I)  with P = (f / p_z) [[1, 0, -x_p], [0, 1, -y_p]],
+// X_g = R X and Q = R K' (A_w = -P R [X]x K' = -P [R X]x R K': R is orthogonal), or X_g = X and Q = I for a camera on the first-order
+// branch (theta^2 <= eps: G = -[X]x exactly).  diag(Q, I) is constant over a 6x6 block of the reduced matrix, so the
+// pair pass sums the blocks in the factored coordinates and applies Q_i^T . Q_j ONCE per block (k_schur_pairs epilogue):
+//   sum_pairs A_a^T (C_a C_b^T) A_b = E_i^T [ sum_pairs G_a^T N G_b ] E_j,   N = P_a^T (C_a C_b^T) P_b  (3 x 3),  G = [ -[X_g]x | I ].
+// Per observation that leaves the projection, B = P R and C = B L^T (24 fp32 operations instead of 60: no [X]x K', no B ([X]x K')).
+//   g[0..2] X_g | g[3] f / p_z | g[4] x_p | g[5] y_p | g[6..11] C (2 x 3, row-major)
+constexpr int GREC = 12;
+template <typename T>
+struct CamG {
+    double v[CT_K];          // R (9), t (3): the projection is evaluated in fp64 like everywhere else
+    T vt[9];                 // (T) R, wave-uniform
+    double small;
+};
+template <typename T>
+__device__ __forceinline__ void load_cam_g(const double* __restrict__ tab, int j_uniform, int ncam, CamG<T>& c) {
+#pragma unroll
+    for (int k = 0; k < CT_K; ++k) c.v[k] = tab[cam_tab_index(k, j_uniform, ncam)];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c.vt[k] = to_uniform((T)c.v[k]);
+    c.small = tab[cam_tab_index(CT_SMALL, j_uniform, ncam)];
+}
+template <typename T>
+__device__ __forceinline__ void obs_factored(const CamG<T>& cam, double focal, const double X[3], const T L[6], T g[GREC]) {
+    const double rx = cam.v[CT_R + 0] * X[0] + cam.v[CT_R + 1] * X[1] + cam.v[CT_R + 2] * X[2];
+    const double ry = cam.v[CT_R + 3] * X[0] + cam.v[CT_R + 4] * X[1] + cam.v[CT_R + 5] * X[2];
+    const double rz = cam.v[CT_R + 6] * X[0] + cam.v[CT_R + 7] * X[1] + cam.v[CT_R + 8] * X[2];
+    const double iz = fast_rcp(rz + cam.v[CT_T + 2]);
+    const double xpd = (rx + cam.v[CT_T + 0]) * iz, ypd = (ry + cam.v[CT_T + 1]) * iz;
+    const bool first_order = cam.small != 0.0;           // wave-uniform
+    g[0] = (T)(first_order ? X[0] : rx); g[1] = (T)(first_order ? X[1] : ry); g[2] = (T)(first_order ? X[2] : rz);
+    const T fz = (T)(focal * iz), xp = (T)xpd, yp = (T)ypd;
+    g[3] = fz; g[4] = xp; g[5] = yp;
+    T B[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                          // B = P R, the expressions of point_block
+        B[c] = fz * (cam.vt[c] - xp * cam.vt[6 + c]);
+        B[3 + c] = fz * (cam.vt[3 + c] - yp * cam.vt[6 + c]);
+    }
+    const T l00 = L[0], l10 = L[1], l11 = L[2], l20 = L[3], l21 = L[4], l22 = L[5];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                          // C = B~ L^-T, as obs_record
+        const T b0 = B[3 * r], b1 = B[3 * r + 1], b2 = B[3 * r + 2];
+        g[6 + 3 * r + 0] = b0 * l00;
+        g[6 + 3 * r + 1] = b0 * l10 + b1 * l11;
+        g[6 + 3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
+    }
+}
+// acc += G_a^T N G_b  (6 x 6 row-major; rows: camera a, columns: camera b; the first three of each are the rotation part)
+//   = [[ -[X_a]x N [X_b]x ,  [X_a]x N ],  [ -N [X_b]x ,  N ]]   with  v [X]x = v x X  and  [X]x v = X x v
+template <typename T>
+__device__ __forceinline__ void pair_product_factored(const T ga[GREC], const T gb[GREC], T acc[36]) {
+    const T ff = ga[3] * gb[3];
+    const T m00 = ff * (ga[6] * gb[6] + ga[7] * gb[7] + ga[8] * gb[8]);
+    const T m01 = ff * (ga[6] * gb[9] + ga[7] * gb[10] + ga[8] * gb[11]);
+    const T m10 = ff * (ga[9] * gb[6] + ga[10] * gb[7] + ga[11] * gb[8]);
+    const T m11 = ff * (ga[9] * gb[9] + ga[10] * gb[10] + ga[11] * gb[11]);
+    const T xa = ga[4], ya = ga[5], xb = gb[4], yb = gb[5];
+    T N[9];
+    N[0] = m00; N[1] = m01; N[2] = -(m00 * xb + m01 * yb);
+    N[3] = m10; N[4] = m11; N[5] = -(m10 * xb + m11 * yb);
+    N[6] = -(xa * N[0] + ya * N[3]); N[7] = -(xa * N[1] + ya * N[4]); N[8] = -(xa * N[2] + ya * N[5]);
+    const T a0 = ga[0], a1 = ga[1], a2 = ga[2], b0 = gb[0], b1 = gb[1], b2 = gb[2];
+    T Tm[9];                                               // T = [X_a]x N: column c = X_a x N[:, c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Tm[c] = a1 * N[6 + c] - a2 * N[3 + c];
+        Tm[3 + c] = a2 * N[c] - a0 * N[6 + c];
+        Tm[6 + c] = a0 * N[3 + c] - a1 * N[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const T t0 = Tm[3 * r], t1 = Tm[3 * r + 1], t2 = Tm[3 * r + 2];
+        // -(T[r, :] [X_b]x) = X_b x T[r, :]
+        acc[6 * r + 0] += b1 * t2 - b2 * t1;
+        acc[6 * r + 1] += b2 * t0 - b0 * t2;
+        acc[6 * r + 2] += b0 * t1 - b1 * t0;
+        acc[6 * r + 3] += t0; acc[6 * r + 4] += t1; acc[6 * r + 5] += t2;
+        const T n0 = N[3 * r], n1 = N[3 * r + 1], n2 = N[3 * r + 2];
+        acc[6 * (3 + r) + 0] += b1 * n2 - b2 * n1;
+        acc[6 * (3 + r) + 1] += b2 * n0 - b0 * n2;
+        acc[6 * (3 + r) + 2] += b0 * n1 - b1 * n0;
+        acc[6 * (3 + r) + 3] += n0; acc[6 * (3 + r) + 4] += n1; acc[6 * (3 + r) + 5] += n2;
+    }
 }
 
 }  // namespace sfmba
