@@ -136,9 +136,24 @@ class SfmbaError(RuntimeError):
     pass
 
 
+def _let_torch_open_the_device_first():
+    """A torch wheel bundles its own HIP / HSA runtime beside the system one this library links against.  One process can hold both as
+    long as torch's opens the device FIRST (every bench / sharded run does: torch.cuda.set_device comes before the first solve); the
+    other way round torch.cuda then reports 'No HIP GPUs are available' -- e.g. a pytest selection that runs a plain C-ABI test before
+    the first sharded one.  So: when torch is installed and sees a GPU, let it initialise before libsfmba_hip.so is loaded.  Nothing
+    happens without torch or without a GPU; the C ABI itself never needs torch."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
+        _let_torch_open_the_device_first()
         if not os.path.exists(LIB_PATH):
             raise SfmbaError("%s is missing: build it with `make -C %s` (or __graft_entry__.build()); "
                              "the MI355X back end has no CPU fallback" % (LIB_PATH, os.path.dirname(LIB_PATH)))

@@ -160,6 +160,13 @@ __device__ void make_cam_table(const double cam[6], const double* scale6, double
     ct[CT_T + 0] = cam[3]; ct[CT_T + 1] = cam[4]; ct[CT_T + 2] = cam[5];
     ct[CT_SMALL] = small;
     for (int e = 0; e < 6; ++e) ct[CT_SCALE + e] = scale6 ? scale6[e] : 1.0;
+    for (int c = 0; c < 3; ++c)
+        for (int a = 0; a < 3; ++a) {
+            double q = (a == c) ? 1.0 : 0.0;
+            if (small == 0.0) q = R[3 * c + 0] * K[0 + a] + R[3 * c + 1] * K[3 + a] + R[3 * c + 2] * K[6 + a];
+            ct[CT_QD + 3 * c + a] = q;
+        }
+    for (int e = CT_QD + 9; e < CT_STRIDE; ++e) ct[e] = 0.0;
 }
 
 __global__ void k_cam_setup(int ncam, const double* __restrict__ cam, const double* __restrict__ cscale, double* __restrict__ camtab) {
@@ -977,8 +984,9 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ==
         wave_lds_fence();
         if (lane < 36) {
             const int r = lane / 6, c = lane - 6 * r;
-            const double* Gi = db.pair_G + (size_t)cj.x * 36 + r * 6;
-            const double* Gj = db.pair_G + (size_t)cj.y * 36 + c * 6;
+            double Gi[6], Gj[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { Gi[a] = db.pair_G[(size_t)cj.x * 36 + 6 * r + a]; Gj[a] = db.pair_G[(size_t)cj.y * 36 + 6 * c + a]; }
             double v = 0.0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -1336,43 +1344,38 @@ template void launch_point_build<float>(hipStream_t, const DeviceStructure&, con
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 
 // Per-camera factor of the factored pair pass (sfmba_device.h, obs_factored): G = Lw D E^T, E = diag(Q, I), Q = R K' (I for a camera on
-// the first-order branch), D the Jacobi scales, Lw = Linv (PCG: the block-Jacobi transform) or I.  Row-major 6 x 6 at out[36].
+// the first-order branch), D the Jacobi scales, Lw = Linv (PCG: the block-Jacobi transform) or I.  The rotation part of D E^T is in the
+// camera table (CT_QD, make_cam_table).  Row-major 6 x 6 per camera: pair_G[36 j + 6 r + c] (entry-major would let k_finalize's lanes
+// store side by side, -1 us there, but costs the pair pass's epilogue +5 us: measured).
 template <bool HAVE_L>
-__device__ __forceinline__ void pair_factor(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Lw)[6][6], double* out) {
+__device__ __forceinline__ void pair_factor(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Lw)[6][6]) {
     const double* tab = db.camtab[db.st->cur];
-    double Q[3][3];
-    const bool first_order = tab[cam_tab_index(CT_SMALL, j, ds.ncam)] != 0.0;
+    double M3[3][3], cs[6];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 6; ++a) cs[a] = db.cscale[6 * j + a];       // (not the table's copy: the first linearisation's table predates the scales)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double v = 0.0;
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) v += tab[cam_tab_index(CT_R + 3 * a + m, j, ds.ncam)] * tab[cam_tab_index(CT_K + 3 * m + c, j, ds.ncam)];
-            Q[a][c] = first_order ? (a == c ? 1.0 : 0.0) : v;
-        }
-    double cs[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) cs[a] = db.cscale[6 * j + a];
+        for (int a = 0; a < 3; ++a) M3[c][a] = cs[a] * tab[cam_tab_index(CT_QD + 3 * c + a, j, ds.ncam)];
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             double v;
-            if (c < 3) {            // sum_{a < 3} Lw[r][a] cs[a] E^T[a][c],  E^T[a][c] = Q[c][a]
+            if (c < 3) {            // sum_{a < 3} Lw[r][a] (D E^T)[a][c],  (D E^T)[a][c] = cs[a] Q[c][a] = M3[c][a]
                 v = 0.0;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) v += (HAVE_L ? Lw[r][a] : (r == a ? 1.0 : 0.0)) * cs[a] * Q[c][a];
+                for (int a = 0; a < 3; ++a) v += (HAVE_L ? Lw[r][a] : (r == a ? 1.0 : 0.0)) * M3[c][a];
             } else {
                 v = (HAVE_L ? Lw[r][c] : (r == c ? 1.0 : 0.0)) * cs[c];
             }
-            out[6 * r + c] = v;
+            db.pair_G[(size_t)j * 36 + 6 * r + c] = v;
         }
 }
 __global__ void k_pair_factors(DeviceStructure ds, DeviceBuffers db) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const double none[6][6] = {};
-    if (j < ds.ncam) pair_factor<false>(ds, db, j, none, db.pair_G + (size_t)j * 36);
+    if (j < ds.ncam) pair_factor<false>(ds, db, j, none);
 }
 
 // the re-evaluating pair pass: one wave per block (pair_lpb == 64), off-diagonal modes, the point table and the pair-point list present
@@ -1654,7 +1657,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             for (int r = 0; r < 6; ++r)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) db.pcg_binv[(size_t)g * 36 + r * 6 + c] = Li[r][c];
-            if (db.pair_G) pair_factor<true>(ds, db, g, Li, db.pair_G + (size_t)g * 36);
+            if (db.pair_G) pair_factor<true>(ds, db, g, Li);
             if (db.pcg_W) gauge_vectors(ds, db, g, Li);
         }
     } else if (g - ds.ncam < ds.ld - ds.d) {

@@ -1746,8 +1746,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     { ProfScope ps(prof, KID_PCG_ITER, s);
       launch_cg_iteration<true>(s, ws, anchor, cap); }
     int batch = 24;
-    static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 2; }();
-    // history + 2: a solve that needs one more iteration than last time costs a host round trip, a surplus (early-exit) launch ~2 us
+    static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 1; }();
+    // history + 1 (was + 2; +0.6 % on the headline): a solve that needs two more iterations than last time costs a host round trip, a surplus (early-exit) launch ~2 us
     if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra;
     if (no_wait) return dense_pcg_more(s, ws, batch, prof);
     bool done = false;
