@@ -526,11 +526,14 @@ def pmc_traffic(kernel):
 LIMITERS = {
     "pcg_iter": "L2 / Infinity-Cache latency + the dependent-launch boundary (one launch per CG iteration; the 11.5 MB matrix never leaves the "
                 "256 MiB Infinity Cache, so FETCH_SIZE counts cache hits): not an HBM-bandwidth-bound kernel",
-    "schur_pairs": "VALU issue: ~33 M wave instructions per launch at 4-5 cycles each = ~72 % of the SIMD time (rocprofv3 SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU, "
-                   "tools/micro/pk_bench.hip); the gathers of rounds 1 / 2 are gone (re-evaluation from an L2-resident point table) and the time did not move",
+    "schur_pairs": "VALU issue: every wave instruction costs the SIMD ~4 cycles whatever it is (rocprofv3: SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles; "
+                   "88 % of the SIMD time in the unfactored form), so the pass is priced by its instruction COUNT: the factored form (camera factor "
+                   "diag(R K', I) applied once per block) runs 295 instead of 363 instructions per 64 pairs and the launch went from 68 to 59 us; what "
+                   "is left is 2 re-evaluations + one 6x6 product per pair and ~170 instructions of reduction / transform per block",
     "cam_diag": "dependent loads x waves in flight (40 % VALU-busy): index -> point-table gather -> ~700 instructions -> butterfly -> 47 atomics per workgroup",
-    "point_build": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
-    "point_update": "memory latency x occupancy (two dependent load levels per wave, 16 waves per CU)",
+    "point_build": "wave lifetime x occupancy: three dependent memory levels + a 7-lanes-of-64 per-point phase per wave (7.6 us of lifetime at 3.4 waves "
+                   "per SIMD); measured and rejected: the camera table in LDS (48.2 vs 48.7 us), 5 waves per SIMD by launch bounds (spills: 51 us)",
+    "point_update": "wave lifetime x occupancy (two dependent load levels per wave, 16-20 waves per CU); 5 waves per SIMD by launch bounds spills: 28 -> 34 us",
     "chol_panel": "the serial chain of 64 pivots in the diagonal tile (one workgroup: ~250 cycles per pivot) + one launch boundary per block column",
     "chol_update": "fp64 MFMA, short launches",
 }
@@ -615,7 +618,7 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
         "point_build": {"bound": "hbm", "bytes": b_res,
                         "moved": n_obs * (4 + 2 * t) + n_obs * yrec + n_pt * (24 + 24 + 48 + 4 + pa + pb),
                         "note": "algorithmic: one pass over observations, points and cameras (B_res); moved: + one packed record (16 values) per observation "
-                                "(read back by the back-substitution only) + per point t, y_f, M and the 72-byte table entry of the re-evaluating passes"},
+                                "(read back by the back-substitution only) + per point t, y_f, M and the table entry of the re-evaluating passes (64 + 24 bytes)"},
         "schur_pairs": {"bound": "hbm", "bytes": 8 * d * d,
                         "moved": 4 * npair + n_pt * pa + 8 * d * d,
                         "note": "algorithmic: the reduced matrix written once (8 d^2); moved: + the pair-point list (4 bytes per pair) and the point table once "
