@@ -1348,24 +1348,16 @@ template void launch_point_build<double>(hipStream_t, const DeviceStructure&, co
 // camera table (CT_QD, make_cam_table).  Row-major 6 x 6 per camera: pair_G[36 j + 6 r + c] (entry-major would let k_finalize's lanes
 // store side by side, -1 us there, but costs the pair pass's epilogue +5 us: measured).
 template <bool HAVE_L>
-__device__ __forceinline__ void pair_factor(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Lw)[6][6]) {
-    const double* tab = db.camtab[db.st->cur];
-    double M3[3][3], cs[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) cs[a] = db.cscale[6 * j + a];       // (not the table's copy: the first linearisation's table predates the scales)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) M3[c][a] = cs[a] * tab[cam_tab_index(CT_QD + 3 * c + a, j, ds.ncam)];
+__device__ __forceinline__ void pair_factor(const DeviceBuffers& db, int j, const double (&Lw)[6][6], const double (&Q9)[9], const double (&cs)[6]) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             double v;
-            if (c < 3) {            // sum_{a < 3} Lw[r][a] (D E^T)[a][c],  (D E^T)[a][c] = cs[a] Q[c][a] = M3[c][a]
+            if (c < 3) {            // sum_{a < 3} Lw[r][a] (D E^T)[a][c],  (D E^T)[a][c] = cs[a] Q[c][a]
                 v = 0.0;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) v += (HAVE_L ? Lw[r][a] : (r == a ? 1.0 : 0.0)) * M3[c][a];
+                for (int a = 0; a < 3; ++a) v += (HAVE_L ? Lw[r][a] : (r == a ? 1.0 : 0.0)) * (cs[a] * Q9[3 * c + a]);
             } else {
                 v = (HAVE_L ? Lw[r][c] : (r == c ? 1.0 : 0.0)) * cs[c];
             }
@@ -1374,8 +1366,14 @@ __device__ __forceinline__ void pair_factor(const DeviceStructure& ds, const Dev
 }
 __global__ void k_pair_factors(DeviceStructure ds, DeviceBuffers db) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ds.ncam) return;
     const double none[6][6] = {};
-    if (j < ds.ncam) pair_factor<false>(ds, db, j, none);
+    double Q9[9], cs[6];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Q9[e] = db.camtab[db.st->cur][cam_tab_index(CT_QD + e, j, ds.ncam)];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) cs[e] = db.cscale[6 * j + e];       // (not the table's copy: the first linearisation's table predates the scales)
+    pair_factor<false>(db, j, none, Q9, cs);
 }
 
 // the re-evaluating pair pass: one wave per block (pair_lpb == 64), off-diagonal modes, the point table and the pair-point list present
@@ -1471,11 +1469,10 @@ __device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffer
 // Jacobi-scaled (x = s x_s) and transformed by the block factor (x~ = Lb^T x_s, Lb^-1 = Li): w~ solves Li^T w~ = w / s.
 // Values are rounded to fp32 so that every consumer (LDS copies included) sees the same numbers; any vectors are a valid
 // coarse space, they only have to be close to the slow directions.
-__device__ void gauge_vectors(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Li)[6][6]) {
-    const LMState* st = db.st;
-    const int cur = st->cur;
-    const CamRow ct = { db.camtab[cur] + 4 * (size_t)j, ds.ncam };
-    const double* cam = db.cam[cur] + 6 * (size_t)j;
+// (the camera's parameters, the rows of R and the Jacobi scales arrive preloaded: k_finalize issues every global load of a camera
+// before its first dependent instruction -- read where they are used they were one more L2 round trip each on a kernel of 200 lanes)
+__device__ __forceinline__ void gauge_vectors_pre(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Li)[6][6],
+                                                  const double (&cam)[6], const double (&Rm)[9], const double (&cs6)[6]) {
     const double w0 = cam[0], w1 = cam[1], w2 = cam[2];
     const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
     double cq = 1.0 / 12.0;                              // limit of the [w]x^2 coefficient for theta -> 0
@@ -1499,11 +1496,11 @@ __device__ void gauge_vectors(const DeviceStructure& ds, const DeviceBuffers& db
         }
     double s6[6], ild[6];       // 1 / Jacobi scale; 1 / Li[r][r]: reciprocals once, not a division per back-substitution step
 #pragma unroll
-    for (int e = 0; e < 6; ++e) { s6[e] = fast_rcp(db.cscale[6 * j + e]); ild[e] = fast_rcp(Li[e][e]); }
+    for (int e = 0; e < 6; ++e) { s6[e] = fast_rcp(cs6[e]); ild[e] = fast_rcp(Li[e][e]); }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         double wv[6] = { 0, 0, 0, 0, 0, 0 };
-        if (k < 3) { for (int r = 0; r < 3; ++r) wv[3 + r] = -ct[CT_R + 3 * r + k]; }
+        if (k < 3) { for (int r = 0; r < 3; ++r) wv[3 + r] = -Rm[3 * r + k]; }
         else if (k < 6) { for (int r = 0; r < 3; ++r) wv[r] = -Ji[r][k - 3]; }
         else if (k == 6) { for (int r = 0; r < 3; ++r) wv[3 + r] = cam[3 + r]; }
         else wv[5] = cam[5];
@@ -1521,6 +1518,15 @@ __device__ void gauge_vectors(const DeviceStructure& ds, const DeviceBuffers& db
 #pragma unroll
         for (int r = 0; r < 6; ++r) db.pcg_W[(size_t)k * ds.ld + 6 * j + r] = (double)(float)wt[r];
     }
+}
+__device__ void gauge_vectors(const DeviceStructure& ds, const DeviceBuffers& db, int j, const double (&Li)[6][6]) {
+    const int cur = db.st->cur;
+    double cam[6], Rm[9], cs6[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { cam[e] = db.cam[cur][6 * (size_t)j + e]; cs6[e] = db.cscale[6 * j + e]; }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rm[e] = db.camtab[cur][cam_tab_index(CT_R + e, j, ds.ncam)];
+    gauge_vectors_pre(ds, db, j, Li, cam, Rm, cs6);
 }
 
 // The gauge vectors for a reduced system whose block factors were formed outside k_finalize (sharded solve: the factors come
@@ -1608,15 +1614,33 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
                 db.rhs[row0 + a] += acc[39 + a];
             }
         }
+        // every global load of this camera first (one L2 round trip instead of four or five: this kernel is 200 lanes of dependent
+        // fp64 work, its length is its chain of round trips): diagonal block, undamped diagonal, gradient, scales, and what the
+        // gauge vectors and the pair pass's camera factor need
+        double Sb[6][6], ud[6], bcv[6], csv[6], rhv[6], camv[6], Rm[9], Q9[9];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            ud[a] = db.udiag[row0 + a]; bcv[a] = db.bc[row0 + a]; csv[a] = db.cscale[row0 + a]; rhv[a] = db.rhs[row0 + a];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) Sb[a][b] = (b >= a) ? db.S[(size_t)(row0 + a) * ds.ld + row0 + b] : 0.0;
+        }
+        if (pcg) {
+            const double* tab = db.camtab[st->cur];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) camv[e] = db.pcg_W ? db.cam[st->cur][6 * (size_t)g + e] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { Rm[e] = db.pcg_W ? tab[cam_tab_index(CT_R + e, g, ds.ncam)] : 0.0; Q9[e] = db.pair_G ? tab[cam_tab_index(CT_QD + e, g, ds.ncam)] : 0.0; }
+        }
         bool bad = false;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             const int e = row0 + a;
-            const double dd = fmin(fmax(db.udiag[e], st->min_diag), st->max_diag) / st->radius;
-            const double v = db.S[(size_t)e * ds.ld + e] + dd;
+            const double dd = fmin(fmax(ud[a], st->min_diag), st->max_diag) / st->radius;
+            const double v = Sb[a][a] + dd;
+            Sb[a][a] = v;
             db.S[(size_t)e * ds.ld + e] = v;
-            gm = fmax(gm, fabs(db.bc[e] / db.cscale[e]));
-            bad = bad || !finite_d(v) || !finite_d(db.rhs[e]);
+            gm = fmax(gm, fabs(bcv[a] / csv[a]));
+            bad = bad || !finite_d(v) || !finite_d(rhv[a]);
         }
         if (bad) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
         if (pcg) {
@@ -1625,7 +1649,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = 0; c < 6; ++c) L[r][c] = (c <= r) ? db.S[(size_t)(row0 + c) * ds.ld + row0 + r] : 0.0;
+                for (int c = 0; c < 6; ++c) L[r][c] = (c <= r) ? Sb[c][r] : 0.0;
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -1657,8 +1681,8 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             for (int r = 0; r < 6; ++r)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) db.pcg_binv[(size_t)g * 36 + r * 6 + c] = Li[r][c];
-            if (db.pair_G) pair_factor<true>(ds, db, g, Li);
-            if (db.pcg_W) gauge_vectors(ds, db, g, Li);
+            if (db.pair_G) pair_factor<true>(db, g, Li, Q9, csv);
+            if (db.pcg_W) gauge_vectors_pre(ds, db, g, Li, camv, Rm, csv);
         }
     } else if (g - ds.ncam < ds.ld - ds.d) {
         const int e = ds.d + (g - ds.ncam);
