@@ -1770,24 +1770,43 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     double step2 = 0.0, xn2 = 0.0;
     if (j < ds.ncam) {
         double dlt[6], cn[6], z[6];
+        // every load of this camera before the first store (the stores below may alias as far as the compiler can tell: a load behind
+        // one of them waits for its own round trip -- six in a row in the loop this replaces)
+        double c0[6], cs[6], xin[6], Lt[6][6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { c0[e] = db.cam[cur][6 * j + e]; cs[e] = db.cscale[6 * j + e]; }
         if (db.pcg_vec) {          // z_j = Linv_j^T x~_j  (block-Jacobi transformed unknowns)
             const double* x = db.pcg_vec + (size_t)db.pcg_flags[2] * ds.ld + 6 * j;
             const double* Li = db.pcg_linv + (size_t)j * 36;
-            for (int c = 0; c < 6; ++c) { double v = 0.0; for (int t = c; t < 6; ++t) v += Li[t * 6 + c] * x[t]; z[c] = v; }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                xin[t] = x[t];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Lt[t][c] = (c <= t) ? Li[t * 6 + c] : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) if (t >= c) v += Lt[t][c] * xin[t];
+                z[c] = v;
+            }
         } else {
+#pragma unroll
             for (int c = 0; c < 6; ++c) z[c] = db.rhs[6 * j + c];
         }
+#pragma unroll
         for (int e = 0; e < 6; ++e) {
-            const double c0 = db.cam[cur][6 * j + e];
-            dlt[e] = db.cscale[6 * j + e] * z[e];
-            cn[e] = c0 - dlt[e];
-            const double df = c0 - cn[e];
+            dlt[e] = cs[e] * z[e];
+            cn[e] = c0[e] - dlt[e];
+            const double df = c0[e] - cn[e];
             step2 += df * df;
             xn2 += cn[e] * cn[e];
-            db.cam[nxt][6 * j + e] = cn[e];
         }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) db.cam[nxt][6 * j + e] = cn[e];
         double ctn[CT_STRIDE];
-        make_cam_table(cn, db.cscale + 6 * j, ctn);
+        make_cam_table(cn, cs, ctn);
         for (int e = 0; e < CT_STRIDE; ++e) db.camtab[nxt][cam_tab_index(e, j, ds.ncam)] = ctn[e];
         double stb[ST_STRIDE] = {};
         for (int e = 0; e < 9; ++e) stb[ST_RN + e] = ctn[CT_R + e];
