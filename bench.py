@@ -333,6 +333,15 @@ def main():
         watchdog = threading.Timer(args.extras_timeout, give_up)
         watchdog.daemon = True
         watchdog.start()
+        # ... and against a PEER that dies in them: the launcher then sends the surviving ranks SIGTERM -- rank 0 prints the line first
+        import signal
+
+        def on_term(signum, frame):
+            if rank == 0:
+                line["sharded"] = dict(sh, error="terminated (signal %d) during the sharded extras: a peer rank ended" % signum)
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        old_term = signal.signal(signal.SIGTERM, on_term)
         for wl in (["cfg3", "cfg5"] if args.workload == "cfg3" else [args.workload]):
             for variant in ("replicated_cg", "distributed_cg"):          # both forms of the reduced-system solve
                 key = wl if variant == "replicated_cg" else wl + "_distributed_cg"
@@ -342,6 +351,7 @@ def main():
                 except Exception as e:                       # never lose the headline line to the extras
                     sh[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         watchdog.cancel()
+        signal.signal(signal.SIGTERM, old_term)
     if rank == 0:
         if sh is not None:
             line["sharded"] = sh
