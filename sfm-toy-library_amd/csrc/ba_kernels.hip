@@ -800,7 +800,7 @@ __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, con
 }
 
 // RECOMP (modes 0 / 1): nothing is gathered per observation.  Both cameras of a block are fixed for the wave, so their table rows sit
-// in scalar registers; per pair a lane loads ONE point-table entry (48 bytes in fp32 mode, from a table that stays in L2) and
+// in scalar registers; per pair a lane loads ONE point-table entry (one 64-byte sector in fp32 mode, from a table that stays in L2) and
 // re-evaluates both observations with the expressions of the point pass (obs_record): the same values, pair for pair and in the
 // same lane, as the record-gathering form -- minus the two random 64-byte gathers per pair from the 64 MB of records.
 // RECOMP = 0: gathering form; 3: re-evaluating form, compiled for three waves per SIMD (162 registers; at four it spills ~40 of them
@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceB
 }
 
 // The same pass WITHOUT the per-observation records: the camera's table row sits in scalar registers (one camera per workgroup), a lane
-// gathers its observation's point-table entries (72 bytes from a table that stays in L2), reads the observation's coordinates from
+// gathers its observation's point-table entries (64 + 24 bytes from a table that stays in L2), reads the observation's coordinates from
 // the camera-major copy (coalesced), and re-evaluates record and residual with the expressions of the point pass (obs_record).
 template <typename T>
 __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, DeviceBuffers db) {

@@ -945,7 +945,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     const size_t ybytes = (size_t)std::max(nobs, 1) * YREC * (f32 ? sizeof(float) : sizeof(double));
     db.Y = p->arena.alloc(ybytes);
     if (!db.Y) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
-    // The reduced-system passes re-evaluate every observation from the camera row and a per-point table (PA / PB, 72 bytes per point)
+    // The reduced-system passes re-evaluate every observation from the camera row and a per-point table (PA / PB, 64 + 24 bytes per point in fp32-Jacobian mode)
     // plus a camera-major copy of the observation coordinates -- no 32-byte side record, and the 64-byte records are only read by the
     // back-substitution.  SFMBA_SCHUR_RECORDS=1 at build time keeps the record-gathering passes of rounds 1 / 2 instead (A/B).
     { const char* e = std::getenv("SFMBA_SCHUR_RECORDS");

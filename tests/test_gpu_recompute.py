@@ -1,9 +1,11 @@
-"""Round 3: the reduced-system passes RE-EVALUATE every observation from the camera's table row and a 72-byte per-point table instead of
+"""Round 3: the reduced-system passes RE-EVALUATE every observation from the camera's table row and a per-point table (64 + 24 bytes) instead of
 gathering a 64-byte record per observation (k_cam_diag_f, k_schur_pairs<.., RECOMP>).  The re-evaluation uses the
 expressions of the point pass, pair for pair in the same lane and in the same summation order.  In fp64 mode the two forms agree
-BIT FOR BIT (asserted on the reduced system and, in deterministic mode, on whole solves); in fp32-Jacobian mode the compiler fuses
-multiply-adds differently in the two kernels, so a value can differ by an fp32 rounding (measured 3.5e-7 relative on an entry of S):
-asserted to 2e-6 of the entry scale there.  A problem built with SFMBA_SCHUR_RECORDS=1 runs the record-gathering passes of rounds 1 / 2."""
+BIT FOR BIT (asserted on the reduced system and, in deterministic mode, on whole solves); in fp32-Jacobian mode the pair pass runs its
+FACTORED form (the camera-constant factor of the blocks applied once per block: the same sums in another order of fp32 operations) and
+the compiler fuses multiply-adds differently in the kernels, so a value can differ by an fp32 rounding (measured 3.5e-7 relative on an
+entry of S): asserted to 2e-6 of the entry scale there.  A problem built with SFMBA_SCHUR_RECORDS=1 runs the record-gathering passes of
+rounds 1 / 2."""
 import numpy as np
 import pytest
 
