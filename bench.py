@@ -540,7 +540,8 @@ LIMITERS = {
                    "88 % of the SIMD time in the unfactored form), so the pass is priced by its instruction COUNT: the factored form (camera factor "
                    "diag(R K', I) applied once per block) runs 295 instead of 363 instructions per 64 pairs and the launch went from 68 to 59 us; what "
                    "is left is 2 re-evaluations + one 6x6 product per pair and ~170 instructions of reduction / transform per block",
-    "cam_diag": "dependent loads x waves in flight (40 % VALU-busy): index -> point-table gather -> ~700 instructions -> butterfly -> 47 atomics per workgroup",
+    "cam_diag": "VALU issue (11.5 M wave instructions per launch = 77 % of the SIMD time at one quad-cycle each): ~740 instructions per wave of 64 observations, "
+                "a third of them the fp64 reduction tree of the 47 sums; index -> point-table gather in front of them",
     "point_build": "wave lifetime x occupancy: three dependent memory levels + a 7-lanes-of-64 per-point phase per wave (7.6 us of lifetime at 3.4 waves "
                    "per SIMD); measured and rejected: the camera table in LDS (48.2 vs 48.7 us), 5 waves per SIMD by launch bounds (spills: 51 us)",
     "point_update": "wave lifetime x occupancy (two dependent load levels per wave, 16-20 waves per CU); 5 waves per SIMD by launch bounds spills: 28 -> 34 us",
