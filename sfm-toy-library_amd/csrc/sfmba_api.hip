@@ -127,6 +127,11 @@ int wait_mailbox(volatile int* word, int want, hipStream_t stream) {
 
 // A behaviour switch of sfmba_options (ABI v4): the environment variable, when set, overrides the field ("0" = off, else on);
 // otherwise the field (1 on, -1 off), otherwise the library default.
+// relative residual AUTO runs the CG to (see run_solve); SFMBA_AUTO_TOL overrides (experiments)
+static double auto_cg_tol() {
+    static const double v = [] { const char* e = std::getenv("SFMBA_AUTO_TOL"); const double t = e ? std::atof(e) : 0.0; return t > 0.0 ? t : 1e-12; }();
+    return v;
+}
 bool option_switch(int field, const char* env_name, bool dflt) {
     if (const char* e = std::getenv(env_name)) return e[0] != '0';
     return field > 0 ? true : field < 0 ? false : dflt;
@@ -376,7 +381,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // AUTO above 256 unknowns = the DENSE_SCHUR result through the CG: plain relative residual <= 1e-12, bounded iteration count,
     // Cholesky on the same linearisation if the CG does not get there (include/sfmba.h)
     const bool exact_pcg = pcg_mode && o.linear_solver == SFMBA_LINEAR_AUTO;
-    const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
+    const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : auto_cg_tol(), auto_cg_tol()) : o.pcg_tolerance;
     const int cg_max_iters = exact_pcg ? (o.pcg_max_iters > 0 ? o.pcg_max_iters : std::min(4 * p->ds.d, 200)) : o.pcg_max_iters;
     const bool anchored_cg = !exact_pcg && o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
     const bool gated_cg = gated_env || exact_pcg;        // (the fallback is decided where the gated loop learns that the batch was too short)
@@ -1503,7 +1508,7 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
         const bool coarse_cg = option_switch(o.pcg_coarse_space, "SFMBA_PCG_COARSE", true);
         if (coarse_cg) { p->db.pcg_W = p->solver.W; launch_gauge(p->stream, p->ds, p->db); }
         const bool exact_pcg = o.linear_solver == SFMBA_LINEAR_AUTO;
-        const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
+        const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : auto_cg_tol(), auto_cg_tol()) : o.pcg_tolerance;
         const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, cg_tol, o.pcg_max_iters, p->d_info, nullptr,
                                        false, p->shard_host_iter, /*pretransformed=*/true, /*anchor=*/(!o.pcg_anchored || exact_pcg) ? 0 : p->shard_host_iter == 0 ? 1 : 2,
                                        /*no_wait=*/false, /*coarse=*/coarse_cg);
@@ -1608,7 +1613,7 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         // AUTO here = the CG run to a plain relative 1e-12 (no Cholesky fallback in the sharded loop: the factorisation would need the
         // unpreconditioned matrix exchanged as well; at max_iters the step is forced, as with PCG)
         const bool exact_pcg = o.linear_solver == SFMBA_LINEAR_AUTO;
-        const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : 1e-12, 1e-12) : o.pcg_tolerance;
+        const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : auto_cg_tol(), auto_cg_tol()) : o.pcg_tolerance;
         // the CG without the redundant solve (dist_cg.h): reduce-scatter of the blocks, products from the owned blocks, one small
         // all-reduce per CG iteration
         const bool dist_cg = option_switch(o.shard_distributed_cg, "SFMBA_SHARD_DIST_CG", false) && (p->shard_world == 1 || p->reduce_scatter != nullptr);
