@@ -1165,6 +1165,119 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
     }
 }
 
+// The small-block pair pass in the RE-EVALUATING, FACTORED form of k_schur_pairs (RECOMP = 4) -- BASELINE config 5's 500k blocks of ~45
+// pairs, every problem with more than ~210 cameras, and every rank of a sharded solve (which owns every block with 1/N of its pairs).
+// Nothing is gathered per observation and there is no (qa, qb) pair list: per pair a lane reads the pair's point slot (pair_pt, coalesced
+// inside its lane group), ONE 64-byte point-table entry, and re-evaluates both observations (obs_factored).  The blocks of a wave are
+// consecutive blocks of ONE block row (build_structure), so the row camera sits in scalar registers for the whole wave; the column
+// camera differs per lane group and is held per lane.  The 36 sums are reduced over the LPB lanes of a group by the VALU-only halving
+// butterfly (DPP row operations never leave a row of 16 lanes), and the per-camera factors G = Lw D E^T (pair_G) are applied from both
+// sides in the epilogue of all NG blocks side by side.
+template <typename T, int MODE, int LPB, int WPS = 3>
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? WPS : 2)) void k_schur_pairs_sub_f(DeviceStructure ds, DeviceBuffers db) {
+    static_assert(LPB == 16, "one DPP row per block");
+    constexpr int NG = 64 / LPB;
+    __shared__ double tile[NG][36];
+    const int lane = threadIdx.x & 63;
+    if (MODE == 1 && blockIdx.x == 0) post_linearisation(ds, db);        // block (0,0) is in the first workgroup; all 64 lanes here
+    const int sub = lane / LPB, li = lane % LPB;
+    const int4 dsc = ds.pwg_desc[(size_t)blockIdx.x * NG + sub];         // one load: block, row camera, pair range
+    const bool have = dsc.x >= 0;
+    const int b = have ? dsc.x : 0;
+    int2 cj;
+    cj.x = dsc.y;
+    cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
+    const bool diag = cj.x == cj.y;
+    const int fo = ds.d - 1;
+    if (MODE == 1 && have && diag) {
+        // glue of the block-Jacobi transform for camera j (see k_schur_pairs)
+        const int j = cj.x, row0 = 6 * j;
+        const double* Li = db.pcg_binv + (size_t)j * 36;
+        const double linv_f = 1.0 / sqrt(db.S[(size_t)fo * ds.ld + fo]);
+        for (int e = li; e < 36; e += LPB) {
+            const int r = e / 6, c = e - 6 * r;
+            store_F(db, (size_t)(row0 + r) * ds.ld + row0 + c, (r == c) ? 1.0 : 0.0);
+        }
+        for (int l = li; l < 6; l += LPB) {
+            double vf = 0.0, vb = 0.0;
+            for (int a = 0; a <= l; ++a) { vf += Li[l * 6 + a] * db.S[(size_t)(row0 + a) * ds.ld + fo]; vb += Li[l * 6 + a] * db.rhs[row0 + a]; }
+            vf *= linv_f;
+            store_F(db, (size_t)(row0 + l) * ds.ld + fo, vf);
+            store_F(db, (size_t)fo * ds.ld + row0 + l, vf);
+            db.pcg_bt[row0 + l] = vb;
+        }
+        if (j == 0 && li == LPB - 1) {
+            store_F(db, (size_t)fo * ds.ld + fo, 1.0);
+            db.pcg_bt[fo] = db.rhs[fo] * linv_f;
+            db.pcg_binv[(size_t)ds.ncam * 36] = linv_f;
+        }
+    }
+    const bool work = have && !diag;
+    if (!__any(work)) return;
+    const LMState* st = db.st;
+    const int cur = st->cur;
+    const double focal = st->focal[cur];
+    const double* tab = db.camtab[cur];
+    // lane group 0 always holds a block of the workgroup's row (the descriptors of a workgroup are filled from the front)
+    CamG<T> ca;
+    load_cam_g<T>(tab, __builtin_amdgcn_readfirstlane(dsc.y), ds.ncam, ca);
+    CamGL<T> cb;
+    load_cam_gl<T>(tab, work ? cj.y : 0, ds.ncam, cb);
+    const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
+    T acc[36];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+    int p0 = work ? dsc.z : 0;
+    const int p1 = work ? dsc.w : 0;
+    // the point slot of a round's pair is fetched one round ahead (a round then costs one dependent memory level: the point-table entry);
+    // lanes beyond the block's last pair re-read it and contribute nothing
+    const bool nonempty = p0 < p1;
+    int pt_next = nonempty ? ds.pair_pt[p0 + li < p1 ? p0 + li : p1 - 1] : 0;
+    // No branch around the body: a lane group whose block is finished (or empty) keeps evaluating its last pair (point 0 if it never had
+    // one) and adds zeros -- a divergent `if` here costs a register copy of all 36 sums per round.
+    while (__any(p0 < p1)) {
+        const PtRecA<T> pa = load_ptrec(PA + pt_next);
+        const bool mine = p0 + li < p1;
+        if (nonempty) { const int p = p0 + LPB + li; pt_next = ds.pair_pt[p < p1 ? p : p1 - 1]; }
+        T ga[GREC], gb[GREC];
+        obs_factored<T>(ca, focal, pa.X, pa.L, ga);
+        obs_factored<T>(cb, focal, pa.X, pa.L, gb);
+        if (!mine) ga[3] = (T)0;                       // (N carries f_a / p_z)
+        pair_product_factored<T>(ga, gb, acc);
+        p0 += LPB;
+    }
+    if (!nonempty) {                                   // never had a pair: whatever point 0 gave under these two cameras (0 x inf) is not a sum
+#pragma unroll
+        for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+    }
+    int base = 0, len = 36;
+    HalvingReduceT<T, 36, LPB / 2>::run(acc, lane, base, len);          // afterwards lane li owns entries base .. base + len - 1 (len <= 3)
+    if (work) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k < len) tile[sub][base + k] = -(double)acc[k];
+    }
+    wave_lds_fence();
+    if (work) {
+        // S_IJ = G_I [sum] G_J^T (see k_schur_pairs, RECOMP = 4)
+        for (int e = li; e < 36; e += LPB) {
+            const int r = e / 6, c = e - 6 * r;
+            double Gi[6], Gj[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { Gi[a] = db.pair_G[(size_t)cj.x * 36 + 6 * r + a]; Gj[a] = db.pair_G[(size_t)cj.y * 36 + 6 * c + a]; }
+            double v = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double u = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < 6; ++bb) u += tile[sub][6 * a + bb] * Gj[bb];
+                v += Gi[a] * u;
+            }
+            if (MODE == 0) db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
+            else store_block_entry(ds, db, b, cj, r, c, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K2b: camera-diagonal pass.  One lane per observation of the camera (no loop, two dependent memory
 // levels), SFMBA_CAM_CHUNK (256) lanes per workgroup = one chunk of one camera.  Each lane forms its 47 terms in T;
@@ -1394,7 +1507,20 @@ void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBu
     if (mode == 2) {
         if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2, 0>), dim3(ds.ndupwg), block, 0, s, ds, db);
     } else if (ds.pair_lpb == 16) {
-        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
+        // small blocks: the re-evaluating factored form whenever the point table is there (both precisions); SFMBA_PAIR_FORM=0 keeps
+        // the record-gathering form of rounds 1 - 3 (A/B)
+        static const bool sub_records = [] { const char* e = std::getenv("SFMBA_PAIR_FORM"); return e && e[0] == '0'; }();
+        const bool sub_f = db.PA != nullptr && ds.pair_pt != nullptr && db.pair_G != nullptr && !sub_records;
+        static const bool sub_w4 = [] { const char* e = std::getenv("SFMBA_SUBF_WAVES"); return e && e[0] == '4'; }();      // (A/B, to be removed)
+        if (sub_f) {
+            if (mode == 1 && sub_w4) hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 1, 16, 4>), grid, dim3(64), 0, s, ds, db);
+            else if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
+            else {
+                hipLaunchKernelGGL(k_pair_factors, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);
+                hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
+            }
+        }
+        else if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs_sub<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
     } else if (mode == 1) {
         if (factored) hipLaunchKernelGGL((k_schur_pairs<T, 1, 4>), grid, block, 0, s, ds, db);
