@@ -12,6 +12,8 @@ from .structs import SfmbaOptions, SfmbaSummary, SfmbaIteration
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsfmba_hip.so")
+if os.environ.get("SFMBA_LIB"):          # development aid: A/B a library built from another commit (tools/ab/) through the same binding
+    LIB_PATH = os.path.abspath(os.environ["SFMBA_LIB"])
 _lib = None
 
 _dp = C.POINTER(C.c_double)
