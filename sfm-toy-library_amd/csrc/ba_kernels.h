@@ -91,9 +91,9 @@ struct DeviceStructure {
     int nblock;
     const int2* blk_cams;     // [nblock] {ja, jb}
     const int* blk_ptr;       // [nblock+1]
-    const int2* pairs;        // [npair] {qa, qb} point-major positions of two observations of one point, qa < qb
-    const int* pair_pt;       // [npair] the point slot of every pair (the re-evaluating pair pass needs nothing else: the cameras follow from the block)
-    int pair_lpb;             // lanes per 6x6 block in the pair pass: 64 (k_schur_pairs) or 16 (k_schur_pairs_sub), from the mean pairs per block
+    const int* pair_pt;       // [npair] the point slot of every pair of observations (qa < qb) of one point, grouped by block, ascending point inside a
+                              //         block (the pair pass needs nothing else per pair: the cameras follow from the block)
+    int pair_lpb;             // lanes per 6x6 block in the pair pass: 64 (k_schur_pairs) or 16 (k_schur_pairs_sub_f), from the mean pairs per block
     int npairwg;
     const int2* pwg_blocks;   // [npairwg] {first block, #blocks <= 4} per workgroup of the pair pass (XCD-grouped rows)
     int pwg_group;            // blocks per workgroup entry (SFMBA_PAIR_WAVES, or 64 / pair_lpb)
@@ -114,12 +114,9 @@ struct DeviceBuffers {
     double* steptab;          // [ncam][ST_STRIDE]
     double* cscale;           // [6*ncam] Jacobi scale of the camera columns
     double* pscale;           // [npt][3]
-    void* Y;                  // [nobs][YREC] float or double
-    void* Z;                  // [nobs][8] float or double: C t, C y_f, residual (side record of the record-gathering camera pass); null = not wanted
-    void* PA;                 // [npt] PtRecA<T>: X, L^-1 diag(s_p) -- the per-point table of the re-evaluating passes (sfmba_device.h); null = not wanted
+    void* PA;                 // [npt] PtRecA<T>: X, L^-1 diag(s_p) -- the per-point table every pass re-evaluates the observations from (sfmba_device.h)
     void* PB;                 // [npt] PtRecB<T>: t = L^-1 b_p, y_f = L^-1 E_f
     double* pt_t;             // [npt][3] L^-1 b_p
-    double* pt_yf;            // [npt][3] L^-1 E_f
     double* pt_M;             // [npt][6] diag(s_p) L^-T (upper triangle, row-major): dX = M z maps the reduced point right-hand side to the unscaled step
     double* S;                // [ld*ld] reduced system: upper triangle of the row-major matrix
     double* rhs;              // [ld]  (overwritten by the solution)
@@ -167,13 +164,10 @@ void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers&
 template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
                                              int ps_mode = 0 /* 0: point scales from db.pscale; 1 / 2: form them here (Jacobi / unit) */);
 // mode 0: off-diagonal blocks of S (upper triangle);  mode 1: the same blocks written straight into S~ = Lb^-1 S Lb^-T
-// (both triangles) + the per-camera glue of the block-Jacobi transform;  mode 2: diagonal blocks with duplicate pairs
+// (both triangles) + the per-camera glue of the block-Jacobi transform;  mode 2: diagonal blocks with duplicate pairs.
+// Both reduced-system passes re-evaluate every observation from the camera row and the per-point table (nothing is stored per observation).
 template <typename T> void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode);
 template <typename T> void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-// Both passes come in two forms: gathering the stored 64-byte records (db.Y / db.Z), or -- when the per-point table exists (db.PA) and
-// the geometry allows (pair pass: one wave per block, modes 0 / 1) -- re-evaluating every observation from the camera row and the point.
-// The launchers pick the second form whenever it applies; schur_recompute_applies() says whether the pair pass does.
-bool schur_recompute_applies(const DeviceStructure& ds, const DeviceBuffers& db, int mode);
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int pcg);
 void launch_cd_fold(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // deterministic + sharded: chunk sums into the partial system (before the exchange)
 void launch_gauge(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // gauge vectors from db.pcg_binv (see k_gauge)
@@ -218,7 +212,7 @@ int build_point_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, i
                       const int* u_perm, const void* u_xy, PointMajor* out);
 // camera-pair lists of the Schur pass (d_pair_off: npt + 1 prefix counts on the device; npair: their total, known to the host)
 int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
-                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr, int** d_pair_pt = nullptr);
+                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int** d_blk_ptr, int** d_pair_pt);
 int build_camera_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch, int nobs, int ncam, const int* d_obs_cam, const int* d_obs_pt,
                        int** d_cam_obs, int** d_cam_obs_pt, int** d_cam_ptr);
 int build_camera_major_xy(hipStream_t s, DeviceArena* arena, int nobs, int xy_bytes, const int* d_cam_obs, const void* d_obs_xy, void** d_cam_obs_xy);

@@ -5,10 +5,9 @@
 // elimination of the points, back-substitution, trial-point cost) -- see DESIGN.md for the
 // kernel-by-kernel map and SURVEY.md Appendix A for the math.
 //
-//   k_point_build     (point-major)  per point: V, b, E_f, Cholesky inverse of V + D^2; per observation the packed record
-//                     {A_w, f/p_z, x_p, y_p, C = B~ L^-T, camera} and the side record {C t, C y_f, r}
-//   k_cam_diag        (camera-major) U_jj minus the self terms, S_jf, b_c, rhs, undamped diagonal of one camera
-//   k_schur_pairs     one wave (k_schur_pairs_sub: one 16-lane group) per off-diagonal 6x6 block over a precomputed pair list
+//   k_point_build     (point-major)  per point: V, b, E_f, Cholesky inverse of V + D^2, the per-point table entry; NOTHING per observation
+//   k_cam_diag_f      (camera-major) U_jj minus the self terms, S_jf, b_c, rhs, undamped diagonal of one camera (re-evaluating)
+//   k_schur_pairs     one wave (k_schur_pairs_sub_f: one 16-lane group) per off-diagonal 6x6 block over a precomputed list of pair points
 //   k_finalize        damping of the reduced diagonal, gradient max-norm, block-Jacobi factors (PCG)
 //   k_cam_update / k_point_update  back-substitution, trial point, trial cost, model cost change
 //   k_lm_control   accept/reject + trust-region update on the device (no host round trip needed)
@@ -360,44 +359,12 @@ __device__ __forceinline__ void load_obs(const void* base, int q, double& ox, do
 }
 
 // ------------------------------------------------------------------------------------------
-// Packed per-observation record written by the point pass (16 values = 64 B in fp32, one 128-B
-// line in fp64):  [0..5] A_w = Aproj G (2x3, unscaled)  [6] fz = f/pz  [7] xp  [8] yp
-//                 [9..14] C = B~ L^-T (2x3)             [15] camera slot (bit pattern)
+// The blocks of one observation in registers (obs_record, sfmba_device.h): 16 values
+//                 [0..5] A_w = Aproj G (2x3, unscaled)  [6] fz = f/pz  [7] xp  [8] yp
+//                 [9..14] C = B~ L^-T (2x3)             [15] unused
 // The whitened Schur block of two observations a, b of one point is
 //   Y_a Y_b^T = S_a A_a^T (C_a C_b^T) A_b S_b,   A = [A_w | Aproj],  S = Jacobi scale of the camera.
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void store_rec(T* Yout, int q, const T rec[YREC]) {
-    T* dst = Yout + (size_t)q * YREC;
-    if (sizeof(T) == 4) {
-        float4* d4 = reinterpret_cast<float4*>(dst);
-        const float* rf = reinterpret_cast<const float*>(rec);
-#pragma unroll
-        for (int v = 0; v < YREC / 4; ++v) d4[v] = make_float4(rf[4 * v], rf[4 * v + 1], rf[4 * v + 2], rf[4 * v + 3]);
-    } else {
-        double2* d2 = reinterpret_cast<double2*>(dst);
-        const double* rd = reinterpret_cast<const double*>(rec);
-#pragma unroll
-        for (int v = 0; v < YREC / 2; ++v) d2[v] = make_double2(rd[2 * v], rd[2 * v + 1]);
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void load_rec(const T* Y, int q, T rec[YREC]) {
-    const T* src = Y + (size_t)q * YREC;
-    if (sizeof(T) == 4) {
-        const float4* s4 = reinterpret_cast<const float4*>(src);
-        float* rf = reinterpret_cast<float*>(rec);
-#pragma unroll
-        for (int v = 0; v < YREC / 4; ++v) { const float4 x = s4[v]; rf[4 * v] = x.x; rf[4 * v + 1] = x.y; rf[4 * v + 2] = x.z; rf[4 * v + 3] = x.w; }
-    } else {
-        const double2* s2 = reinterpret_cast<const double2*>(src);
-        double* rd = reinterpret_cast<double*>(rec);
-#pragma unroll
-        for (int v = 0; v < YREC / 2; ++v) { const double2 x = s2[v]; rd[2 * v] = x.x; rd[2 * v + 1] = x.y; }
-    }
-}
-
 // unscaled camera block A (2x6, row-major) from a record
 template <typename T>
 __device__ __forceinline__ void rec_camera_block(const T rec[YREC], T A[12]) {
@@ -437,6 +404,10 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Since round 4 the point pass leaves NOTHING per observation behind (rounds 1 - 3 wrote a 64-byte record per observation for the
+// back-substitution: 64 MB written and read per LM iteration at BASELINE config 3): per point the table entry the reduced-system passes
+// and the back-substitution re-evaluate from (PtRecA / PtRecB), t, y_f, M.  A lane needs the camera's R and t only (three component quads
+// of the table instead of six: K' is the reduced-system passes' business).
 template <typename T>
 __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode_flags) {
     // bit 2: enqueued BEFORE the host saw the outcome of the control kernel in front of it (run_solve keeps the queue from draining
@@ -445,8 +416,6 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
     const int ps_mode = ps_mode_flags & 3;
     __shared__ T sv[WPB][64][PB_LD];
     __shared__ double sb[WPB][64][3];
-    __shared__ T sl[WPB][64][6];
-    __shared__ T st_yf[WPB][64][6];          // per local point: t = L^-1 b_p (3), y_f = L^-1 E_f (3)
     __shared__ double scratch[WPB * 4];
     const LMState* st = db.st;
     const int cur = st->cur;
@@ -455,12 +424,11 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
     const T fscale = (T)st->fscale;
     const double radius = st->radius;
     const double* pts = db.pts[cur];
-    T* Yout = reinterpret_cast<T*>(db.Y);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int gw = blockIdx.x * WPB + w;
     double lin_cost = 0.0, sff = 0.0, rhsf = 0.0, gmax = 0.0, bad = 0.0;
 
-    // clear what k_cam_diag (and the duplicate-pair pass) accumulate with atomics: per camera the 6x6 diagonal block,
+    // clear what k_cam_diag_f (and the duplicate-pair pass) accumulate with atomics: per camera the 6x6 diagonal block,
     // its focal column, the undamped diagonal, the scaled gradient and the reduced right-hand side
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ds.ncam * 60; e += gridDim.x * blockDim.x) {
         const int j = e / 60, k = e - 60 * j, row0 = 6 * j;
@@ -475,20 +443,17 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
         const int4 wd = ds.wv_desc[gw];
         const int pt0 = wd.x, pt1 = wd.y;
         const int npts = pt1 - pt0;
-        const int o0 = wd.z, o1 = wd.w;
-        const bool single = (o1 - o0) <= 64;           // false only for a point with more than 64 observations
+        const int o0 = wd.z, o1 = wd.w;                // (more than 64 observations only for a point that has a wave of its own)
         double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 }, Ef[3] = { 0, 0, 0 };
         const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
         const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
-        // the Jacobi scales of this lane's point, issued with the first loads (used after the reduction)
-        double sp[3] = { 1.0, 1.0, 1.0 };
-        if (ps_mode == 0 && lane < npts) {
-            sp[0] = db.pscale[3 * (size_t)(pt0 + lane)]; sp[1] = db.pscale[3 * (size_t)(pt0 + lane) + 1]; sp[2] = db.pscale[3 * (size_t)(pt0 + lane) + 2];
+        // this lane's point and its Jacobi scales, issued with the first loads (used after the reduction)
+        double sp[3] = { 1.0, 1.0, 1.0 }, Xl[3] = { 0.0, 0.0, 0.0 };
+        if (lane < npts) {
+            const size_t i = (size_t)(pt0 + lane);
+            Xl[0] = pts[3 * i]; Xl[1] = pts[3 * i + 1]; Xl[2] = pts[3 * i + 2];
+            if (ps_mode == 0) { sp[0] = db.pscale[3 * i]; sp[1] = db.pscale[3 * i + 1]; sp[2] = db.pscale[3 * i + 2]; }
         }
-        T Bk[6], Ak[12];                                // kept for the record sweep when single
-        Proj prk = { 0.0, 0.0, 0.0 };
-        int ik = 0, jk = 0;
-        T rk0 = (T)0, rk1 = (T)0;
 
         for (int c0 = o0; c0 < o1; c0 += 64) {
             const int q = c0 + lane;
@@ -503,7 +468,6 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
                 lin_cost += r0 * r0 + r1 * r1;
                 T B[6];
                 point_block<T>(ct, pr, focal, B);
-                camera_block<T>(ct, pr, focal, X, B, Ak);
                 // (the point's Jacobi scales are applied to the per-point sums below, not to every observation)
                 const T g0 = (T)pr.xp * fscale, g1 = (T)pr.yp * fscale;
                 T* o = sv[w][lane];
@@ -518,9 +482,6 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
                     o[6 + c] = B[c] * g0 + B[3 + c] * g1;
                     sb[w][lane][c] = (double)B[c] * r0 + (double)B[3 + c] * r1;
                 }
-#pragma unroll
-                for (int c = 0; c < 6; ++c) Bk[c] = B[c];
-                prk = pr; ik = i; jk = j; rk0 = (T)r0; rk1 = (T)r1;
             }
             wave_lds_fence();
             if (lane < npts) {
@@ -567,78 +528,21 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
             // M = diag(s_p) L^-T for the back-substitution (k_point_update): dX = M (t - sum C^T u)
             db.pt_M[6 * i] = sp[0] * Li[0]; db.pt_M[6 * i + 1] = sp[0] * Li[1]; db.pt_M[6 * i + 2] = sp[0] * Li[3];
             db.pt_M[6 * i + 3] = sp[1] * Li[2]; db.pt_M[6 * i + 4] = sp[1] * Li[4]; db.pt_M[6 * i + 5] = sp[2] * Li[5];
-            db.pt_yf[3 * i] = y0; db.pt_yf[3 * i + 1] = y1; db.pt_yf[3 * i + 2] = y2;
             sff -= y0 * y0 + y1 * y1 + y2 * y2;
             rhsf -= y0 * t0 + y1 * t1 + y2 * t2;
             if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2)) bad = 1.0;
-            // L^-1 with the point scales folded in: the record sweep forms C = B~ L^-T = B diag(s) L^-T from the UNSCALED blocks
-            sl[w][lane][0] = (T)(Li[0] * sp[0]); sl[w][lane][1] = (T)(Li[1] * sp[0]); sl[w][lane][2] = (T)(Li[2] * sp[1]);
-            sl[w][lane][3] = (T)(Li[3] * sp[0]); sl[w][lane][4] = (T)(Li[4] * sp[1]); sl[w][lane][5] = (T)(Li[5] * sp[2]);
-            st_yf[w][lane][0] = (T)t0; st_yf[w][lane][1] = (T)t1; st_yf[w][lane][2] = (T)t2;
-            st_yf[w][lane][3] = (T)y0; st_yf[w][lane][4] = (T)y1; st_yf[w][lane][5] = (T)y2;
-            // the per-point table of the re-evaluating reduced-system passes (sfmba_device.h): the point itself, the SAME L values the
-            // record sweep below uses, and t, y_f as the side record sees them
-            if (db.PA) {
-                PtRecA<T> ra;
-                ra.X[0] = pts[3 * i]; ra.X[1] = pts[3 * i + 1]; ra.X[2] = pts[3 * i + 2];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) ra.L[c] = sl[w][lane][c];
-                if (sizeof(T) == 8) reinterpret_cast<double*>(&ra)[9] = 0.0;
-                reinterpret_cast<PtRecA<T>*>(db.PA)[i] = ra;
-                PtRecB<T> rb;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { rb.t[c] = st_yf[w][lane][c]; rb.yf[c] = st_yf[w][lane][3 + c]; }
-                reinterpret_cast<PtRecB<T>*>(db.PB)[i] = rb;
-            }
-        }
-        wave_lds_fence();
-        // record sweep: one packed 64-byte (fp32) record per observation
-        for (int c0 = o0; c0 < o1; c0 += 64) {
-            const int q = c0 + lane;
-            if (q >= o1) continue;
-            if (!single) {      // more than 64 observations on one point: recompute this round's blocks
-                ik = ds.obs_pt[q]; jk = ds.obs_cam[q];
-                const double X[3] = { pts[3 * (size_t)ik], pts[3 * (size_t)ik + 1], pts[3 * (size_t)ik + 2] };
-                const CamRow ct = { tab + 4 * (size_t)(jk), ds.ncam };
-                prk = project_point(ct, CT_R, CT_T, X);
-                { double ox, oy; load_obs<T>(ds.obs_xy, q, ox, oy); rk0 = (T)(focal * prk.xp - ox); rk1 = (T)(focal * prk.yp - oy); }
-                point_block<T>(ct, prk, focal, Bk);
-                camera_block<T>(ct, prk, focal, X, Bk, Ak);
-            }
-            const T* Lp = sl[w][ik - pt0];
-            const T l00 = Lp[0], l10 = Lp[1], l11 = Lp[2], l20 = Lp[3], l21 = Lp[4], l22 = Lp[5];
-            T rec[YREC];
-            rec[0] = Ak[0]; rec[1] = Ak[1]; rec[2] = Ak[2]; rec[3] = Ak[6]; rec[4] = Ak[7]; rec[5] = Ak[8];
-            rec[6] = (T)(focal * prk.iz); rec[7] = (T)prk.xp; rec[8] = (T)prk.yp;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {   // C = B~ L^-T
-                const T b0 = Bk[3 * r], b1 = Bk[3 * r + 1], b2 = Bk[3 * r + 2];
-                rec[9 + 3 * r + 0] = b0 * l00;
-                rec[9 + 3 * r + 1] = b0 * l10 + b1 * l11;
-                rec[9 + 3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
-            }
-            if (sizeof(T) == 4) rec[15] = (T)__int_as_float(jk); else rec[15] = (T)__longlong_as_double((long long)jk);
-            store_rec<T>(Yout, q, rec);
-            // side record for k_cam_diag: C t, C y_f, residual
-            const T* ty = st_yf[w][ik - pt0];
-            T z[8];
-            z[0] = rec[9] * ty[0] + rec[10] * ty[1] + rec[11] * ty[2];
-            z[1] = rec[12] * ty[0] + rec[13] * ty[1] + rec[14] * ty[2];
-            z[2] = rec[9] * ty[3] + rec[10] * ty[4] + rec[11] * ty[5];
-            z[3] = rec[12] * ty[3] + rec[13] * ty[4] + rec[14] * ty[5];
-            z[4] = rk0; z[5] = rk1; z[6] = (T)0; z[7] = (T)0;
-            if (db.Z) {
-            T* zd = reinterpret_cast<T*>(db.Z) + (size_t)q * 8;
-            if (sizeof(T) == 4) {
-                float4* z4 = reinterpret_cast<float4*>(zd);
-                z4[0] = make_float4((float)z[0], (float)z[1], (float)z[2], (float)z[3]);
-                z4[1] = make_float4((float)z[4], (float)z[5], 0.f, 0.f);
-            } else {
-                double2* z2 = reinterpret_cast<double2*>(zd);
-                z2[0] = make_double2((double)z[0], (double)z[1]); z2[1] = make_double2((double)z[2], (double)z[3]);
-                z2[2] = make_double2((double)z[4], (double)z[5]); z2[3] = make_double2(0.0, 0.0);
-            }
-            }
+            // the per-point table (sfmba_device.h): the point itself; L^-1 with the point scales folded in, so that C = B~ L^-T =
+            // B diag(s) L^-T comes from the UNSCALED point block of an observation; t and y_f in the precision of the Jacobian blocks
+            PtRecA<T> ra;
+            ra.X[0] = Xl[0]; ra.X[1] = Xl[1]; ra.X[2] = Xl[2];
+            ra.L[0] = (T)(Li[0] * sp[0]); ra.L[1] = (T)(Li[1] * sp[0]); ra.L[2] = (T)(Li[2] * sp[1]);
+            ra.L[3] = (T)(Li[3] * sp[0]); ra.L[4] = (T)(Li[4] * sp[1]); ra.L[5] = (T)(Li[5] * sp[2]);
+            if (sizeof(T) == 8) reinterpret_cast<double*>(&ra)[9] = 0.0;
+            reinterpret_cast<PtRecA<T>*>(db.PA)[i] = ra;
+            PtRecB<T> rb;
+            rb.t[0] = (T)t0; rb.t[1] = (T)t1; rb.t[2] = (T)t2;
+            rb.yf[0] = (T)y0; rb.yf[1] = (T)y1; rb.yf[2] = (T)y2;
+            reinterpret_cast<PtRecB<T>*>(db.PB)[i] = rb;
         }
     }
     if (!finite_d(lin_cost)) bad = 1.0;
@@ -654,13 +558,15 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
 }
 
 // ------------------------------------------------------------------------------------------
-// K2a: reduced-system pass over camera pairs.  One wave per 6x6 block (ja < jb, plus the rare
-// same-camera duplicates on the diagonal): the pairs of observations (one of camera ja, one of
-// camera jb, same point) were listed once on the host, so the block is the plain sum
+// K2a: reduced-system pass over camera pairs.  One wave per 6x6 block (ja < jb): the pairs of observations (one of camera ja,
+// one of camera jb, same point) were listed once at build time (structure_build.hip: per pair its POINT, grouped by block),
+// so the block is the plain sum
 //   -S_a [ sum_pairs A_a^T (C_a C_b^T) A_b ] S_b
 // -- no atomics, every block written exactly once per iteration (empty blocks are written as zero:
 // the in-place Cholesky destroyed the previous contents).  Workgroups are grouped so that all
-// blocks of one block-row run on one XCD (blockIdx % 8): the records of camera ja stay in that L2.
+// blocks of one block-row run on one XCD (blockIdx % 8).  Nothing is stored per observation (rounds 1 / 2 gathered two 64-byte
+// records per pair: 19x the algorithmic traffic): both observations of a pair are RE-EVALUATED from the two camera rows (scalar
+// registers) and one 64-byte point-table entry, in the FACTORED form of sfmba_device.h (obs_factored).
 // ------------------------------------------------------------------------------------------
 // Sum of N per-lane values over the lanes that differ in the bits OFF, OFF/2, ..., 1: at every level a lane keeps one half of
 // the values and sends the other half to its partner, so the whole reduction moves N/2 + N/4 + ... values instead of N per level.
@@ -721,65 +627,6 @@ __device__ __forceinline__ void pair_product(const T ra[YREC], const T rb[YREC],
         }
 }
 
-// quad helpers: the four lanes 4g..4g+3 cooperate on loading four pairs
-// exchange with the lane whose quad position differs in one bit (quad_perm [1,0,3,2] / [2,3,0,1])
-template <int CTRL>
-__device__ __forceinline__ float quad_xchg(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ double quad_xchg(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// In-place 4x4 transpose across the four lanes of a quad: on entry r[u] (lane s) = element (u, s); on exit r[j] (lane s)
-// = element (s, j).  Two butterfly stages, 8 selects + 4 DPP moves; b0/b1 = bits of the lane's quad position.
-template <typename T>
-__device__ __forceinline__ void quad_transpose(T r[4], bool b0, bool b1) {
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {
-        const T got = quad_xchg<0xB1>(b0 ? r[k] : r[k + 1]);
-        r[k] = b0 ? got : r[k];
-        r[k + 1] = b0 ? r[k + 1] : got;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const T got = quad_xchg<0x4E>(b1 ? r[k] : r[k + 2]);
-        r[k] = b1 ? got : r[k];
-        r[k + 2] = b1 ? r[k + 2] : got;
-    }
-}
-// The quad loaded four pairs cooperatively (lane s holds quarter s of each record); afterwards lane s owns pair s whole.
-template <typename T>
-__device__ __forceinline__ void quad_distribute(T q[4][4], T rec[YREC], bool b0, bool b1) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        T r[4] = { q[0][m], q[1][m], q[2][m], q[3][m] };
-        quad_transpose<T>(r, b0, b1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rec[4 * j + m] = r[j];
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void load_quarter(const T* Y, int q, int s, T out[4]) {
-    const T* src = Y + (size_t)q * YREC + 4 * s;
-    if (sizeof(T) == 4) {
-        const float4 x = *reinterpret_cast<const float4*>(src);
-        out[0] = (T)x.x; out[1] = (T)x.y; out[2] = (T)x.z; out[3] = (T)x.w;
-    } else {
-        const double2 x = reinterpret_cast<const double2*>(src)[0], y = reinterpret_cast<const double2*>(src)[1];
-        out[0] = (T)x.x; out[1] = (T)x.y; out[2] = (T)y.x; out[3] = (T)y.y;
-    }
-}
-
-// Pair pass.  One wave per 6x6 block of the reduced matrix; 64 pairs per round.  Loads are quad-cooperative (each
-// 64-byte record is ONE request of four adjacent lanes instead of four requests of one lane: the vector-memory pipe
-// walks lines, not bytes), compute is lane-per-pair after a DPP transpose; lane-local sums stay in T, the sum over the
-// wave is carried in fp64.
-
 __device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db);
 
 // one entry of the preconditioned reduced matrix (fp64, or fp32 when the streaming CG path asked for it)
@@ -799,36 +646,23 @@ __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, con
     store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
 }
 
-// RECOMP (modes 0 / 1): nothing is gathered per observation.  Both cameras of a block are fixed for the wave, so their table rows sit
-// in scalar registers; per pair a lane loads ONE point-table entry (one 64-byte sector in fp32 mode, from a table that stays in L2) and
-// re-evaluates both observations with the expressions of the point pass (obs_record): the same values, pair for pair and in the
-// same lane, as the record-gathering form -- minus the two random 64-byte gathers per pair from the 64 MB of records.
-// RECOMP = 0: gathering form; 3: re-evaluating form, compiled for three waves per SIMD (162 registers; at four it spills ~40 of them
-// and runs 2.3x slower: measured 163 vs 71 us at BASELINE config 3); 4: re-evaluating FACTORED form (fp32-Jacobian mode): the per-camera
-// factor diag(R K', I) of the camera blocks is taken out of the pair loop (sfmba_device.h, obs_factored) -- 295 instead of 363 wave
-// instructions per round, 128 registers (four waves per SIMD): 60 vs 68 us.
-template <typename T, int MODE, int RECOMP>
-__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP == 3 ? 3 : 4) : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+// Lane-local sums stay in T for at most PAIR_FLUSH rounds (64 pairs each), then the wave sum is taken and carried on in fp64: a block
+// with tens of thousands of pairs (two cameras sharing most of a large cloud) would otherwise pile thousands of fp32 additions
+// into one accumulator.  Blocks up to 64 * PAIR_FLUSH pairs -- all of BASELINE config 3 -- never take the branch.
+// The per-camera factor diag(R K', I) of the camera blocks is applied once per block in the epilogue (pair_G), the pair loop works on
+// [ -[R X]x | I ], the projection Jacobian and C: 295 wave instructions per 64 pairs, 128 registers (four waves per SIMD) in fp32 mode.
+template <typename T, int MODE>
+__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double tile[SFMBA_PAIR_WAVES][36];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int b, pbeg, pend;
+    const int4 dsc = ds.pwg_desc[(size_t)blockIdx.x * SFMBA_PAIR_WAVES + w];      // one load: block, row camera, pair range
+    if (dsc.x < 0) return;
+    const int b = dsc.x, pbeg = dsc.z, p1 = dsc.w;
     int2 cj;
-    if (MODE == 2) {
-        const int2 wg = ds.dup_blocks[blockIdx.x];       // {first block, number of blocks (<= 4)}
-        if (w >= wg.y) return;
-        b = wg.x + w;
-        cj = ds.blk_cams[b];
-        pbeg = ds.blk_ptr[b]; pend = ds.blk_ptr[b + 1];
-    } else {
-        const int4 dsc = ds.pwg_desc[(size_t)blockIdx.x * SFMBA_PAIR_WAVES + w];      // one load: block, row camera, pair range
-        if (dsc.x < 0) return;
-        b = dsc.x; pbeg = dsc.z; pend = dsc.w;
-        cj.x = dsc.y;
-        cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
-    }
-    const bool diag = cj.x == cj.y;
+    cj.x = dsc.y;
+    cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
     const int fo = ds.d - 1;
-    if (MODE != 2 && diag) {
+    if (cj.x == cj.y) {
         if (MODE == 1) {
             // k_finalize(pcg = 1) left the post-linearisation bookkeeping (gradient tolerance, cost of iteration 0, failed
             // evaluation) to this launch, which starts after it in stream order: no arrival counter, no fences there
@@ -855,24 +689,16 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ==
                 db.pcg_binv[(size_t)ds.ncam * 36] = linv_f;
             }
         }
-        return;     // pairs inside diagonal blocks (duplicates) were added by the MODE 2 pass before k_finalize
+        return;     // pairs inside diagonal blocks (duplicates) were added by k_schur_dups before k_finalize
     }
-    const T* Y = reinterpret_cast<const T*>(db.Y);
     const int s = lane & 3, g = lane >> 2;
-    const bool b0 = (s & 1) != 0, b1 = (s & 2) != 0;
     T acc[36];
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-    const int p1 = pend;
-    // Lane-local sums stay in T for at most PAIR_FLUSH rounds (64 pairs each), then the wave sum is taken and carried on in fp64: a block
-    // with tens of thousands of pairs (two cameras sharing most of a large cloud) would otherwise pile thousands of fp32 additions
-    // into one accumulator.  Blocks up to 64 * PAIR_FLUSH pairs -- all of BASELINE config 3 -- never take the branch.
     constexpr int PAIR_FLUSH = 64;
     double total = 0.0;            // this lane's entry of the 6x6 block (lanes that own one), over the flushes so far
     int base = 0, len = 36, rounds = 0;
-    if (RECOMP == 4) {
-        // Factored form (sfmba_device.h, obs_factored): the per-camera factor diag(R K', I) of the camera blocks is applied once per
-        // block in the epilogue, the pair loop works on [ -[R X]x | I ], the projection Jacobian and C.
+    {
         const LMState* st = db.st;
         const int cur = st->cur;
         const double focal = st->focal[cur];
@@ -880,6 +706,8 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ==
         load_cam_g<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.x), ds.ncam, ca);
         load_cam_g<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.y), ds.ncam, cb);
         const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
+        // lane (s, g) owns pair p0 + 16 s + g of a round; the point slot of the NEXT round's pair is fetched one round ahead (one
+        // dependent memory level per round: the point-table entry)
         const int mine = 16 * s + g;
         int pt_next = ds.pair_pt[pbeg < p1 ? (pbeg + mine < p1 ? pbeg + mine : p1 - 1) : 0];
         for (int p0 = pbeg; p0 < p1; p0 += 64) {
@@ -898,274 +726,77 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? (RECOMP ==
                 for (int e = 0; e < 36; ++e) acc[e] = (T)0;
             }
         }
-    } else if (RECOMP) {
-        const LMState* st = db.st;
-        const int cur = st->cur;
-        const double focal = st->focal[cur];
-        CamU<T> ca, cb;
-        load_cam_u<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.x), ds.ncam, ca);
-        load_cam_u<T>(db.camtab[cur], __builtin_amdgcn_readfirstlane(cj.y), ds.ncam, cb);
-        const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
-        // lane (s, g) owns pair p0 + 16 s + g of a round -- the pair the DPP transpose of the gathering form hands it -- so the
-        // lane-local sums (and every bit of the block) come out the same in both forms.  The point index of the NEXT round's pair
-        // is fetched one round ahead (one dependent memory level per round: the point-table entry).
-        const int mine = 16 * s + g;
-        int pt_next = ds.pair_pt[pbeg < p1 ? (pbeg + mine < p1 ? pbeg + mine : p1 - 1) : 0];
-        for (int p0 = pbeg; p0 < p1; p0 += 64) {
-            const PtRecA<T> pa = load_ptrec(PA + pt_next);
-            { const int p = p0 + 64 + mine; pt_next = ds.pair_pt[p < p1 ? p : p1 - 1]; }
-            T ra[YREC], rb[YREC];
-            obs_record<T>(ca, focal, pa.X, pa.L, ra);
-            obs_record<T>(cb, focal, pa.X, pa.L, rb);
-            if (p0 + mine >= p1) {              // this lane's pair lies beyond the block: contribute nothing
-#pragma unroll
-                for (int e = 9; e < 15; ++e) ra[e] = (T)0;
-            }
-            pair_product<T>(ra, rb, false, acc);
-            if (sizeof(T) == 4 && ++rounds == PAIR_FLUSH && p0 + 64 < p1) {
-                rounds = 0; base = 0; len = 36;
-                HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
-                total += len >= 1 ? (double)acc[0] : 0.0;
-#pragma unroll
-                for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-            }
-        }
-    } else {
-    // A quad LOADS four pairs cooperatively (each 64-byte record is one request of four adjacent lanes: the vector-memory
-    // pipe walks lines, not bytes) and then transposes them with DPP so that every lane COMPUTES one pair on its own:
-    // the first version had all four lanes form the same 2x2 core and the same T block (75 % VALU-busy, 7.1 wave
-    // instructions per pair); this one needs 3.8.
-    // the pair indices of a round are fetched one round ahead: a round then costs ONE dependent memory level (the record
-    // gathers) instead of two (indices, then records)
-    int2 pr[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int p = pbeg + 16 * u + g; pr[u] = ds.pairs[pbeg < p1 ? (p < p1 ? p : p1 - 1) : 0]; }
-    for (int p0 = pbeg; p0 < p1; p0 += 64) {
-        T qa[4][4], qb[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            load_quarter<T>(Y, pr[u].x, s, qa[u]);
-            load_quarter<T>(Y, pr[u].y, s, qb[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {      // next round's indices (clamped: the last round re-reads its own)
-            const int p = p0 + 64 + 16 * u + g;
-            pr[u] = ds.pairs[p < p1 ? p : p1 - 1];
-        }
-        T ra[YREC], rb[YREC];
-        quad_distribute<T>(qa, ra, b0, b1);
-        quad_distribute<T>(qb, rb, b0, b1);
-        if (p0 + 16 * s + g >= p1) {        // this lane's pair lies beyond the block: contribute nothing
-#pragma unroll
-            for (int e = 9; e < 15; ++e) ra[e] = (T)0;
-        }
-        pair_product<T>(ra, rb, MODE == 2, acc);
-        if (sizeof(T) == 4 && ++rounds == PAIR_FLUSH && p0 + 64 < p1) {
-            rounds = 0; base = 0; len = 36;
-            HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
-            total += len >= 1 ? (double)acc[0] : 0.0;
-#pragma unroll
-            for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-        }
     }
-    }
-    // Sum of the 36 entries over the 64 lanes by a halving butterfly (38 shuffles instead of 72 + 96: the epilogue was as long as
-    // the pair loop): afterwards lane `base` -- 36 of the 64 lanes -- owns ONE entry of the 6x6 block.
+    // Sum of the 36 entries over the 64 lanes by a halving butterfly: afterwards lane `base` -- 36 of the 64 lanes -- owns ONE
+    // entry of the 6x6 block.
     base = 0; len = 36;
     HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
     total += len >= 1 ? (double)acc[0] : 0.0;
-    const bool owner = len >= 1;
-    const int er = owner ? base / 6 : 0, ec = owner ? base - 6 * (base / 6) : 0;
-    if (RECOMP == 4) {
-        // the sums are in the factored coordinates (sfmba_device.h): S_IJ = G_I [sum] G_J^T with the per-camera G = Lw D E^T that
-        // k_finalize (PCG: Lw = Linv, so this IS the preconditioned block) or k_pair_factors (exact solver: Lw = I) left in pair_G --
-        // the same two-sided 6 x 6 transform, and the same loads, as the Linv transform of the unfactored forms below
-        if (owner) tile[w][base] = -total;
-        wave_lds_fence();
-        if (lane < 36) {
-            const int r = lane / 6, c = lane - 6 * r;
-            double Gi[6], Gj[6];
+    // the sums are in the factored coordinates (sfmba_device.h): S_IJ = G_I [sum] G_J^T with the per-camera G = Lw D E^T that
+    // k_finalize (PCG: Lw = Linv, so this IS the preconditioned block) or k_pair_factors (exact solver: Lw = I) left in pair_G
+    if (len >= 1) tile[w][base] = -total;
+    wave_lds_fence();
+    if (lane < 36) {
+        const int r = lane / 6, c = lane - 6 * r;
+        double Gi[6], Gj[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) { Gi[a] = db.pair_G[(size_t)cj.x * 36 + 6 * r + a]; Gj[a] = db.pair_G[(size_t)cj.y * 36 + 6 * c + a]; }
-            double v = 0.0;
+        for (int a = 0; a < 6; ++a) { Gi[a] = db.pair_G[(size_t)cj.x * 36 + 6 * r + a]; Gj[a] = db.pair_G[(size_t)cj.y * 36 + 6 * c + a]; }
+        double v = 0.0;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double u = 0.0;
+        for (int a = 0; a < 6; ++a) {
+            double u = 0.0;
 #pragma unroll
-                for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Gj[bb];
-                v += Gi[a] * u;
-            }
-            if (MODE == 0) db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
-            else store_block_entry(ds, db, b, cj, r, c, v);
+            for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Gj[bb];
+            v += Gi[a] * u;
         }
-        return;
-    }
-    const double entry = owner ? -total * db.cscale[6 * cj.x + er] * db.cscale[6 * cj.y + ec] : 0.0;
-    if (MODE == 0 || MODE == 2) {
-        if (owner) {
-            double* dst = db.S + (size_t)(6 * cj.x + er) * ds.ld + 6 * cj.y + ec;
-            if (MODE == 0) *dst = entry; else if (ec >= er) atomicAdd(dst, entry);     // MODE 2: upper part of the diagonal block
-        }
-    } else {
-        // S~_IJ = Linv_I S_IJ Linv_J^T written to both triangles of the preconditioned matrix
-        if (owner) tile[w][base] = entry;
-        wave_lds_fence();
-        if (lane < 36) {
-            const int r = lane / 6, c = lane - 6 * r;
-            const double* Li = db.pcg_binv + (size_t)cj.x * 36 + r * 6;     // row r of Linv_I (lower triangular)
-            const double* Lj = db.pcg_binv + (size_t)cj.y * 36 + c * 6;     // row c of Linv_J
-            double v = 0.0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double u = 0.0;
-#pragma unroll
-                for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Lj[bb];
-                v += Li[a] * u;
-            }
-            store_block_entry(ds, db, b, cj, r, c, v);
-        }
+        if (MODE == 0) db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
+        else store_block_entry(ds, db, b, cj, r, c, v);
     }
 }
 
-// Pair pass for SMALL blocks: LPB = 16 lanes per 6x6 block, 64 / LPB consecutive blocks of one block row per wave
-// (a quad per block was measured too: slower than 16 lanes at every density, 346 vs 280 us at 5.6 pairs per block).
-// With a whole wave per block the per-block epilogue (reductions, scaling, Linv transform, stores: ~400 instructions)
-// dominates once a block has only a few dozen pairs -- 1000 cameras: 500k blocks of ~45 pairs; a rank of the sharded
-// mode owns every block with 1/N of its pairs -- here the epilogues of the blocks of a wave run side by side in its
-// lane groups and the reductions are two (or zero) shuffle stages shorter.  Same arithmetic per pair as k_schur_pairs.
-template <typename T, int MODE, int LPB>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_sub(DeviceStructure ds, DeviceBuffers db) {
-    constexpr int NG = 64 / LPB;
-    __shared__ double tile[NG][36];
+// Pairs INSIDE a diagonal block: one camera observing a point twice (two features matched to the same 3D point).  Both observations
+// of such a pair have the same camera and the same point, hence the same Jacobian blocks (only their coordinates differ):
+// Y_a Y_b^T + Y_b Y_a^T = 2 Y Y^T, one evaluation per pair.  One wave per diagonal block that has pairs (usually none); added to the
+// upper part of the block with atomics BEFORE k_finalize damps and factors it.
+template <typename T>
+__global__ __launch_bounds__(64) void k_schur_dups(DeviceStructure ds, DeviceBuffers db) {
     const int lane = threadIdx.x & 63;
-    if (MODE == 1 && blockIdx.x == 0) post_linearisation(ds, db);        // block (0,0) is in the first workgroup; all 64 lanes here
-    const int sub = lane / LPB, li = lane % LPB;
-    const int4 dsc = ds.pwg_desc[(size_t)blockIdx.x * NG + sub];         // one load: block, row camera, pair range
-    const bool have = dsc.x >= 0;
-    const int b = have ? dsc.x : 0;
-    int2 cj;
-    cj.x = dsc.y;
-    cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
-    const bool diag = cj.x == cj.y;
-    const int fo = ds.d - 1;
-    if (MODE == 1 && have && diag) {
-        // glue of the block-Jacobi transform for camera j (see k_schur_pairs)
-        const int j = cj.x, row0 = 6 * j;
-        const double* Li = db.pcg_binv + (size_t)j * 36;
-        const double linv_f = 1.0 / sqrt(db.S[(size_t)fo * ds.ld + fo]);
-        for (int e = li; e < 36; e += LPB) {
-            const int r = e / 6, c = e - 6 * r;
-            store_F(db, (size_t)(row0 + r) * ds.ld + row0 + c, (r == c) ? 1.0 : 0.0);
-        }
-        for (int l = li; l < 6; l += LPB) {
-            double vf = 0.0, vb = 0.0;
-            for (int a = 0; a <= l; ++a) { vf += Li[l * 6 + a] * db.S[(size_t)(row0 + a) * ds.ld + fo]; vb += Li[l * 6 + a] * db.rhs[row0 + a]; }
-            vf *= linv_f;
-            store_F(db, (size_t)(row0 + l) * ds.ld + fo, vf);
-            store_F(db, (size_t)fo * ds.ld + row0 + l, vf);
-            db.pcg_bt[row0 + l] = vb;
-        }
-        if (j == 0 && li == LPB - 1) {
-            store_F(db, (size_t)fo * ds.ld + fo, 1.0);
-            db.pcg_bt[fo] = db.rhs[fo] * linv_f;
-            db.pcg_binv[(size_t)ds.ncam * 36] = linv_f;
-        }
-    }
-    const bool work = have && !diag;
-    const T* Y = reinterpret_cast<const T*>(db.Y);
-    const int s = lane & 3, g = li >> 2;
-    const bool b0 = (s & 1) != 0, b1 = (s & 2) != 0;
-    T acc[36];
+    const int b = ds.dup_blocks[blockIdx.x].x;
+    const int j = ds.blk_cams[b].x;
+    const int pbeg = ds.blk_ptr[b], p1 = ds.blk_ptr[b + 1];
+    const LMState* st = db.st;
+    const int cur = st->cur;
+    const double focal = st->focal[cur];
+    CamRegs ct;
+    load_cam_regs(db.camtab[cur], __builtin_amdgcn_readfirstlane(j), ds.ncam, ct);
+    const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
+    double total[36];
 #pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-    int p0 = work ? dsc.z : 0;
-    const int p1 = work ? dsc.w : 0;
-    while (__any(p0 < p1)) {
-        const bool act = p0 < p1;                      // uniform inside a lane group (hence inside every quad)
-        T qa[4][4], qb[4][4];
+    for (int e = 0; e < 36; ++e) total[e] = 0.0;
+    for (int p0 = pbeg; p0 < p1; p0 += 64) {
+        const int p = p0 + lane;
+        const PtRecA<T> pa = load_ptrec(PA + ds.pair_pt[p < p1 ? p : p1 - 1]);
+        T rec[YREC], acc[36];
+        obs_record<T>(ct, focal, pa.X, pa.L, rec);
+        if (p >= p1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (act) {
-                const int p = p0 + (LPB / 4) * u + g;
-                const int2 pr = ds.pairs[p < p1 ? p : p1 - 1];
-                load_quarter<T>(Y, pr.x, s, qa[u]);
-                load_quarter<T>(Y, pr.y, s, qb[u]);
-            } else {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { qa[u][m] = (T)0; qb[u][m] = (T)0; }
-            }
+            for (int e = 9; e < 15; ++e) rec[e] = (T)0;
         }
-        T ra[YREC], rb[YREC];
-        quad_distribute<T>(qa, ra, b0, b1);
-        quad_distribute<T>(qb, rb, b0, b1);
-        if (!act || p0 + (LPB / 4) * s + g >= p1) {
 #pragma unroll
-            for (int e = 9; e < 15; ++e) ra[e] = (T)0;
-        }
-        pair_product<T>(ra, rb, false, acc);
-        p0 += LPB;
+        for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+        pair_product<T>(rec, rec, true, acc);
+#pragma unroll
+        for (int e = 0; e < 36; ++e) total[e] += (double)acc[e];
     }
 #pragma unroll
     for (int e = 0; e < 36; ++e) {
-        T v = acc[e];
-        v += quad_xchg<0xB1>(v);
-        v += quad_xchg<0x4E>(v);
-        acc[e] = v;
-    }
-    double accd[12];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const T r0 = s == 0 ? acc[c] : s == 1 ? acc[6 + c] : s == 2 ? acc[12 + c] : acc[18 + c];
-        const T r1 = s == 0 ? acc[24 + c] : s == 1 ? acc[30 + c] : (T)0;
-        double v = (double)r0, w2 = (double)r1;
-        // (a true lane ^ off exchange: lane s of every quad carries row s -- the lane ^ 7 partner of the VALU butterfly would mix the rows)
-#pragma unroll
-        for (int off = 4; off < LPB; off <<= 1) { v += __shfl_xor(v, off, 64); w2 += __shfl_xor(w2, off, 64); }
-        accd[c] = v; accd[6 + c] = w2;
-    }
-    const double* sa = db.cscale + 6 * cj.x;
-    const double* sb = db.cscale + 6 * cj.y;
-    if (MODE == 0) {
-        if (work && li < 4) {
-            double* Srow0 = db.S + (size_t)(6 * cj.x + s) * ds.ld + 6 * cj.y;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Srow0[c] = -accd[c] * sa[s] * sb[c];
-            if (s < 2) {
-                double* Srow1 = db.S + (size_t)(6 * cj.x + s + 4) * ds.ld + 6 * cj.y;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) Srow1[c] = -accd[6 + c] * sa[s + 4] * sb[c];
-            }
-        }
-    } else {
-        if (work && li < 4) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) tile[sub][6 * s + c] = -accd[c] * sa[s] * sb[c];
-            if (s < 2) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) tile[sub][6 * (s + 4) + c] = -accd[6 + c] * sa[s + 4] * sb[c];
-            }
-        }
-        wave_lds_fence();
-        if (work) {
-            for (int e = li; e < 36; e += LPB) {
-                const int r = e / 6, c = e - 6 * r;
-                const double* Li = db.pcg_binv + (size_t)cj.x * 36 + r * 6;
-                const double* Lj = db.pcg_binv + (size_t)cj.y * 36 + c * 6;
-                double v = 0.0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    double u = 0.0;
-#pragma unroll
-                    for (int bb = 0; bb < 6; ++bb) u += tile[sub][6 * a + bb] * Lj[bb];
-                    v += Li[a] * u;
-                }
-                store_block_entry(ds, db, b, cj, r, c, v);
-            }
-        }
+        const double v = wave_allsum(total[e]);
+        const int r = e / 6, c = e - 6 * r;
+        if (lane == e && c >= r) atomicAdd(db.S + (size_t)(6 * j + r) * ds.ld + 6 * j + c, -v * db.cscale[6 * j + r] * db.cscale[6 * j + c]);
     }
 }
 
-// The small-block pair pass in the RE-EVALUATING, FACTORED form of k_schur_pairs (RECOMP = 4) -- BASELINE config 5's 500k blocks of ~45
+// The pair pass for SMALL blocks, LPB = 16 lanes per 6x6 block and 64 / LPB blocks per wave -- BASELINE config 5's 500k blocks of ~45
 // pairs, every problem with more than ~210 cameras, and every rank of a sharded solve (which owns every block with 1/N of its pairs).
 // Nothing is gathered per observation and there is no (qa, qb) pair list: per pair a lane reads the pair's point slot (pair_pt, coalesced
 // inside its lane group), ONE 64-byte point-table entry, and re-evaluates both observations (obs_factored).  The blocks of a wave are
@@ -1173,8 +804,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs_su
 // camera differs per lane group and is held per lane.  The 36 sums are reduced over the LPB lanes of a group by the VALU-only halving
 // butterfly (DPP row operations never leave a row of 16 lanes), and the per-camera factors G = Lw D E^T (pair_G) are applied from both
 // sides in the epilogue of all NG blocks side by side.
-template <typename T, int MODE, int LPB, int WPS = 3>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? WPS : 2)) void k_schur_pairs_sub_f(DeviceStructure ds, DeviceBuffers db) {
+template <typename T, int MODE, int LPB>
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 2)) void k_schur_pairs_sub_f(DeviceStructure ds, DeviceBuffers db) {
     static_assert(LPB == 16, "one DPP row per block");
     constexpr int NG = 64 / LPB;
     __shared__ double tile[NG][36];
@@ -1258,7 +889,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? WPS : 2)) void k_schur_pairs_
     }
     wave_lds_fence();
     if (work) {
-        // S_IJ = G_I [sum] G_J^T (see k_schur_pairs, RECOMP = 4)
+        // S_IJ = G_I [sum] G_J^T (see k_schur_pairs)
         for (int e = li; e < 36; e += LPB) {
             const int r = e / 6, c = e - 6 * r;
             double Gi[6], Gj[6];
@@ -1374,42 +1005,9 @@ __device__ __forceinline__ void cam_diag_finish(const DeviceStructure& ds, const
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(CD_BLK) void k_cam_diag(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double red[CD_BLK / 64][CD_N];
-    const int4 ch = ds.chunks[blockIdx.x];
-    const int j = ch.x;
-    const LMState* st = db.st;
-    const T fscale = (T)st->fscale;
-    const T* Y = reinterpret_cast<const T*>(db.Y);
-    T v[CD_N];
-#pragma unroll
-    for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
-    // (SFMBA_CAM_CHUNK / CD_BLK observations per lane, summed in the lane before the one reduction of the workgroup; 1 by default)
-#pragma unroll 1
-    for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {
-        const int q = ds.cam_obs[e];
-        T rec[YREC];
-        load_rec<T>(Y, q, rec);
-        T z[8];
-        {
-            const T* zs = reinterpret_cast<const T*>(db.Z) + (size_t)q * 8;
-            if (sizeof(T) == 4) {
-                const float4 a = reinterpret_cast<const float4*>(zs)[0], b = reinterpret_cast<const float4*>(zs)[1];
-                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)a.z; z[3] = (T)a.w; z[4] = (T)b.x; z[5] = (T)b.y;
-            } else {
-                const double2 a = reinterpret_cast<const double2*>(zs)[0], b = reinterpret_cast<const double2*>(zs)[1], c = reinterpret_cast<const double2*>(zs)[2];
-                z[0] = (T)a.x; z[1] = (T)a.y; z[2] = (T)b.x; z[3] = (T)b.y; z[4] = (T)c.x; z[5] = (T)c.y;
-            }
-        }
-        cam_diag_terms<T, (CD_OBS > 1)>(rec, z, db.cscale + 6 * j, fscale, v);
-    }
-    cam_diag_finish<T>(ds, db, j, v, red);
-}
-
-// The same pass WITHOUT the per-observation records: the camera's table row sits in scalar registers (one camera per workgroup), a lane
-// gathers its observation's point-table entries (64 + 24 bytes from a table that stays in L2), reads the observation's coordinates from
-// the camera-major copy (coalesced), and re-evaluates record and residual with the expressions of the point pass (obs_record).
+// Nothing is stored per observation: the camera's table row sits in scalar registers (one camera per workgroup), a lane gathers its
+// observation's point-table entries (64 + 24 bytes from a table that stays in L2), reads the observation's coordinates from the
+// camera-major copy (coalesced), and re-evaluates blocks and residual with the expressions of the point pass (obs_record).
 template <typename T>
 __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double red[CD_BLK / 64][CD_N];
@@ -1425,7 +1023,7 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
 #pragma unroll
     for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
 #pragma unroll 1
-    for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {      // (see k_cam_diag)
+    for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {      // (SFMBA_CAM_CHUNK / CD_BLK observations per lane; 1 by default)
         // two coalesced streams (point slot, observation coordinates in camera-major order) and two gathers from the L2-resident point table
         const int i = ds.cam_obs_pt[e];
         const typename ObsXY<T>::type oxy = reinterpret_cast<const typename ObsXY<T>::type*>(ds.cam_obs_xy)[e];
@@ -1489,50 +1087,24 @@ __global__ void k_pair_factors(DeviceStructure ds, DeviceBuffers db) {
     pair_factor<false>(db, j, none, Q9, cs);
 }
 
-// the re-evaluating pair pass: one wave per block (pair_lpb == 64), off-diagonal modes, the point table and the pair-point list present
-// (a problem built with SFMBA_SCHUR_RECORDS=1 has no point table: the record-gathering forms run -- A/B measurements and the
-// bit-for-bit comparison test)
-bool schur_recompute_applies(const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
-    return db.PA != nullptr && ds.pair_pt != nullptr && ds.pair_lpb == 64 && mode != 2;
-}
-
+// mode 0: off-diagonal blocks of S (upper triangle; exact solver);  mode 1: the same blocks written straight into S~ = Lb^-1 S Lb^-T
+// (both triangles, or the exchange buffer of a sharded solve) + the per-camera glue of the block-Jacobi transform;  mode 2: the
+// duplicate pairs inside diagonal blocks.  One wave per block, or -- small blocks (ds.pair_lpb == 16) -- 16 lanes per block.
 template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
-    const bool rc = schur_recompute_applies(ds, db, mode);
-    // fp32-Jacobian mode: the factored form (RECOMP = 4); fp64 mode keeps the unfactored one, whose sums are bit for bit those of the
-    // record-gathering passes (tests/test_gpu_recompute.py).  SFMBA_PAIR_FORM=3 forces the unfactored form (A/B).
-    static const bool unfactored = [] { const char* e = std::getenv("SFMBA_PAIR_FORM"); return e && e[0] == '3'; }();
-    const bool factored = rc && sizeof(T) == 4 && !unfactored && db.pair_G != nullptr;
-    const dim3 grid(ds.npairwg), block(64 * SFMBA_PAIR_WAVES);
+    const dim3 grid(ds.npairwg);
     if (mode == 2) {
-        if (ds.ndupwg > 0) hipLaunchKernelGGL((k_schur_pairs<T, 2, 0>), dim3(ds.ndupwg), block, 0, s, ds, db);
-    } else if (ds.pair_lpb == 16) {
-        // small blocks: the re-evaluating factored form whenever the point table is there (both precisions); SFMBA_PAIR_FORM=0 keeps
-        // the record-gathering form of rounds 1 - 3 (A/B)
-        static const bool sub_records = [] { const char* e = std::getenv("SFMBA_PAIR_FORM"); return e && e[0] == '0'; }();
-        const bool sub_f = db.PA != nullptr && ds.pair_pt != nullptr && db.pair_G != nullptr && !sub_records;
-        static const bool sub_w4 = [] { const char* e = std::getenv("SFMBA_SUBF_WAVES"); return e && e[0] == '4'; }();      // (A/B, to be removed)
-        if (sub_f) {
-            if (mode == 1 && sub_w4) hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 1, 16, 4>), grid, dim3(64), 0, s, ds, db);
-            else if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
-            else {
-                hipLaunchKernelGGL(k_pair_factors, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);
-                hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
-            }
-        }
-        else if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
-        else hipLaunchKernelGGL((k_schur_pairs_sub<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
-    } else if (mode == 1) {
-        if (factored) hipLaunchKernelGGL((k_schur_pairs<T, 1, 4>), grid, block, 0, s, ds, db);
-        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 1, 3>), grid, block, 0, s, ds, db);
-        else hipLaunchKernelGGL((k_schur_pairs<T, 1, 0>), grid, block, 0, s, ds, db);
+        if (ds.ndupwg > 0) hipLaunchKernelGGL(k_schur_dups<T>, dim3(ds.ndupwg), dim3(64), 0, s, ds, db);
+        return;
+    }
+    if (mode == 0) hipLaunchKernelGGL(k_pair_factors, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);      // D E^T per camera (PCG: k_finalize wrote Linv D E^T)
+    if (ds.pair_lpb == 16) {
+        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
+        else hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
     } else {
-        if (factored) {
-            hipLaunchKernelGGL(k_pair_factors, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);      // D E^T per camera (PCG: k_finalize wrote Linv D E^T)
-            hipLaunchKernelGGL((k_schur_pairs<T, 0, 4>), grid, block, 0, s, ds, db);
-        }
-        else if (rc) hipLaunchKernelGGL((k_schur_pairs<T, 0, 3>), grid, block, 0, s, ds, db);
-        else hipLaunchKernelGGL((k_schur_pairs<T, 0, 0>), grid, block, 0, s, ds, db);
+        const dim3 block(64 * SFMBA_PAIR_WAVES);
+        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs<T, 1>), grid, block, 0, s, ds, db);
+        else hipLaunchKernelGGL((k_schur_pairs<T, 0>), grid, block, 0, s, ds, db);
     }
 }
 template void launch_schur_pairs<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
@@ -1540,8 +1112,7 @@ template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, co
 
 template <typename T>
 void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    if (db.PA && ds.cam_obs_xy) hipLaunchKernelGGL(k_cam_diag_f<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
-    else hipLaunchKernelGGL(k_cam_diag<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
+    hipLaunchKernelGGL(k_cam_diag_f<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
 }
 template void launch_cam_diag<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
@@ -1898,9 +1469,14 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
         double dlt[6], cn[6], z[6];
         // every load of this camera before the first store (the stores below may alias as far as the compiler can tell: a load behind
         // one of them waits for its own round trip -- six in a row in the loop this replaces)
-        double c0[6], cs[6], xin[6], Lt[6][6];
+        double c0[6], cs[6], xin[6], Lt[6][6], Q9[9];
 #pragma unroll
         for (int e = 0; e < 6; ++e) { c0[e] = db.cam[cur][6 * j + e]; cs[e] = db.cscale[6 * j + e]; }
+        // Q = R K' and the first-order flag of the camera AT THE LINEARISATION POINT: the back-substitution re-evaluates the camera
+        // block of an observation in the factored form A = P [ -[X_g]x | I ] diag(Q, I) (sfmba_device.h), so the step arrives as Q dw
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Q9[e] = db.camtab[cur][cam_tab_index(CT_QD + e, j, ds.ncam)];
+        const double small_cur = db.camtab[cur][cam_tab_index(CT_SMALL, j, ds.ncam)];
         if (db.pcg_vec) {          // z_j = Linv_j^T x~_j  (block-Jacobi transformed unknowns)
             const double* x = db.pcg_vec + (size_t)db.pcg_flags[2] * ds.ld + 6 * j;
             const double* Li = db.pcg_linv + (size_t)j * 36;
@@ -1936,7 +1512,11 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
         for (int e = 0; e < CT_STRIDE; ++e) db.camtab[nxt][cam_tab_index(e, j, ds.ncam)] = ctn[e];
         double stb[ST_STRIDE] = {};
         for (int e = 0; e < 9; ++e) stb[ST_RN + e] = ctn[CT_R + e];
-        for (int e = 0; e < 3; ++e) { stb[ST_DW + e] = dlt[e]; stb[ST_DT + e] = dlt[3 + e]; stb[ST_TN + e] = ctn[CT_T + e]; }
+        for (int e = 0; e < 3; ++e) {
+            stb[ST_DQ + e] = Q9[3 * e] * dlt[0] + Q9[3 * e + 1] * dlt[1] + Q9[3 * e + 2] * dlt[2];
+            stb[ST_DT + e] = dlt[3 + e]; stb[ST_TN + e] = ctn[CT_T + e];
+        }
+        stb[ST_SMALL] = small_cur;
         for (int e = 0; e < ST_STRIDE; ++e) db.steptab[cam_tab_index(e, j, ds.ncam)] = stb[e];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1956,123 +1536,169 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
 
 // Obs-parallel back-substitution: same workgroup/point ownership as k_point_build.
 //   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost.
-// Nothing of the linearisation is recomputed: with V + D^2 = L L^T, t = L^-1 b_p and C = B~ L^-T (all left behind by
-// k_point_build: pt_t, the packed record, M = diag(s_p) L^-T),
-//   u   = A (camera step) + g (focal step)     per observation, from the record's A_w, f/p_z, x_p, y_p and the camera's step
-//   z   = t - sum_obs C^T u                      per point (three sums through the wave's LDS instead of nine)
+// With V + D^2 = L L^T, t = L^-1 b_p and C = B~ L^-T (left behind per POINT by k_point_build: pt_t, M = diag(s_p) L^-T, the table entry):
+//   u   = A (camera step) + g (focal step)     per observation
+//   z   = t - sum_obs C^T u                      per point (three sums through the wave's LDS)
 //   dX  = M z ;   J step = -(u + C z)            (model cost change; B~ y_p = C L^T y_p = C z)
-// so the pass streams the 64-byte record of every observation once and gathers 6 + 12 values per camera (step, trial pose)
-// instead of re-projecting every observation and rebuilding its blocks from a 31-value table row (285 -> ~110 fp64
-// instructions per observation; the pass was VALU-bound: SQ_ACTIVE_INST_VALU = 57 % of the SIMD time).  Only the TRIAL
-// residual is a true re-evaluation (fp64).  The model cost change uses the residual f x_p - obs with the record's x_p
-// (fp32 in F32J mode: ~3e-5 px, i.e. ~1e-4 relative on the model term that only feeds the accept / reject ratio; exact in F64 mode).
+// Nothing per observation is read but its indices and coordinates (rounds 2 / 3 streamed a 64-byte record per observation here: 64 MB
+// per launch at BASELINE config 3, the pass ran at HBM speed): the projection at the linearisation point is re-evaluated in fp64 from
+// the camera's R, t and the point-table entry, the camera block acts on the step in the factored form of sfmba_device.h,
+//   A [dw; dt] = P (Q dw x X_g + dt),   P = (f / p_z) [[1, 0, -x_p], [0, 1, -y_p]],
+// with Q dw formed once per camera by k_cam_update, and C = (P R) L~ in the precision of the Jacobian blocks, exactly as the
+// reduced-system passes form it.  The residual of the model cost change is the fp64 residual (it used to be rebuilt from the
+// record's fp32 x_p).  The TRIAL residual is evaluated at the trial camera / point (fp64).
+// everything the passes read per observation that is not the observation itself
 template <typename T>
-__global__ PB_BOUNDS void k_point_update(DeviceStructure ds, DeviceBuffers db) {
+struct PointUpdateCtx {
+    const double* tab;        // camera table at the linearisation point
+    const double* stab;       // step table
+    const PtRecA<T>* PA;
+    double focal, focal_n, dfoc;
+};
+
+// one observation of the first sweep: residual, C, u (see above)
+template <typename T>
+__device__ __forceinline__ void point_update_obs(const DeviceStructure& ds, const PointUpdateCtx<T>& cx, int q, int& i, int& j, double& ox, double& oy,
+                                                 double& r0, double& r1, T (&C)[6], double& u0, double& u1) {
+    i = ds.obs_pt[q]; j = ds.obs_cam[q];
+    load_obs<T>(ds.obs_xy, q, ox, oy);
+    const PtRecA<T> pa = load_ptrec(cx.PA + i);
+    const CamRow ct = { cx.tab + 4 * (size_t)(j), ds.ncam };
+    const CamRow stb = { cx.stab + 4 * (size_t)(j), ds.ncam };
+    const double dq0 = stb[ST_DQ], dq1 = stb[ST_DQ + 1], dq2 = stb[ST_DQ + 2];
+    const double dt0 = stb[ST_DT], dt1 = stb[ST_DT + 1], dt2 = stb[ST_DT + 2];
+    const bool first_order = stb[ST_SMALL] != 0.0;
+    const double rx = ct[CT_R + 0] * pa.X[0] + ct[CT_R + 1] * pa.X[1] + ct[CT_R + 2] * pa.X[2];
+    const double ry = ct[CT_R + 3] * pa.X[0] + ct[CT_R + 4] * pa.X[1] + ct[CT_R + 5] * pa.X[2];
+    const double rz = ct[CT_R + 6] * pa.X[0] + ct[CT_R + 7] * pa.X[1] + ct[CT_R + 8] * pa.X[2];
+    Proj pr;
+    pr.iz = fast_rcp(rz + ct[CT_T + 2]);
+    pr.xp = (rx + ct[CT_T + 0]) * pr.iz;
+    pr.yp = (ry + ct[CT_T + 1]) * pr.iz;
+    r0 = cx.focal * pr.xp - ox; r1 = cx.focal * pr.yp - oy;
+    const double g0 = first_order ? pa.X[0] : rx, g1 = first_order ? pa.X[1] : ry, g2 = first_order ? pa.X[2] : rz;
+    // v = Q dw x X_g + dt ;  u = P v + (x_p, y_p) df
+    const double v0 = dq1 * g2 - dq2 * g1 + dt0, v1 = dq2 * g0 - dq0 * g2 + dt1, v2 = dq0 * g1 - dq1 * g0 + dt2;
+    const double fz = cx.focal * pr.iz;
+    u0 = fz * (v0 - pr.xp * v2) + pr.xp * cx.dfoc;
+    u1 = fz * (v1 - pr.yp * v2) + pr.yp * cx.dfoc;
+    T B[6];
+    point_block<T>(ct, pr, cx.focal, B);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {          // C = B~ L^-T, the expressions of obs_record / obs_factored
+        const T b0 = B[3 * r], b1 = B[3 * r + 1], b2 = B[3 * r + 2];
+        C[3 * r + 0] = b0 * pa.L[0];
+        C[3 * r + 1] = b0 * pa.L[1] + b1 * pa.L[2];
+        C[3 * r + 2] = b0 * pa.L[3] + b1 * pa.L[4] + b2 * pa.L[5];
+    }
+}
+
+// One wave of the pass.  SINGLE: at most 64 observations (every wave but those of a point with more than 64 observations) -- straight
+// line code: every load of the wave is issued in one go (its observation, the point-table entry, the camera's rows of both tables, this
+// lane's point), the trial pose of the lane's camera rides along behind the first sweep's arithmetic, and what the second sweep needs
+// of the first stays in registers.  !SINGLE: rounds of 64 observations, the second sweep re-evaluates.
+template <typename T, bool SINGLE>
+__device__ __forceinline__ void point_update_wave(const DeviceStructure& ds, const DeviceBuffers& db, const PointUpdateCtx<T>& cx, const int4 wd, int nxt, int cur,
+                                                  double (*sz)[3], double (*sx)[6], double& trial, double& model, double& step2, double& xn2, double& bad) {
+    const int lane = threadIdx.x & 63;
+    const int pt0 = wd.x, npts = wd.y - wd.x;
+    const int o0 = wd.z, o1 = wd.w;
+    const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
+    const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
+    double tp[3] = { 0, 0, 0 }, Mp[6] = { 0, 0, 0, 0, 0, 0 }, Xp[3] = { 0, 0, 0 };
+    if (lane < npts) {
+        const size_t i = (size_t)(pt0 + lane);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { tp[c] = db.pt_t[3 * i + c]; Xp[c] = db.pts[cur][3 * i + c]; }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Mp[c] = db.pt_M[6 * i + c];
+    }
+    double zacc[3] = { 0, 0, 0 };
+    double u0k = 0, u1k = 0, oxk = 0, oyk = 0, r0k = 0, r1k = 0;
+    T Ck[6] = { (T)0, (T)0, (T)0, (T)0, (T)0, (T)0 };
+    int ik = 0, jk = 0;
+    double RTn[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // R, t of the lane's camera at the trial point
+    for (int c0 = o0; c0 < (SINGLE ? o0 + 1 : o1); c0 += 64) {
+        const int q = c0 + lane;
+        if (q < o1) {
+            point_update_obs<T>(ds, cx, q, ik, jk, oxk, oyk, r0k, r1k, Ck, u0k, u1k);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sz[lane][c] = (double)Ck[c] * u0k + (double)Ck[3 + c] * u1k;
+            if (SINGLE) {
+                const CamRow stb = { cx.stab + 4 * (size_t)(jk), ds.ncam };
+#pragma unroll
+                for (int e = 0; e < 12; ++e) RTn[e] = stb[ST_RN + e];
+            }
+        }
+        wave_lds_fence();
+        if (lane < npts) {
+            const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
+            for (int e = a; e < b; ++e) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) zacc[c] += sz[e][c];
+            }
+        }
+        wave_lds_fence();
+    }
+    if (lane < npts) {
+        const size_t i = (size_t)(pt0 + lane);
+        const double z0 = tp[0] - zacc[0], z1 = tp[1] - zacc[1], z2 = tp[2] - zacc[2];
+        const double dX[3] = { Mp[0] * z0 + Mp[1] * z1 + Mp[2] * z2, Mp[3] * z1 + Mp[4] * z2, Mp[5] * z2 };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double x = Xp[c];
+            const double xn = x - dX[c];
+            const double df = x - xn;
+            step2 += df * df;
+            xn2 += xn * xn;
+            db.pts[nxt][3 * i + c] = xn;
+            sx[lane][3 + c] = xn;
+        }
+        sx[lane][0] = z0; sx[lane][1] = z1; sx[lane][2] = z2;
+    }
+    wave_lds_fence();
+    for (int c0 = o0; c0 < (SINGLE ? o0 + 1 : o1); c0 += 64) {
+        const int q = c0 + lane;
+        if (q >= o1) continue;
+        if (!SINGLE) {
+            point_update_obs<T>(ds, cx, q, ik, jk, oxk, oyk, r0k, r1k, Ck, u0k, u1k);
+            const CamRow stb = { cx.stab + 4 * (size_t)(jk), ds.ncam };
+#pragma unroll
+            for (int e = 0; e < 12; ++e) RTn[e] = stb[ST_RN + e];
+        }
+        const double* pl = sx[ik - pt0];
+        const double z0 = pl[0], z1 = pl[1], z2 = pl[2];
+        const double Xn[3] = { pl[3], pl[4], pl[5] };
+        // model residual m = J step = -(u + C z)
+        const double m0 = -(u0k + (double)Ck[0] * z0 + (double)Ck[1] * z1 + (double)Ck[2] * z2);
+        const double m1 = -(u1k + (double)Ck[3] * z0 + (double)Ck[4] * z1 + (double)Ck[5] * z2);
+        model -= m0 * (r0k + 0.5 * m0) + m1 * (r1k + 0.5 * m1);
+        const Proj pn = project_point(RTn, 0, 9, Xn);
+        const double n0 = cx.focal_n * pn.xp - oxk, n1 = cx.focal_n * pn.yp - oyk;
+        if (!finite_d(n0) || !finite_d(n1)) bad = 1.0;
+        trial += n0 * n0 + n1 * n1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double sz[WPB][64][3];      // per observation of the round: C^T u
     __shared__ double sx[WPB][64][6];      // per local point: z (3), Xn (3)
     __shared__ double scratch[WPB * 5];
     if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // see k_cam_update
     const LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
-    const double* tab = db.steptab;
-    const double focal = st->focal[cur], focal_n = st->focal[nxt];
-    const double dfoc = focal - focal_n;           // unscaled focal step to SUBTRACT (= fscale * y_f)
-    const double* pts = db.pts[cur];
-    const T* Y = reinterpret_cast<const T*>(db.Y);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    PointUpdateCtx<T> cx;
+    cx.tab = db.camtab[cur]; cx.stab = db.steptab; cx.PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
+    cx.focal = st->focal[cur]; cx.focal_n = st->focal[nxt];
+    cx.dfoc = cx.focal - cx.focal_n;               // unscaled focal step to SUBTRACT (= fscale * y_f)
+    const int w = threadIdx.x >> 6;
     const int gw = blockIdx.x * WPB + w;
     double trial = 0.0, model = 0.0, step2 = 0.0, xn2 = 0.0, bad = 0.0;
-
     if (gw < ds.nwv) {
         const int4 wd = ds.wv_desc[gw];
-        const int pt0 = wd.x, pt1 = wd.y;
-        const int npts = pt1 - pt0;
-        const int o0 = wd.z, o1 = wd.w;
-        const bool single = (o1 - o0) <= 64;
-        const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
-        const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
-        // this lane's point (issued with the first loads, used after the reduction)
-        double tp[3] = { 0, 0, 0 }, Mp[6] = { 0, 0, 0, 0, 0, 0 }, Xp[3] = { 0, 0, 0 };
-        if (lane < npts) {
-            const size_t i = (size_t)(pt0 + lane);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { tp[c] = db.pt_t[3 * i + c]; Xp[c] = pts[3 * i + c]; }
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Mp[c] = db.pt_M[6 * i + c];
-        }
-        double zacc[3] = { 0, 0, 0 };
-        // kept for the second sweep when single
-        double u0k = 0, u1k = 0, oxk = 0, oyk = 0, xpk = 0, ypk = 0, Ck[6] = { 0, 0, 0, 0, 0, 0 };
-        int ik = 0, jk = 0;
-
-        auto obs_terms = [&](int q, int& i, int& j, double& ox, double& oy, double& xp, double& yp, double (&C)[6], double& u0, double& u1) {
-            i = ds.obs_pt[q]; j = ds.obs_cam[q];
-            load_obs<T>(ds.obs_xy, q, ox, oy);
-            T rec[YREC];
-            load_rec<T>(Y, q, rec);
-            const CamRow stb = { tab + 4 * (size_t)(j), ds.ncam };
-            const double dw0 = stb[ST_DW], dw1 = stb[ST_DW + 1], dw2 = stb[ST_DW + 2];
-            const double dt0 = stb[ST_DT], dt1 = stb[ST_DT + 1], dt2 = stb[ST_DT + 2];
-            const double fz = (double)rec[6];
-            xp = (double)rec[7]; yp = (double)rec[8];
-            u0 = (double)rec[0] * dw0 + (double)rec[1] * dw1 + (double)rec[2] * dw2 + fz * (dt0 - xp * dt2) + xp * dfoc;
-            u1 = (double)rec[3] * dw0 + (double)rec[4] * dw1 + (double)rec[5] * dw2 + fz * (dt1 - yp * dt2) + yp * dfoc;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) C[c] = (double)rec[9 + c];
-        };
-
-        for (int c0 = o0; c0 < o1; c0 += 64) {
-            const int q = c0 + lane;
-            if (q < o1) {
-                obs_terms(q, ik, jk, oxk, oyk, xpk, ypk, Ck, u0k, u1k);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) sz[w][lane][c] = Ck[c] * u0k + Ck[3 + c] * u1k;
-            }
-            wave_lds_fence();
-            if (lane < npts) {
-                const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
-                for (int e = a; e < b; ++e) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) zacc[c] += sz[w][e][c];
-                }
-            }
-            wave_lds_fence();
-        }
-        if (lane < npts) {
-            const size_t i = (size_t)(pt0 + lane);
-            const double z0 = tp[0] - zacc[0], z1 = tp[1] - zacc[1], z2 = tp[2] - zacc[2];
-            const double dX[3] = { Mp[0] * z0 + Mp[1] * z1 + Mp[2] * z2, Mp[3] * z1 + Mp[4] * z2, Mp[5] * z2 };
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double x = Xp[c];
-                const double xn = x - dX[c];
-                const double df = x - xn;
-                step2 += df * df;
-                xn2 += xn * xn;
-                db.pts[nxt][3 * i + c] = xn;
-                sx[w][lane][3 + c] = xn;
-            }
-            sx[w][lane][0] = z0; sx[w][lane][1] = z1; sx[w][lane][2] = z2;
-        }
-        wave_lds_fence();
-        for (int c0 = o0; c0 < o1; c0 += 64) {
-            const int q = c0 + lane;
-            if (q >= o1) continue;
-            if (!single) obs_terms(q, ik, jk, oxk, oyk, xpk, ypk, Ck, u0k, u1k);
-            const CamRow stb = { tab + 4 * (size_t)(jk), ds.ncam };
-            const double* pl = sx[w][ik - pt0];
-            const double z0 = pl[0], z1 = pl[1], z2 = pl[2];
-            const double Xn[3] = { pl[3], pl[4], pl[5] };
-            // model residual m = J step = -(u + C z)
-            const double m0 = -(u0k + Ck[0] * z0 + Ck[1] * z1 + Ck[2] * z2);
-            const double m1 = -(u1k + Ck[3] * z0 + Ck[4] * z1 + Ck[5] * z2);
-            const double r0 = focal * xpk - oxk, r1 = focal * ypk - oyk;
-            model -= m0 * (r0 + 0.5 * m0) + m1 * (r1 + 0.5 * m1);
-            const Proj pn = project_point(stb, ST_RN, ST_TN, Xn);
-            const double n0 = focal_n * pn.xp - oxk, n1 = focal_n * pn.yp - oyk;
-            if (!finite_d(n0) || !finite_d(n1)) bad = 1.0;
-            trial += n0 * n0 + n1 * n1;
-        }
+        if (wd.w - wd.z <= 64) point_update_wave<T, true>(ds, db, cx, wd, nxt, cur, sz[w], sx[w], trial, model, step2, xn2, bad);
+        else point_update_wave<T, false>(ds, db, cx, wd, nxt, cur, sz[w], sx[w], trial, model, step2, xn2, bad);
     }
     double sums[5] = { trial, model, step2, xn2, bad };
     const double tot = block_sums<5>(sums, scratch);

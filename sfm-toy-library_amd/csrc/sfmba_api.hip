@@ -221,7 +221,7 @@ struct sfmba_problem {
     bool cam_identity = false, pt_identity = false;   // slot == caller index for every camera / point (arrays copied as they are)
     bool reset_pending = false;             // sfmba_problem_reset() was called: the initial parameters are restored by the next solve's first kernel
                                             // (or by flush_reset() if anything else looks at the problem first)
-    int2 *d_pairs = nullptr, *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
+    int2 *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pair_pt = nullptr;
     void* d_cam_obs_xy = nullptr;
     int* d_pwg_ptr = nullptr;
@@ -238,7 +238,6 @@ struct sfmba_problem {
     int cur = 0;                                  // which buffer holds the current parameters
     double focal = 0.0;
     bool empty = false;                           // no observations
-    bool auto_prefers_cholesky = false;           // AUTO: the CG of the last linearisation cost more than a factorisation would have (sticky until the structure changes)
     bool poisoned = false;                        // an append failed half way: only sfmba_problem_destroy is valid (include/sfmba.h)
     // sharded-mode state
     sfmba_options shard_opt;
@@ -396,12 +395,16 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     bool build_enqueued = false;
     std::vector<int> lin_hist;
     int cholesky_fallbacks = 0;
+    // AUTO: a linearisation of this solve cost more CG iterations than a factorisation would have.  Local to the solve: a
+    // resident problem solved twice from the same point takes the same path twice -- solve / reset / solve is bitwise repeatable in
+    // deterministic mode.
+    bool auto_prefers_cholesky = false;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
         if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
-        const bool pcg = pcg_mode && !(exact_pcg && p->auto_prefers_cholesky);
+        const bool pcg = pcg_mode && !(exact_pcg && auto_prefers_cholesky);
         if (pcg) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
@@ -508,7 +511,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 lin_hist.push_back(it);
             } else if (pcg_gated || (pcg && exact_pcg && dbu.cg_gate == nullptr)) {
                 const int it = (pcg_gated || dbu.pcg_vec) ? mb[4] : p->solver.run.launched;      // after a fallback: the launches that were spent
-                if (exact_pcg && it > cg_break_even) p->auto_prefers_cholesky = true;              // the next linearisations are factorised
+                if (exact_pcg && it > cg_break_even) auto_prefers_cholesky = true;                 // the next linearisations of THIS solve are factorised
                 dense_pcg_note(&p->solver, (int)lin_hist.size(), it);
                 sum.linear_iters += it;
                 lin_hist.push_back(it);
@@ -864,10 +867,11 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         return fail(SFMBA_ERR_HIP, "observation counts out of step with the observation list");
     }
     // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the self pairs are folded
-    // into the camera-diagonal pass) goes to block (ja, jb) of the upper triangle of S
+    // into the camera-diagonal pass) goes to block (ja, jb) of the upper triangle of S -- listed as the pair's POINT, which is all the
+    // re-evaluating pair pass reads per pair
     {
         const int brc = build_pair_lists(p->stream, &p->arena, &staging, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pm.pair_off, npair_total,
-                                         &p->d_pairs, &p->d_blk_ptr, &p->d_pair_pt);
+                                         &p->d_blk_ptr, &p->d_pair_pt);
         if (brc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc)); }
     }
     {
@@ -931,7 +935,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
     ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
     ds.obs_pt = p->d_obs_pt;
-    ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pairs = p->d_pairs; ds.pair_pt = p->d_pair_pt;
+    ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pair_pt = p->d_pair_pt;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
     ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
     ds.ndupwg = 0; ds.dup_blocks = p->d_dup_blocks;          // count: after the wait at the end
@@ -947,23 +951,13 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     HIP_TRY(dev_alloc(&db.steptab, (size_t)ST_STRIDE * ncam));
     HIP_TRY(dev_alloc(&db.cscale, (size_t)6 * ncam));
     HIP_TRY(dev_alloc(&db.pscale, (size_t)3 * npt));
-    const size_t ybytes = (size_t)std::max(nobs, 1) * YREC * (f32 ? sizeof(float) : sizeof(double));
-    db.Y = p->arena.alloc(ybytes);
-    if (!db.Y) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
-    // The reduced-system passes re-evaluate every observation from the camera row and a per-point table (PA / PB, 64 + 24 bytes per point in fp32-Jacobian mode)
-    // plus a camera-major copy of the observation coordinates -- no 32-byte side record, and the 64-byte records are only read by the
-    // back-substitution.  SFMBA_SCHUR_RECORDS=1 at build time keeps the record-gathering passes of rounds 1 / 2 instead (A/B).
-    { const char* e = std::getenv("SFMBA_SCHUR_RECORDS");
-      if (e && e[0] == '1') {
-          db.Z = p->arena.alloc(ybytes / 2);
-          if (!db.Z) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
-      } else {
-          db.PA = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecA<float>) : sizeof(PtRecA<double>)));
-          db.PB = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecB<float>) : sizeof(PtRecB<double>)));
-          if (!db.PA || !db.PB) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
-      } }
+    // Nothing is stored per observation: the reduced-system passes and the back-substitution re-evaluate every observation from the
+    // camera row and a per-point table (PA / PB, 64 + 24 bytes per point in fp32-Jacobian mode) plus a camera-major copy of the
+    // observation coordinates (rounds 1 - 3 kept a 64-byte record per observation: 64 MB at BASELINE config 3).
+    db.PA = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecA<float>) : sizeof(PtRecA<double>)));
+    db.PB = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecB<float>) : sizeof(PtRecB<double>)));
+    if (!db.PA || !db.PB) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
-    HIP_TRY(dev_alloc(&db.pt_yf, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_M, (size_t)6 * npt));
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
     HIP_TRY(dev_alloc(&p->d_sys, sys_len));
@@ -1021,7 +1015,6 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     if (build_report[0] < 0 || (((long long)build_report[3] << 32) | (unsigned)build_report[2]) != npair_total)
         return fail(SFMBA_ERR_HIP, "structure build: the device's pair count differs from the host's");
     ds.ndupwg = build_report[0];
-    p->auto_prefers_cholesky = false;
     bt_mark("wait for device");
     return sfmba_problem_reset(p);
 }

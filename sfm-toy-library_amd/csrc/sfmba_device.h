@@ -28,14 +28,16 @@ constexpr int CT_QD = 28;      // Q = R K' (3 x 3 row-major; I when small-angle)
 constexpr int CT_STRIDE = 40;  // 37 used; whole component quads
 
 // ---- per-camera step table used by the back-substitution / trial-point kernel (component quads like the camera tables) ----
-constexpr int ST_DW = 0;       // dw[3]: unscaled rotation step (the step is SUBTRACTED: trial = current - step)
-constexpr int ST_DT = 3;       // dt[3]: unscaled translation step            (quads 0, 1; two pad values)
+constexpr int ST_DQ = 0;       // Q dw (3): the unscaled rotation step through Q = R K' of the linearisation point (I on the first-order branch);
+                               //   the step is SUBTRACTED: trial = current - step
+constexpr int ST_DT = 3;       // dt[3]: unscaled translation step
+constexpr int ST_SMALL = 6;    // 1.0 if the camera is on the first-order branch at the linearisation point   (quads 0, 1; one pad value)
 constexpr int ST_RN = 8;       // R[9] at the trial point
 constexpr int ST_TN = 17;      // t[3] at the trial point                     (quads 2, 3, 4)
 constexpr int ST_STRIDE = 20;
 
-// One packed record per observation written by the point pass and read by the reduced-system passes
-// (layout in ba_kernels.hip): 16 values = 64 B in fp32 (one sector), 128 B in fp64 (one line).
+// The blocks of one observation as the camera pass (and the duplicate-pair pass) evaluate them (obs_record below): 16 values.  Rounds
+// 1 - 3 STORED this record per observation (64 B in fp32); since round 4 it only ever lives in registers.
 constexpr int YREC = 16;
 
 // ---- per-point table (round 3): what the reduced-system passes need about a POINT to RE-EVALUATE the blocks of one of its
@@ -89,29 +91,10 @@ __device__ __forceinline__ void load_cam_regs(const double* __restrict__ tab, in
     for (int k = 0; k < CT_SCALE; ++k) c.v[k] = tab[cam_tab_index(k, j_uniform, ncam)];
 }
 
-// The same for the pair pass, which holds TWO rows for the whole block: R and t in fp64 (projection) plus R and K' converted to T
-// ONCE and moved to scalar registers -- left to itself the compiler hoists the conversions out of the pair loop into 36 vector
-// registers of wave-uniform values, which is what pushed the kernel over its register budget.
+// table entry k as T (converted on the spot)
+template <typename T, typename CamPtr> __device__ __forceinline__ T cam_val(const CamPtr& cam, int k) { return (T)cam[k]; }
 __device__ __forceinline__ float to_uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 __device__ __forceinline__ double to_uniform(double x) { return x; }       // (already scalar: loaded with a uniform index)
-template <typename T>
-struct CamU {
-    double v[CT_K];          // R (9), t (3)
-    T vt[CT_SMALL];          // (T)R at 0..8, (T)K' at 12..20
-    double small;
-    __device__ __forceinline__ double operator[](int k) const { return k == CT_SMALL ? small : v[k]; }
-};
-template <typename T>
-__device__ __forceinline__ void load_cam_u(const double* __restrict__ tab, int j_uniform, int ncam, CamU<T>& c) {
-#pragma unroll
-    for (int k = 0; k < CT_K; ++k) c.v[k] = tab[cam_tab_index(k, j_uniform, ncam)];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { c.vt[k] = to_uniform((T)c.v[k]); c.vt[CT_K + k] = to_uniform((T)tab[cam_tab_index(CT_K + k, j_uniform, ncam)]); }
-    c.small = tab[cam_tab_index(CT_SMALL, j_uniform, ncam)];
-}
-// table entry k as T: converted on the spot, or taken from the pre-converted copy
-template <typename T, typename CamPtr> __device__ __forceinline__ T cam_val(const CamPtr& cam, int k) { return (T)cam[k]; }
-template <typename T> __device__ __forceinline__ T cam_val(const CamU<T>& cam, int k) { return cam.vt[k]; }
 
 template <typename T> struct ObsXY;
 template <> struct ObsXY<float>  { typedef float2 type; };

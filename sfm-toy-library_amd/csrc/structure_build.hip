@@ -26,10 +26,11 @@ __device__ __forceinline__ unsigned block_of(int ja, int jb, int ncam) {
     return (unsigned)((long long)ja * ncam - (long long)ja * (ja - 1) / 2 + (jb - ja));
 }
 
-// One lane per observation a (point-major position): writes the pairs (a, b), b = a+1 .. end of the point.
+// One lane per observation a (point-major position): writes its pairs (a, b), b = a+1 .. end of the point -- the block as key, the POINT
+// as value (the pair pass re-evaluates both observations from the block's two cameras and the point: it needs nothing else).
 __global__ __launch_bounds__(256) void k_pair_gen(int nobs, int ncam, const int* __restrict__ pt_ptr, const int* __restrict__ obs_pt,
                                                   const int* __restrict__ obs_cam, const long long* __restrict__ pair_off,
-                                                  unsigned* __restrict__ keys, unsigned long long* __restrict__ vals) {
+                                                  unsigned* __restrict__ keys, int* __restrict__ vals) {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nobs) return;
     const int i = obs_pt[a];
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void k_pair_gen(int nobs, int ncam, const int*
     const int ca = obs_cam[a];
     for (int b = a + 1; b < end; ++b, ++o) {
         keys[o] = block_of(ca, obs_cam[b], ncam);        // cameras ascend inside a point: ca <= cam(b)
-        vals[o] = (unsigned long long)(unsigned)a | ((unsigned long long)(unsigned)b << 32);   // == int2{a, b}
+        vals[o] = i;
     }
 }
 
@@ -55,53 +56,42 @@ __global__ void k_block_ptr(int nblock, int npair, const unsigned* __restrict__ 
     blk_ptr[b] = lo;
 }
 
-__global__ __launch_bounds__(256) void k_pair_points(int npair, const int2* __restrict__ pairs, const int* __restrict__ obs_pt, int* __restrict__ pair_pt) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < npair) pair_pt[p] = obs_pt[pairs[p].x];
-}
-
 }  // namespace
 
 // d_pair_off[i] = number of pairs of the points before i (npt + 1 entries, device; build_point_major), npair their total (the caller
-// knows it from its per-point observation counts).  On success *d_pairs (npair int2) and *d_blk_ptr (nblock + 1 ints) live in
+// knows it from its per-point observation counts).  On success *d_pair_pt (npair point slots) and *d_blk_ptr (nblock + 1 ints) live in
 // `arena`; the sort's temporaries come from `scratch`, which the caller keeps until the stream has drained: nothing here waits
 // for the device (the whole structure build is ONE enqueue, sfmba_api.hip build_structure).  Returns 0, or a hipError_t value.
 int build_pair_lists(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_arena, int npt, int nobs, int ncam, int nblock, const int* d_pt_ptr, const int* d_obs_pt,
-                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int2** d_pairs, int** d_blk_ptr, int** d_pair_pt) {
-    *d_pairs = nullptr; *d_blk_ptr = nullptr;
-    if (d_pair_pt) *d_pair_pt = nullptr;
+                     const int* d_obs_cam, const long long* d_pair_off, long long npair, int** d_blk_ptr, int** d_pair_pt) {
+    *d_blk_ptr = nullptr; *d_pair_pt = nullptr;
     (void)npt;
     hipError_t e;
     DeviceArena& scratch = *scratch_arena;
 #define SB_TRY(expr) do { e = (expr); if (e != hipSuccess) return (int)e; } while (0)
 #define SB_ALLOC(ptr, ar, T, n) do { ptr = (ar)->alloc_n<T>(n); if (!ptr) return (int)hipErrorOutOfMemory; } while (0)
     const size_t np = (size_t)(npair > 0 ? npair : 1);
-    unsigned long long* d_v1 = nullptr;
     SB_ALLOC(*d_blk_ptr, arena, int, (size_t)nblock + 1);
-    SB_ALLOC(d_v1, arena, unsigned long long, np);
-    *d_pairs = reinterpret_cast<int2*>(d_v1);
-    if (d_pair_pt) SB_ALLOC(*d_pair_pt, arena, int, np);
+    SB_ALLOC(*d_pair_pt, arena, int, np);
     if (npair == 0) {
         SB_TRY(hipMemsetAsync(*d_blk_ptr, 0, sizeof(int) * ((size_t)nblock + 1), s));
+        SB_TRY(hipMemsetAsync(*d_pair_pt, 0, sizeof(int) * np, s));
         return 0;
     }
-    const long long* d_off = d_pair_off;
     unsigned *d_k0 = nullptr, *d_k1 = nullptr;
-    unsigned long long* d_v0 = nullptr;
+    int* d_v0 = nullptr;
     SB_ALLOC(d_k0, &scratch, unsigned, np);
     SB_ALLOC(d_k1, &scratch, unsigned, np);
-    SB_ALLOC(d_v0, &scratch, unsigned long long, np);
-    hipLaunchKernelGGL(k_pair_gen, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, ncam, d_pt_ptr, d_obs_pt, d_obs_cam, d_off, d_k0, d_v0);
+    SB_ALLOC(d_v0, &scratch, int, np);
+    hipLaunchKernelGGL(k_pair_gen, dim3((nobs + 255) / 256), dim3(256), 0, s, nobs, ncam, d_pt_ptr, d_obs_pt, d_obs_cam, d_pair_off, d_k0, d_v0);
     int end_bit = 1;
     while (end_bit < 32 && ((unsigned long long)1 << end_bit) < (unsigned long long)nblock) ++end_bit;
     size_t tmp_bytes = 0;
-    SB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
+    SB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, *d_pair_pt, (int)npair, 0, end_bit, s));
     void* d_tmp = scratch.alloc(tmp_bytes ? tmp_bytes : 1);
     if (!d_tmp) return (int)hipErrorOutOfMemory;
-    SB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)npair, 0, end_bit, s));
+    SB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, *d_pair_pt, (int)npair, 0, end_bit, s));
     hipLaunchKernelGGL(k_block_ptr, dim3((nblock + 1 + 255) / 256), dim3(256), 0, s, nblock, (int)npair, d_k1, *d_blk_ptr);
-    // the point of every pair, in list order: all the re-evaluating pair pass reads per pair
-    if (d_pair_pt) hipLaunchKernelGGL(k_pair_points, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, s, (int)npair, *d_pairs, d_obs_pt, *d_pair_pt);
     SB_TRY(hipGetLastError());
 #undef SB_TRY
 #undef SB_ALLOC

@@ -244,9 +244,7 @@ def test_banded_visibility_bench_mode_and_default_match_oracle(capi, sfm, banded
         assert_same_solve(banded, (cam, pt, f, s, tr), banded_oracle, param_atol=5e-5, trace_rtol=5e-5, point_atol=5e-3)
         assert tr[1]["linear_iters"] > 60 and all(r["linear_iters"] == 0 for r in tr[2:])      # one linearisation on the CG, the rest factorised
         P.reset()
-        s2, tr2 = P.solve(capi.default_options(max_seconds=0.0, precision=1))                  # the preference is remembered with the structure
-        # (one linearisation solved by the CG to 1e-12 there, by the factorisation here: on this ill-conditioned reduced system the two
-        # steps differ by ~1e-6 relative, the converged costs by a few 1e-9 -- 3.8e-9 measured; both runs stop on function_tolerance 1e-6)
-        assert s2["linear_iters"] == 0 and abs(s2["final_cost"] - s["final_cost"]) <= 5e-8 * s["final_cost"]
+        s2, tr2 = P.solve(capi.default_options(max_seconds=0.0, precision=1))                  # the same path again: the preference lives and dies with a solve
+        assert [r["linear_iters"] for r in tr2] == [r["linear_iters"] for r in tr] and abs(s2["final_cost"] - s["final_cost"]) <= 1e-9 * s["final_cost"]
     got = capi.solve(banded, capi.default_options(max_seconds=0.0, precision=0, linear_solver=0))
     assert_same_solve(banded, got, banded_oracle, param_atol=1e-7, cost_rtol=1e-9, point_atol=1e-6)

@@ -138,6 +138,25 @@ def test_deterministic_create_flag(capi, sfm, mid):
         capi.Problem(mid, precision=1, flags=64)              # unknown flag: refused
 
 
+def test_auto_takes_the_same_path_on_every_solve_of_a_resident_problem(capi, sfm):
+    """AUTO's "this structure prefers the factorisation" used to be remembered on the problem, so solve / reset / solve took CG
+    then Cholesky the first time and Cholesky only the second -- results ~1e-10 apart, against the bitwise guarantee of
+    SFMBA_CREATE_DETERMINISTIC.  The switch is local to a solve now.  A banded reduced system makes AUTO switch mid-solve."""
+    prob = sfm.make_problem("cfg3_banded", n_cam=60, n_pt=8000)
+    opt = capi.default_options(max_seconds=0.0, precision=1)           # the library default: SFMBA_LINEAR_AUTO
+    runs = []
+    with capi.Problem(prob, precision=1, flags=sfm.CREATE_DETERMINISTIC) as P:
+        for rep in range(3):
+            P.reset()
+            s, tr = P.solve(opt)
+            runs.append((P.get_params(), s, [r["cost"] for r in tr], [r["linear_iters"] for r in tr]))
+    assert runs[0][1]["termination_name"] == "CONVERGENCE"
+    for (cam, pt, f), s, costs, lin in runs[1:]:
+        assert lin == runs[0][3]                                          # the same solver path, iteration by iteration
+        assert np.array_equal(cam, runs[0][0][0]) and np.array_equal(pt, runs[0][0][1]) and f == runs[0][0][2]
+        assert s["final_cost"] == runs[0][1]["final_cost"] and costs == runs[0][2]
+
+
 def test_sharded_switches_and_deterministic_sharded(capi, sfm, mid):
     """One rank of the native sharded loop (the collectives are no-ops; pack / unpack and the kernels are not): two-phase exchange off,
     deterministic accumulation in the sharded path (ABI v4: was excluded), each against the unsharded solve."""

@@ -338,3 +338,14 @@ def test_duplicate_camera_point_pairs(capi, sfm, oracle):
     s_o = oracle.solve(dup, _opts(sfm))[3]
     s = capi.solve(dup, capi.default_options(max_seconds=0.0))[3]
     assert s["iterations"] == s_o["iterations"] and abs(s["final_cost"] - s_o["final_cost"]) <= 1e-6 * s_o["final_cost"]
+
+
+def test_cross_lane_exchanges_on_the_hardware():
+    """csrc/sfmba_device.h builds every wave reduction on DPP permutes and v_permlane16/32_swap; tools/micro/permtest.hip checks each helper
+    lane by lane against the plain definition on the device (the binary is built by __graft_entry__.build())."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "micro", "permtest")
+    if not os.path.exists(exe):
+        pytest.skip("tools/micro/permtest not built")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr

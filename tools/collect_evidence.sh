@@ -23,20 +23,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/pmc_$c.err
 done
 python $REPO/tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_pmc_traffic.txt "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic   (cfg3, f32j, PCG)" > /dev/null
-# 3b. round 3: the library default (AUTO), the realistic-visibility workload, and the record-gathering passes of rounds 1 / 2 as A/B
+# 3b. the library default (AUTO) and the realistic-visibility workload
 $BENCH --linear auto --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_auto_bench.json 2> $OUT/bench_auto.err
 $BENCH --workload cfg3_banded --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_banded_pcg_bench.json 2> $OUT/bench_banded.err
-SFMBA_SCHUR_RECORDS=1 $BENCH --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_pcg_records_form_bench.json 2> $OUT/bench_rec.err
-SFMBA_SCHUR_RECORDS=1 $BENCH --workload cfg3_banded --no-cpu-baseline --no-live-traffic > $OUT/${TAG}_cfg3_banded_pcg_records_form_bench.json 2> $OUT/bench_banded_rec.err
 rm -rf $OUT/stats_banded
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_banded -- $BENCH --workload cfg3_banded --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/stats_banded.err
 python $REPO/tools/rocprof_summary.py $OUT/stats_banded $OUT/${TAG}_cfg3_banded_pcg_kernel_stats.txt "$TAG: bench.py --workload cfg3_banded --steps 10 --warmup 2 (f32j, PCG) under rocprofv3 --kernel-trace --stats" > /dev/null
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $OUT/pmcr_$c
-  SFMBA_SCHUR_RECORDS=1 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcr_$c -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/pmcr_$c.err
-done
-python $REPO/tools/pmc_summary.py $OUT/pmcr_FETCH_SIZE $OUT/pmcr_WRITE_SIZE $OUT/${TAG}_cfg3_pcg_records_form_pmc_traffic.txt.ab "SFMBA_SCHUR_RECORDS=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic   (cfg3, f32j, PCG, record-gathering passes of rounds 1 / 2)" > /dev/null
-rm -rf $OUT/stats_banded $OUT/pmcr_FETCH_SIZE $OUT/pmcr_WRITE_SIZE
+rm -rf $OUT/stats_banded
 $REPO/tools/micro/pk_bench > $OUT/${TAG}_valu_issue_microbench.txt 2>&1
 # 4. the sharded path on this box's one rank (RCCL communicator of one rank; the exchange is a no-op, its pack / unpack kernels are not)
 for wl in cfg3 cfg5; do
