@@ -213,9 +213,11 @@ def main():
     # per-kernel average launch durations for the roofline object (not part of `value`) ----
     P.set_profiling(True)
     t1 = time.perf_counter()
+    lin_iters_prof = 0
     for _ in range(args.steps):
         P.reset()
-        P.solve(opt)
+        sp, _ = P.solve(opt)
+        lin_iters_prof += sp["linear_iters"]
     barrier()
     dt_prof = time.perf_counter() - t1
     profile = P.get_profile()
@@ -269,6 +271,23 @@ def main():
             globals()["LIVE_PMC"] = live_pmc_passes(args)
         line["roofline"] = roofline_entry(profile, prob, precision)
         line["roofline_all_kernels"] = roofline_entry(profile, prob, precision, all_kernels=True)
+        if linear != 0 and "pcg_iter" in profile and lin_iters_prof > 0:
+            # the launch-per-iteration CG is enqueued in batches sized from the previous solve (+1): launches behind the converging one
+            # test the done flag and return.  The event brackets see whole batches, so the surplus cannot be timed on its own here:
+            # both counts, the plain average, and the time per REAL iteration with all of the surplus charged to it (an upper bound).
+            pl = profile["pcg_iter"]
+            cg = {"launches": pl["launches"], "cg_iterations_reported_by_the_solver": lin_iters_prof,
+                  "surplus_early_exit_launches": max(0, pl["launches"] - lin_iters_prof),
+                  "avg_us_per_launch": pl["avg_us"], "us_per_real_iteration_upper_bound": pl["total_us"] / lin_iters_prof,
+                  "note": "rocprofv3 (profiles/*_kernel_stats.txt) times every launch on its own: the early-exit launches are the ~2 us tail of its histogram"}
+            for ent in [line["roofline"]] + list(line["roofline_all_kernels"] or []):
+                if ent and ent.get("kernel") == "pcg_iter":
+                    ent["launch_accounting"] = cg
+                    if ent.get("algorithmic_bytes_per_launch"):
+                        b = ent["algorithmic_bytes_per_launch"]
+                        ent["per_real_iteration"] = {"us_upper_bound": cg["us_per_real_iteration_upper_bound"],
+                                                     "frac_of_8TBps": b / (cg["us_per_real_iteration_upper_bound"] * 1e-6) / 8.0e12,
+                                                     "frac_of_L2_34.5TBps": b / (cg["us_per_real_iteration_upper_bound"] * 1e-6) / 34.5e12}
         line["ms_per_step_with_event_bracketing"] = 1e3 * dt_prof / args.steps
         line["kernel_profile_us"] = {k: round(v["avg_us"], 2) for k, v in profile.items()}
         line["kernel_profile_share"] = {k: round(v["total_us"] / max(1e-9, sum(x["total_us"] for x in profile.values())), 4)
@@ -509,7 +528,7 @@ def pmc_traffic(kernel):
     want = PMC_KERNEL_NAMES.get(kernel)
     if not want:
         return None
-    wide = kernel in ("pcg_iter", "point_build", "point_update")     # 16-byte-per-lane coalesced streams
+    wide = kernel in ("pcg_iter",)     # 16-byte-per-lane coalesced streams (the point passes stream 4- and 8-byte items since round 4: no correction)
 
     def entry(fetch_kb, write_kb, source, live):
         return {"bytes": (fetch_kb * (2.0 if wide else 1.0) + write_kb) * 1024.0, "fetch_kb": fetch_kb, "write_kb": write_kb,
@@ -542,9 +561,10 @@ LIMITERS = {
                    "is left is 2 re-evaluations + one 6x6 product per pair and ~170 instructions of reduction / transform per block",
     "cam_diag": "VALU issue (11.5 M wave instructions per launch = 77 % of the SIMD time at one quad-cycle each): ~740 instructions per wave of 64 observations, "
                 "a third of them the fp64 reduction tree of the 47 sums; index -> point-table gather in front of them",
-    "point_build": "wave lifetime x occupancy: three dependent memory levels + a 7-lanes-of-64 per-point phase per wave (7.6 us of lifetime at 3.4 waves "
-                   "per SIMD); measured and rejected: the camera table in LDS (48.2 vs 48.7 us), 5 waves per SIMD by launch bounds (spills: 51 us)",
-    "point_update": "wave lifetime x occupancy (two dependent load levels per wave, 16-20 waves per CU); 5 waves per SIMD by launch bounds spills: 28 -> 34 us",
+    "point_build": "VALU issue at ~60 % + wave lifetime: two dependent memory levels and a 7-lanes-of-64 per-point phase per wave; since round 4 it "
+                   "writes nothing per observation and gathers three component quads of the camera table instead of six (48 -> 35 us)",
+    "point_update": "VALU issue + wave lifetime: re-evaluates every observation from the camera rows and the point table instead of streaming a 64-byte "
+                    "record (92.8 -> ~35 MB per launch, +5 us of arithmetic: the pass was not bandwidth-bound)",
     "chol_panel": "the serial chain of 64 pivots in the diagonal tile (one workgroup: ~250 cycles per pivot) + one launch boundary per block column",
     "chol_update": "fp64 MFMA, short launches",
 }
@@ -565,13 +585,24 @@ def roofline_one(name, profile, model, overhead_us):
     if m is None:
         base.update({"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None})
         return base
+    if m.get("overhead_only"):
+        # a pass a fused design would not have: no roofline fraction (its algorithmic bytes are a few KB), reported as pure overhead
+        base.update({"overhead_only": True, "bound": "overhead", "achieved": None, "peak": None, "unit": None, "frac": None,
+                     "design_bytes_per_launch": m["moved"], "note": m["note"]})
+        return base
     if m["bound"] == "hbm":
         ach = m["bytes"] / (avg_us * 1e-6) / 1e9
         # `bound` names what limits the kernel; kernels whose bytes never leave the caches are priced against the same 8 TB/s (the
         # only byte peak the guide states) but labelled for what they are
         base.update({"bound": m.get("label", "hbm"), "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                      "algorithmic_bytes_per_launch": m["bytes"], "note": m["note"]})
-        if "moved" in m:     # bytes this design moves by construction (materialised records, index lists): NOT algorithmic
+        if m.get("cache_resident"):
+            # the matrix of this kernel never leaves the caches (11.5 MB at cfg 3): 8 TB/s is not its roof.  The same bytes against the
+            # guide's L2 row (MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate), labelled as such
+            base.update({"cache_side": {"peak_GBps": 34500.0, "frac": ach / 34500.0,
+                                        "label": "same algorithmic bytes / launch time against the aggregate L2 bandwidth of MI355X_MICROARCH.md (34.5 TB/s): "
+                                                 "the matrix is Infinity-Cache / L2 resident, HBM is not this kernel's roof"}})
+        if "moved" in m:     # bytes this design moves by construction (index lists, per-point tables): NOT algorithmic
             base.update({"design_bytes_per_launch": m["moved"], "overhead_ratio": m["moved"] / max(m["bytes"], 1.0),
                          "frac_on_design_bytes": m["moved"] / (avg_us * 1e-6) / 8.0e12})
     else:
@@ -609,7 +640,7 @@ def roofline_entry(profile, prob, precision, all_kernels=False):
                         "counter_traffic_bytes": counter, "counter_traffic_kernels": covered,
                         "counter_overhead_ratio": None if counter is None else counter / alg,
                         "note": "algorithmic = SURVEY 8(d) fused model: observations once, points once, cameras once, S written once; "
-                                "design bytes add the materialised 96 B/obs records (written once, re-read by two passes) and the pair list"})
+                                "design bytes add the index lists, the per-point table and the pair-point list (nothing is materialised per observation)"})
         return out
     name = max(names, key=lambda k: profile[k]["total_us"])
     return roofline_one(name, profile, model, overhead)
@@ -627,20 +658,24 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
     pb = 24 if t == 4 else 48
     return {
         "point_build": {"bound": "hbm", "bytes": b_res,
-                        "moved": n_obs * (4 + 2 * t) + n_obs * yrec + n_pt * (24 + 24 + 48 + 4 + pa + pb),
-                        "note": "algorithmic: one pass over observations, points and cameras (B_res); moved: + one packed record (16 values) per observation "
-                                "(read back by the back-substitution only) + per point t, y_f, M and the table entry of the re-evaluating passes (64 + 24 bytes)"},
+                        "moved": n_obs * (4 + 4 + 2 * t) + n_pt * (24 + 24 + 24 + 48 + pa + pb),
+                        "note": "algorithmic: one pass over observations, points and cameras (B_res); moved: the two observation indices and the coordinates, "
+                                "per point the scales, t, M and the table entry every other pass re-evaluates from (64 + 24 bytes); nothing is written per "
+                                "observation (rounds 1 - 3 wrote a 64-byte record each)"},
         "schur_pairs": {"bound": "hbm", "bytes": 8 * d * d,
                         "moved": 4 * npair + n_pt * pa + 8 * d * d,
                         "note": "algorithmic: the reduced matrix written once (8 d^2); moved: + the pair-point list (4 bytes per pair) and the point table once "
-                                "(it stays in L2: every pair re-reads its entry from there); no per-observation record is gathered any more (round 3)"},
-        "cam_diag": {"bound": "hbm", "bytes": 96 * n_cam + 8 * d,
+                                "(it stays in L2: every pair re-reads its entry from there); no per-observation record is gathered"},
+        "cam_diag": {"overhead_only": True, "bytes": 96 * n_cam + 8 * d,
                      "moved": n_obs * (4 + 2 * t) + n_pt * (pa + pb),
-                     "note": "algorithmic: the camera-diagonal blocks and right-hand side written once -- in a fused design this pass would "
-                             "not exist; moved: the camera-major point index and observation coordinates (coalesced) and the point table once (L2-resident gathers)"},
+                     "note": "a fused design has no such pass (its result is 96 bytes per camera): everything this kernel moves and every microsecond it "
+                             "takes is overhead of forming the camera-diagonal blocks in a pass of their own; moved: the camera-major point index and "
+                             "observation coordinates (coalesced) and the point table once (L2-resident gathers)"},
         "point_update": {"bound": "hbm", "bytes": b_res + 24 * n_pt,
-                         "note": "one residual evaluation (B_res) + the trial points written"},
-        "pcg_iter": {"bound": "hbm", "label": "l2_mall_latency", "bytes": 8 * d * d + 9 * 8 * d,
+                         "moved": n_obs * (4 + 4 + 2 * t) + n_pt * (pa + 24 + 48 + 24 + 24),
+                         "note": "one residual evaluation (B_res) + the trial points written; moved: observation indices and coordinates, per point the table "
+                                 "entry, t, M, the point and the trial point (no per-observation record since round 4)"},
+        "pcg_iter": {"bound": "hbm", "label": "l2_mall_latency", "bytes": 8 * d * d + 9 * 8 * d, "cache_resident": 8 * d * d <= 64 << 20,
                      "note": "one CG iteration = one launch: reads its rows of the preconditioned reduced matrix S~ once "
                              "(8 d^2 bytes) + the x/r/p/q vectors; launch/latency bound (d = %d): the matrix is re-read from "
                              "L2/MALL every launch because L2 does not survive the kernel boundary" % d},

@@ -59,16 +59,30 @@ enum { SFMBA_LINEAR_CHOLESKY = 0,   /* exact Schur + dense LLT == DENSE_SCHUR (B
                                        CHOLESKY.  Above: the same PCG run to a plain relative residual of min(pcg_tolerance, 1e-12)
                                        -- the step then agrees with the factorised solve to ~1e-10 relative, below what the float
                                        containers of adjustBundle() resolve -- and, if the CG has not converged after
-                                       pcg_max_iters (0 = min(4 dim, 200)) iterations or breaks down, the SAME linearisation is solved
-                                       by CHOLESKY instead (the matrix is re-formed unpreconditioned; nothing is skipped).  A linearisation
-                                       that needed more CG iterations than a factorisation costs (~3.3 per block column of 64) makes the
-                                       following ones go straight to CHOLESKY, for as long as the problem's structure stays. */
+                                       pcg_max_iters (0 = min(4 dim, 200)) iterations, the SAME linearisation is solved by CHOLESKY
+                                       instead (the matrix is re-formed unpreconditioned; nothing is skipped).  A CG that BREAKS DOWN
+                                       (non-positive curvature, NaN) is not retried: the step is invalid, exactly as after a failed
+                                       factorisation (radius halved, FAILURE after five in a row).  A linearisation that needed more
+                                       CG iterations than a factorisation costs (~3.3 per block column of 64) makes the following
+                                       ones OF THE SAME SOLVE go straight to CHOLESKY (the preference is not remembered across
+                                       solves: a resident problem solved twice from the same point takes the same path twice).
+                                       Sharded solves (sfmba_problem_solve_sharded, sfmba_shard_*) have no fallback: AUTO there is the
+                                       CG at 1e-12 with the step forced at pcg_max_iters.  Above 1280 reduced unknowns in
+                                       SFMBA_PRECISION_F32J the CG iterates on an fp32-rounded copy of the preconditioned matrix
+                                       (pcg_f32_matrix = -1 keeps fp64): the converged step is that of the rounded matrix, ~1e-7
+                                       relative from the fp64 one -- inside what F32J promises, not the DENSE_SCHUR digits. */
 
 enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
        SFMBA_PRECISION_F32J = 1 };  /* fp32 Jacobian blocks AND fp32 observation coordinates (BASELINE config 3; the reference's
                                        observations are cv::Point2f anyway, BA.cpp:149-153 -- a caller holding genuinely double
                                        observations loses ~1e-4 px at 2k-px coordinates); residuals, cost, sums and the reduced
-                                       system in fp64 */
+                                       system in fp64.  What to expect (tests/test_gpu_baseline_parity.py): final cost within 1e-6
+                                       relative (measured 3e-13) and final RMS within 1e-4 px of the fp64 solve (measured < 1e-9 px),
+                                       parameters within ~2e-5 -- EXCEPT points on weakly constrained tracks: a point seen by two
+                                       nearly parallel views has almost no depth information, its 3x3 block is ill-conditioned and
+                                       the fp32 rounding of its Jacobian moves it by up to ~1e-3..5e-3 scene units along the ray at
+                                       (numerically) the same cost (cfg3_banded: 8e-4 and 2.1e-3 seen).  Use F64 if such points'
+                                       coordinates matter beyond that. */
 
 /* Return codes of every entry point. */
 enum {
