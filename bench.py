@@ -53,6 +53,7 @@ def parse():
                     help="after the headline run also time ONE problem sharded over all ranks (cfg3 and cfg5) with the RCCL all-reduce "
                          "of the reduced camera system: 1 = yes, 0 = no, -1 (default) = only when N > 1")
     ap.add_argument("--distributed-cg", action="store_true", help="--mode sharded: the CG without the redundant solve (reduce-scatter + one small all-reduce per CG iteration)")
+    ap.add_argument("--implicit-cg", action="store_true", help="--mode sharded: the CG with the product formed implicitly from every rank's own points (no exchange of the reduced matrix at all)")
     ap.add_argument("--extras-timeout", type=int, default=300, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -362,11 +363,11 @@ def main():
             os._exit(0)
         old_term = signal.signal(signal.SIGTERM, on_term)
         for wl in (["cfg3", "cfg5"] if args.workload == "cfg3" else [args.workload]):
-            for variant in ("replicated_cg", "distributed_cg"):          # both forms of the reduced-system solve
-                key = wl if variant == "replicated_cg" else wl + "_distributed_cg"
+            for variant in ("replicated_cg", "distributed_cg", "implicit_schur_cg"):          # the three forms of the reduced-system solve
+                key = wl if variant == "replicated_cg" else wl + "_" + variant
                 try:
                     sh[key] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)),
-                                          distributed=(variant == "distributed_cg"))
+                                          distributed={"replicated_cg": 0, "distributed_cg": 1, "implicit_schur_cg": 2}[variant])
                 except Exception as e:                       # never lose the headline line to the extras
                     sh[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         watchdog.cancel()
@@ -388,7 +389,7 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
     prob = sfm.make_problem(workload)
     be = sharded.HipShardBackend(prob, rank, world, device=local_rank, precision=precision)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol,
-                               shard_distributed_cg=1 if distributed else 0)
+                               shard_distributed_cg=int(distributed))
     comm = sharded.RcclComm(dist, rank, world, device=local_rank)
 
     def barrier():
@@ -431,12 +432,16 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         g_dt, g_ar = [float(v) for v in tmax.tolist()]
         dist_note = None
-        if summ.get("distributed_cg"):
+        if summ.get("implicit_schur_cg"):
+            dist_note = ("no exchange of the reduced matrix: per CG iteration every rank applies its own points' W V^-1 W^T to the vector (two passes over "
+                         "its observations) and ONE all-reduce of %d doubles sums the partial products; vector updates replicated" % ld)
+        elif summ.get("distributed_cg"):
             dist_note = ("reduce-scatter of the upper-triangle blocks of the preconditioned matrix into ranges of block rows (%d bytes in the buffer, a rank "
                          "receives 1 / %d of it), then per CG iteration ONE all-reduce of %d doubles (the partial product from the owned blocks); "
                          "vector updates replicated" % (ex_bytes[1], world, ld))
         return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
-                "reduced_system_solve": "distributed CG (no redundant solve)" if summ.get("distributed_cg") else "every rank runs the CG on the summed matrix (redundant)",
+                "reduced_system_solve": ("implicit Schur CG (no reduced matrix formed or exchanged)" if summ.get("implicit_schur_cg") else
+                                         "distributed CG (no redundant solve)" if summ.get("distributed_cg") else "every rank runs the CG on the summed matrix (redundant)"),
                 "distributed_cg_exchange": dist_note,
                 "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
                 "ms_per_step": 1e3 * g_dt / steps, "lm_iterations_per_step": iters / steps,
@@ -456,7 +461,7 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
 
 def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear):
     """--mode sharded: the sharded run IS the headline line (strong scaling)."""
-    r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps, distributed=args.distributed_cg)
+    r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps, distributed=2 if args.implicit_cg else 1 if args.distributed_cg else 0)
     if rank == 0:
         print(json.dumps({
             "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,

@@ -128,7 +128,11 @@ typedef struct sfmba_options {
     int    shard_distributed_cg;      /* SFMBA_SHARD_DIST_CG      default off: sharded CG path WITHOUT the redundant solve -- exchange (B) is a
                                          reduce-scatter of the upper-triangle blocks of S~ into ranges of block rows (half the bytes of the
                                          all-reduce), every rank multiplies the blocks it owns, one all-reduce of ld doubles per CG
-                                         iteration's partial product (needs sfmba_problem_set_reduce_scatter when world > 1) */
+                                         iteration's partial product (needs sfmba_problem_set_reduce_scatter when world > 1).
+                                         2 (SFMBA_SHARD_DIST_CG=2): the same CG with the product formed IMPLICITLY -- no pair pass, no
+                                         exchange (B) at all: per CG iteration every rank applies its own points' W V^-1 W^T to the
+                                         all-reduced vector (two passes over its observations) and the ranks all-reduce ld doubles
+                                         (needs no reduce-scatter; a problem with duplicate (camera, point) observations runs as 1) */
 } sfmba_options;
 
 /* Flags of sfmba_problem_create_ex (ABI v4; were environment variables read at create time). */

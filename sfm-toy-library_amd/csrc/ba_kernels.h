@@ -179,6 +179,20 @@ template <typename T> void launch_eval_residuals(hipStream_t s, const DeviceStru
                                                  const int* perm, double* res_out, double* cost_out);
 template <typename T> void launch_eval_jacobian(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
                                                 const int* obs_pt, const int* perm, double* jc, double* jp, double* jf);
+// Implicit Schur product of the sharded solve (ba_kernels.hip, "Implicit Schur product"): out = this rank's part of S~ p~ from its own
+// points (+ on rank 0 what every rank knows: identity diagonal blocks, focal row / column); summed over the ranks it is S~ p~.
+struct ImplicitProduct {
+    DeviceStructure ds;
+    DeviceBuffers db;
+    double* dtab = nullptr;            // [ncam][8] direction table (two component quads per camera)
+    double* spt = nullptr;             // [npt][3] per-point sums
+    double* acc = nullptr;             // [ncam][6] per-camera sums
+    const double* focal_row = nullptr; const float* focal_row32 = nullptr;     // row d-1 of the CG's matrix (left by the glue)
+    int rank = 0;
+    bool f32 = false;                  // precision of the Jacobian blocks
+};
+void launch_implicit_product(hipStream_t s, const ImplicitProduct& ip, const double* p_tilde, double* out, const int* flags);
+void launch_pcg_glue(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 // sharded mode: move slotted accumulators to / from the all-reduce scalar block
 void launch_shard_pack(hipStream_t s, const DeviceBuffers& db, double* scal, int phase, int rank);
 void launch_shard_tri(hipStream_t s, double* sys, double* packed, int ld, long long tail, bool unpack);

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_arena.h"
+#include "ba_kernels.h"
 #include <vector>
 
 namespace sfmba {
@@ -19,7 +20,7 @@ struct DistCg {
     int* d_row_shift = nullptr;          // [ncam] block offset to ADD to a block's upper-triangle list position (pair pass -> reduce-scatter layout)
     double *qa = nullptr, *qb = nullptr; // [ld] row part / transposed part of the partial product
     double* qred = nullptr;              // [9 * ld] the all-reduce buffer: partial products (one per CG iteration; eight at the coarse setup)
-    double *x = nullptr, *r = nullptr, *p = nullptr, *z = nullptr;   // [ld] each, replicated (x: the caller's buffer -- DenseSolver::vec, where k_cam_update looks)
+    double *x = nullptr, *r = nullptr, *p = nullptr;   // [ld] each, replicated (x: the caller's buffer -- DenseSolver::vec, where k_cam_update looks)
     double* AW = nullptr;                // [8][ld] S~ W~
     double* scal = nullptr;              // [128] rz, thresholds, E^-1 (64), ...
     bool ready = false;
@@ -41,6 +42,9 @@ struct DcgSolveArgs {
     int* flags = nullptr;               // DenseSolver::flags: [0] done, [1] iterations, [2] x buffer (always 0 here)
     int* info = nullptr;                // linear-solver status word (set on breakdown)
     double tol = 1e-8; int anchor = 0; double cap = 1.0;
+    // non-null: the product is formed IMPLICITLY from the rank's own points (ba_kernels.hip, "Implicit Schur product") -- no block of S~
+    // exists anywhere, `owned` is ignored and nothing of the reduced matrix was exchanged (options.shard_distributed_cg = 2)
+    const ImplicitProduct* implicit = nullptr;
 };
 // setup of one solve (coarse space: 8 products + ONE all-reduce, then E^-1; x = 0, r = b~, z, p); returns 0 or an error of the collective
 int  dcg_begin(hipStream_t s, DistCg* g, const DcgSolveArgs& a, dcg_allreduce_fn ar, void* ctx);

@@ -298,19 +298,24 @@ int dcg_create(DistCg* g, int d, int ld, int ncam, int rank, int world, DeviceAr
         const long long first = (long long)g->rows[(size_t)k] * ncam - (long long)g->rows[(size_t)k] * (g->rows[(size_t)k] + 1) / 2;
         for (int I = g->rows[(size_t)k]; I < g->rows[(size_t)k + 1]; ++I) shift[(size_t)I] = (int)(k * g->chunk_blocks - first);
     }
-    g->d_row_shift = arena->alloc_n<int>(shift.size());
-    g->qa = arena->alloc_n<double>((size_t)ld); g->qb = arena->alloc_n<double>((size_t)ld);
-    g->qred = arena->alloc_n<double>((size_t)9 * ld);
-    g->r = arena->alloc_n<double>((size_t)ld); g->p = arena->alloc_n<double>((size_t)ld); g->z = arena->alloc_n<double>((size_t)ld);
-    g->scal = arena->alloc_n<double>(128);
-    if (!g->d_row_shift || !g->qa || !g->qb || !g->qred || !g->r || !g->p || !g->z || !g->scal) return -1;
-    if (hipMemcpy(g->d_row_shift, shift.data(), sizeof(int) * shift.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    // all or nothing: a workspace that fails half way leaves nothing behind in *g (the arena keeps the bytes until the problem goes)
+    int* d_row_shift = arena->alloc_n<int>(shift.size());
+    double* qa = arena->alloc_n<double>((size_t)ld); double* qb = arena->alloc_n<double>((size_t)ld);
+    double* qred = arena->alloc_n<double>((size_t)9 * ld);
+    double* r = arena->alloc_n<double>((size_t)ld); double* pp = arena->alloc_n<double>((size_t)ld);
+    double* scal = arena->alloc_n<double>(128);
+    if (!d_row_shift || !qa || !qb || !qred || !r || !pp || !scal) return -1;
+    if (hipMemcpy(d_row_shift, shift.data(), sizeof(int) * shift.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    // the collectives carry ld doubles per vector, the kernels write d of them: the padding is zero once and for all
+    if (hipMemset(qred, 0, sizeof(double) * (size_t)9 * ld) != hipSuccess) return -1;
+    g->d_row_shift = d_row_shift; g->qa = qa; g->qb = qb; g->qred = qred; g->r = r; g->p = pp; g->scal = scal;
     g->AW = g->qred;                  // slots 0..7 of the all-reduce buffer ARE S~ W~ after the setup; slot 8 carries the iterations' products
     g->ready = true;
     return 0;
 }
 
 static void launch_product(hipStream_t s, const DistCg* g, const DcgSolveArgs& a, const double* p, double* out, const int* flags) {
+    if (a.implicit) { launch_implicit_product(s, *a.implicit, p, out, flags); return; }
     const int nA = g->row1 - g->row0, nB = std::max(0, g->ncam - g->row0 - 1);
     if (nA + nB > 0) {
         if (a.owned_f32) hipLaunchKernelGGL(k_dcg_spmv<float>, dim3(nA + nB), dim3(256), 0, s, g->ncam, g->row0, g->row1, static_cast<const float*>(a.owned), p, g->qa, g->qb, flags);

@@ -251,6 +251,7 @@ struct sfmba_problem {
     sfmba_allreduce_f32_fn allreduce_f32 = nullptr;   // optional: exchange (B) in fp32 where the CG stores S~ in fp32
     sfmba_reduce_scatter_fn reduce_scatter = nullptr; // optional: the distributed CG's exchange (B)
     DistCg dcg;                                       // distributed CG workspace (created by the first solve that asks for it)
+    double *imp_dtab = nullptr, *imp_spt = nullptr, *imp_acc = nullptr;   // implicit Schur product workspace (shard_distributed_cg = 2; allocated by the first solve that asks)
     long long shard_blocks_off = 0;                   // doubles: where the block region of d_red starts (behind the region of exchange (A))
     int dcg_last_f32 = -1;
     sfmba_summary shard_sum;
@@ -972,6 +973,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         const size_t dist = (size_t)p->shard_blocks_off + (size_t)p->shard_world * (size_t)chunk * 36;
         HIP_TRY(dev_alloc(&p->d_red, std::max(std::max(tri, dist), (size_t)std::max(shard_diag_len(ds), shard_offdiag_len(ds)))));
         p->dcg = DistCg(); p->dcg_last_f32 = -1;
+        p->imp_dtab = p->imp_spt = p->imp_acc = nullptr;
     }
     db.S = p->d_sys;
     db.rhs = db.S + (size_t)ds.ld * ds.ld;
@@ -1609,7 +1611,14 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : auto_cg_tol(), auto_cg_tol()) : o.pcg_tolerance;
         // the CG without the redundant solve (dist_cg.h): reduce-scatter of the blocks, products from the owned blocks, one small
         // all-reduce per CG iteration
-        const bool dist_cg = option_switch(o.shard_distributed_cg, "SFMBA_SHARD_DIST_CG", false) && (p->shard_world == 1 || p->reduce_scatter != nullptr);
+        // ... or WITHOUT any exchange of the reduced matrix (shard_distributed_cg = 2 / SFMBA_SHARD_DIST_CG=2): the product of a CG iteration is
+        // formed implicitly from every rank's own points (ba_kernels.hip, "Implicit Schur product"); duplicates live in diagonal blocks the
+        // implicit form does not see: such a problem takes the explicit distributed form
+        int dist_mode = o.shard_distributed_cg > 0 ? o.shard_distributed_cg : 0;
+        if (const char* e = std::getenv("SFMBA_SHARD_DIST_CG")) dist_mode = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
+        if (dist_mode == 2 && p->ds.ndupwg > 0) dist_mode = 1;
+        const bool implicit_cg = dist_mode == 2;
+        const bool dist_cg = dist_mode > 0 && (implicit_cg || p->shard_world == 1 || p->reduce_scatter != nullptr);
         struct ArCtx { sfmba_allreduce_fn fn; void* ctx; } arctx{ allreduce, ctx };
         auto ar_thunk = [](void* c, void* buf, long long n, hipStream_t st) -> int { ArCtx* a = static_cast<ArCtx*>(c); return a->fn ? a->fn(a->ctx, buf, (int64_t)n, (void*)st) : 0; };
         int dcg_launched = 0, dcg_max = o.pcg_max_iters > 0 ? o.pcg_max_iters : 4 * p->ds.d;
@@ -1617,12 +1626,20 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             ArenaScope as(&p->arena);
             if (dcg_create(&p->dcg, p->ds.d, p->ds.ld, p->ds.ncam, p->shard_rank, p->shard_world, &p->arena)) return fail(SFMBA_ERR_ALLOC, "distributed CG workspace allocation failed");
         }
+        if (implicit_cg && !p->imp_dtab) {
+            ArenaScope as(&p->arena);
+            p->imp_dtab = p->arena.alloc_n<double>((size_t)8 * std::max(p->ds.ncam, 1));
+            p->imp_spt = p->arena.alloc_n<double>((size_t)3 * std::max(p->ds.npt, 1));
+            p->imp_acc = p->arena.alloc_n<double>((size_t)6 * std::max(p->ds.ncam, 1));
+            if (!p->imp_dtab || !p->imp_spt || !p->imp_acc) { p->imp_dtab = nullptr; return fail(SFMBA_ERR_ALLOC, "implicit Schur workspace allocation failed"); }
+        }
+        ImplicitProduct ip;
         int first_build = o.jacobi_scaling ? 1 : 2;          // the first point pass also forms the point scales
         for (;;) {
             if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             p->db.pcg_F = p->solver.Sfull;
             p->db.pcg_W = coarse_cg ? p->solver.W : nullptr;
-            float* F32 = f32 ? dense_pcg_want_f32(&p->solver) : nullptr;
+            float* F32 = (f32 && !implicit_cg) ? dense_pcg_want_f32(&p->solver) : nullptr;      // (implicit product: there is no matrix to store)
             p->solver.use_f32 = F32 != nullptr;
             // the streaming CG path stores S~ in fp32: with a single-precision all-reduce the partial blocks are exchanged in fp32 and
             // the sum is the CG's matrix (what the camera pass and the pair epilogue write directly -- diagonal blocks, focal column --
@@ -1644,6 +1661,15 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             // the pair pass stores its transformed blocks straight into the all-reduce buffer
             DcgSolveArgs da;
             if (dist_cg) {
+              const int fo = p->ds.d - 1;
+              if (implicit_cg) {
+                // no pair pass, no exchange (B): the glue the pair pass does on the way (focal row of S~, b~, post-linearisation) on its own
+                launch_pcg_glue(p->stream, p->ds, p->db);
+                ip.ds = p->ds; ip.db = p->db; ip.dtab = p->imp_dtab; ip.spt = p->imp_spt; ip.acc = p->imp_acc;
+                ip.focal_row = p->solver.Sfull + (size_t)fo * p->ds.ld; ip.focal_row32 = nullptr; ip.rank = p->shard_rank; ip.f32 = f32;
+                da.implicit = &ip;
+                p->shard_exchange[1] = 0; p->shard_exchange[3] = 2 | 4;
+              } else {
                 // ... in the reduce-scatter layout (`world` equal chunks of whole block rows behind the region of exchange (A); padding zero)
                 double* blocks = p->d_red + p->shard_blocks_off;
                 const long long cv = dcg_chunk_values(p->dcg), total = cv * p->shard_world;
@@ -1658,9 +1684,9 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                     if (rrc != 0) return fail(SFMBA_ERR_HIP, "reduce-scatter failed (rc " + std::to_string(rrc) + ")");
                 }
                 p->shard_exchange[1] = (x32 ? 4 : 8) * total; p->shard_exchange[3] = (x32 ? 1 : 0) | 2;
-                const int fo = p->ds.d - 1;
                 da.owned = mine; da.owned_f32 = x32;
                 if (p->db.pcg_F32) da.focal_row32 = p->db.pcg_F32 + (size_t)fo * p->ds.ld; else da.focal_row = p->solver.Sfull + (size_t)fo * p->ds.ld;
+              }
                 da.bt = p->solver.vec + (size_t)8 * p->ds.ld; da.W = coarse_cg ? p->solver.W : nullptr;
                 da.flags = p->solver.flags; da.info = p->d_info; da.tol = cg_tol;
                 da.anchor = (!o.pcg_anchored || exact_pcg) ? 0 : first_linear_solve ? 1 : 2;

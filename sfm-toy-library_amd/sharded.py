@@ -209,6 +209,7 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
     out["exchange_bytes"] = [int(ex[0]), int(ex[1]), int(ex[2])]
     out["exchange_b_fp32"] = bool(ex[3] & 1)
     out["distributed_cg"] = bool(ex[3] & 2)
+    out["implicit_schur_cg"] = bool(ex[3] & 4)
     return out
 
 

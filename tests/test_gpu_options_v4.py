@@ -166,13 +166,13 @@ def test_sharded_switches_and_deterministic_sharded(capi, sfm, mid):
     be = HipShardBackend(mid, 0, 1, device=0, precision=1)
     try:
         for okw in (dict(), dict(shard_two_phase=-1), dict(early_linearise=-1), dict(pcg_coarse_space=-1), dict(shard_distributed_cg=1),
-                    dict(shard_distributed_cg=1, pcg_coarse_space=-1)):
+                    dict(shard_distributed_cg=1, pcg_coarse_space=-1), dict(shard_distributed_cg=2), dict(shard_distributed_cg=2, pcg_coarse_space=-1)):
             be.reset()
             s = solve_sharded_native(be, capi.default_options(max_seconds=0.0, linear_solver=1, precision=1, **okw), comm=None)
             assert s["termination_name"] == "CONVERGENCE" and s["iterations"] == ref[3]["iterations"]
             assert abs(s["final_cost"] - ref[3]["final_cost"]) <= 1e-9 * ref[3]["final_cost"]
-            assert np.abs(be.get_params()[0] - ref[0]).max() < 2e-6
-            assert s["distributed_cg"] == bool(okw.get("shard_distributed_cg", 0) == 1)
+            assert np.abs(be.get_params()[0] - ref[0]).max() < (5e-6 if okw.get("shard_distributed_cg", 0) == 2 else 2e-6)     # (F32J: the implicit product rounds elsewhere)
+            assert s["distributed_cg"] == bool(okw.get("shard_distributed_cg", 0) >= 1) and s["implicit_schur_cg"] == bool(okw.get("shard_distributed_cg", 0) == 2)
     finally:
         be.close()
     runs = []

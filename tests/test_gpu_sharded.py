@@ -32,6 +32,13 @@ CASES = {
     "dist_wide": (dict(name="cfg3", n_cam=230, n_pt=6001, seed=78), 1, 1, dict(shard_distributed_cg=1)),
     "dist_auto": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 0, 2, dict(shard_distributed_cg=1)),
     "dist_plain": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 1, 1, dict(shard_distributed_cg=1, pcg_coarse_space=-1)),
+    # ... and WITHOUT any exchange of the reduced matrix: the CG product formed implicitly from every rank's own points
+    # (ba_kernels.hip "Implicit Schur product"), one all-reduce of ld doubles per CG iteration and nothing else -- fp64, fp32 Jacobian
+    # blocks at d = 1381, the library default (AUTO), plain block-Jacobi
+    "dist_imp_cfg2": (dict(name="cfg2", n_pt=5003), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0, shard_distributed_cg=2)),
+    "dist_imp_wide": (dict(name="cfg3", n_cam=230, n_pt=6001, seed=78), 1, 1, dict(shard_distributed_cg=2)),
+    "dist_imp_auto": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 0, 2, dict(shard_distributed_cg=2)),
+    "dist_imp_plain": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 1, 1, dict(shard_distributed_cg=2, pcg_coarse_space=-1)),
 }
 
 
@@ -165,7 +172,9 @@ def test_sharded_exchange_variants_agree(sfm, monkeypatch, linear):
 
 @pytest.mark.parametrize("world,case", [(2, "cfg2_uneven"), (3, "cfg2_uneven"), (4, "cfg2_uneven"), (3, "wide_uneven"), (4, "wide_uneven"),
                                         (3, "auto_uneven"), (4, "chol_uneven"),
-                                        (2, "dist_cfg2"), (3, "dist_cfg2"), (4, "dist_wide"), (3, "dist_auto"), (2, "dist_plain")])
+                                        (2, "dist_cfg2"), (3, "dist_cfg2"), (4, "dist_wide"), (3, "dist_auto"), (2, "dist_plain"),
+                                        (2, "dist_imp_cfg2"), (3, "dist_imp_cfg2"), (4, "dist_imp_wide"), (3, "dist_imp_auto"), (2, "dist_imp_plain"),
+                                        (4, "dist_imp_cfg2")])
 def test_multi_rank_uneven_sharded_hip_solve(sfm, oracle, world, case):
     """2, 3 and 4 ranks (processes) on the one MI355X of the box, point counts the world size does not divide
     (shards of different sizes), native C loop with the collectives through the callback -- against the ORACLE's solve of the whole
@@ -188,7 +197,9 @@ def test_multi_rank_uneven_sharded_hip_solve(sfm, oracle, world, case):
     assert ranges[0][0] == 0 and ranges[-1][1] == prob.n_pt and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
     assert len({hi - lo for lo, hi in ranges}) > 1                       # genuinely uneven
     cam0, f0, s0 = results[0][2], results[0][4], results[0][1]
-    assert s0["distributed_cg"] == case.startswith("dist_")
+    assert s0["distributed_cg"] == case.startswith("dist_") and s0["implicit_schur_cg"] == case.startswith("dist_imp_")
+    if case.startswith("dist_imp_"):
+        assert s0["exchange_bytes"][1] == 0                              # nothing of the reduced matrix crosses the ranks
     for r in results[1:]:
         assert np.array_equal(r[2], cam0) and r[4] == f0 and r[1]["final_cost"] == s0["final_cost"]     # replicas bit-identical
         for a, b in zip(results[0][6], r[6]):
