@@ -12,9 +12,9 @@
 #define SFMBA_CAM_CHUNK 256
 #endif
 
-// 6x6 blocks (one wave each) handled by one workgroup of k_schur_pairs; the host groups consecutive blocks of a block row
-#ifndef SFMBA_PAIR_WAVES
-#define SFMBA_PAIR_WAVES 1
+// pairs per wave of k_schur_pairs: a 6x6 block with more pairs is cut into chunks (eight rounds of 64 pairs)
+#ifndef SFMBA_PAIR_CHUNK
+#define SFMBA_PAIR_CHUNK 512
 #endif
 
 namespace sfmba {
@@ -99,6 +99,10 @@ struct DeviceStructure {
     int pwg_group;            // blocks per workgroup entry (SFMBA_PAIR_WAVES, or 64 / pair_lpb)
     const int4* pwg_desc;     // [npairwg * pwg_group] {block or -1, row camera ja, first pair, last pair + 1}: everything a wave (or lane
                               //       group) needs about its block in ONE load; jb follows from the block index
+    const int2* pwg_chunk;    // wave-per-block pass: [npairwg] {chunk index, chunks of the block}: heavy blocks are cut into chunks of
+                              //       SFMBA_PAIR_CHUNK pairs, one wave each (consecutive slots); null for the sixteen-lane pass
+    int nmulti;               // blocks of more than one chunk ...
+    const int* multi_slots;   // ... [nmulti] and the first slot of each (k_schur_combine adds their partial sums)
     int ndupwg;
     const int2* dup_blocks;   // [ndupwg] like pwg_blocks, but only diagonal blocks that have pairs (same camera seeing a point twice)
     int nwv;
@@ -143,6 +147,7 @@ struct DeviceBuffers {
     float* pcg_F32;           // the same in fp32 instead (streaming CG path, d > 1280: the matvec is HBM-bound); else null
     double* pcg_bt;           // [ld]    Lb^-1 rhs
     double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
+    double* pair_partial;     // [npairwg][36] partial sums (factored coordinates) of the chunks of multi-chunk blocks
     double* pair_G;           // [ncam*36] per-camera factor the factored pair pass applies from both sides of a block (row-major 6 x 6):
                               // Linv D E^T (PCG: k_finalize) or D E^T (exact solver: k_pair_factors), E = diag(R K', I) -- sfmba_device.h
     double* pcg_W;            // [8][ld] gauge vectors in the transformed unknowns (coarse space of the two-level CG preconditioner,
@@ -240,6 +245,11 @@ struct StageObs {
 void launch_stage_obs(hipStream_t s, const StageObs& so, int xy_bytes);
 // pair-pass descriptors and the list of diagonal blocks with pairs, from the block CSR on the device
 void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, int4* desc);
+// wave-per-block pair pass: one descriptor per chunk of SFMBA_PAIR_CHUNK pairs (structure_build.hip); counters: two zeroed ints; the slot
+// total, the number of multi-chunk blocks and the number of non-empty off-diagonal blocks go to report[4], report[5], report[1]
+int build_pair_chunks(hipStream_t s, DeviceArena* scratch, int nwg, int chunk, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr,
+                      int4* desc, int2* info, int* multi, int* counters, int* report);
+void launch_block_fill(hipStream_t s, int nblock, const int2* blk_cams, const int* blk_ptr, int* counters, int* report);
 void launch_dup_blocks(hipStream_t s, int ncam, const int* blk_ptr, const long long* pair_total, int2* dup, int* report);
 
 // triangulate.hip: two-view DLT triangulation + reprojection filter (SfMStereoUtilities::triangulateViews), device pointers

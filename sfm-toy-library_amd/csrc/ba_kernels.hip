@@ -646,17 +646,40 @@ __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, con
     store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
 }
 
-// Lane-local sums stay in T for at most PAIR_FLUSH rounds (64 pairs each), then the wave sum is taken and carried on in fp64: a block
-// with tens of thousands of pairs (two cameras sharing most of a large cloud) would otherwise pile thousands of fp32 additions
-// into one accumulator.  Blocks up to 64 * PAIR_FLUSH pairs -- all of BASELINE config 3 -- never take the branch.
-// The per-camera factor diag(R K', I) of the camera blocks is applied once per block in the epilogue (pair_G), the pair loop works on
-// [ -[R X]x | I ], the projection Jacobian and C: 295 wave instructions per 64 pairs, 128 registers (four waves per SIMD) in fp32 mode.
+// the two-sided transform of one block's sums (factored coordinates, sfmba_device.h): S_IJ = G_I [sum] G_J^T with the per-camera
+// G = Lw D E^T that k_finalize (PCG: Lw = Linv, so this IS the preconditioned block) or k_pair_factors (exact solver: Lw = I) left in
+// pair_G.  tile: the 36 sums (negated) in LDS; lanes 0..35 write one entry each.
+template <int MODE>
+__device__ __forceinline__ void pair_epilogue(const DeviceStructure& ds, const DeviceBuffers& db, int b, int2 cj, const double* tile, int lane) {
+    if (lane < 36) {
+        const int r = lane / 6, c = lane - 6 * r;
+        double Gi[6], Gj[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { Gi[a] = db.pair_G[(size_t)cj.x * 36 + 6 * r + a]; Gj[a] = db.pair_G[(size_t)cj.y * 36 + 6 * c + a]; }
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double u = 0.0;
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) u += tile[6 * a + bb] * Gj[bb];
+            v += Gi[a] * u;
+        }
+        if (MODE == 0) db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
+        else store_block_entry(ds, db, b, cj, r, c, v);
+    }
+}
+
+// One wave per CHUNK of a block: at most SFMBA_PAIR_CHUNK pairs (eight rounds of 64), so lane-local sums in T never pile up more than eight
+// terms and no wave runs longer than eight rounds whatever the co-visibility (structure_build.hip, build_pair_chunks).  The per-camera
+// factor diag(R K', I) of the camera blocks is applied once per block in the epilogue (pair_G), the pair loop works on [ -[R X]x | I ], the
+// projection Jacobian and C: 295 wave instructions per 64 pairs, 128 registers (four waves per SIMD) in fp32 mode.  A block of several
+// chunks leaves its partial sums in pair_partial; k_schur_combine (the next launch) adds them and runs the epilogue.
 template <typename T, int MODE>
-__global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double tile[SFMBA_PAIR_WAVES][36];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int4 dsc = ds.pwg_desc[(size_t)blockIdx.x * SFMBA_PAIR_WAVES + w];      // one load: block, row camera, pair range
-    if (dsc.x < 0) return;
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double tile[36];
+    const int lane = threadIdx.x & 63;
+    const int4 dsc = ds.pwg_desc[blockIdx.x];       // one load: block, row camera, pair range of the chunk
+    const int2 chunk = ds.pwg_chunk[blockIdx.x];    // {chunk index, chunks of the block}
     const int b = dsc.x, pbeg = dsc.z, p1 = dsc.w;
     int2 cj;
     cj.x = dsc.y;
@@ -695,9 +718,6 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
     T acc[36];
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-    constexpr int PAIR_FLUSH = 64;
-    double total = 0.0;            // this lane's entry of the 6x6 block (lanes that own one), over the flushes so far
-    int base = 0, len = 36, rounds = 0;
     {
         const LMState* st = db.st;
         const int cur = st->cur;
@@ -716,42 +736,43 @@ __global__ __launch_bounds__(64 * SFMBA_PAIR_WAVES, (sizeof(T) == 4 ? 4 : 2)) vo
             T ga[GREC], gb[GREC];
             obs_factored<T>(ca, focal, pa.X, pa.L, ga);
             obs_factored<T>(cb, focal, pa.X, pa.L, gb);
-            if (p0 + mine >= p1) ga[3] = (T)0;      // this lane's pair lies beyond the block: contribute nothing (N carries f_a / p_z)
+            if (p0 + mine >= p1) ga[3] = (T)0;      // this lane's pair lies beyond the chunk: contribute nothing (N carries f_a / p_z)
             pair_product_factored<T>(ga, gb, acc);
-            if (sizeof(T) == 4 && ++rounds == PAIR_FLUSH && p0 + 64 < p1) {
-                rounds = 0; base = 0; len = 36;
-                HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
-                total += len >= 1 ? (double)acc[0] : 0.0;
-#pragma unroll
-                for (int e = 0; e < 36; ++e) acc[e] = (T)0;
-            }
         }
     }
     // Sum of the 36 entries over the 64 lanes by a halving butterfly: afterwards lane `base` -- 36 of the 64 lanes -- owns ONE
     // entry of the 6x6 block.
-    base = 0; len = 36;
+    int base = 0, len = 36;
     HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
-    total += len >= 1 ? (double)acc[0] : 0.0;
-    // the sums are in the factored coordinates (sfmba_device.h): S_IJ = G_I [sum] G_J^T with the per-camera G = Lw D E^T that
-    // k_finalize (PCG: Lw = Linv, so this IS the preconditioned block) or k_pair_factors (exact solver: Lw = I) left in pair_G
-    if (len >= 1) tile[w][base] = -total;
-    wave_lds_fence();
-    if (lane < 36) {
-        const int r = lane / 6, c = lane - 6 * r;
-        double Gi[6], Gj[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { Gi[a] = db.pair_G[(size_t)cj.x * 36 + 6 * r + a]; Gj[a] = db.pair_G[(size_t)cj.y * 36 + 6 * c + a]; }
-        double v = 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            double u = 0.0;
-#pragma unroll
-            for (int bb = 0; bb < 6; ++bb) u += tile[w][6 * a + bb] * Gj[bb];
-            v += Gi[a] * u;
-        }
-        if (MODE == 0) db.S[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
-        else store_block_entry(ds, db, b, cj, r, c, v);
+    const double total = len >= 1 ? (double)acc[0] : 0.0;
+    if (chunk.y > 1) {                              // one of several chunks: the partial sums of this one
+        if (len >= 1) db.pair_partial[(size_t)blockIdx.x * 36 + base] = -total;
+        return;
     }
+    if (len >= 1) tile[base] = -total;
+    wave_lds_fence();
+    pair_epilogue<MODE>(ds, db, b, cj, tile, lane);
+}
+
+// the blocks of several chunks: their partial sums added in chunk order, then the epilogue of k_schur_pairs
+template <int MODE>
+__global__ __launch_bounds__(64) void k_schur_combine(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double tile[36];
+    const int lane = threadIdx.x & 63;
+    const int slot0 = ds.multi_slots[blockIdx.x];
+    const int4 dsc = ds.pwg_desc[slot0];
+    const int nch = ds.pwg_chunk[slot0].y;
+    const int b = dsc.x;
+    int2 cj;
+    cj.x = dsc.y;
+    cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
+    if (lane < 36) {
+        double v = 0.0;
+        for (int c = 0; c < nch; ++c) v += db.pair_partial[(size_t)(slot0 + c) * 36 + lane];
+        tile[lane] = v;
+    }
+    wave_lds_fence();
+    pair_epilogue<MODE>(ds, db, b, cj, tile, lane);
 }
 
 // Pairs INSIDE a diagonal block: one camera observing a point twice (two features matched to the same 3D point).  Both observations
@@ -1102,9 +1123,12 @@ void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBu
         if (mode == 1) hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 1, 16>), grid, dim3(64), 0, s, ds, db);
         else hipLaunchKernelGGL((k_schur_pairs_sub_f<T, 0, 16>), grid, dim3(64), 0, s, ds, db);
     } else {
-        const dim3 block(64 * SFMBA_PAIR_WAVES);
-        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs<T, 1>), grid, block, 0, s, ds, db);
-        else hipLaunchKernelGGL((k_schur_pairs<T, 0>), grid, block, 0, s, ds, db);
+        if (mode == 1) hipLaunchKernelGGL((k_schur_pairs<T, 1>), grid, dim3(64), 0, s, ds, db);
+        else hipLaunchKernelGGL((k_schur_pairs<T, 0>), grid, dim3(64), 0, s, ds, db);
+        if (ds.nmulti > 0) {
+            if (mode == 1) hipLaunchKernelGGL(k_schur_combine<1>, dim3(ds.nmulti), dim3(64), 0, s, ds, db);
+            else hipLaunchKernelGGL(k_schur_combine<0>, dim3(ds.nmulti), dim3(64), 0, s, ds, db);
+        }
     }
 }
 template void launch_schur_pairs<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);

@@ -215,6 +215,8 @@ struct sfmba_problem {
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_wv_desc = nullptr, *d_pwg_desc = nullptr;
+    int2* d_pwg_chunk = nullptr; int* d_multi_slots = nullptr; int* d_build_counters = nullptr;
+    double block_fill = 1.0;              // non-empty off-diagonal blocks of the reduced matrix / all of them
     int* d_blk_ptr = nullptr;
     int* d_cam_chunk_ptr = nullptr;
     bool deterministic = false;             // SFMBA_DETERMINISTIC=1 at build time
@@ -400,6 +402,11 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // resident problem solved twice from the same point takes the same path twice -- solve / reset / solve is bitwise repeatable in
     // deterministic mode.
     bool auto_prefers_cholesky = false;
+    // ... and what the STRUCTURE says before the first iteration: a sparsely filled reduced matrix is a camera graph of large diameter
+    // (views along a path, tracks of neighbouring cameras: SfM.cpp:366-469 builds exactly that) -- block-Jacobi CG then needs hundreds of
+    // iterations per linearisation (cfg3_banded, fill 0.29: ~160 at 1e-12) and the factorisation is the cheaper way to the DENSE_SCHUR
+    // result from the first linearisation on.  A property of the problem, not of the call history: deterministic.
+    if (exact_pcg && p->block_fill < 0.5) auto_prefers_cholesky = true;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
@@ -731,6 +738,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     std::vector<double> cam0, pts0;
     std::vector<char> blob;
     int pair_lpb = 64, blocks_per_wg = 1;
+    size_t pair_slot_cap = 0;
     auto host_half = [&]() -> int {
         for (int i = 0; i < npt; ++i) { const long long m = p->h_pt_cnt[(size_t)i]; pt_ptr[(size_t)i + 1] = pt_ptr[(size_t)i] + (int)m; npair_total += m * (m - 1) / 2; }
         for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] = cam_ptr[(size_t)j] + p->h_cam_cnt[(size_t)j];
@@ -765,7 +773,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         const double mean_pairs = (double)npair_total / (double)std::max(1, nblock - ncam);
         pair_lpb = mean_pairs >= 128.0 ? 64 : 16;
         if (const char* e = std::getenv("SFMBA_PAIR_LPB")) { const int v = std::atoi(e); if (v == 64 || v == 16) pair_lpb = v; }
-        blocks_per_wg = pair_lpb == 64 ? SFMBA_PAIR_WAVES : 64 / pair_lpb;
+        blocks_per_wg = pair_lpb == 64 ? 1 : 64 / pair_lpb;
         {
             std::vector<std::vector<int2>> per_xcd(8);
             for (int ja = 0; ja < ncam; ++ja) {
@@ -820,7 +828,14 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             p->d_pwg_blocks = reinterpret_cast<int2*>(d_blob + o_pwg); p->d_pwg_ptr = reinterpret_cast<int*>(d_blob + o_wvp);
             p->d_wv_desc = reinterpret_cast<int4*>(d_blob + o_wvd);
         }
-        HIP_TRY(dev_alloc(&p->d_pwg_desc, pwg_blocks.size() * (size_t)blocks_per_wg));
+        // (wave-per-block pass: one descriptor per chunk of SFMBA_PAIR_CHUNK pairs -- as many as the pair total allows at most)
+        pair_slot_cap = pair_lpb == 64 ? pwg_blocks.size() + (size_t)(npair_total / SFMBA_PAIR_CHUNK) + 1 : pwg_blocks.size() * (size_t)blocks_per_wg;
+        HIP_TRY(dev_alloc(&p->d_pwg_desc, pair_slot_cap));
+        if (pair_lpb == 64) {
+            HIP_TRY(dev_alloc(&p->d_pwg_chunk, pair_slot_cap));
+            HIP_TRY(dev_alloc(&p->d_multi_slots, pwg_blocks.size() + 1));
+        }
+        HIP_TRY(dev_alloc(&p->d_build_counters, (size_t)2));
         HIP_TRY(dev_alloc(&p->d_dup_blocks, (size_t)ncam));
         return SFMBA_OK;
     };
@@ -921,8 +936,18 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
     volatile int* build_report = reinterpret_cast<volatile int*>(p->kit.pinned + 1536);      // [1536, 1552) of the mailbox slice
     build_report[0] = -1;
-    launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, p->d_pwg_desc);
-    launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, reinterpret_cast<int*>(p->d_pinned + 1536));
+    int* d_report = reinterpret_cast<int*>(p->d_pinned + 1536);
+    build_report[1] = -1; build_report[4] = -1; build_report[5] = -1;
+    HIP_TRY(hipMemsetAsync(p->d_build_counters, 0, 2 * sizeof(int), p->stream));
+    if (pair_lpb == 64) {
+        const int crc = build_pair_chunks(p->stream, &staging, (int)pwg_blocks.size(), SFMBA_PAIR_CHUNK, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr,
+                                          p->d_pwg_desc, p->d_pwg_chunk, p->d_multi_slots, p->d_build_counters, d_report);
+        if (crc) return fail(SFMBA_ERR_HIP, std::string("pair-chunk descriptors: ") + hipGetErrorString((hipError_t)crc));
+    } else {
+        launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, p->d_pwg_desc);
+    }
+    launch_block_fill(p->stream, nblock, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
+    launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, d_report);
     HIP_TRY(hipGetLastError());
     p->focal0 = p->focal = focal;
 
@@ -939,6 +964,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pair_pt = p->d_pair_pt;
     ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
     ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
+    ds.pwg_chunk = pair_lpb == 64 ? p->d_pwg_chunk : nullptr; ds.nmulti = 0; ds.multi_slots = p->d_multi_slots;      // counts: after the wait at the end
     ds.ndupwg = 0; ds.dup_blocks = p->d_dup_blocks;          // count: after the wait at the end
     ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr; ds.wv_desc = p->d_wv_desc;
 
@@ -1011,12 +1037,19 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
     HIP_TRY(dev_alloc(&db.pair_G, (size_t)36 * std::max(ncam, 1)));
+    if (pair_lpb == 64) HIP_TRY(dev_alloc(&db.pair_partial, (size_t)36 * pair_slot_cap));
     bt_mark("alloc buffers");
     // the one wait of the build: sorts, lists and descriptors are in place; the staging arena and the host vectors may go
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (build_report[0] < 0 || (((long long)build_report[3] << 32) | (unsigned)build_report[2]) != npair_total)
         return fail(SFMBA_ERR_HIP, "structure build: the device's pair count differs from the host's");
     ds.ndupwg = build_report[0];
+    if (pair_lpb == 64) {
+        if (build_report[4] < 0 || (size_t)build_report[4] > pair_slot_cap || build_report[5] < 0) return fail(SFMBA_ERR_HIP, "structure build: pair-chunk descriptors out of range");
+        ds.npairwg = build_report[4]; ds.nmulti = build_report[5];
+    }
+    // fill of the reduced matrix: non-empty off-diagonal blocks / all of them (what SFMBA_LINEAR_AUTO reads the co-visibility from)
+    p->block_fill = ncam > 1 ? (double)std::max((int)build_report[1], 0) / ((double)ncam * (ncam - 1) / 2.0) : 1.0;
     bt_mark("wait for device");
     return sfmba_problem_reset(p);
 }

@@ -308,6 +308,90 @@ void launch_stage_obs(hipStream_t s, const StageObs& so, int xy_bytes) {
     if (xy_bytes == 8) hipLaunchKernelGGL(k_stage_obs<float2>, dim3((n + 255) / 256), dim3(256), 0, s, so);
     else hipLaunchKernelGGL(k_stage_obs<double2>, dim3((n + 255) / 256), dim3(256), 0, s, so);
 }
+// ---- wave-per-block pair pass: heavy blocks are cut into chunks of PAIR_CHUNK pairs, one wave each ----
+// Realistic co-visibility concentrates the pairs in few blocks (cameras on a path, tracks of neighbouring cameras: 5 800 non-empty blocks
+// of 19 900 with ~1 300 pairs on average and up to 4 650 at BASELINE-config-3 size), and a wave per block then leaves the launch to its
+// longest waves (73 rounds of 64 pairs) at a third of the machine's occupancy.  One descriptor per CHUNK, in the order of the host's
+// workgroup list; a block of several chunks leaves partial sums behind that k_schur_combine adds (list `multi`: the first slot of every
+// such block).  The slot total and the number of multi-chunk blocks go to host-mapped memory (report[4], report[5]).
+namespace {
+__global__ __launch_bounds__(256) void k_chunk_count(int nwg, int chunk, const int2* __restrict__ pwg_blocks, const int2* __restrict__ blk_cams,
+                                                     const int* __restrict__ blk_ptr, int* __restrict__ cnt) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nwg) return;
+    int c = 0;
+    if (s < nwg) {
+        const int2 w = pwg_blocks[s];
+        if (w.y > 0) {
+            const int2 cj = blk_cams[w.x];
+            const int n = blk_ptr[w.x + 1] - blk_ptr[w.x];
+            c = cj.x == cj.y ? 1 : (n + chunk - 1) / chunk;
+            if (c < 1) c = 1;
+        }
+    }
+    cnt[s] = c;
+}
+__global__ __launch_bounds__(256) void k_chunk_fill(int nwg, int chunk, const int2* __restrict__ pwg_blocks, const int2* __restrict__ blk_cams,
+                                                    const int* __restrict__ blk_ptr, const int* __restrict__ off, int4* __restrict__ desc,
+                                                    int2* __restrict__ info, int* __restrict__ multi, int* __restrict__ counters) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nwg) return;
+    const int2 w = pwg_blocks[s];
+    if (w.y <= 0) return;
+    const int b = w.x;
+    const int2 cj = blk_cams[b];
+    const int pb = blk_ptr[b], pe = blk_ptr[b + 1];
+    const int o = off[s], nch = off[s + 1] - o;
+    for (int c = 0; c < nch; ++c) {
+        int4 d; d.x = b; d.y = cj.x;
+        d.z = nch == 1 ? pb : pb + c * chunk;
+        d.w = nch == 1 ? pe : min(pe, pb + (c + 1) * chunk);
+        desc[o + c] = d;
+        int2 ci; ci.x = c; ci.y = nch;
+        info[o + c] = ci;
+    }
+    if (nch > 1) multi[atomicAdd(&counters[0], 1)] = o;
+}
+__global__ void k_chunk_report(int nwg, const int* __restrict__ off, const int* __restrict__ counters, int* __restrict__ report) {
+    report[4] = off[nwg];
+    report[5] = counters[0];
+    __threadfence_system();
+}
+// number of off-diagonal blocks of the upper triangle that hold at least one pair -> report[1] (the fill of the reduced matrix: what
+// SFMBA_LINEAR_AUTO reads the co-visibility structure from)
+__global__ __launch_bounds__(256) void k_block_fill(int nblock, const int2* __restrict__ blk_cams, const int* __restrict__ blk_ptr, int* __restrict__ counters) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int has = 0;
+    if (b < nblock) { const int2 cj = blk_cams[b]; has = cj.x != cj.y && blk_ptr[b + 1] > blk_ptr[b]; }
+    const unsigned long long m = __ballot(has);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[1], __popcll(m));
+}
+__global__ void k_fill_report(const int* __restrict__ counters, int* __restrict__ report) { report[1] = counters[1]; __threadfence_system(); }
+}  // namespace
+
+int build_pair_chunks(hipStream_t s, DeviceArena* scratch, int nwg, int chunk, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr,
+                      int4* desc, int2* info, int* multi, int* counters, int* report) {
+    if (nwg <= 0) return 0;
+    int* cnt = scratch->alloc_n<int>((size_t)nwg + 1);
+    int* off = scratch->alloc_n<int>((size_t)nwg + 1);
+    if (!cnt || !off) return (int)hipErrorOutOfMemory;
+    hipLaunchKernelGGL(k_chunk_count, dim3((nwg + 1 + 255) / 256), dim3(256), 0, s, nwg, chunk, pwg_blocks, blk_cams, blk_ptr, cnt);
+    size_t tmp_bytes = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, off, nwg + 1, s);
+    if (e != hipSuccess) return (int)e;
+    void* tmp = scratch->alloc(tmp_bytes ? tmp_bytes : 1);
+    if (!tmp) return (int)hipErrorOutOfMemory;
+    e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, off, nwg + 1, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_chunk_fill, dim3((nwg + 255) / 256), dim3(256), 0, s, nwg, chunk, pwg_blocks, blk_cams, blk_ptr, off, desc, info, multi, counters);
+    hipLaunchKernelGGL(k_chunk_report, dim3(1), dim3(1), 0, s, nwg, off, counters, report);
+    return (int)hipGetLastError();
+}
+void launch_block_fill(hipStream_t s, int nblock, const int2* blk_cams, const int* blk_ptr, int* counters, int* report) {
+    if (nblock > 0) hipLaunchKernelGGL(k_block_fill, dim3((nblock + 255) / 256), dim3(256), 0, s, nblock, blk_cams, blk_ptr, counters);
+    hipLaunchKernelGGL(k_fill_report, dim3(1), dim3(1), 0, s, counters, report);
+}
+
 void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, int4* desc) {
     const int nslot = nwg * group;
     if (nslot > 0) hipLaunchKernelGGL(k_pair_desc, dim3((nslot + 255) / 256), dim3(256), 0, s, nslot, group, pwg_blocks, blk_cams, blk_ptr, desc);

@@ -261,7 +261,9 @@ def test_banded_visibility_bench_mode_and_default_match_oracle(capi, sfm, banded
         s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=1))                    # AUTO
         cam, pt, f = P.get_params()
         assert_same_solve(banded, (cam, pt, f, s, tr), banded_oracle, param_atol=5e-5, trace_rtol=5e-5, point_atol=5e-3)
-        assert tr[1]["linear_iters"] > 60 and all(r["linear_iters"] == 0 for r in tr[2:])      # one linearisation on the CG, the rest factorised
+        # fill of the reduced matrix 0.29 (< 0.5): AUTO factorises from the first linearisation on -- decided from the structure, not
+        # from the history of the handle (round 3 ran ~160 CG iterations on the first linearisation of the first solve to find out)
+        assert all(r["linear_iters"] == 0 for r in tr[1:]) and s["cholesky_fallbacks"] == 0
         P.reset()
         s2, tr2 = P.solve(capi.default_options(max_seconds=0.0, precision=1))                  # the same path again: the preference lives and dies with a solve
         assert [r["linear_iters"] for r in tr2] == [r["linear_iters"] for r in tr] and abs(s2["final_cost"] - s["final_cost"]) <= 1e-9 * s["final_cost"]
