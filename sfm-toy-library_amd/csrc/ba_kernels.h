@@ -75,6 +75,7 @@ struct DeviceStructure {
     int ncam, npt, nobs;      // active cameras / points, observations
     int d, ld;                // reduced dim 6*ncam+1, padded leading dimension (multiple of 64)
     const int* pt_ptr;        // [npt+1] point-major CSR
+    const int* pt_order;      // [npt] point slots sorted by number of observations (lane-group point passes: the quads of a wave loop alike); null = slot order
     const int* obs_cam;       // [nobs] camera slot, point-major order (ascending inside a point)
     const void* obs_xy;       // [nobs] float2 or double2, point-major order
     const int* cam_ptr;       // [ncam+1] camera-major CSR
@@ -105,10 +106,6 @@ struct DeviceStructure {
     const int* multi_slots;   // ... [nmulti] and the first slot of each (k_schur_combine adds their partial sums)
     int ndupwg;
     const int2* dup_blocks;   // [ndupwg] like pwg_blocks, but only diagonal blocks that have pairs (same camera seeing a point twice)
-    int nwv;
-    const int* wv_ptr;        // [nwv+1] point ranges of the point-pass waves (whole points, <= 64 observations each)
-    const int4* wv_desc;      // [nwv] {first point, last point + 1, first observation, last observation + 1}: ONE load instead of the
-                              //       dependent wv_ptr -> pt_ptr chain in front of the observation loads
 };
 
 struct DeviceBuffers {

@@ -374,14 +374,6 @@ __device__ __forceinline__ void rec_camera_block(const T rec[YREC], T A[12]) {
     A[9] = (T)0; A[10] = rec[6]; A[11] = -rec[6] * rec[8];
 }
 
-// ------------------------------------------------------------------------------------------
-// K1: point pass.  One lane per observation, one wave per contiguous range of whole points with at
-// most 64 observations (host-built wv_ptr).  Every global load of a lane (its observation, its point,
-// its camera-table row) is issued up front: two dependent memory levels per wave, no load-bearing
-// loop (measured loaded latency on MI355X is 1-6 us per dependent access, so depth is what costs).
-// Per-point sums go through wave-private LDS: lane p adds up the <= 64 rows of its point.
-// ------------------------------------------------------------------------------------------
-#define PB_LD 10     // V(6) E_f(3) + pad, products of T values; B~^T r separately in fp64
 // workgroup of the two point passes: PBK / 64 waves that share nothing but the final block reduction
 #ifndef PBK
 #define PBK 128
@@ -404,30 +396,87 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// Since round 4 the point pass leaves NOTHING per observation behind (rounds 1 - 3 wrote a 64-byte record per observation for the
+// Per point, once its sums over the observations are known: Jacobi scales, LM damping, the inverse Cholesky factor of V + D^2, t, y_f, M and
+// the table entry every other pass re-evaluates from.  `store`: this lane writes the point's results (lanes that share a point compute the
+// same values; one of them stores and contributes to the block sums).
+template <typename T>
+__device__ __forceinline__ void point_finish(const DeviceBuffers& db, const LMState* st, size_t i, int ps_mode, const double (&Xl)[3], double (&V)[6], double (&bp)[3],
+                                             double (&Ef)[3], double (&sp)[3], bool store, double& gmax, double& sff, double& rhsf, double& bad) {
+    const double radius = st->radius;
+    // Jacobi scales of the point's three columns: loaded, or -- first linearisation of a solve -- formed here from the
+    // column norms this lane has just summed (s = 1 / (1 + ||J_col||), [Ceres-upstream] EstimateScale)
+    if (ps_mode != 0) {
+        sp[0] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[0])) : 1.0;
+        sp[1] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[2])) : 1.0;
+        sp[2] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[5])) : 1.0;
+        if (store) { db.pscale[3 * i] = sp[0]; db.pscale[3 * i + 1] = sp[1]; db.pscale[3 * i + 2] = sp[2]; }
+    }
+    if (store) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c]));           // gradient of the unscaled problem
+    }
+    V[0] *= sp[0] * sp[0]; V[1] *= sp[1] * sp[0]; V[2] *= sp[1] * sp[1];
+    V[3] *= sp[2] * sp[0]; V[4] *= sp[2] * sp[1]; V[5] *= sp[2] * sp[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { bp[c] *= sp[c]; Ef[c] *= sp[c]; }
+    // LM damping D^2 = clamp(diag(J~^T J~)) / radius   [LevenbergMarquardtStrategy::ComputeStep]
+    V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
+    V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
+    V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
+    double Li[6];
+    const bool pd = chol3_inverse(V, Li);
+    const double t0 = Li[0] * bp[0];
+    const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
+    const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
+    const double y0 = Li[0] * Ef[0];
+    const double y1 = Li[1] * Ef[0] + Li[2] * Ef[1];
+    const double y2 = Li[3] * Ef[0] + Li[4] * Ef[1] + Li[5] * Ef[2];
+    if (!store) return;
+    db.pt_t[3 * i] = t0; db.pt_t[3 * i + 1] = t1; db.pt_t[3 * i + 2] = t2;
+    // M = diag(s_p) L^-T for the back-substitution (k_point_update): dX = M (t - sum C^T u)
+    db.pt_M[6 * i] = sp[0] * Li[0]; db.pt_M[6 * i + 1] = sp[0] * Li[1]; db.pt_M[6 * i + 2] = sp[0] * Li[3];
+    db.pt_M[6 * i + 3] = sp[1] * Li[2]; db.pt_M[6 * i + 4] = sp[1] * Li[4]; db.pt_M[6 * i + 5] = sp[2] * Li[5];
+    sff -= y0 * y0 + y1 * y1 + y2 * y2;
+    rhsf -= y0 * t0 + y1 * t1 + y2 * t2;
+    if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2)) bad = 1.0;
+    // the per-point table (sfmba_device.h): the point itself; L^-1 with the point scales folded in, so that C = B~ L^-T =
+    // B diag(s) L^-T comes from the UNSCALED point block of an observation; t and y_f in the precision of the Jacobian blocks
+    PtRecA<T> ra;
+    ra.X[0] = Xl[0]; ra.X[1] = Xl[1]; ra.X[2] = Xl[2];
+    ra.L[0] = (T)(Li[0] * sp[0]); ra.L[1] = (T)(Li[1] * sp[0]); ra.L[2] = (T)(Li[2] * sp[1]);
+    ra.L[3] = (T)(Li[3] * sp[0]); ra.L[4] = (T)(Li[4] * sp[1]); ra.L[5] = (T)(Li[5] * sp[2]);
+    if (sizeof(T) == 8) reinterpret_cast<double*>(&ra)[9] = 0.0;
+    reinterpret_cast<PtRecA<T>*>(db.PA)[i] = ra;
+    PtRecB<T> rb;
+    rb.t[0] = (T)t0; rb.t[1] = (T)t1; rb.t[2] = (T)t2;
+    rb.yf[0] = (T)y0; rb.yf[1] = (T)y1; rb.yf[2] = (T)y2;
+    reinterpret_cast<PtRecB<T>*>(db.PB)[i] = rb;
+}
+
+// K1: point pass.  The point pass leaves NOTHING per observation behind (rounds 1 - 3 wrote a 64-byte record per observation for the
 // back-substitution: 64 MB written and read per LM iteration at BASELINE config 3): per point the table entry the reduced-system passes
-// and the back-substitution re-evaluate from (PtRecA / PtRecB), t, y_f, M.  A lane needs the camera's R and t only (three component quads
-// of the table instead of six: K' is the reduced-system passes' business).
+// and the back-substitution re-evaluate from (PtRecA / PtRecB), t, M.  LPP = 4 LANES PER POINT: a wave owns 16 points, the four lanes of
+// a point take its observations in turn (4 at a time) and keep the point's sums in registers; one quad reduction (DPP) and the
+// per-point arithmetic on every lane of the quad.  (Rounds 1 - 3 and the first half of round 4 gave every observation a lane and every
+// wave 64 consecutive observations: of its ~750 wave instructions ~360 were a serial row loop through LDS and ~130 the per-point phase,
+// both at a tenth of the lanes -- 34.5 against 22.7 us at BASELINE config 3, 150 against 98 at config 5.)  Waves take points in the order
+// of ds.pt_order (sorted by number of rounds of four observations: the quads of a wave then loop alike whatever the track lengths).  A
+// lane needs the camera's R and t only (three component quads of the table: K' is the reduced-system passes' business).
+#define PB_LPP 4
 template <typename T>
 __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode_flags) {
-    // bit 2: enqueued BEFORE the host saw the outcome of the control kernel in front of it (run_solve keeps the queue from draining
-    // across the mailbox round trip): nothing to do if the solve has ended there or the LM iteration is waiting for more CG
     if ((ps_mode_flags & 4) && (db.st->termination != -1 || db.st->retry != 0)) return;
     const int ps_mode = ps_mode_flags & 3;
-    __shared__ T sv[WPB][64][PB_LD];
-    __shared__ double sb[WPB][64][3];
     __shared__ double scratch[WPB * 4];
     const LMState* st = db.st;
     const int cur = st->cur;
     const double* tab = db.camtab[cur];
     const double focal = st->focal[cur];
     const T fscale = (T)st->fscale;
-    const double radius = st->radius;
     const double* pts = db.pts[cur];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int gw = blockIdx.x * WPB + w;
     double lin_cost = 0.0, sff = 0.0, rhsf = 0.0, gmax = 0.0, bad = 0.0;
-
     // clear what k_cam_diag_f (and the duplicate-pair pass) accumulate with atomics: per camera the 6x6 diagonal block,
     // its focal column, the undamped diagonal, the scaled gradient and the reduced right-hand side
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ds.ncam * 60; e += gridDim.x * blockDim.x) {
@@ -438,115 +487,64 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
         else if (k < 54) db.rhs[row0 + k - 48] = 0.0;
         else db.S[(size_t)(row0 + k - 54) * ds.ld + ds.d - 1] = 0.0;
     }
-
-    if (gw < ds.nwv) {
-        const int4 wd = ds.wv_desc[gw];
-        const int pt0 = wd.x, pt1 = wd.y;
-        const int npts = pt1 - pt0;
-        const int o0 = wd.z, o1 = wd.w;                // (more than 64 observations only for a point that has a wave of its own)
-        double V[6] = { 0, 0, 0, 0, 0, 0 }, bp[3] = { 0, 0, 0 }, Ef[3] = { 0, 0, 0 };
-        const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
-        const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
-        // this lane's point and its Jacobi scales, issued with the first loads (used after the reduction)
-        double sp[3] = { 1.0, 1.0, 1.0 }, Xl[3] = { 0.0, 0.0, 0.0 };
-        if (lane < npts) {
-            const size_t i = (size_t)(pt0 + lane);
-            Xl[0] = pts[3 * i]; Xl[1] = pts[3 * i + 1]; Xl[2] = pts[3 * i + 2];
-            if (ps_mode == 0) { sp[0] = db.pscale[3 * i]; sp[1] = db.pscale[3 * i + 1]; sp[2] = db.pscale[3 * i + 2]; }
-        }
-
-        for (int c0 = o0; c0 < o1; c0 += 64) {
-            const int q = c0 + lane;
-            if (q < o1) {
-                const int i = ds.obs_pt[q], j = ds.obs_cam[q];
-                double ox, oy;
-                load_obs<T>(ds.obs_xy, q, ox, oy);
-                const double X[3] = { pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2] };
-                const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
-                const Proj pr = project_point(ct, CT_R, CT_T, X);
-                const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
-                lin_cost += r0 * r0 + r1 * r1;
-                T B[6];
-                point_block<T>(ct, pr, focal, B);
-                // (the point's Jacobi scales are applied to the per-point sums below, not to every observation)
-                const T g0 = (T)pr.xp * fscale, g1 = (T)pr.yp * fscale;
-                T* o = sv[w][lane];
-                o[0] = B[0] * B[0] + B[3] * B[3];
-                o[1] = B[1] * B[0] + B[4] * B[3];
-                o[2] = B[1] * B[1] + B[4] * B[4];
-                o[3] = B[2] * B[0] + B[5] * B[3];
-                o[4] = B[2] * B[1] + B[5] * B[4];
-                o[5] = B[2] * B[2] + B[5] * B[5];
+    const int sub = lane & (PB_LPP - 1);
+    const int slot = gw * (64 / PB_LPP) + (lane / PB_LPP);
+    const bool have = slot < ds.npt;
+    const int ip = have ? (ds.pt_order ? ds.pt_order[slot] : slot) : 0;
+    const size_t i = (size_t)ip;
+    const int q0 = have ? ds.pt_ptr[ip] : 0, q1 = have ? ds.pt_ptr[ip + 1] : 0;
+    double Xl[3] = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] };
+    double sp[3] = { 1.0, 1.0, 1.0 };
+    if (ps_mode == 0) { sp[0] = db.pscale[3 * i]; sp[1] = db.pscale[3 * i + 1]; sp[2] = db.pscale[3 * i + 2]; }
+    T Va[6] = { (T)0, (T)0, (T)0, (T)0, (T)0, (T)0 }, Ea[3] = { (T)0, (T)0, (T)0 };
+    double bp[3] = { 0, 0, 0 };
+    // the camera and the coordinates of the NEXT round's observation are fetched one round ahead: a round costs one dependent memory
+    // level (the camera's table row)
+    int q = q0 + sub;
+    int j_next = q < q1 ? ds.obs_cam[q] : 0;
+    double ox_next = 0.0, oy_next = 0.0;
+    if (q < q1) load_obs<T>(ds.obs_xy, q, ox_next, oy_next);
+    while (__any(q < q1)) {
+        const bool act = q < q1;
+        const int j = j_next;
+        const double ox = ox_next, oy = oy_next;
+        const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
+        double Rt[12];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    o[6 + c] = B[c] * g0 + B[3 + c] * g1;
-                    sb[w][lane][c] = (double)B[c] * r0 + (double)B[3 + c] * r1;
-                }
+        for (int e = 0; e < 12; ++e) Rt[e] = ct[CT_R + e];
+        q += PB_LPP;
+        if (q < q1) { j_next = ds.obs_cam[q]; load_obs<T>(ds.obs_xy, q, ox_next, oy_next); }
+        if (act) {
+            const Proj pr = project_point(Rt, 0, 9, Xl);
+            const double r0 = focal * pr.xp - ox, r1 = focal * pr.yp - oy;
+            lin_cost += r0 * r0 + r1 * r1;
+            T B[6];
+            point_block<T>(Rt, pr, focal, B);
+            const T g0 = (T)pr.xp * fscale, g1 = (T)pr.yp * fscale;
+            Va[0] += B[0] * B[0] + B[3] * B[3];
+            Va[1] += B[1] * B[0] + B[4] * B[3];
+            Va[2] += B[1] * B[1] + B[4] * B[4];
+            Va[3] += B[2] * B[0] + B[5] * B[3];
+            Va[4] += B[2] * B[1] + B[5] * B[4];
+            Va[5] += B[2] * B[2] + B[5] * B[5];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Ea[c] += B[c] * g0 + B[3 + c] * g1;
+                bp[c] += (double)B[c] * r0 + (double)B[3 + c] * r1;
             }
-            wave_lds_fence();
-            if (lane < npts) {
-                const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
-                for (int e = a; e < b; ++e) {
-                    const T* o = sv[w][e];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) V[c] += (double)o[c];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { Ef[c] += (double)o[6 + c]; bp[c] += sb[w][e][c]; }
-                }
-            }
-            wave_lds_fence();
-        }
-        if (lane < npts) {
-            const size_t i = (size_t)(pt0 + lane);
-            // Jacobi scales of the point's three columns: loaded, or -- first linearisation of a solve -- formed here from the
-            // column norms this lane has just summed (s = 1 / (1 + ||J_col||), [Ceres-upstream] EstimateScale)
-            if (ps_mode != 0) {
-                sp[0] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[0])) : 1.0;
-                sp[1] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[2])) : 1.0;
-                sp[2] = ps_mode == 1 ? 1.0 / (1.0 + sqrt(V[5])) : 1.0;
-                db.pscale[3 * i] = sp[0]; db.pscale[3 * i + 1] = sp[1]; db.pscale[3 * i + 2] = sp[2];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gmax = fmax(gmax, fabs(bp[c]));           // gradient of the unscaled problem
-            V[0] *= sp[0] * sp[0]; V[1] *= sp[1] * sp[0]; V[2] *= sp[1] * sp[1];
-            V[3] *= sp[2] * sp[0]; V[4] *= sp[2] * sp[1]; V[5] *= sp[2] * sp[2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { bp[c] *= sp[c]; Ef[c] *= sp[c]; }
-            // LM damping D^2 = clamp(diag(J~^T J~)) / radius   [LevenbergMarquardtStrategy::ComputeStep]
-            V[0] += fmin(fmax(V[0], st->min_diag), st->max_diag) / radius;
-            V[2] += fmin(fmax(V[2], st->min_diag), st->max_diag) / radius;
-            V[5] += fmin(fmax(V[5], st->min_diag), st->max_diag) / radius;
-            double Li[6];
-            const bool pd = chol3_inverse(V, Li);
-            const double t0 = Li[0] * bp[0];
-            const double t1 = Li[1] * bp[0] + Li[2] * bp[1];
-            const double t2 = Li[3] * bp[0] + Li[4] * bp[1] + Li[5] * bp[2];
-            const double y0 = Li[0] * Ef[0];
-            const double y1 = Li[1] * Ef[0] + Li[2] * Ef[1];
-            const double y2 = Li[3] * Ef[0] + Li[4] * Ef[1] + Li[5] * Ef[2];
-            db.pt_t[3 * i] = t0; db.pt_t[3 * i + 1] = t1; db.pt_t[3 * i + 2] = t2;
-            // M = diag(s_p) L^-T for the back-substitution (k_point_update): dX = M (t - sum C^T u)
-            db.pt_M[6 * i] = sp[0] * Li[0]; db.pt_M[6 * i + 1] = sp[0] * Li[1]; db.pt_M[6 * i + 2] = sp[0] * Li[3];
-            db.pt_M[6 * i + 3] = sp[1] * Li[2]; db.pt_M[6 * i + 4] = sp[1] * Li[4]; db.pt_M[6 * i + 5] = sp[2] * Li[5];
-            sff -= y0 * y0 + y1 * y1 + y2 * y2;
-            rhsf -= y0 * t0 + y1 * t1 + y2 * t2;
-            if (!pd || !finite_d(t0 + t1 + t2 + y0 + y1 + y2)) bad = 1.0;
-            // the per-point table (sfmba_device.h): the point itself; L^-1 with the point scales folded in, so that C = B~ L^-T =
-            // B diag(s) L^-T comes from the UNSCALED point block of an observation; t and y_f in the precision of the Jacobian blocks
-            PtRecA<T> ra;
-            ra.X[0] = Xl[0]; ra.X[1] = Xl[1]; ra.X[2] = Xl[2];
-            ra.L[0] = (T)(Li[0] * sp[0]); ra.L[1] = (T)(Li[1] * sp[0]); ra.L[2] = (T)(Li[2] * sp[1]);
-            ra.L[3] = (T)(Li[3] * sp[0]); ra.L[4] = (T)(Li[4] * sp[1]); ra.L[5] = (T)(Li[5] * sp[2]);
-            if (sizeof(T) == 8) reinterpret_cast<double*>(&ra)[9] = 0.0;
-            reinterpret_cast<PtRecA<T>*>(db.PA)[i] = ra;
-            PtRecB<T> rb;
-            rb.t[0] = (T)t0; rb.t[1] = (T)t1; rb.t[2] = (T)t2;
-            rb.yf[0] = (T)y0; rb.yf[1] = (T)y1; rb.yf[2] = (T)y2;
-            reinterpret_cast<PtRecB<T>*>(db.PB)[i] = rb;
         }
     }
+    // the point's sums over its quad (every lane of the quad ends up with them)
+    double V[6], Ef[3];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { double v = (double)Va[c]; v = xlane_add<1>(v); v = xlane_add<2>(v); V[c] = v; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = (double)Ea[c]; v = xlane_add<1>(v); v = xlane_add<2>(v); Ef[c] = v;
+        double u = bp[c]; u = xlane_add<1>(u); u = xlane_add<2>(u); bp[c] = u;
+    }
+    if (have) point_finish<T>(db, st, i, ps_mode, Xl, V, bp, Ef, sp, sub == 0, gmax, sff, rhsf, bad);
     if (!finite_d(lin_cost)) bad = 1.0;
-    // block reductions -> global accumulators
     const double gm = wave_max(gmax);
     if ((threadIdx.x & 63) == 0 && gm > 0.0) atomic_max_nonneg(slot_ptr(db, ACC_GMAX), gm);
     double sums[4] = { lin_cost, sff, rhsf, bad };
@@ -1070,7 +1068,8 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
 
 template <typename T>
 void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int ps_mode) {
-    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, db, ps_mode);
+    const int per_wg = WPB * (64 / PB_LPP);
+    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.npt + per_wg - 1) / per_wg), dim3(PBK), 0, s, ds, db, ps_mode);
 }
 template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
@@ -1558,207 +1557,8 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), db.shared_weight * s2); atomicAdd(slot_ptr(db, ACC_XNEW2), db.shared_weight * x2); }
 }
 
-// Obs-parallel back-substitution: same workgroup/point ownership as k_point_build.
-//   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost.
-// With V + D^2 = L L^T, t = L^-1 b_p and C = B~ L^-T (left behind per POINT by k_point_build: pt_t, M = diag(s_p) L^-T, the table entry):
-//   u   = A (camera step) + g (focal step)     per observation
-//   z   = t - sum_obs C^T u                      per point (three sums through the wave's LDS)
-//   dX  = M z ;   J step = -(u + C z)            (model cost change; B~ y_p = C L^T y_p = C z)
-// Nothing per observation is read but its indices and coordinates (rounds 2 / 3 streamed a 64-byte record per observation here: 64 MB
-// per launch at BASELINE config 3, the pass ran at HBM speed): the projection at the linearisation point is re-evaluated in fp64 from
-// the camera's R, t and the point-table entry, the camera block acts on the step in the factored form of sfmba_device.h,
-//   A [dw; dt] = P (Q dw x X_g + dt),   P = (f / p_z) [[1, 0, -x_p], [0, 1, -y_p]],
-// with Q dw formed once per camera by k_cam_update, and C = (P R) L~ in the precision of the Jacobian blocks, exactly as the
-// reduced-system passes form it.  The residual of the model cost change is the fp64 residual (it used to be rebuilt from the
-// record's fp32 x_p).  The TRIAL residual is evaluated at the trial camera / point (fp64).
-// everything the passes read per observation that is not the observation itself
-template <typename T>
-struct PointUpdateCtx {
-    const double* tab;        // camera table at the linearisation point
-    const double* stab;       // step table
-    const PtRecA<T>* PA;
-    double focal, focal_n, dfoc;
-};
-
-// one observation of the first sweep: residual, C, u (see above)
-template <typename T>
-__device__ __forceinline__ void point_update_obs(const DeviceStructure& ds, const PointUpdateCtx<T>& cx, int q, int& i, int& j, double& ox, double& oy,
-                                                 double& r0, double& r1, T (&C)[6], double& u0, double& u1) {
-    i = ds.obs_pt[q]; j = ds.obs_cam[q];
-    load_obs<T>(ds.obs_xy, q, ox, oy);
-    const PtRecA<T> pa = load_ptrec(cx.PA + i);
-    const CamRow ct = { cx.tab + 4 * (size_t)(j), ds.ncam };
-    const CamRow stb = { cx.stab + 4 * (size_t)(j), ds.ncam };
-    const double dq0 = stb[ST_DQ], dq1 = stb[ST_DQ + 1], dq2 = stb[ST_DQ + 2];
-    const double dt0 = stb[ST_DT], dt1 = stb[ST_DT + 1], dt2 = stb[ST_DT + 2];
-    const bool first_order = stb[ST_SMALL] != 0.0;
-    const double rx = ct[CT_R + 0] * pa.X[0] + ct[CT_R + 1] * pa.X[1] + ct[CT_R + 2] * pa.X[2];
-    const double ry = ct[CT_R + 3] * pa.X[0] + ct[CT_R + 4] * pa.X[1] + ct[CT_R + 5] * pa.X[2];
-    const double rz = ct[CT_R + 6] * pa.X[0] + ct[CT_R + 7] * pa.X[1] + ct[CT_R + 8] * pa.X[2];
-    Proj pr;
-    pr.iz = fast_rcp(rz + ct[CT_T + 2]);
-    pr.xp = (rx + ct[CT_T + 0]) * pr.iz;
-    pr.yp = (ry + ct[CT_T + 1]) * pr.iz;
-    r0 = cx.focal * pr.xp - ox; r1 = cx.focal * pr.yp - oy;
-    const double g0 = first_order ? pa.X[0] : rx, g1 = first_order ? pa.X[1] : ry, g2 = first_order ? pa.X[2] : rz;
-    // v = Q dw x X_g + dt ;  u = P v + (x_p, y_p) df
-    const double v0 = dq1 * g2 - dq2 * g1 + dt0, v1 = dq2 * g0 - dq0 * g2 + dt1, v2 = dq0 * g1 - dq1 * g0 + dt2;
-    const double fz = cx.focal * pr.iz;
-    u0 = fz * (v0 - pr.xp * v2) + pr.xp * cx.dfoc;
-    u1 = fz * (v1 - pr.yp * v2) + pr.yp * cx.dfoc;
-    T B[6];
-    point_block<T>(ct, pr, cx.focal, B);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {          // C = B~ L^-T, the expressions of obs_record / obs_factored
-        const T b0 = B[3 * r], b1 = B[3 * r + 1], b2 = B[3 * r + 2];
-        C[3 * r + 0] = b0 * pa.L[0];
-        C[3 * r + 1] = b0 * pa.L[1] + b1 * pa.L[2];
-        C[3 * r + 2] = b0 * pa.L[3] + b1 * pa.L[4] + b2 * pa.L[5];
-    }
-}
-
-// One wave of the pass.  SINGLE: at most 64 observations (every wave but those of a point with more than 64 observations) -- straight
-// line code: every load of the wave is issued in one go (its observation, the point-table entry, the camera's rows of both tables, this
-// lane's point), the trial pose of the lane's camera rides along behind the first sweep's arithmetic, and what the second sweep needs
-// of the first stays in registers.  !SINGLE: rounds of 64 observations, the second sweep re-evaluates.
-template <typename T, bool SINGLE>
-__device__ __forceinline__ void point_update_wave(const DeviceStructure& ds, const DeviceBuffers& db, const PointUpdateCtx<T>& cx, const int4 wd, int nxt, int cur,
-                                                  double (*sz)[3], double (*sx)[6], double& trial, double& model, double& step2, double& xn2, double& bad) {
-    const int lane = threadIdx.x & 63;
-    const int pt0 = wd.x, npts = wd.y - wd.x;
-    const int o0 = wd.z, o1 = wd.w;
-    const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
-    const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
-    double tp[3] = { 0, 0, 0 }, Mp[6] = { 0, 0, 0, 0, 0, 0 }, Xp[3] = { 0, 0, 0 };
-    if (lane < npts) {
-        const size_t i = (size_t)(pt0 + lane);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { tp[c] = db.pt_t[3 * i + c]; Xp[c] = db.pts[cur][3 * i + c]; }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) Mp[c] = db.pt_M[6 * i + c];
-    }
-    double zacc[3] = { 0, 0, 0 };
-    double u0k = 0, u1k = 0, oxk = 0, oyk = 0, r0k = 0, r1k = 0;
-    T Ck[6] = { (T)0, (T)0, (T)0, (T)0, (T)0, (T)0 };
-    int ik = 0, jk = 0;
-    double RTn[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // R, t of the lane's camera at the trial point
-    for (int c0 = o0; c0 < (SINGLE ? o0 + 1 : o1); c0 += 64) {
-        const int q = c0 + lane;
-        if (q < o1) {
-            point_update_obs<T>(ds, cx, q, ik, jk, oxk, oyk, r0k, r1k, Ck, u0k, u1k);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) sz[lane][c] = (double)Ck[c] * u0k + (double)Ck[3 + c] * u1k;
-            if (SINGLE) {
-                const CamRow stb = { cx.stab + 4 * (size_t)(jk), ds.ncam };
-#pragma unroll
-                for (int e = 0; e < 12; ++e) RTn[e] = stb[ST_RN + e];
-            }
-        }
-        wave_lds_fence();
-        if (lane < npts) {
-            const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
-            for (int e = a; e < b; ++e) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) zacc[c] += sz[e][c];
-            }
-        }
-        wave_lds_fence();
-    }
-    if (lane < npts) {
-        const size_t i = (size_t)(pt0 + lane);
-        const double z0 = tp[0] - zacc[0], z1 = tp[1] - zacc[1], z2 = tp[2] - zacc[2];
-        const double dX[3] = { Mp[0] * z0 + Mp[1] * z1 + Mp[2] * z2, Mp[3] * z1 + Mp[4] * z2, Mp[5] * z2 };
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double x = Xp[c];
-            const double xn = x - dX[c];
-            const double df = x - xn;
-            step2 += df * df;
-            xn2 += xn * xn;
-            db.pts[nxt][3 * i + c] = xn;
-            sx[lane][3 + c] = xn;
-        }
-        sx[lane][0] = z0; sx[lane][1] = z1; sx[lane][2] = z2;
-    }
-    wave_lds_fence();
-    for (int c0 = o0; c0 < (SINGLE ? o0 + 1 : o1); c0 += 64) {
-        const int q = c0 + lane;
-        if (q >= o1) continue;
-        if (!SINGLE) {
-            point_update_obs<T>(ds, cx, q, ik, jk, oxk, oyk, r0k, r1k, Ck, u0k, u1k);
-            const CamRow stb = { cx.stab + 4 * (size_t)(jk), ds.ncam };
-#pragma unroll
-            for (int e = 0; e < 12; ++e) RTn[e] = stb[ST_RN + e];
-        }
-        const double* pl = sx[ik - pt0];
-        const double z0 = pl[0], z1 = pl[1], z2 = pl[2];
-        const double Xn[3] = { pl[3], pl[4], pl[5] };
-        // model residual m = J step = -(u + C z)
-        const double m0 = -(u0k + (double)Ck[0] * z0 + (double)Ck[1] * z1 + (double)Ck[2] * z2);
-        const double m1 = -(u1k + (double)Ck[3] * z0 + (double)Ck[4] * z1 + (double)Ck[5] * z2);
-        model -= m0 * (r0k + 0.5 * m0) + m1 * (r1k + 0.5 * m1);
-        const Proj pn = project_point(RTn, 0, 9, Xn);
-        const double n0 = cx.focal_n * pn.xp - oxk, n1 = cx.focal_n * pn.yp - oyk;
-        if (!finite_d(n0) || !finite_d(n1)) bad = 1.0;
-        trial += n0 * n0 + n1 * n1;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double sz[WPB][64][3];      // per observation of the round: C^T u
-    __shared__ double sx[WPB][64][6];      // per local point: z (3), Xn (3)
-    __shared__ double scratch[WPB * 5];
-    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // see k_cam_update
-    const LMState* st = db.st;
-    const int cur = st->cur, nxt = cur ^ 1;
-    PointUpdateCtx<T> cx;
-    cx.tab = db.camtab[cur]; cx.stab = db.steptab; cx.PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
-    cx.focal = st->focal[cur]; cx.focal_n = st->focal[nxt];
-    cx.dfoc = cx.focal - cx.focal_n;               // unscaled focal step to SUBTRACT (= fscale * y_f)
-    const int w = threadIdx.x >> 6;
-    const int gw = blockIdx.x * WPB + w;
-    double trial = 0.0, model = 0.0, step2 = 0.0, xn2 = 0.0, bad = 0.0;
-    if (gw < ds.nwv) {
-        const int4 wd = ds.wv_desc[gw];
-        if (wd.w - wd.z <= 64) point_update_wave<T, true>(ds, db, cx, wd, nxt, cur, sz[w], sx[w], trial, model, step2, xn2, bad);
-        else point_update_wave<T, false>(ds, db, cx, wd, nxt, cur, sz[w], sx[w], trial, model, step2, xn2, bad);
-    }
-    double sums[5] = { trial, model, step2, xn2, bad };
-    const double tot = block_sums<5>(sums, scratch);
-    if (threadIdx.x < 5) {
-        const int which = threadIdx.x == 0 ? ACC_TRIAL_COST : threadIdx.x == 1 ? ACC_MODEL : threadIdx.x == 2 ? ACC_STEP2 : threadIdx.x == 3 ? ACC_XNEW2 : ACC_BAD_TRIAL;
-        if (threadIdx.x < 4 || tot != 0.0) atomicAdd(slot_ptr(db, which), tot);
-    }
-}
-
-void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_cam_update, dim3((ds.ncam + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db);
-}
-
-template <typename T>
-void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_point_update<T>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, db);
-}
-template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-
-// ------------------------------------------------------------------------------------------
-// Implicit Schur product (sharded solve, options.shard_distributed_cg = 2; DESIGN.md section 6): q~ = S~ p~ WITHOUT forming S~ --
-// nothing of the reduced matrix is exchanged between the ranks, a rank applies its own points' W V^-1 W^T to the vector:
-//   S_off y = - sum_points sum_{a != b} A~_a^T C_a C_b^T A~_b y_cam(b),      S~ = Lb^-1 S Lb^-T,  y = Lb^-T p~
-// (the diagonal blocks and the focal border of S~ are known on every rank from exchange (A): identity, S~_jf).  Per product:
-//   k_imp_dir     per camera: v = D Linv^T p~_j, the direction in the factored coordinates of sfmba_device.h (Q v_w, v_t) -- the layout of
-//                 the step table's first two quads; clears the per-camera sums
-//   k_imp_points  point-major, one lane per observation (the waves of the point passes): u = A v = P (Q v_w x X_g + v_t), w = C^T u,
-//                 s_i = sum_obs w (through the wave's LDS) -> spt[i]
-//   k_imp_cams    camera-major, one workgroup per chunk of a camera's observations (the chunks of k_cam_diag_f): e = C (s_i - w),
-//                 h = P^T e, sums of X_g x h and h over the camera's observations -> acc[j] (six values per camera)
-//   k_imp_out     per camera: q~_j = -Linv D [Q^T a; b] (+ on rank 0 the identity / focal part, as k_dcg_comb adds it)
-// Every observation is evaluated twice per product, with the expressions of k_point_update; C = (P R) L~ in the precision of the
-// Jacobian blocks.  Pairs of observations of ONE camera on a point (duplicates) live in the diagonal blocks: a problem that has them
-// does not take this path (the caller checks ds.ndupwg).
-// ------------------------------------------------------------------------------------------
+// one observation in the factored form of sfmba_device.h, as the back-substitution and the implicit Schur product need it: projection,
+// X_g, u = P (Q dw x X_g + dt) for the direction in `dr` (step-table layout), C = (P R) L~
 struct ImpObs { double xg[3], u[2], fz, xp, yp; };
 template <typename T, typename CamPtr, typename DirPtr>
 __device__ __forceinline__ void imp_eval(const CamPtr& ct, const DirPtr& dr, double focal, const PtRecA<T>& pa, ImpObs& o, T (&C)[6]) {
@@ -1787,6 +1587,165 @@ __device__ __forceinline__ void imp_eval(const CamPtr& ct, const DirPtr& dr, dou
     }
 }
 
+// Back-substitution + trial point, four lanes per point like k_point_build:
+//   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost.
+// With V + D^2 = L L^T, t = L^-1 b_p and C = B~ L^-T (left behind per POINT by k_point_build: pt_t, M = diag(s_p) L^-T, the table entry):
+//   u   = A (camera step) + g (focal step)     per observation
+//   z   = t - sum_obs C^T u                      per point
+//   dX  = M z ;   J step = -(u + C z)            (model cost change; B~ y_p = C L^T y_p = C z)
+// Nothing per observation is read but its camera and coordinates (rounds 2 / 3 streamed a 64-byte record per observation here): the
+// projection at the linearisation point is re-evaluated in fp64 from the camera's R, t and the point-table entry, the camera block acts
+// on the step in the factored form of sfmba_device.h,  A [dw; dt] = P (Q dw x X_g + dt),  P = (f / p_z) [[1, 0, -x_p], [0, 1, -y_p]],
+// with Q dw formed once per camera by k_cam_update, and C = (P R) L~ in the precision of the Jacobian blocks, exactly as the
+// reduced-system passes form it.  The quad's lanes take the point's observations in turn and keep
+//   sum C^T u (3),  sum u.r,  sum |u|^2,  sum C^T C (6)
+// in registers; after ONE quad reduction every lane of the quad has z = t - sum C^T u, the trial point, and the point's share of the model
+// cost change in closed form --
+//   sum_obs [ (u + C z).r - |u + C z|^2 / 2 ] = sum u.r + z.t - sum |u|^2 / 2 - z.(sum C^T u) - z^T (sum C^T C) z / 2      (sum C^T r = L^-1 b_p = t)
+// -- so the second sweep over the observations only evaluates the TRIAL residual (projection with the trial pose at the trial point): nothing
+// per observation has to survive the first sweep, no LDS, and the per-point arithmetic runs on all lanes (the lane-per-observation form
+// of the first half of round 4: 33.6 against 29.9 us at BASELINE config 3, 242 against 189 at config 5).
+template <typename T>
+__global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
+    __shared__ double scratch[WPB * 5];
+    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // see k_cam_update
+    const LMState* st = db.st;
+    const int cur = st->cur, nxt = cur ^ 1;
+    const double* tab = db.camtab[cur];
+    const double* stab = db.steptab;
+    const double focal = st->focal[cur], focal_n = st->focal[nxt];
+    const double dfoc = focal - focal_n;           // unscaled focal step to SUBTRACT (= fscale * y_f)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gw = blockIdx.x * WPB + w;
+    double trial = 0.0, model = 0.0, step2 = 0.0, xn2 = 0.0, bad = 0.0;
+    const int sub = lane & (PB_LPP - 1);
+    const int slot = gw * (64 / PB_LPP) + (lane / PB_LPP);
+    const bool have = slot < ds.npt;
+    const int ip = have ? (ds.pt_order ? ds.pt_order[slot] : slot) : 0;
+    const size_t i = (size_t)ip;
+    const int q0 = have ? ds.pt_ptr[ip] : 0, q1 = have ? ds.pt_ptr[ip + 1] : 0;
+    const PtRecA<T> pa = load_ptrec(reinterpret_cast<const PtRecA<T>*>(db.PA) + i);
+    double zacc[3] = { 0, 0, 0 }, ur = 0.0, uu = 0.0;
+    T G[6] = { (T)0, (T)0, (T)0, (T)0, (T)0, (T)0 };       // (sum C^T C: a second-order term of the model cost change; summed in the precision of C)
+    {
+        int q = q0 + sub;
+        int j_next = q < q1 ? ds.obs_cam[q] : 0;
+        double ox_next = 0.0, oy_next = 0.0;
+        if (q < q1) load_obs<T>(ds.obs_xy, q, ox_next, oy_next);
+        while (__any(q < q1)) {
+            const bool act = q < q1;
+            const int j = j_next;
+            const double ox = ox_next, oy = oy_next;
+            const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
+            const CamRow stb = { stab + 4 * (size_t)(j), ds.ncam };
+            double Rt[12], dr[8];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) Rt[e] = ct[CT_R + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dr[e] = stb[e];
+            q += PB_LPP;
+            if (q < q1) { j_next = ds.obs_cam[q]; load_obs<T>(ds.obs_xy, q, ox_next, oy_next); }
+            if (act) {
+                ImpObs o; T C[6];
+                imp_eval<T>(Rt, dr, focal, pa, o, C);                    // projection, X_g, u = P (Q dw x X_g + dt), C = (P R) L~
+                const double u0 = o.u[0] + o.xp * dfoc, u1 = o.u[1] + o.yp * dfoc;      // + the focal step
+                const double r0 = focal * o.xp - ox, r1 = focal * o.yp - oy;
+                ur += u0 * r0 + u1 * r1;
+                uu += u0 * u0 + u1 * u1;
+                zacc[0] += (double)C[0] * u0 + (double)C[3] * u1; zacc[1] += (double)C[1] * u0 + (double)C[4] * u1; zacc[2] += (double)C[2] * u0 + (double)C[5] * u1;
+                G[0] += C[0] * C[0] + C[3] * C[3]; G[1] += C[0] * C[1] + C[3] * C[4]; G[2] += C[0] * C[2] + C[3] * C[5];
+                G[3] += C[1] * C[1] + C[4] * C[4]; G[4] += C[1] * C[2] + C[4] * C[5]; G[5] += C[2] * C[2] + C[5] * C[5];
+            }
+        }
+    }
+#define SFMBA_QUADSUM(x) { x = xlane_add<1>(x); x = xlane_add<2>(x); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) SFMBA_QUADSUM(zacc[c])
+    SFMBA_QUADSUM(ur) SFMBA_QUADSUM(uu)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) SFMBA_QUADSUM(G[c])
+#undef SFMBA_QUADSUM
+    // (the point's t and M: loaded here, behind the sweep -- in front of it they cost the sweep its fourth wave per SIMD)
+    double tp[3], Mp[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tp[c] = db.pt_t[3 * i + c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Mp[c] = db.pt_M[6 * i + c];
+    const double z0 = tp[0] - zacc[0], z1 = tp[1] - zacc[1], z2 = tp[2] - zacc[2];
+    const double dX[3] = { Mp[0] * z0 + Mp[1] * z1 + Mp[2] * z2, Mp[3] * z1 + Mp[4] * z2, Mp[5] * z2 };
+    double Xn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Xn[c] = pa.X[c] - dX[c];
+    if (have && sub == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double df = pa.X[c] - Xn[c];
+            step2 += df * df;
+            xn2 += Xn[c] * Xn[c];
+            db.pts[nxt][3 * i + c] = Xn[c];
+        }
+        const double zGz = (double)G[0] * z0 * z0 + (double)G[3] * z1 * z1 + (double)G[5] * z2 * z2 + 2.0 * ((double)G[1] * z0 * z1 + (double)G[2] * z0 * z2 + (double)G[4] * z1 * z2);
+        model += ur + (z0 * tp[0] + z1 * tp[1] + z2 * tp[2]) - 0.5 * uu - (z0 * zacc[0] + z1 * zacc[1] + z2 * zacc[2]) - 0.5 * zGz;
+    }
+    {
+        int q = q0 + sub;
+        int j_next = q < q1 ? ds.obs_cam[q] : 0;
+        double ox_next = 0.0, oy_next = 0.0;
+        if (q < q1) load_obs<T>(ds.obs_xy, q, ox_next, oy_next);
+        while (__any(q < q1)) {
+            const bool act = q < q1;
+            const int j = j_next;
+            const double ox = ox_next, oy = oy_next;
+            const CamRow stb = { stab + 4 * (size_t)(j), ds.ncam };
+            double RTn[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) RTn[e] = stb[ST_RN + e];
+            q += PB_LPP;
+            if (q < q1) { j_next = ds.obs_cam[q]; load_obs<T>(ds.obs_xy, q, ox_next, oy_next); }
+            if (act) {
+                const Proj pn = project_point(RTn, 0, 9, Xn);
+                const double n0 = focal_n * pn.xp - ox, n1 = focal_n * pn.yp - oy;
+                if (!finite_d(n0) || !finite_d(n1)) bad = 1.0;
+                trial += n0 * n0 + n1 * n1;
+            }
+        }
+    }
+    double sums[5] = { trial, model, step2, xn2, bad };
+    const double tot = block_sums<5>(sums, scratch);
+    if (threadIdx.x < 5) {
+        const int which = threadIdx.x == 0 ? ACC_TRIAL_COST : threadIdx.x == 1 ? ACC_MODEL : threadIdx.x == 2 ? ACC_STEP2 : threadIdx.x == 3 ? ACC_XNEW2 : ACC_BAD_TRIAL;
+        if (threadIdx.x < 4 || tot != 0.0) atomicAdd(slot_ptr(db, which), tot);
+    }
+}
+
+void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+    hipLaunchKernelGGL(k_cam_update, dim3((ds.ncam + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db);
+}
+
+template <typename T>
+void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+    const int per_wg = WPB * (64 / PB_LPP);
+    hipLaunchKernelGGL(k_point_update<T>, dim3((ds.npt + per_wg - 1) / per_wg), dim3(PBK), 0, s, ds, db);
+}
+template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+
+// ------------------------------------------------------------------------------------------
+// Implicit Schur product (sharded solve, options.shard_distributed_cg = 2; DESIGN.md section 6): q~ = S~ p~ WITHOUT forming S~ --
+// nothing of the reduced matrix is exchanged between the ranks, a rank applies its own points' W V^-1 W^T to the vector:
+//   S_off y = - sum_points sum_{a != b} A~_a^T C_a C_b^T A~_b y_cam(b),      S~ = Lb^-1 S Lb^-T,  y = Lb^-T p~
+// (the diagonal blocks and the focal border of S~ are known on every rank from exchange (A): identity, S~_jf).  Per product:
+//   k_imp_dir     per camera: v = D Linv^T p~_j, the direction in the factored coordinates of sfmba_device.h (Q v_w, v_t) -- the layout of
+//                 the step table's first two quads; clears the per-camera sums
+//   k_imp_points  point-major, one lane per observation (the waves of the point passes): u = A v = P (Q v_w x X_g + v_t), w = C^T u,
+//                 s_i = sum_obs w (through the wave's LDS) -> spt[i]
+//   k_imp_cams    camera-major, one workgroup per chunk of a camera's observations (the chunks of k_cam_diag_f): e = C (s_i - w),
+//                 h = P^T e, sums of X_g x h and h over the camera's observations -> acc[j] (six values per camera)
+//   k_imp_out     per camera: q~_j = -Linv D [Q^T a; b] (+ on rank 0 the identity / focal part, as k_dcg_comb adds it)
+// Every observation is evaluated twice per product, with the expressions of k_point_update; C = (P R) L~ in the precision of the
+// Jacobian blocks.  Pairs of observations of ONE camera on a point (duplicates) live in the diagonal blocks: a problem that has them
+// does not take this path (the caller checks ds.ndupwg).
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_imp_dir(DeviceStructure ds, DeviceBuffers db, const double* __restrict__ pt, double* __restrict__ dtab,
                                                  double* __restrict__ acc, const int* __restrict__ flags) {
     if (flags && flags[0]) return;
@@ -1819,47 +1778,45 @@ __global__ __launch_bounds__(256) void k_imp_dir(DeviceStructure ds, DeviceBuffe
 
 template <typename T>
 __global__ PB_BOUNDS void k_imp_points(DeviceStructure ds, DeviceBuffers db, const double* __restrict__ dtab, double* __restrict__ spt, const int* __restrict__ flags) {
-    __shared__ double sz[WPB][64][3];
     if (flags && flags[0]) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int gw = blockIdx.x * WPB + w;
-    if (gw >= ds.nwv) return;
     const LMState* st = db.st;
     const int cur = st->cur;
     const double focal = st->focal[cur];
     const double* tab = db.camtab[cur];
-    const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
-    const int4 wd = ds.wv_desc[gw];
-    const int pt0 = wd.x, npts = wd.y - wd.x, o0 = wd.z, o1 = wd.w;
-    const int my_q0 = lane < npts ? ds.pt_ptr[pt0 + lane] : 0;
-    const int my_q1 = lane < npts ? ds.pt_ptr[pt0 + lane + 1] : 0;
+    const int sub = lane & (PB_LPP - 1);
+    const int slot = gw * (64 / PB_LPP) + (lane / PB_LPP);        // four lanes per point, as the point passes
+    const bool have = slot < ds.npt;
+    const int ip = have ? (ds.pt_order ? ds.pt_order[slot] : slot) : 0;
+    const size_t i = (size_t)ip;
+    const int q0 = have ? ds.pt_ptr[ip] : 0, q1 = have ? ds.pt_ptr[ip + 1] : 0;
+    const PtRecA<T> pa = load_ptrec(reinterpret_cast<const PtRecA<T>*>(db.PA) + i);
     double s[3] = { 0, 0, 0 };
-    for (int c0 = o0; c0 < o1; c0 += 64) {
-        const int q = c0 + lane;
-        if (q < o1) {
-            const int i = ds.obs_pt[q], j = ds.obs_cam[q];
-            const PtRecA<T> pa = load_ptrec(PA + i);
-            const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
-            const CamRow dr = { dtab + 4 * (size_t)(j), ds.ncam };
+    int q = q0 + sub;
+    int j_next = q < q1 ? ds.obs_cam[q] : 0;
+    while (__any(q < q1)) {
+        const bool act = q < q1;
+        const int j = j_next;
+        const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
+        const CamRow drw = { dtab + 4 * (size_t)(j), ds.ncam };
+        double Rt[12], dr[8];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Rt[e] = ct[CT_R + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dr[e] = drw[e];
+        q += PB_LPP;
+        if (q < q1) j_next = ds.obs_cam[q];
+        if (act) {
             ImpObs o; T C[6];
-            imp_eval<T>(ct, dr, focal, pa, o, C);
+            imp_eval<T>(Rt, dr, focal, pa, o, C);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) sz[w][lane][c] = (double)C[c] * o.u[0] + (double)C[3 + c] * o.u[1];
+            for (int c = 0; c < 3; ++c) s[c] += (double)C[c] * o.u[0] + (double)C[3 + c] * o.u[1];
         }
-        wave_lds_fence();
-        if (lane < npts) {
-            const int a = max(my_q0, c0) - c0, b = min(my_q1, c0 + 64) - c0;
-            for (int e = a; e < b; ++e) {
+    }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) s[c] += sz[w][e][c];
-            }
-        }
-        wave_lds_fence();
-    }
-    if (lane < npts) {
-        const size_t i = (size_t)(pt0 + lane);
-        spt[3 * i] = s[0]; spt[3 * i + 1] = s[1]; spt[3 * i + 2] = s[2];
-    }
+    for (int c = 0; c < 3; ++c) { s[c] = xlane_add<1>(s[c]); s[c] = xlane_add<2>(s[c]); }
+    if (have && sub == 0) { spt[3 * i] = s[0]; spt[3 * i + 1] = s[1]; spt[3 * i + 2] = s[2]; }
 }
 
 template <typename T>
@@ -1962,10 +1919,10 @@ void launch_implicit_product(hipStream_t s, const ImplicitProduct& ip, const dou
     const DeviceStructure& ds = ip.ds;
     hipLaunchKernelGGL(k_imp_dir, dim3((ds.ncam + 255) / 256), dim3(256), 0, s, ds, ip.db, p_tilde, ip.dtab, ip.acc, flags);
     if (ip.f32) {
-        hipLaunchKernelGGL(k_imp_points<float>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
+        hipLaunchKernelGGL(k_imp_points<float>, dim3((ds.npt + WPB * (64 / PB_LPP) - 1) / (WPB * (64 / PB_LPP))), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
         hipLaunchKernelGGL(k_imp_cams<float>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.acc, flags);
     } else {
-        hipLaunchKernelGGL(k_imp_points<double>, dim3((ds.nwv + WPB - 1) / WPB), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
+        hipLaunchKernelGGL(k_imp_points<double>, dim3((ds.npt + WPB * (64 / PB_LPP) - 1) / (WPB * (64 / PB_LPP))), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
         hipLaunchKernelGGL(k_imp_cams<double>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.acc, flags);
     }
     if (ip.focal_row32) hipLaunchKernelGGL(k_imp_out<float>, dim3(1), dim3(1024), 0, s, ds, ip.db, ip.rank, p_tilde, ip.acc, ip.focal_row32, out, flags);

@@ -214,8 +214,8 @@ struct sfmba_problem {
     int *d_pt_ptr = nullptr, *d_obs_cam = nullptr, *d_cam_ptr = nullptr, *d_cam_obs = nullptr, *d_cam_obs_pt = nullptr;   // (all in `arena`)
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
-    int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_wv_desc = nullptr, *d_pwg_desc = nullptr;
-    int2* d_pwg_chunk = nullptr; int* d_multi_slots = nullptr; int* d_build_counters = nullptr;
+    int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_pwg_desc = nullptr;
+    int2* d_pwg_chunk = nullptr; int* d_multi_slots = nullptr; int* d_build_counters = nullptr; int* d_pt_order = nullptr;
     double block_fill = 1.0;              // non-empty off-diagonal blocks of the reduced matrix / all of them
     int* d_blk_ptr = nullptr;
     int* d_cam_chunk_ptr = nullptr;
@@ -226,7 +226,6 @@ struct sfmba_problem {
     int2 *d_blk_cams = nullptr, *d_pwg_blocks = nullptr, *d_dup_blocks = nullptr;
     int* d_pair_pt = nullptr;
     void* d_cam_obs_xy = nullptr;
-    int* d_pwg_ptr = nullptr;
     double* d_facc = nullptr;
     double *d_cam0 = nullptr, *d_pts0 = nullptr;  // parameters given at create time
     double focal0 = 0.0;
@@ -732,8 +731,8 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     std::vector<int> pt_ptr((size_t)npt + 1, 0), cam_ptr((size_t)ncam + 1, 0);
     long long npair_total = 0;
     std::atomic<int> counts_state(0);            // 1 = pointers and pair total ready, -1 = counts inconsistent
-    std::vector<int4> chunks, chunks_coarse, wv_desc;
-    std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0), wv_ptr;
+    std::vector<int4> chunks, chunks_coarse;
+    std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0), pt_order;
     std::vector<int2> blk_cams, pwg_blocks;
     std::vector<double> cam0, pts0;
     std::vector<char> blob;
@@ -789,44 +788,43 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
                     pwg_blocks.push_back(w);
                 }
         }
-        // waves of the point passes: contiguous ranges of whole points with at most 64 observations (a point
-        // with more observations than that gets a wave of its own and is swept in several rounds)
-        wv_ptr.push_back(0);
+        // order of the points in the point passes (k_point_build / k_point_update: four lanes per point, sixteen points per
+        // wave): by number of rounds of four observations, stable -- the quads of a wave then loop alike whatever the track lengths
+        // (tracks of 2..30 views: a wave of unsorted points runs to its longest track).  Uniform track length: slot order, no array.
         {
-            int cnt = 0, npts_in = 0;
-            for (int i = 0; i < npt; ++i) {
-                const int k = pt_ptr[(size_t)i + 1] - pt_ptr[i];
-                if (npts_in > 0 && (cnt + k > 64 || npts_in >= 64)) { wv_ptr.push_back(i); cnt = 0; npts_in = 0; }
-                cnt += k; ++npts_in;
+            constexpr int NB = 18;                 // rounds 1 .. 16, > 16 in one bucket (+ the empty bucket 0)
+            int cnt_b[NB + 1] = {};
+            auto bucket = [&](int i) { const int k = pt_ptr[(size_t)i + 1] - pt_ptr[i]; return std::min((k + 3) / 4, NB - 1); };
+            for (int i = 0; i < npt; ++i) ++cnt_b[bucket(i) + 1];
+            int used = 0;
+            for (int b = 0; b < NB; ++b) used += cnt_b[b + 1] > 0;
+            if (used > 1) {
+                for (int b = 0; b < NB; ++b) cnt_b[b + 1] += cnt_b[b];
+                pt_order.resize((size_t)npt);
+                for (int i = 0; i < npt; ++i) pt_order[(size_t)cnt_b[bucket(i)]++] = i;
             }
-            wv_ptr.push_back(npt);
-        }
-        wv_desc.resize(wv_ptr.size() - 1);
-        for (size_t g = 0; g + 1 < wv_ptr.size(); ++g) {
-            int4 wd; wd.x = wv_ptr[g]; wd.y = wv_ptr[g + 1]; wd.z = pt_ptr[(size_t)wv_ptr[g]]; wd.w = pt_ptr[(size_t)wv_ptr[g + 1]];
-            wv_desc[g] = wd;
         }
         // upload: ONE synchronous copy on the NULL stream (the problem's stream is non-blocking: it runs beside the sorts) of the
-        // seven arrays laid out back to back, 256-byte aligned
+        // arrays laid out back to back, 256-byte aligned
         {
             size_t off = 0;
             auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
             const size_t o_chunks = place(sizeof(int4) * chunks.size()), o_coarse = place(sizeof(int4) * chunks_coarse.size()),
                          o_ccp = place(sizeof(int) * cam_chunk_ptr.size()), o_bc = place(sizeof(int2) * blk_cams.size()),
-                         o_pwg = place(sizeof(int2) * pwg_blocks.size()), o_wvp = place(sizeof(int) * wv_ptr.size()), o_wvd = place(sizeof(int4) * wv_desc.size());
+                         o_pwg = place(sizeof(int2) * pwg_blocks.size()), o_pto = place(sizeof(int) * pt_order.size());
             blob.resize(off ? off : 1);
             auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(blob.data() + o, src, bytes); };
             put(o_chunks, chunks.data(), sizeof(int4) * chunks.size()); put(o_coarse, chunks_coarse.data(), sizeof(int4) * chunks_coarse.size());
             put(o_ccp, cam_chunk_ptr.data(), sizeof(int) * cam_chunk_ptr.size()); put(o_bc, blk_cams.data(), sizeof(int2) * blk_cams.size());
-            put(o_pwg, pwg_blocks.data(), sizeof(int2) * pwg_blocks.size()); put(o_wvp, wv_ptr.data(), sizeof(int) * wv_ptr.size());
-            put(o_wvd, wv_desc.data(), sizeof(int4) * wv_desc.size());
+            put(o_pwg, pwg_blocks.data(), sizeof(int2) * pwg_blocks.size());
+            put(o_pto, pt_order.data(), sizeof(int) * pt_order.size());
             char* d_blob = nullptr;
             HIP_TRY(dev_alloc(&d_blob, blob.size()));
             HIP_TRY(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
             p->d_chunks = reinterpret_cast<int4*>(d_blob + o_chunks); p->d_chunks_coarse = reinterpret_cast<int4*>(d_blob + o_coarse);
             p->d_cam_chunk_ptr = reinterpret_cast<int*>(d_blob + o_ccp); p->d_blk_cams = reinterpret_cast<int2*>(d_blob + o_bc);
-            p->d_pwg_blocks = reinterpret_cast<int2*>(d_blob + o_pwg); p->d_pwg_ptr = reinterpret_cast<int*>(d_blob + o_wvp);
-            p->d_wv_desc = reinterpret_cast<int4*>(d_blob + o_wvd);
+            p->d_pwg_blocks = reinterpret_cast<int2*>(d_blob + o_pwg);
+            p->d_pt_order = pt_order.empty() ? nullptr : reinterpret_cast<int*>(d_blob + o_pto);
         }
         // (wave-per-block pass: one descriptor per chunk of SFMBA_PAIR_CHUNK pairs -- as many as the pair total allows at most)
         pair_slot_cap = pair_lpb == 64 ? pwg_blocks.size() + (size_t)(npair_total / SFMBA_PAIR_CHUNK) + 1 : pwg_blocks.size() * (size_t)blocks_per_wg;
@@ -956,7 +954,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.ncam = ncam; ds.npt = npt; ds.nobs = nobs;
     ds.d = 6 * ncam + 1;
     ds.ld = dense_padded_dim(ds.d);
-    ds.pt_ptr = p->d_pt_ptr; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
+    ds.pt_ptr = p->d_pt_ptr; ds.pt_order = p->d_pt_order; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
     ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt; ds.cam_obs_xy = p->d_cam_obs_xy;
     ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
     ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
@@ -966,7 +964,6 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
     ds.pwg_chunk = pair_lpb == 64 ? p->d_pwg_chunk : nullptr; ds.nmulti = 0; ds.multi_slots = p->d_multi_slots;      // counts: after the wait at the end
     ds.ndupwg = 0; ds.dup_blocks = p->d_dup_blocks;          // count: after the wait at the end
-    ds.nwv = (int)wv_ptr.size() - 1; ds.wv_ptr = p->d_pwg_ptr; ds.wv_desc = p->d_wv_desc;
 
     DeviceBuffers& db = p->db;
     db = DeviceBuffers{};
@@ -1015,7 +1012,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.nslot = NSLOT;
     db.cd_part = nullptr;
     if (p->deterministic) {
-        const int grid = std::max(std::max(1024, (ds.nwv + 1) / 2 + 1), std::max(ds.nchunk, ds.nchunk_coarse));
+        const int grid = std::max(std::max(1024, (ds.npt + 31) / 32 + 1), std::max(ds.nchunk, ds.nchunk_coarse));      // (point passes: 32 points per workgroup)
         db.nslot = (grid + 63) / 64 * 64;
         HIP_TRY(dev_alloc(&db.cd_part, (size_t)std::max(ds.nchunk, 1) * 48));
     }
