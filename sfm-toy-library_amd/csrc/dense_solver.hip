@@ -821,25 +821,41 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(int d, int ld, const FT* __r
         for (int k = 0; k < PCG_NW; ++k) acc[r][k] = 0.0;
     for (int t0 = 0; t0 < d; t0 += CO_TILE) {
         __syncthreads();
-        for (int idx = tid; idx < PCG_NW * CO_TILE; idx += 256) {
-            const int k = idx / CO_TILE, c = idx - k * CO_TILE;
-            wt[k][c] = (t0 + c < d) ? (float)W[(size_t)k * ld + t0 + c] : 0.0f;       // W~ holds fp32-representable values: lossless
+        // (eight loads in flight per thread: left as one load per loop iteration the staging was a chain of L2 round trips per tile and
+        // cost more than the pass over the matrix it serves)
+#pragma unroll
+        for (int b = 0; b < CO_TILE / 256; ++b) {
+            double wv[PCG_NW];
+            const int c = tid + 256 * b;
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) wv[k] = W[(size_t)k * ld + (t0 + c < d ? t0 + c : 0)];
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) wt[k][c] = (t0 + c < d) ? (float)wv[k] : 0.0f;       // W~ holds fp32-representable values: lossless
         }
         __syncthreads();
+        // column chunks outermost: a lane's eight W~ values of a column are read from LDS (and widened) ONCE and used by all of the wave's
+        // rows (they used to be re-read per row: 8 LDS reads + 8 conversions per matrix element, more than the eight FMAs they feed)
+        for (int c0 = 0; c0 < CO_TILE && t0 + c0 < d; c0 += 256) {
+            FT f[CO_MAXROWS][4];
 #pragma unroll
-        for (int r = 0; r < CO_MAXROWS; ++r) {
-            const int row = row0 + w + 4 * r;
-            if (row >= row1) continue;
-            const FT* Fr = F + (size_t)row * ld + t0;
-            for (int c0 = 0; c0 < CO_TILE && t0 + c0 < d; c0 += 256) {      // four loads in flight per lane
-                FT f[4];
+            for (int r = 0; r < CO_MAXROWS; ++r) {
+                const int row = row0 + w + 4 * r;
+                const FT* Fr = F + (size_t)(row < row1 ? row : row0) * ld + t0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; f[u] = (t0 + c < d) ? Fr[c] : (FT)0; }
+                for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; f[r][u] = (row < row1 && t0 + c < d) ? Fr[c] : (FT)0; }
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c = c0 + 64 * u + lane;
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 64 * u + lane;
+                double wk[PCG_NW];
 #pragma unroll
-                    for (int k = 0; k < PCG_NW; ++k) acc[r][k] = fma((double)f[u], (double)wt[k][c], acc[r][k]);
+                for (int k = 0; k < PCG_NW; ++k) wk[k] = (double)wt[k][c];
+#pragma unroll
+                for (int r = 0; r < CO_MAXROWS; ++r) {
+                    if (row0 + w + 4 * r >= row1) continue;          // wave-uniform
+                    const double fv = (double)f[r][u];
+#pragma unroll
+                    for (int k = 0; k < PCG_NW; ++k) acc[r][k] = fma(fv, wk[k], acc[r][k]);
                 }
             }
         }

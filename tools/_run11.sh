@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+pick='import json,sys; d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith("{")][-1]); print(round(d["value"],1), round(d["ms_per_step"],4), d["final_cost"], d["kernel_profile_us"])'
+for wl in cfg5; do
+  echo "== $wl"; python $R/bench.py --workload $wl --no-cpu-baseline --no-live-traffic --steps 5 --warmup 3 2>/dev/null | python -c "$pick"
+done
+cd $R && timeout 1200 python -m pytest tests/test_gpu_baseline_parity.py tests/test_gpu_sharded.py -q -x -k "cfg5 or wide" 2>&1 | grep -v "Ceres Solver Report" | tail -5
