@@ -125,10 +125,12 @@ __device__ void make_cam_table(const double cam[6], const double* scale6, double
     const double theta2 = w0 * w0 + w1 * w1 + w2 * w2;
     double R[9], K[9];
     double small = 0.0;
+    double cq = 1.0 / 12.0;
     if (theta2 > DBL_EPSILON) {
         const double theta = sqrt(theta2);
         double s, c;
         sincos(theta, &s, &c);
+        if (theta2 > 1e-8) { const double den = 2.0 * theta * s; cq = fabs(den) > 1e-12 ? 1.0 / theta2 - (1.0 + c) / den : 0.0; }
         const double ti = 1.0 / theta;
         const double k0 = w0 * ti, k1 = w1 * ti, k2 = w2 * ti;
         const double oc = 1.0 - c;
@@ -166,6 +168,9 @@ __device__ void make_cam_table(const double cam[6], const double* scale6, double
             ct[CT_QD + 3 * c + a] = q;
         }
     for (int e = CT_QD + 9; e < CT_STRIDE; ++e) ct[e] = 0.0;
+    // coefficient of [w]x^2 in Jr(w)^-1 = I + [w]x / 2 + cq [w]x^2 (gauge vectors, k_finalize): 1 / theta^2 - (1 + cos) / (2 theta sin), 1 / 12
+    // in the limit; formed here, where sin and cos of theta are at hand anyway (theta near pi: the term is dropped, any vector will do)
+    ct[CT_CQ] = cq;
 }
 
 __global__ void k_cam_setup(int ncam, const double* __restrict__ cam, const double* __restrict__ cscale, double* __restrict__ camtab) {
@@ -1275,13 +1280,55 @@ void launch_gauge(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers&
     if (db.pcg_W) hipLaunchKernelGGL(k_gauge, dim3((ds.ncam + 63) / 64), dim3(64), 0, s, ds, db);
 }
 
-// damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding; in PCG mode also
-// Linv of every damped 6x6 diagonal block (the block-Jacobi preconditioner).  One thread per camera, then per
-// padding row; the focal entries are owned by the last wave of the last workgroup.  The last workgroup to arrive
-// (agent-scope release/acquire around an arrival counter) runs post_linearisation.
+// ONE gauge vector (k = 0 .. 7, a per-lane value) of camera j: the body of gauge_vectors_pre for a runtime k -- the vector's entries are
+// picked by selects (no dynamically indexed registers), the back substitution with Li^T is the same for every k.
+__device__ __forceinline__ void gauge_vector_k(const DeviceStructure& ds, const DeviceBuffers& db, int j, int k, const double (&Li)[6][6], const double (&cam)[6],
+                                               const double (&Rm)[9], const double (&cs6)[6], double cq) {
+    const double w0 = cam[0], w1 = cam[1], w2 = cam[2];
+    const double K[3][3] = { { 0.0, -w2, w1 }, { w2, 0.0, -w0 }, { -w1, w0, 0.0 } };
+    double wv[6];
+    const int c3 = k - 3;                                     // world rotation: column k - 3 of -Jr^-1
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double k2c[3], ji[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            k2c[c] = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) k2c[c] += K[r][m] * K[m][c];
+            ji[c] = (r == c ? 1.0 : 0.0) + 0.5 * K[r][c] + cq * k2c[c];
+        }
+        // (0 / 1 weights instead of select chains: the compiler turns a chain of selects over array elements into a dynamically indexed
+        // array -- in scratch memory)
+        const double jsel = (c3 == 0 ? 1.0 : 0.0) * ji[0] + (c3 == 1 ? 1.0 : 0.0) * ji[1] + (c3 == 2 ? 1.0 : 0.0) * ji[2];
+        wv[r] = -jsel;
+        const double rsel = (k == 0 ? 1.0 : 0.0) * Rm[3 * r] + (k == 1 ? 1.0 : 0.0) * Rm[3 * r + 1] + (k == 2 ? 1.0 : 0.0) * Rm[3 * r + 2];
+        wv[3 + r] = -rsel + (k == 6 ? 1.0 : 0.0) * cam[3 + r] + ((k == 7 && r == 2) ? 1.0 : 0.0) * cam[5];
+    }
+    double wt[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) wv[e] *= fast_rcp(cs6[e]);
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {                            // back substitution with the upper triangular Li^T
+        double v = wv[r];
+#pragma unroll
+        for (int t = 5; t > r; --t) v -= Li[t][r] * wt[t];
+        wt[r] = v * fast_rcp(Li[r][r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) db.pcg_W[(size_t)k * ds.ld + 6 * j + r] = (double)(float)wt[r];
+}
+
+// damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding; in PCG mode also Linv of every damped 6x6
+// diagonal block (the block-Jacobi preconditioner), the pair pass's per-camera factor and the gauge vectors.  EIGHT LANES PER CAMERA
+// (round 4; one lane per camera made this kernel a 1000-deep dependent fp64 chain on 200 lanes: 14 us): every lane of a camera's group
+// loads the block and factors it (the same instructions, no divergence), then lane t writes row t of the pair factor (rows picked by
+// selects), gauge vector t and its share of Linv.  The focal entries are owned by the last wave of the last workgroup.  pcg = 0: the last
+// workgroup to arrive (agent-scope release/acquire around an arrival counter) runs post_linearisation.
+constexpr int FIN_LANES = 8;
 __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuffers db, int pcg) {
     __shared__ int is_last;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const LMState* st = db.st;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
         // focal-focal entries were accumulated in the slotted buffer: the last wave of the last block owns them
@@ -1309,38 +1356,17 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
         }
     }
     double gm = 0.0;
+    const int g = gt / FIN_LANES, t = gt % FIN_LANES;         // camera, lane of its group
     if (g < ds.ncam) {
-        const int row0 = 6 * g;
-        if (db.cd_part) {
-            // deterministic mode: this camera's k_cam_diag chunks, in chunk order, on top of what the (single-writer) passes left
-            double acc[45];
-#pragma unroll
-            for (int k = 0; k < 45; ++k) acc[k] = 0.0;
-            for (int c = ds.cam_chunk_ptr[g]; c < ds.cam_chunk_ptr[g + 1]; ++c) {
-#pragma unroll
-                for (int k = 0; k < 45; ++k) acc[k] += db.cd_part[(size_t)c * 48 + k];
-            }
-            const int fo = ds.d - 1;
-            int u = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) db.S[(size_t)(row0 + a) * ds.ld + row0 + b] += acc[u++];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                db.udiag[row0 + a] += acc[21 + a];
-                db.S[(size_t)(row0 + a) * ds.ld + fo] += acc[27 + a];
-                db.bc[row0 + a] += acc[33 + a];
-                db.rhs[row0 + a] += acc[39 + a];
-            }
-        }
-        // every global load of this camera first (one L2 round trip instead of four or five: this kernel is 200 lanes of dependent
-        // fp64 work, its length is its chain of round trips): diagonal block, undamped diagonal, gradient, scales, and what the
-        // gauge vectors and the pair pass's camera factor need
-        double Sb[6][6], ud[6], bcv[6], csv[6], rhv[6], camv[6], Rm[9], Q9[9];
+        const int row0 = 6 * g, fo = ds.d - 1;
+        const bool writer = t == 0;
+        // every global load of this camera first (one L2 round trip): diagonal block, focal column, undamped diagonal, gradient, scales,
+        // and what the gauge vectors and the pair pass's camera factor need
+        double Sb[6][6], ud[6], bcv[6], csv[6], rhv[6], sjf[6], camv[6], Rm[9], Q9[9], cq = 0.0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             ud[a] = db.udiag[row0 + a]; bcv[a] = db.bc[row0 + a]; csv[a] = db.cscale[row0 + a]; rhv[a] = db.rhs[row0 + a];
+            sjf[a] = db.cd_part ? db.S[(size_t)(row0 + a) * ds.ld + fo] : 0.0;
 #pragma unroll
             for (int b = 0; b < 6; ++b) Sb[a][b] = (b >= a) ? db.S[(size_t)(row0 + a) * ds.ld + row0 + b] : 0.0;
         }
@@ -1350,6 +1376,33 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             for (int e = 0; e < 6; ++e) camv[e] = db.pcg_W ? db.cam[st->cur][6 * (size_t)g + e] : 0.0;
 #pragma unroll
             for (int e = 0; e < 9; ++e) { Rm[e] = db.pcg_W ? tab[cam_tab_index(CT_R + e, g, ds.ncam)] : 0.0; Q9[e] = db.pair_G ? tab[cam_tab_index(CT_QD + e, g, ds.ncam)] : 0.0; }
+            cq = db.pcg_W ? tab[cam_tab_index(CT_CQ, g, ds.ncam)] : 0.0;
+        }
+        if (db.cd_part) {
+            // deterministic mode: this camera's k_cam_diag_f chunks, in chunk order, on top of what the (single-writer) passes left -- added in
+            // registers by every lane of the group, written back by one (the exact solver and the AUTO fallback read the block from memory)
+            double acc[45];
+#pragma unroll
+            for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+            for (int c = ds.cam_chunk_ptr[g]; c < ds.cam_chunk_ptr[g + 1]; ++c) {
+#pragma unroll
+                for (int k = 0; k < 45; ++k) acc[k] += db.cd_part[(size_t)c * 48 + k];
+            }
+            int u = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) Sb[a][b] += acc[u++];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { ud[a] += acc[21 + a]; sjf[a] += acc[27 + a]; bcv[a] += acc[33 + a]; rhv[a] += acc[39 + a]; }
+            if (writer) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    db.udiag[row0 + a] = ud[a]; db.S[(size_t)(row0 + a) * ds.ld + fo] = sjf[a]; db.bc[row0 + a] = bcv[a]; db.rhs[row0 + a] = rhv[a];
+#pragma unroll
+                    for (int b = a + 1; b < 6; ++b) db.S[(size_t)(row0 + a) * ds.ld + row0 + b] = Sb[a][b];
+                }
+            }
         }
         bool bad = false;
 #pragma unroll
@@ -1358,11 +1411,11 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             const double dd = fmin(fmax(ud[a], st->min_diag), st->max_diag) / st->radius;
             const double v = Sb[a][a] + dd;
             Sb[a][a] = v;
-            db.S[(size_t)e * ds.ld + e] = v;
+            if (writer) db.S[(size_t)e * ds.ld + e] = v;
             gm = fmax(gm, fabs(bcv[a] / csv[a]));
             bad = bad || !finite_d(v) || !finite_d(rhv[a]);
         }
-        if (bad) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
+        if (bad && writer) atomicAdd(slot_ptr(db, ACC_BAD_LIN), 1.0);
         if (pcg) {
             // Linv of the damped block (row-major lower, zeros above), see dense_solver.hip
             double L[6][6], Li[6][6];
@@ -1375,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
             for (int j = 0; j < 6; ++j) {
                 double dj = L[j][j];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) if (t < j) dj -= L[j][t] * L[j][t];
+                for (int tt = 0; tt < 6; ++tt) if (tt < j) dj -= L[j][tt] * L[j][tt];
                 ok = ok && (dj > 0.0);
                 const double lji = fast_rsq(dj > 0.0 ? dj : 1.0);
                 L[j][j] = lji;              // the RECIPROCAL of the pivot is what the inverse needs
@@ -1383,29 +1436,52 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
                 for (int i = 0; i < 6; ++i) if (i > j) {
                     double v = L[i][j];
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) if (t < j) v -= L[i][t] * L[j][t];
+                    for (int tt = 0; tt < 6; ++tt) if (tt < j) v -= L[i][tt] * L[j][tt];
                     L[i][j] = v * lji;
                 }
             }
-            if (!ok) atomicCAS(db.lin_info, 0, row0 + 1);
+            if (!ok && writer) atomicCAS(db.lin_info, 0, row0 + 1);
 #pragma unroll
             for (int c = 0; c < 6; ++c)
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     double v = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) if (t >= c && t < r) v -= L[r][t] * Li[t][c];
+                    for (int tt = 0; tt < 6; ++tt) if (tt >= c && tt < r) v -= L[r][tt] * Li[tt][c];
                     Li[r][c] = (r < c) ? 0.0 : v * L[r][r];
                 }
+            // lane t < 6 owns row t of Linv (store) and of the pair factor G = Linv D E^T (pair_factor<true>): the row by selects
+            double lrow[6];
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                double v = 0.0;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) db.pcg_binv[(size_t)g * 36 + r * 6 + c] = Li[r][c];
-            if (db.pair_G) pair_factor<true>(db, g, Li, Q9, csv);
-            if (db.pcg_W) gauge_vectors_pre(ds, db, g, Li, camv, Rm, csv);
+                for (int r = 0; r < 6; ++r) v += (t == r ? 1.0 : 0.0) * Li[r][c];      // (weights, not selects: see gauge_vector_k)
+                lrow[c] = v;
+            }
+            if (t < 6) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) db.pcg_binv[(size_t)g * 36 + t * 6 + c] = lrow[c];
+                if (db.pair_G) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double v;
+                        if (c < 3) {            // sum_{a < 3} Lw[r][a] (D E^T)[a][c],  (D E^T)[a][c] = cs[a] Q[c][a]
+                            v = 0.0;
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) v += lrow[a] * (csv[a] * Q9[3 * c + a]);
+                        } else {
+                            v = lrow[c] * csv[c];
+                        }
+                        db.pair_G[(size_t)g * 36 + 6 * t + c] = v;
+                    }
+                }
+            }
+            if (db.pcg_W) gauge_vector_k(ds, db, g, t, Li, camv, Rm, csv, cq);
         }
-    } else if (g - ds.ncam < ds.ld - ds.d) {
-        const int e = ds.d + (g - ds.ncam);
+        if (!writer) gm = 0.0;
+    } else if (gt - ds.ncam * FIN_LANES < ds.ld - ds.d) {
+        const int e = ds.d + (gt - ds.ncam * FIN_LANES);
         db.S[(size_t)e * ds.ld + e] = 1.0;
         db.rhs[e] = 0.0;
     }
@@ -1461,7 +1537,7 @@ void launch_cd_fold(hipStream_t s, const DeviceStructure& ds, const DeviceBuffer
 }
 
 void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int pcg) {
-    const int work = ds.ncam + (ds.ld - ds.d) + 64;     // cameras, padding rows, room for the focal wave
+    const int work = ds.ncam * FIN_LANES + (ds.ld - ds.d) + 64;     // eight lanes per camera, padding rows, room for the focal wave
     hipLaunchKernelGGL(k_finalize, dim3((work + 255) / 256), dim3(256), 0, s, ds, db, pcg);
 }
 

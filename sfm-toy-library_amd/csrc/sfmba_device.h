@@ -25,7 +25,8 @@ constexpr int CT_K = 12;       // K'[9] row-major (identity when small-angle)
 constexpr int CT_SMALL = 21;   // 1.0 if theta^2 <= DBL_EPSILON
 constexpr int CT_SCALE = 22;   // Jacobi column scale of the 6 camera parameters
 constexpr int CT_QD = 28;      // Q = R K' (3 x 3 row-major; I when small-angle): the rotation part of the pair pass's camera factor E
-constexpr int CT_STRIDE = 40;  // 37 used; whole component quads
+constexpr int CT_CQ = 37;      // coefficient of [w]x^2 in the inverse right Jacobian of SO(3) (gauge vectors of the two-level CG preconditioner)
+constexpr int CT_STRIDE = 40;  // 38 used; whole component quads
 
 // ---- per-camera step table used by the back-substitution / trial-point kernel (component quads like the camera tables) ----
 constexpr int ST_DQ = 0;       // Q dw (3): the unscaled rotation step through Q = R K' of the linearisation point (I on the first-order branch);
