@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BLK) void k_colnorm_points(DeviceStructure ds, Devi
 // squared column norms of the camera / focal columns -> udiag (atomics), one block per chunk
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double scratch[BLK / 64];
+    __shared__ double scratch[(BLK / 64) * 7];
     const int4 ch = ds.chunks_coarse[blockIdx.x];
     const int j = ch.x;
     const int cur = db.st->cur;
@@ -292,10 +292,8 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
         for (int c = 0; c < 6; ++c) n[c] += (double)A[c] * (double)A[c] + (double)A[6 + c] * (double)A[6 + c];
         n[6] += pr.xp * pr.xp + pr.yp * pr.yp;
     }
-    for (int c = 0; c < 7; ++c) {
-        const double s = block_sum(n[c], scratch);
-        if (threadIdx.x == 0) atomicAdd(c < 6 ? &db.udiag[6 * j + c] : slot_ptr(db, ACC_UDF), s);
-    }
+    const double tot = block_sums<7>(n, scratch);            // (one barrier instead of seven pairs of them)
+    if (threadIdx.x < 7) atomicAdd(threadIdx.x < 6 ? &db.udiag[6 * j + threadIdx.x] : slot_ptr(db, ACC_UDF), tot);
 }
 
 __global__ void k_colnorm_finish(DeviceStructure ds, DeviceBuffers db, int jacobi, int finish_xnorm) {

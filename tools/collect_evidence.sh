@@ -31,10 +31,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_banded -- $BE
 python $REPO/tools/rocprof_summary.py $OUT/stats_banded $OUT/${TAG}_cfg3_banded_pcg_kernel_stats.txt "$TAG: bench.py --workload cfg3_banded --steps 10 --warmup 2 (f32j, PCG) under rocprofv3 --kernel-trace --stats" > /dev/null
 rm -rf $OUT/stats_banded
 $REPO/tools/micro/pk_bench > $OUT/${TAG}_valu_issue_microbench.txt 2>&1
-# 4. the sharded path on this box's one rank (RCCL communicator of one rank; the exchange is a no-op, its pack / unpack kernels are not)
+# 4. the sharded path on this box's one rank (RCCL communicator of one rank; the exchange is a no-op, its pack / unpack kernels are not):
+#    replicated CG, distributed CG (reduce-scatter of the blocks), implicit Schur CG (no exchange of the reduced matrix)
 for wl in cfg3 cfg5; do
   $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline --no-live-traffic 2> $OUT/sharded_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_bench.json
+  $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline --no-live-traffic --distributed-cg 2> $OUT/sharded_d_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_distributed_cg_bench.json
+  $BENCH --mode sharded --workload $wl --steps 5 --no-cpu-baseline --no-live-traffic --implicit-cg 2> $OUT/sharded_i_$wl.err | grep '^{' > $OUT/${TAG}_${wl}_sharded_1rank_implicit_cg_bench.json
 done
+rm -rf $OUT/stats_sh
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sh -- $BENCH --mode sharded --workload cfg3 --steps 20 --no-cpu-baseline --no-live-traffic > /dev/null 2> $OUT/stats_sh.err
+python $REPO/tools/rocprof_summary.py $OUT/stats_sh $OUT/${TAG}_cfg3_sharded_1rank_kernel_stats.txt "$TAG: bench.py --mode sharded --workload cfg3 --steps 20 (one rank, RCCL communicator of one rank) under rocprofv3 --kernel-trace --stats" > /dev/null
+rm -rf $OUT/stats_sh
 # 5. the drop-in shim in the reference's call pattern: one view added to 199 (SfM.cpp:464-466)
 echo "== SFMBA_LINEAR=pcg (block-Jacobi + gauge coarse space CG) ==" > $OUT/${TAG}_shim_incremental.txt
 SFMBA_BUILD_TIMING=1 python $REPO/tools/time_shim_incremental.py >> $OUT/${TAG}_shim_incremental.txt 2>&1
