@@ -826,8 +826,11 @@ __global__ __launch_bounds__(64) void k_schur_dups(DeviceStructure ds, DeviceBuf
 // camera differs per lane group and is held per lane.  The 36 sums are reduced over the LPB lanes of a group by the VALU-only halving
 // butterfly (DPP row operations never leave a row of 16 lanes), and the per-camera factors G = Lw D E^T (pair_G) are applied from both
 // sides in the epilogue of all NG blocks side by side.
+#ifndef SFMBA_SUBF_WPS
+#define SFMBA_SUBF_WPS 3
+#endif
 template <typename T, int MODE, int LPB>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 2)) void k_schur_pairs_sub_f(DeviceStructure ds, DeviceBuffers db) {
+__global__ __launch_bounds__(64, (sizeof(T) == 4 ? SFMBA_SUBF_WPS : 2)) void k_schur_pairs_sub_f(DeviceStructure ds, DeviceBuffers db) {
     static_assert(LPB == 16, "one DPP row per block");
     constexpr int NG = 64 / LPB;
     __shared__ double tile[NG][36];
@@ -871,11 +874,17 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 2)) void k_schur_pairs_su
     const int cur = st->cur;
     const double focal = st->focal[cur];
     const double* tab = db.camtab[cur];
-    // lane group 0 always holds a block of the workgroup's row (the descriptors of a workgroup are filled from the front)
-    CamG<T> ca;
-    load_cam_g<T>(tab, __builtin_amdgcn_readfirstlane(dsc.y), ds.ncam, ca);
-    CamGL<T> cb;
-    load_cam_gl<T>(tab, work ? cj.y : 0, ds.ncam, cb);
+    // lane group 0 always holds a block of the workgroup's row (the descriptors of a workgroup are filled from the front).  Both rows in
+    // the precision of the Jacobian blocks (obs_factored_t): the row camera's wave-uniform, the column camera's per lane.
+    T Ra[12], Rb[12];
+    {
+        const int ja = __builtin_amdgcn_readfirstlane(dsc.y), jb = work ? cj.y : 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { Ra[k] = to_uniform((T)tab[cam_tab_index(k, ja, ds.ncam)]); Rb[k] = (T)tab[cam_tab_index(k, jb, ds.ncam)]; }
+    }
+    const bool fo_a = tab[cam_tab_index(CT_SMALL, __builtin_amdgcn_readfirstlane(dsc.y), ds.ncam)] != 0.0;
+    const bool fo_b = tab[cam_tab_index(CT_SMALL, work ? cj.y : 0, ds.ncam)] != 0.0;
+    const T focal_t = (T)focal;
     const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
     T acc[36];
 #pragma unroll
@@ -893,8 +902,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 3 : 2)) void k_schur_pairs_su
         const bool mine = p0 + li < p1;
         if (nonempty) { const int p = p0 + LPB + li; pt_next = ds.pair_pt[p < p1 ? p : p1 - 1]; }
         T ga[GREC], gb[GREC];
-        obs_factored<T>(ca, focal, pa.X, pa.L, ga);
-        obs_factored<T>(cb, focal, pa.X, pa.L, gb);
+        const T X0 = (T)pa.X[0], X1 = (T)pa.X[1], X2 = (T)pa.X[2];
+        obs_factored_t<T>(Ra, fo_a, focal_t, X0, X1, X2, pa.L, ga);
+        obs_factored_t<T>(Rb, fo_b, focal_t, X0, X1, X2, pa.L, gb);
         if (!mine) ga[3] = (T)0;                       // (N carries f_a / p_z)
         pair_product_factored<T>(ga, gb, acc);
         p0 += LPB;

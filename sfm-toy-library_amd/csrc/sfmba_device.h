@@ -364,6 +364,37 @@ __device__ __forceinline__ void obs_factored(const Cam& cam, double focal, const
         g[6 + 3 * r + 2] = b0 * l20 + b1 * l21 + b2 * l22;
     }
 }
+// The same with the PROJECTION in the precision of the Jacobian blocks as well (small-block pair pass in fp32-Jacobian mode: every value
+// the pair product uses is rounded to T anyway, the pass needs no residual, and a camera row held per lane is 12 registers instead of 24;
+// measured at BASELINE config 5: 468 -> 431 us per launch.  The wave-per-chunk pass keeps the fp64 projection: with its two rows in
+// scalar registers the fp32 form is SLOWER, 62 -> 72 us).  Rt: R (9, row-major) and t (3) in T.
+template <typename T>
+__device__ __forceinline__ void obs_factored_t(const T (&Rt)[12], bool first_order, T focal, T X0, T X1, T X2, const T L[6], T g[GREC]) {
+    const T rx = Rt[0] * X0 + Rt[1] * X1 + Rt[2] * X2;
+    const T ry = Rt[3] * X0 + Rt[4] * X1 + Rt[5] * X2;
+    const T rz = Rt[6] * X0 + Rt[7] * X1 + Rt[8] * X2;
+    const T pz = rz + Rt[11];
+    T iz;
+    if constexpr (sizeof(T) == 4) { iz = __builtin_amdgcn_rcpf(pz); iz = iz * ((T)2 - pz * iz); }      // estimate + one Newton step
+    else iz = (T)fast_rcp((double)pz);
+    const T xp = (rx + Rt[9]) * iz, yp = (ry + Rt[10]) * iz;
+    g[0] = first_order ? X0 : rx; g[1] = first_order ? X1 : ry; g[2] = first_order ? X2 : rz;
+    const T fz = focal * iz;
+    g[3] = fz; g[4] = xp; g[5] = yp;
+    T B[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        B[c] = fz * (Rt[c] - xp * Rt[6 + c]);
+        B[3 + c] = fz * (Rt[3 + c] - yp * Rt[6 + c]);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const T b0 = B[3 * r], b1 = B[3 * r + 1], b2 = B[3 * r + 2];
+        g[6 + 3 * r + 0] = b0 * L[0];
+        g[6 + 3 * r + 1] = b0 * L[1] + b1 * L[2];
+        g[6 + 3 * r + 2] = b0 * L[3] + b1 * L[4] + b2 * L[5];
+    }
+}
 // acc += G_a^T N G_b  (6 x 6 row-major; rows: camera a, columns: camera b; the first three of each are the rotation part)
 //   = [[ -[X_a]x N [X_b]x ,  [X_a]x N ],  [ -N [X_b]x ,  N ]]   with  v [X]x = v x X  and  [X]x v = X x v
 template <typename T>
