@@ -241,7 +241,8 @@ struct StageObs {
 };
 void launch_stage_obs(hipStream_t s, const StageObs& so, int xy_bytes);
 // pair-pass descriptors and the list of diagonal blocks with pairs, from the block CSR on the device
-void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, int4* desc);
+void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, const int* perm, int4* desc);
+void launch_row_order(hipStream_t s, int ncam, int lpb, const int* blk_ptr, int* perm);      // blocks of every block row grouped by rounds of `lpb` pairs
 // wave-per-block pair pass: one descriptor per chunk of SFMBA_PAIR_CHUNK pairs (structure_build.hip); counters: two zeroed ints; the slot
 // total, the number of multi-chunk blocks and the number of non-empty off-diagonal blocks go to report[4], report[5], report[1]
 int build_pair_chunks(hipStream_t s, DeviceArena* scratch, int nwg, int chunk, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr,

@@ -942,7 +942,11 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
                                           p->d_pwg_desc, p->d_pwg_chunk, p->d_multi_slots, p->d_build_counters, d_report);
         if (crc) return fail(SFMBA_ERR_HIP, std::string("pair-chunk descriptors: ") + hipGetErrorString((hipError_t)crc));
     } else {
-        launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, p->d_pwg_desc);
+        // sixteen lanes per block: the blocks of a row grouped by rounds of sixteen pairs (a wave holds four of them and loops to the longest)
+        int* d_perm = staging.alloc_n<int>((size_t)nblock);
+        if (!d_perm) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+        launch_row_order(p->stream, ncam, pair_lpb, p->d_blk_ptr, d_perm);
+        launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, d_perm, p->d_pwg_desc);
     }
     launch_block_fill(p->stream, nblock, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
     launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, d_report);

@@ -245,14 +245,32 @@ int build_camera_major(hipStream_t s, DeviceArena* arena, DeviceArena* scratch_a
 namespace {
 // Pair-pass descriptors of every workgroup slot: (block, its row camera, pair range) from the block CSR on the device
 __global__ __launch_bounds__(256) void k_pair_desc(int nslot, int group, const int2* __restrict__ pwg_blocks, const int2* __restrict__ blk_cams,
-                                                   const int* __restrict__ blk_ptr, int4* __restrict__ desc) {
+                                                   const int* __restrict__ blk_ptr, const int* __restrict__ perm, int4* __restrict__ desc) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslot) return;
     const int2 w = pwg_blocks[t / group];
     const int k = t % group;
     int4 d; d.x = -1; d.y = 0; d.z = 0; d.w = 0;
-    if (k < w.y) { const int b = w.x + k; d.x = b; d.y = blk_cams[b].x; d.z = blk_ptr[b]; d.w = blk_ptr[b + 1]; }
+    if (k < w.y) { const int b = perm ? perm[w.x + k] : w.x + k; d.x = b; d.y = blk_cams[b].x; d.z = blk_ptr[b]; d.w = blk_ptr[b + 1]; }
     desc[t] = d;
+}
+// Order of the blocks of one block row in the sixteen-lanes-per-block pair pass: by ROUNDS of sixteen pairs (the diagonal block first).  A wave
+// of that pass holds four consecutive blocks of the row and loops to the longest of them: with ~45 pairs per block (Poisson) four blocks
+// in list order need 4 rounds for 2.8 rounds of work; grouped by rounds a wave's blocks loop alike.  One workgroup per row; the order
+// inside a bucket is whatever the atomics give (every block is computed on its own: the order changes no result).
+__global__ __launch_bounds__(256) void k_row_order(int ncam, int lpb, const int* __restrict__ blk_ptr, int* __restrict__ perm) {
+    constexpr int NBK = 34;
+    __shared__ int start[NBK + 1], cursor[NBK];
+    const int ja = blockIdx.x, nb = ncam - ja;
+    const int b0 = (int)block_of(ja, ja, ncam);
+    for (int k = threadIdx.x; k <= NBK; k += blockDim.x) { start[k] = 0; if (k < NBK) cursor[k] = 0; }
+    __syncthreads();
+    auto bucket = [&](int t) { if (t == 0) return 0; const int n = blk_ptr[b0 + t + 1] - blk_ptr[b0 + t]; const int r = 1 + (n + lpb - 1) / lpb; return r < NBK ? r : NBK - 1; };
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) atomicAdd(&start[bucket(t) + 1], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int k = 0; k < NBK; ++k) start[k + 1] += start[k]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) { const int k = bucket(t); perm[b0 + start[k] + atomicAdd(&cursor[k], 1)] = b0 + t; }
 }
 // Diagonal blocks that hold pairs (one camera observing a point twice), ascending camera order; their number and the device's own
 // total pair count go to host-mapped memory (report[0] = blocks, report[2..3] = pairs), read by the host once the stream has drained.
@@ -392,9 +410,12 @@ void launch_block_fill(hipStream_t s, int nblock, const int2* blk_cams, const in
     hipLaunchKernelGGL(k_fill_report, dim3(1), dim3(1), 0, s, counters, report);
 }
 
-void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, int4* desc) {
+void launch_row_order(hipStream_t s, int ncam, int lpb, const int* blk_ptr, int* perm) {
+    if (ncam > 0) hipLaunchKernelGGL(k_row_order, dim3(ncam), dim3(256), 0, s, ncam, lpb, blk_ptr, perm);
+}
+void launch_pair_desc(hipStream_t s, int nwg, int group, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr, const int* perm, int4* desc) {
     const int nslot = nwg * group;
-    if (nslot > 0) hipLaunchKernelGGL(k_pair_desc, dim3((nslot + 255) / 256), dim3(256), 0, s, nslot, group, pwg_blocks, blk_cams, blk_ptr, desc);
+    if (nslot > 0) hipLaunchKernelGGL(k_pair_desc, dim3((nslot + 255) / 256), dim3(256), 0, s, nslot, group, pwg_blocks, blk_cams, blk_ptr, perm, desc);
 }
 void launch_dup_blocks(hipStream_t s, int ncam, const int* blk_ptr, const long long* pair_total, int2* dup, int* report) {
     hipLaunchKernelGGL(k_dup_blocks, dim3(1), dim3(256), 0, s, ncam, blk_ptr, pair_total, dup, report);
