@@ -1054,19 +1054,32 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
     T v[CD_N];
 #pragma unroll
     for (int k = 0; k < CD_N; ++k) v[k] = (T)0;
+    const typename ObsXY<T>::type* xy = reinterpret_cast<const typename ObsXY<T>::type*>(ds.cam_obs_xy);
+    const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
+    const PtRecB<T>* PB = reinterpret_cast<const PtRecB<T>*>(db.PB);
+    // SFMBA_CAM_CHUNK / CD_BLK observations per lane (1 by default).  With several, the loop is software-pipelined: the point slot is fetched
+    // two rounds ahead and the point-table entries one round ahead, so that a round's arithmetic runs under the next round's gathers.
+    int e = ch.y + threadIdx.x;
+    int i_nn = 0;
+    PtRecA<T> pa_n = PA[0]; PtRecB<T> pb_n = PB[0];
+    typename ObsXY<T>::type oxy_n = xy[e < ch.z ? e : ch.y];
+    if (e < ch.z) { const int i0 = ds.cam_obs_pt[e]; pa_n = PA[i0]; pb_n = PB[i0]; }
+    if (CD_OBS > 1 && e + CD_BLK < ch.z) i_nn = ds.cam_obs_pt[e + CD_BLK];
 #pragma unroll 1
-    for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {      // (SFMBA_CAM_CHUNK / CD_BLK observations per lane; 1 by default)
-        // two coalesced streams (point slot, observation coordinates in camera-major order) and two gathers from the L2-resident point table
-        const int i = ds.cam_obs_pt[e];
-        const typename ObsXY<T>::type oxy = reinterpret_cast<const typename ObsXY<T>::type*>(ds.cam_obs_xy)[e];
-        const PtRecA<T> pa = reinterpret_cast<const PtRecA<T>*>(db.PA)[i];
-        const PtRecB<T> pb = reinterpret_cast<const PtRecB<T>*>(db.PB)[i];
+    for (; e < ch.z; e += CD_BLK) {
+        const PtRecA<T> pa = pa_n;
+        const PtRecB<T> pb = pb_n;
+        const typename ObsXY<T>::type oxy = oxy_n;
+        if (CD_OBS > 1) {
+            if (e + CD_BLK < ch.z) { pa_n = PA[i_nn]; pb_n = PB[i_nn]; oxy_n = xy[e + CD_BLK]; }
+            if (e + 2 * CD_BLK < ch.z) i_nn = ds.cam_obs_pt[e + 2 * CD_BLK];
+        }
         T rec[YREC], z[8];
         obs_record<T>(ct, focal, pa.X, pa.L, rec);
         // the residual as the point pass forms it: fp64 projection, fp64 subtraction, then rounded to T
         typename ObsXY<T>::type rr;
         { const Proj pr = project_point(ct, CT_R, CT_T, pa.X); rr.x = (T)(focal * pr.xp - (double)oxy.x); rr.y = (T)(focal * pr.yp - (double)oxy.y); }
-        // side values exactly as the record sweep of k_point_build forms them: C t, C y_f, residual
+        // side values: C t, C y_f, residual
         z[0] = rec[9] * pb.t[0] + rec[10] * pb.t[1] + rec[11] * pb.t[2];
         z[1] = rec[12] * pb.t[0] + rec[13] * pb.t[1] + rec[14] * pb.t[2];
         z[2] = rec[9] * pb.yf[0] + rec[10] * pb.yf[1] + rec[11] * pb.yf[2];
