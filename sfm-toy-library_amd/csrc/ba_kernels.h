@@ -181,7 +181,7 @@ template <typename T> void launch_eval_residuals(hipStream_t s, const DeviceStru
                                                  const int* perm, double* res_out, double* cost_out);
 template <typename T> void launch_eval_jacobian(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,
                                                 const int* obs_pt, const int* perm, double* jc, double* jp, double* jf);
-// Implicit Schur product of the sharded solve (ba_kernels.hip, "Implicit Schur product"): out = this rank's part of S~ p~ from its own
+// Implicit Schur product of the sharded solve (implicit_schur.hip): out = this rank's part of S~ p~ from its own
 // points (+ on rank 0 what every rank knows: identity diagonal blocks, focal row / column); summed over the ranks it is S~ p~.
 struct ImplicitProduct {
     DeviceStructure ds;

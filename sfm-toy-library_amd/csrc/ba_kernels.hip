@@ -13,109 +13,11 @@
 //   k_lm_control   accept/reject + trust-region update on the device (no host round trip needed)
 #include "ba_kernels.h"
 #include "sfmba_device.h"
+#include "ba_common.h"
 #include "../../include/sfmba.h"
 #include <cstdlib>
 
 namespace sfmba {
-
-#define BLK 256
-
-__device__ __forceinline__ double wave_max(double v) {
-    v = fmax(v, xlane_get<32>(v)); v = fmax(v, xlane_get<16>(v)); v = fmax(v, xlane_get<8>(v));
-    v = fmax(v, xlane_get<4>(v)); v = fmax(v, xlane_get<2>(v)); v = fmax(v, xlane_get<1>(v));
-    return v;
-}
-
-__device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; }
-
-// N block-wide sums at once: the wave reductions advance in lock step (a shuffle is ~50 cycles of latency: N dependent chains
-// of six in sequence, each with its own pair of barriers, were ~1 us at the tail of every wave of the point passes), one
-// barrier; thread t < N returns the sum of value t (other threads: 0).  scratch: >= (blockDim.x / 64) * N doubles.
-template <int N>
-__device__ __forceinline__ double block_sums(double (&v)[N], double* scratch) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wave_allsum(v[k]);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) scratch[w * N + k] = v[k];
-    }
-    __syncthreads();
-    double s = 0.0;
-    if ((int)threadIdx.x < N) {
-        const int nw = (blockDim.x + 63) >> 6;
-        for (int i = 0; i < nw; ++i) s += scratch[i * N + threadIdx.x];
-    }
-    return s;
-}
-
-// slotted accumulators: one atomic per value per workgroup, spread over NSLOT addresses
-__device__ __forceinline__ double* slot_ptr(const DeviceBuffers& db, int which) {
-    return db.slots + (size_t)(blockIdx.x % (unsigned)db.nslot) * SLOT_W + which;
-}
-// sum (or max for ACC_GMAX) of one accumulator over the NSLOT (= 64) slots, then clear it.
-// Must be called by all 64 lanes of one wave; every lane returns the result.
-__device__ double slots_take(const DeviceBuffers& db, int which) {
-    const int lane = threadIdx.x & 63;
-    if (which == ACC_GMAX) {
-        double v = 0.0;
-        for (int i = lane; i < db.nslot; i += 64) {
-            double* p = db.slots + (size_t)i * SLOT_W + which;
-            const double o = *p;
-            *p = 0.0;
-            v = (o > v || o != o) ? o : v;
-        }
-#define SFMBA_MAXSTEP(OFF) { const double o = xlane_get<OFF>(v); v = (o > v || o != o) ? o : v; }
-        SFMBA_MAXSTEP(32) SFMBA_MAXSTEP(16) SFMBA_MAXSTEP(8) SFMBA_MAXSTEP(4) SFMBA_MAXSTEP(2) SFMBA_MAXSTEP(1)
-#undef SFMBA_MAXSTEP
-        return v;
-    }
-    double v = 0.0;
-    for (int i0 = lane; i0 < db.nslot; i0 += 512) {    // fixed order: lane-strided (eight loads in flight), then the butterfly
-        double t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; t[u] = db.slots[(size_t)(i < db.nslot ? i : lane) * SLOT_W + which]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; if (i < db.nslot) { v += t[u]; db.slots[(size_t)i * SLOT_W + which] = 0.0; } }
-    }
-    return wave_sum(v);
-}
-
-// N accumulators at once: all slot loads in flight together, then the clears, then the N butterflies in lock step.  Back-to-back
-// slots_take() calls cannot overlap (the clearing stores of one fence off the loads of the next): four of them were most of
-// k_finalize's 14 us (the focal wave), five of them of k_lm_control's 7.  Same summation order as slots_take (bitwise identical).
-template <int N>
-__device__ __forceinline__ void slots_take_n(const DeviceBuffers& db, const int (&which)[N], double (&out)[N]) {
-    const int lane = threadIdx.x & 63;
-    double v[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = 0.0;
-    for (int i0 = lane; i0 < db.nslot; i0 += 512) {
-        double t[N][8];
-#pragma unroll
-        for (int k = 0; k < N; ++k)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; t[k][u] = (u == 0 || db.nslot > 64) ? db.slots[(size_t)(i < db.nslot ? i : lane) * SLOT_W + which[k]] : 0.0; }
-#pragma unroll
-        for (int k = 0; k < N; ++k)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 64 * u;
-                if (i < db.nslot) {
-                    if (which[k] == ACC_GMAX) v[k] = (t[k][u] > v[k] || t[k][u] != t[k][u]) ? t[k][u] : v[k]; else v[k] += t[k][u];
-                    db.slots[(size_t)i * SLOT_W + which[k]] = 0.0;
-                }
-            }
-    }
-#define SFMBA_TAKE_STEP(OFF) \
-    _Pragma("unroll") for (int k = 0; k < N; ++k) { \
-        const double o = xlane_get<OFF>(v[k]); \
-        if (which[k] == ACC_GMAX) v[k] = (o > v[k] || o != o) ? o : v[k]; else v[k] += o; }
-    SFMBA_TAKE_STEP(32) SFMBA_TAKE_STEP(16) SFMBA_TAKE_STEP(8) SFMBA_TAKE_STEP(4) SFMBA_TAKE_STEP(2) SFMBA_TAKE_STEP(1)
-#undef SFMBA_TAKE_STEP
-#pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = v[k];
-}
 
 // ------------------------------------------------------------------------------------------
 // camera tables
@@ -355,12 +257,6 @@ __device__ __forceinline__ bool chol3_inverse(const double V[6] /* v00 v10 v11 v
     return (V[0] > 0.0) && (d1 > 0.0) && (d2 > 0.0);
 }
 
-template <typename T>
-__device__ __forceinline__ void load_obs(const void* base, int q, double& ox, double& oy) {
-    const typename ObsXY<T>::type v = reinterpret_cast<const typename ObsXY<T>::type*>(base)[q];
-    ox = (double)v.x; oy = (double)v.y;
-}
-
 // ------------------------------------------------------------------------------------------
 // The blocks of one observation in registers (obs_record, sfmba_device.h): 16 values
 //                 [0..5] A_w = Aproj G (2x3, unscaled)  [6] fz = f/pz  [7] xp  [8] yp
@@ -375,28 +271,6 @@ __device__ __forceinline__ void rec_camera_block(const T rec[YREC], T A[12]) {
     A[3] = rec[6]; A[4] = (T)0; A[5] = -rec[6] * rec[7];
     A[6] = rec[3]; A[7] = rec[4]; A[8] = rec[5];
     A[9] = (T)0; A[10] = rec[6]; A[11] = -rec[6] * rec[8];
-}
-
-// workgroup of the two point passes: PBK / 64 waves that share nothing but the final block reduction
-#ifndef PBK
-#define PBK 128
-#endif
-#define WPB (PBK / 64)
-// minimum waves per SIMD the point passes are compiled for (register budget 512 / this); 0 = let the compiler decide
-#ifndef SFMBA_PB_WAVES
-#define SFMBA_PB_WAVES 0
-#endif
-#if SFMBA_PB_WAVES > 0
-#define PB_BOUNDS __launch_bounds__(PBK, SFMBA_PB_WAVES)
-#else
-#define PB_BOUNDS __launch_bounds__(PBK)
-#endif
-
-__device__ __forceinline__ void wave_lds_fence() {
-    // LDS traffic of one wave is processed in order; this only stops the compiler from moving the
-    // accesses and waits for outstanding LDS writes before other lanes of the wave read them
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
 }
 
 // Per point, once its sums over the observations are known: Jacobi scales, LM damping, the inverse Cholesky factor of V + D^2, t, y_f, M and
@@ -465,7 +339,6 @@ __device__ __forceinline__ void point_finish(const DeviceBuffers& db, const LMSt
 // both at a tenth of the lanes -- 34.5 against 22.7 us at BASELINE config 3, 150 against 98 at config 5.)  Waves take points in the order
 // of ds.pt_order (sorted by number of rounds of four observations: the quads of a wave then loop alike whatever the track lengths).  A
 // lane needs the camera's R and t only (three component quads of the table: K' is the reduced-system passes' business).
-#define PB_LPP 4
 template <typename T>
 __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, int ps_mode_flags) {
     if ((ps_mode_flags & 4) && (db.st->termination != -1 || db.st->retry != 0)) return;
@@ -626,25 +499,6 @@ __device__ __forceinline__ void pair_product(const T ra[YREC], const T rb[YREC],
             acc[6 * r + c] += v;
             if (diag) acc[6 * c + r] += v;   // same camera twice: Y_a Y_b^T + Y_b Y_a^T
         }
-}
-
-__device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db);
-
-// one entry of the preconditioned reduced matrix (fp64, or fp32 when the streaming CG path asked for it)
-__device__ __forceinline__ void store_F(const DeviceBuffers& db, size_t idx, double v) {
-    if (db.pcg_F32) db.pcg_F32[idx] = (float)v; else db.pcg_F[idx] = v;
-}
-
-// one entry of an off-diagonal block of the preconditioned matrix: both triangles of the CG's matrix, or -- sharded CG path -- the
-// block's slot in the all-reduce buffer (k_shard_offdiag's layout; the matrix is written after the sum over the ranks)
-__device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, const DeviceBuffers& db, int b, int2 cj, int r, int c, double v) {
-    if (db.shard_blocks32 || db.shard_blocks) {
-        const size_t o = (size_t)((long long)(b - cj.x - 1) + (db.shard_row_shift ? db.shard_row_shift[cj.x] : 0)) * 36 + 6 * r + c;
-        if (db.shard_blocks32) db.shard_blocks32[o] = (float)v; else db.shard_blocks[o] = v;
-        return;
-    }
-    store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
-    store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
 }
 
 // the two-sided transform of one block's sums (factored coordinates, sfmba_device.h): S_IJ = G_I [sum] G_J^T with the per-camera
@@ -948,11 +802,6 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? SFMBA_SUBF_WPS : 2)) void k_s
 // one atomic per value per workgroup.
 //   S_jj += A~^T (I - C C^T) A~   (U_jj minus the self term Y_a Y_a^T), undamped diagonal, S_jf, b_c, rhs
 // ------------------------------------------------------------------------------------------
-#define CD_N 48      // Sjj(21) udiag(6) Sjf(6) bc(6) rhs(6) uff bf + pad
-#define CD_BLK 256   // threads of a workgroup; a lane takes SFMBA_CAM_CHUNK / CD_BLK observations of the chunk, one after the other
-#define CD_OBS (SFMBA_CAM_CHUNK / CD_BLK)
-static_assert(SFMBA_CAM_CHUNK % CD_BLK == 0, "camera chunk length");
-
 // the 47 terms (ACCUM: added to v, else stored) one observation contributes to its camera's diagonal block, focal column, gradient and right-hand side, from its packed
 // record and side values z = {C t (2), C y_f (2), residual (2)} -- shared by the record-gathering and the re-evaluating camera pass
 template <typename T, bool ACCUM>
@@ -1169,40 +1018,6 @@ template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const
 // ------------------------------------------------------------------------------------------
 // finalize: damping of the reduced diagonal, camera/focal part of the gradient max-norm, padding
 // ------------------------------------------------------------------------------------------
-// after a linearisation: initial cost (iteration 0), gradient tolerance, evaluation failure.  One wave.
-__device__ void post_linearisation(const DeviceStructure& ds, const DeviceBuffers& db) {
-    LMState* st = db.st;
-    const int lin_acc[3] = { ACC_GMAX, ACC_BAD_LIN, ACC_LIN_COST };
-    double lin[3];
-    slots_take_n<3>(db, lin_acc, lin);
-    const double gmax = lin[0], bad_lin = lin[1], lin_cost = lin[2];
-    if ((threadIdx.x & 63) != 0) return;
-    if (st->termination != -1) return;
-    if (bad_lin != 0.0) {
-        st->termination = SFMBA_FAILURE;
-        st->message = st->iter == 0 ? MSG_INITIAL_EVAL_FAILED : MSG_EVAL_FAILED;
-    }
-    if (st->x_is_new) {
-        st->jacobian_evals++;
-        st->gmax = gmax;
-        if (st->iter == 0) {
-            st->cost = 0.5 * lin_cost;
-            if (db.trace_cap > 0) {
-                TraceRow row = {};
-                row.iteration = 0; row.cost = st->cost; row.gradient_max_norm = gmax; row.trust_region_radius = st->radius;
-                db.trace[0] = row;
-            }
-        } else if (st->iter < db.trace_cap) {
-            db.trace[st->iter].gradient_max_norm = gmax;
-        }
-        if (st->termination == -1 && gmax <= st->gradient_tolerance) {
-            st->termination = SFMBA_CONVERGENCE;
-            st->message = MSG_GRADIENT_TOL;
-        }
-        st->x_is_new = 0;
-    }
-}
-
 // Rows of camera j in the 8 gauge vectors of the problem, in the unknowns of the block-Jacobi transformed reduced system
 // (coarse space of the two-level CG preconditioner, dense_solver.hip).  adjustBundle() holds no block constant
 // (BA.cpp:160-164), so the undamped problem does not change under a similarity transform of the scene; in camera
@@ -1654,36 +1469,6 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), db.shared_weight * s2); atomicAdd(slot_ptr(db, ACC_XNEW2), db.shared_weight * x2); }
 }
 
-// one observation in the factored form of sfmba_device.h, as the back-substitution and the implicit Schur product need it: projection,
-// X_g, u = P (Q dw x X_g + dt) for the direction in `dr` (step-table layout), C = (P R) L~
-struct ImpObs { double xg[3], u[2], fz, xp, yp; };
-template <typename T, typename CamPtr, typename DirPtr>
-__device__ __forceinline__ void imp_eval(const CamPtr& ct, const DirPtr& dr, double focal, const PtRecA<T>& pa, ImpObs& o, T (&C)[6]) {
-    const double rx = ct[CT_R + 0] * pa.X[0] + ct[CT_R + 1] * pa.X[1] + ct[CT_R + 2] * pa.X[2];
-    const double ry = ct[CT_R + 3] * pa.X[0] + ct[CT_R + 4] * pa.X[1] + ct[CT_R + 5] * pa.X[2];
-    const double rz = ct[CT_R + 6] * pa.X[0] + ct[CT_R + 7] * pa.X[1] + ct[CT_R + 8] * pa.X[2];
-    Proj pr;
-    pr.iz = fast_rcp(rz + ct[CT_T + 2]);
-    pr.xp = (rx + ct[CT_T + 0]) * pr.iz;
-    pr.yp = (ry + ct[CT_T + 1]) * pr.iz;
-    const bool first_order = dr[ST_SMALL] != 0.0;
-    o.xg[0] = first_order ? pa.X[0] : rx; o.xg[1] = first_order ? pa.X[1] : ry; o.xg[2] = first_order ? pa.X[2] : rz;
-    const double dq0 = dr[ST_DQ], dq1 = dr[ST_DQ + 1], dq2 = dr[ST_DQ + 2];
-    const double v0 = dq1 * o.xg[2] - dq2 * o.xg[1] + dr[ST_DT], v1 = dq2 * o.xg[0] - dq0 * o.xg[2] + dr[ST_DT + 1], v2 = dq0 * o.xg[1] - dq1 * o.xg[0] + dr[ST_DT + 2];
-    o.fz = focal * pr.iz; o.xp = pr.xp; o.yp = pr.yp;
-    o.u[0] = o.fz * (v0 - pr.xp * v2);
-    o.u[1] = o.fz * (v1 - pr.yp * v2);
-    T B[6];
-    point_block<T>(ct, pr, focal, B);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const T b0 = B[3 * r], b1 = B[3 * r + 1], b2 = B[3 * r + 2];
-        C[3 * r + 0] = b0 * pa.L[0];
-        C[3 * r + 1] = b0 * pa.L[1] + b1 * pa.L[2];
-        C[3 * r + 2] = b0 * pa.L[3] + b1 * pa.L[4] + b2 * pa.L[5];
-    }
-}
-
 // Back-substitution + trial point, four lanes per point like k_point_build:
 //   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost.
 // With V + D^2 = L L^T, t = L^-1 b_p and C = B~ L^-T (left behind per POINT by k_point_build: pt_t, M = diag(s_p) L^-T, the table entry):
@@ -1828,232 +1613,6 @@ template void launch_point_update<float>(hipStream_t, const DeviceStructure&, co
 template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 
 // ------------------------------------------------------------------------------------------
-// Implicit Schur product (sharded solve, options.shard_distributed_cg = 2): q~ = S~ p~ WITHOUT forming S~ --
-// nothing of the reduced matrix is exchanged between the ranks, a rank applies its own points' W V^-1 W^T to the vector:
-//   S_off y = - sum_points sum_{a != b} A~_a^T C_a C_b^T A~_b y_cam(b),      S~ = Lb^-1 S Lb^-T,  y = Lb^-T p~
-// (the diagonal blocks and the focal border of S~ are known on every rank from exchange (A): identity, S~_jf).  Per product:
-//   k_imp_dir     per camera: v = D Linv^T p~_j, the direction in the factored coordinates of sfmba_device.h (Q v_w, v_t) -- the layout of
-//                 the step table's first two quads; clears the per-camera sums
-//   k_imp_points  point-major, one lane per observation (the waves of the point passes): u = A v = P (Q v_w x X_g + v_t), w = C^T u,
-//                 s_i = sum_obs w (through the wave's LDS) -> spt[i]
-//   k_imp_cams    camera-major, one workgroup per chunk of a camera's observations (the chunks of k_cam_diag_f): e = C (s_i - w),
-//                 h = P^T e, sums of X_g x h and h over the camera's observations -> acc[j] (six values per camera)
-//   k_imp_out     per camera: q~_j = -Linv D [Q^T a; b] (+ on rank 0 the identity / focal part, as k_dcg_comb adds it)
-// Every observation is evaluated twice per product, with the expressions of k_point_update; C = (P R) L~ in the precision of the
-// Jacobian blocks.  Pairs of observations of ONE camera on a point (duplicates) live in the diagonal blocks: a problem that has them
-// does not take this path (the caller checks ds.ndupwg).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_imp_dir(DeviceStructure ds, DeviceBuffers db, const double* __restrict__ pt, double* __restrict__ dtab,
-                                                 double* __restrict__ acc, const int* __restrict__ flags) {
-    if (flags && flags[0]) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ds.ncam) return;
-    const int cur = db.st->cur;
-    const double* Li = db.pcg_binv + (size_t)j * 36;
-    double x[6], z[6], Q9[9];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) x[t] = pt[6 * j + t];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) Q9[e] = db.camtab[cur][cam_tab_index(CT_QD + e, j, ds.ncam)];
-    const double small_cur = db.camtab[cur][cam_tab_index(CT_SMALL, j, ds.ncam)];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {          // z = Linv^T x (Linv lower triangular, row-major), then the Jacobi scales
-        double v = 0.0;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) if (t >= c) v += Li[t * 6 + c] * x[t];
-        z[c] = v * db.cscale[6 * j + c];
-    }
-    double row[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-    for (int e = 0; e < 3; ++e) { row[ST_DQ + e] = Q9[3 * e] * z[0] + Q9[3 * e + 1] * z[1] + Q9[3 * e + 2] * z[2]; row[ST_DT + e] = z[3 + e]; }
-    row[ST_SMALL] = small_cur;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dtab[cam_tab_index(e, j, ds.ncam)] = row[e];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) acc[6 * j + e] = 0.0;
-}
-
-template <typename T>
-__global__ PB_BOUNDS void k_imp_points(DeviceStructure ds, DeviceBuffers db, const double* __restrict__ dtab, double* __restrict__ spt, const int* __restrict__ flags) {
-    if (flags && flags[0]) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int gw = blockIdx.x * WPB + w;
-    const LMState* st = db.st;
-    const int cur = st->cur;
-    const double focal = st->focal[cur];
-    const double* tab = db.camtab[cur];
-    const int sub = lane & (PB_LPP - 1);
-    const int slot = gw * (64 / PB_LPP) + (lane / PB_LPP);        // four lanes per point, as the point passes
-    const bool have = slot < ds.npt;
-    const int ip = have ? (ds.pt_order ? ds.pt_order[slot] : slot) : 0;
-    const size_t i = (size_t)ip;
-    const int q0 = have ? ds.pt_ptr[ip] : 0, q1 = have ? ds.pt_ptr[ip + 1] : 0;
-    const PtRecA<T> pa = load_ptrec(reinterpret_cast<const PtRecA<T>*>(db.PA) + i);
-    double s[3] = { 0, 0, 0 };
-    int q = q0 + sub;
-    int j_next = q < q1 ? ds.obs_cam[q] : 0;
-    while (__any(q < q1)) {
-        const bool act = q < q1;
-        const int j = j_next;
-        const CamRow ct = { tab + 4 * (size_t)(j), ds.ncam };
-        const CamRow drw = { dtab + 4 * (size_t)(j), ds.ncam };
-        double Rt[12], dr[8];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) Rt[e] = ct[CT_R + e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dr[e] = drw[e];
-        q += PB_LPP;
-        if (q < q1) j_next = ds.obs_cam[q];
-        if (act) {
-            ImpObs o; T C[6];
-            imp_eval<T>(Rt, dr, focal, pa, o, C);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) s[c] += (double)C[c] * o.u[0] + (double)C[3 + c] * o.u[1];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { s[c] = xlane_add<1>(s[c]); s[c] = xlane_add<2>(s[c]); }
-    if (have && sub == 0) { spt[3 * i] = s[0]; spt[3 * i + 1] = s[1]; spt[3 * i + 2] = s[2]; }
-}
-
-template <typename T>
-__global__ __launch_bounds__(CD_BLK) void k_imp_cams(DeviceStructure ds, DeviceBuffers db, const double* __restrict__ dtab, const double* __restrict__ spt,
-                                                     double* __restrict__ acc, const int* __restrict__ flags) {
-    __shared__ double red[CD_BLK / 64][6];
-    if (flags && flags[0]) return;
-    const int4 ch = ds.chunks[blockIdx.x];
-    const int j = ch.x;
-    const LMState* st = db.st;
-    const int cur = st->cur;
-    const double focal = st->focal[cur];
-    CamRegs ct;
-    load_cam_regs(db.camtab[cur], j, ds.ncam, ct);
-    double dr[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dr[e] = dtab[cam_tab_index(e, j, ds.ncam)];
-    const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
-    double v[6] = { 0, 0, 0, 0, 0, 0 };
-#pragma unroll 1
-    for (int e = ch.y + threadIdx.x; e < ch.z; e += CD_BLK) {
-        const int i = ds.cam_obs_pt[e];
-        const PtRecA<T> pa = load_ptrec(PA + i);
-        const double s0 = spt[3 * (size_t)i], s1 = spt[3 * (size_t)i + 1], s2 = spt[3 * (size_t)i + 2];
-        ImpObs o; T C[6];
-        imp_eval<T>(ct, dr, focal, pa, o, C);
-        // everything the OTHER observations of the point contribute: s_i - w, then e = C (.), h = P^T e
-        const double d0 = s0 - ((double)C[0] * o.u[0] + (double)C[3] * o.u[1]);
-        const double d1 = s1 - ((double)C[1] * o.u[0] + (double)C[4] * o.u[1]);
-        const double d2 = s2 - ((double)C[2] * o.u[0] + (double)C[5] * o.u[1]);
-        const double e0 = (double)C[0] * d0 + (double)C[1] * d1 + (double)C[2] * d2;
-        const double e1 = (double)C[3] * d0 + (double)C[4] * d1 + (double)C[5] * d2;
-        const double h0 = o.fz * e0, h1 = o.fz * e1, h2 = -o.fz * (o.xp * e0 + o.yp * e1);
-        v[0] += o.xg[1] * h2 - o.xg[2] * h1;
-        v[1] += o.xg[2] * h0 - o.xg[0] * h2;
-        v[2] += o.xg[0] * h1 - o.xg[1] * h0;
-        v[3] += h0; v[4] += h1; v[5] += h2;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = wave_allsum(v[k]);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) red[w][k] = v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        double t = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < CD_BLK / 64; ++ww) t += red[ww][threadIdx.x];
-        atomicAdd(&acc[6 * j + threadIdx.x], t);
-    }
-}
-
-// FF: the type the focal row of S~ is stored in (the CG's matrix: fp64, or fp32 on the streaming path)
-template <typename FF>
-__global__ __launch_bounds__(1024) void k_imp_out(DeviceStructure ds, DeviceBuffers db, int rank, const double* __restrict__ pt, const double* __restrict__ acc,
-                                                  const FF* __restrict__ focal_row, double* __restrict__ out, const int* __restrict__ flags) {
-    if (flags && flags[0]) return;
-    __shared__ double sh[16];
-    const int fo = ds.d - 1;
-    const int cur = db.st->cur;
-    double fdot = 0.0;
-    if (rank == 0) { for (int i = threadIdx.x; i < fo; i += blockDim.x) fdot += (double)focal_row[i] * pt[i]; }
-    fdot = wave_allsum(fdot);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = fdot;
-    __syncthreads();
-    const double pf = pt[fo];
-    for (int j = threadIdx.x; j < ds.ncam; j += blockDim.x) {
-        double a[6], g[6], Q9[9];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) a[e] = acc[6 * j + e];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Q9[e] = db.camtab[cur][cam_tab_index(CT_QD + e, j, ds.ncam)];
-        // A^T e summed over the camera's observations in the factored coordinates: [Q^T (sum X_g x h); sum h], Jacobi scales, sign of S_off
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            g[c] = -db.cscale[6 * j + c] * (Q9[c] * a[0] + Q9[3 + c] * a[1] + Q9[6 + c] * a[2]);
-            g[3 + c] = -db.cscale[6 * j + 3 + c] * a[3 + c];
-        }
-        const double* Li = db.pcg_binv + (size_t)j * 36;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            double v = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) if (c <= r) v += Li[r * 6 + c] * g[c];
-            const int i = 6 * j + r;
-            if (rank == 0) v += pt[i] + (double)focal_row[i] * pf;
-            out[i] = v;
-        }
-    }
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[k];
-        out[fo] = rank == 0 ? pf + t : 0.0;
-    }
-}
-
-void launch_implicit_product(hipStream_t s, const ImplicitProduct& ip, const double* p_tilde, double* out, const int* flags) {
-    const DeviceStructure& ds = ip.ds;
-    hipLaunchKernelGGL(k_imp_dir, dim3((ds.ncam + 255) / 256), dim3(256), 0, s, ds, ip.db, p_tilde, ip.dtab, ip.acc, flags);
-    if (ip.f32) {
-        hipLaunchKernelGGL(k_imp_points<float>, dim3((ds.npt + WPB * (64 / PB_LPP) - 1) / (WPB * (64 / PB_LPP))), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
-        hipLaunchKernelGGL(k_imp_cams<float>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.acc, flags);
-    } else {
-        hipLaunchKernelGGL(k_imp_points<double>, dim3((ds.npt + WPB * (64 / PB_LPP) - 1) / (WPB * (64 / PB_LPP))), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
-        hipLaunchKernelGGL(k_imp_cams<double>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.acc, flags);
-    }
-    if (ip.focal_row32) hipLaunchKernelGGL(k_imp_out<float>, dim3(1), dim3(1024), 0, s, ds, ip.db, ip.rank, p_tilde, ip.acc, ip.focal_row32, out, flags);
-    else hipLaunchKernelGGL(k_imp_out<double>, dim3(1), dim3(1024), 0, s, ds, ip.db, ip.rank, p_tilde, ip.acc, ip.focal_row, out, flags);
-}
-
-// The glue of the block-Jacobi transform on its own (the pair pass does it on the way when it runs, k_schur_pairs MODE 1): focal row /
-// column of S~, b~ = Lb^-1 rhs, 1 / sqrt(S_ff), and the post-linearisation bookkeeping that k_finalize(pcg = 1) leaves to its successor.
-__global__ __launch_bounds__(256) void k_pcg_glue(DeviceStructure ds, DeviceBuffers db) {
-    if (blockIdx.x == 0 && threadIdx.x < 64) post_linearisation(ds, db);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ds.ncam) return;
-    const int fo = ds.d - 1, row0 = 6 * j;
-    const double* Li = db.pcg_binv + (size_t)j * 36;
-    const double linv_f = 1.0 / sqrt(db.S[(size_t)fo * ds.ld + fo]);
-    for (int l = 0; l < 6; ++l) {
-        double vf = 0.0, vb = 0.0;
-        for (int a = 0; a <= l; ++a) { vf += Li[l * 6 + a] * db.S[(size_t)(row0 + a) * ds.ld + fo]; vb += Li[l * 6 + a] * db.rhs[row0 + a]; }
-        vf *= linv_f;
-        store_F(db, (size_t)(row0 + l) * ds.ld + fo, vf);
-        store_F(db, (size_t)fo * ds.ld + row0 + l, vf);
-        db.pcg_bt[row0 + l] = vb;
-    }
-    if (j == 0) {
-        store_F(db, (size_t)fo * ds.ld + fo, 1.0);
-        db.pcg_bt[fo] = db.rhs[fo] * linv_f;
-        db.pcg_binv[(size_t)ds.ncam * 36] = linv_f;
-    }
-}
-void launch_pcg_glue(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_pcg_glue, dim3((ds.ncam + 255) / 256), dim3(256), 0, s, ds, db);
-}
-
-// ------------------------------------------------------------------------------------------
 // LM control: the accept/reject logic of ceres::internal::TrustRegionMinimizer::Minimize()
 // [Ceres-upstream], one thread.
 // ------------------------------------------------------------------------------------------
@@ -2163,177 +1722,6 @@ void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffer
     (void)ds;
     hipLaunchKernelGGL(k_lm_control, dim3(1), dim3(64), 0, s, db);
 }
-
-// ------------------------------------------------------------------------------------------
-// sharded mode: the slotted accumulators travel through one all-reduce(SUM) as a small scalar block.
-//   phase 0 (setup):  [0] ||x||^2  [1] focal column norm^2
-//   phase 1 (build):  [0] sum r^2  [1] bad linearisation  [2..5] focal-focal sums  [16 + rank] gradient max-norm
-//   phase 2 (update): [0] trial sum r^2  [1] model change  [2] step^2  [3] ||x_trial||^2  [4] bad trial
-// ------------------------------------------------------------------------------------------
-// scalars of one phase out of the slotted accumulators into the all-reduce block (called by all 64 lanes of ONE wave)
-__device__ __forceinline__ void shard_pack_scalars(const DeviceBuffers& db, double* scal, int phase, int rank) {
-    double v[6] = { 0, 0, 0, 0, 0, 0 };
-    double gmax = 0.0;
-    if (phase == 0) { v[0] = slots_take(db, ACC_XNEW2); v[1] = slots_take(db, ACC_UDF); }
-    else if (phase == 1) {
-        v[0] = slots_take(db, ACC_LIN_COST); v[1] = slots_take(db, ACC_BAD_LIN);
-        v[2] = slots_take(db, ACC_SFF); v[3] = slots_take(db, ACC_RHSF); v[4] = slots_take(db, ACC_UDF); v[5] = slots_take(db, ACC_BCF);
-        gmax = slots_take(db, ACC_GMAX);
-    } else {
-        v[0] = slots_take(db, ACC_TRIAL_COST); v[1] = slots_take(db, ACC_MODEL); v[2] = slots_take(db, ACC_STEP2);
-        v[3] = slots_take(db, ACC_XNEW2); v[4] = slots_take(db, ACC_BAD_TRIAL);
-    }
-    // every entry of the block is written exactly once (the sums are uniform over the wave: each lane picks its own)
-    for (int e = threadIdx.x & 63; e < SFMBA_SHARD_SCALARS; e += 64) {
-        double val = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) val = e == k ? v[k] : val;
-        if (phase == 1 && e == 16 + rank) val = gmax;
-        scal[e] = val;
-    }
-}
-// and back, summed over the ranks, into slot 0 (all slots are empty after the pack); one thread
-__device__ __forceinline__ void shard_unpack_scalars(const DeviceBuffers& db, const double* scal, int phase, int world) {
-    double* s0 = db.slots;
-    if (phase == 0) { s0[ACC_XNEW2] = scal[0]; s0[ACC_UDF] = scal[1]; }
-    else if (phase == 1) {
-        s0[ACC_LIN_COST] = scal[0]; s0[ACC_BAD_LIN] = scal[1];
-        s0[ACC_SFF] = scal[2]; s0[ACC_RHSF] = scal[3]; s0[ACC_UDF] = scal[4]; s0[ACC_BCF] = scal[5];
-        double g = 0.0;
-        for (int r = 0; r < world; ++r) { const double v = scal[16 + r]; g = (v > g || v != v) ? v : g; }
-        reinterpret_cast<unsigned long long*>(s0)[ACC_GMAX] = (unsigned long long)__double_as_longlong(g);
-    } else {
-        s0[ACC_TRIAL_COST] = scal[0]; s0[ACC_MODEL] = scal[1]; s0[ACC_STEP2] = scal[2]; s0[ACC_XNEW2] = scal[3]; s0[ACC_BAD_TRIAL] = scal[4];
-    }
-}
-
-__global__ void k_shard_pack(DeviceBuffers db, double* scal, int phase, int rank) { shard_pack_scalars(db, scal, phase, rank); }
-
-__global__ void k_shard_unpack(DeviceBuffers db, const double* scal, int phase, int world) {
-    if (threadIdx.x != 0) return;
-    shard_unpack_scalars(db, scal, phase, world);
-}
-
-// Sharded mode with the CG solver: TWO all-reduces per linearisation instead of one over the whole reduced system.
-//   (A) what the block-Jacobi factors and the LM bookkeeping need -- the 6x6 diagonal blocks, the camera-focal column, right-hand
-//       side, undamped diagonal, gradient, scalars (27 ncam + 3 ld + 80 doubles);
-//   (B) with the factors known on every rank, the off-diagonal blocks of the PRECONDITIONED matrix: S~ = Linv S Linv^T is linear in
-//       S, so every rank transforms its own partial blocks in the pair pass -- exactly what the one-GPU path does -- and the sum over
-//       the ranks is S~ (18 ncam (ncam - 1) doubles, as much as the packed triangle of S carried).
-// The transform, the block factorisation and the gauge vectors then cost what they cost on one GPU (fused into k_finalize and the
-// pair pass) instead of three more kernels over the reduced system behind the all-reduce.
-// Layout A: [ncam][21] upper triangles of the diagonal blocks | [ncam][6] S_jf | rhs[ld] udiag[ld] bc[ld] | scalars
-__global__ __launch_bounds__(256) void k_shard_diag(DeviceStructure ds, DeviceBuffers db, double* __restrict__ buf, int unpack, int rank, int world) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nc = ds.ncam, ld = ds.ld, fo = ds.d - 1;
-    const long long n_tri = 21ll * nc, n_f = 6ll * nc, n_tail = 3ll * ld;
-    double* scal = buf + n_tri + n_f + n_tail;
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        if (!unpack) shard_pack_scalars(db, scal, 1, rank);
-        else if (threadIdx.x == 0) shard_unpack_scalars(db, scal, 1, world);
-    }
-    if (e < n_tri) {
-        const int j = (int)(e / 21), u = (int)(e - 21ll * j);
-        int r = 0, off = u;                          // u-th entry of the row-major upper triangle of a 6 x 6 block
-        while (off >= 6 - r) { off -= 6 - r; ++r; }
-        double* sp = db.S + (size_t)(6 * j + r) * ld + 6 * j + r + off;
-        if (unpack) *sp = buf[e]; else buf[e] = *sp;
-    } else if (e < n_tri + n_f) {
-        const long long k = e - n_tri;
-        double* sp = db.S + (size_t)k * ld + fo;     // row 6 j + a, focal column
-        if (unpack) *sp = buf[e]; else buf[e] = *sp;
-    } else if (e < n_tri + n_f + n_tail) {
-        const long long k = e - n_tri - n_f;         // rhs | udiag | bc are contiguous
-        if (unpack) db.rhs[k] = buf[e]; else buf[e] = db.rhs[k];
-    }
-}
-long long shard_diag_len(const DeviceStructure& ds) { return 27ll * ds.ncam + 3ll * ds.ld + SFMBA_SHARD_SCALARS; }
-void launch_shard_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, double* buf, bool unpack, int rank, int world) {
-    const long long n = 27ll * ds.ncam + 3ll * ds.ld;
-    hipLaunchKernelGGL(k_shard_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, db, buf, unpack ? 1 : 0, rank, world);
-}
-
-// Layout B: the 36 entries of every off-diagonal block (ja < jb) of the preconditioned matrix, blocks in list order.  Unpacking
-// writes both triangles of the CG's matrix.
-__global__ __launch_bounds__(256) void k_shard_offdiag(DeviceStructure ds, double* __restrict__ F, double* __restrict__ buf, int unpack) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = (int)(t / 36), e = (int)(t - 36ll * b);
-    if (b >= ds.nblock) return;
-    const int2 cj = ds.blk_cams[b];
-    if (cj.x == cj.y) return;
-    const int r = e / 6, c = e - 6 * r;
-    const size_t o = (size_t)(b - cj.x - 1) * 36 + e;        // block row ja holds ja + 1 diagonal blocks up to and including its own
-    const size_t up = (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, lo = (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r;
-    if (unpack) { const double v = buf[o]; F[up] = v; F[lo] = v; }
-    else buf[o] = F[up];
-}
-long long shard_offdiag_len(const DeviceStructure& ds) { return 36ll * (ds.nblock - ds.ncam); }
-void launch_shard_offdiag(hipStream_t s, const DeviceStructure& ds, double* F, double* buf, bool unpack) {
-    const long long n = 36ll * ds.nblock;
-    hipLaunchKernelGGL(k_shard_offdiag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, F, buf, unpack ? 1 : 0);
-}
-// the fp32 exchange: the summed blocks ARE the CG's (fp32) matrix entries
-__global__ __launch_bounds__(256) void k_shard_offdiag_f32(DeviceStructure ds, float* __restrict__ F, const float* __restrict__ buf) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = (int)(t / 36), e = (int)(t - 36ll * b);
-    if (b >= ds.nblock) return;
-    const int2 cj = ds.blk_cams[b];
-    if (cj.x == cj.y) return;
-    const int r = e / 6, c = e - 6 * r;
-    const float v = buf[(size_t)(b - cj.x - 1) * 36 + e];
-    F[(size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c] = v;
-    F[(size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r] = v;
-}
-void launch_shard_offdiag_f32(hipStream_t s, const DeviceStructure& ds, float* F32, const float* buf) {
-    const long long n = 36ll * ds.nblock;
-    hipLaunchKernelGGL(k_shard_offdiag_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, F32, buf);
-}
-__global__ void k_narrow_matrix(const double* __restrict__ src, float* __restrict__ dst, long long n) {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dst[e] = (float)src[e];
-}
-void launch_narrow_matrix(hipStream_t s, const double* src, float* dst, long long n) {
-    hipLaunchKernelGGL(k_narrow_matrix, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, src, dst, n);
-}
-
-__global__ void k_clear_slots(DeviceBuffers db) {
-    for (int e = 0; e < SLOT_W; ++e) (void)slots_take(db, e);
-    if (threadIdx.x == 0) *db.fin_counter = 0;
-}
-
-__global__ void k_shard_xnorm_finish(DeviceBuffers db) {
-    const double x2 = slots_take(db, ACC_XNEW2);
-    if (threadIdx.x == 0) db.st->x_norm = sqrt(x2);
-}
-
-// Sharded mode: the all-reduce carries only what is meaningful -- the upper triangle of S (row r: columns r .. ld-1, packed
-// row after row) followed by the tail [rhs | udiag | bc | scalars] -- i.e. ld (ld + 1) / 2 + 3 ld + 80 doubles instead of
-// ld^2 + ...: half the xGMI traffic per LM iteration (145 MB instead of 289 MB at 1000 cameras).
-__global__ __launch_bounds__(256) void k_shard_tri(double* __restrict__ sys, double* __restrict__ packed, int ld, long long tail, int unpack) {
-    const int r = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const long long ntri = (long long)ld * (ld + 1) / 2;
-    if (c >= r && c < ld) {
-        const long long o = (long long)r * ld - (long long)r * (r - 1) / 2 + (c - r);
-        if (unpack) sys[(size_t)r * ld + c] = packed[o]; else packed[o] = sys[(size_t)r * ld + c];
-    }
-    if (r == 0) {       // the tail is contiguous behind S in both layouts
-        for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tail; e += (long long)gridDim.x * blockDim.x) {
-            if (unpack) sys[(size_t)ld * ld + e] = packed[ntri + e]; else packed[ntri + e] = sys[(size_t)ld * ld + e];
-        }
-    }
-}
-void launch_shard_tri(hipStream_t s, double* sys, double* packed, int ld, long long tail, bool unpack) {
-    hipLaunchKernelGGL(k_shard_tri, dim3((ld + 255) / 256, ld), dim3(256), 0, s, sys, packed, ld, tail, unpack ? 1 : 0);
-}
-
-void launch_shard_pack(hipStream_t s, const DeviceBuffers& db, double* scal, int phase, int rank) {
-    hipLaunchKernelGGL(k_shard_pack, dim3(1), dim3(64), 0, s, db, scal, phase, rank);
-}
-void launch_shard_unpack(hipStream_t s, const DeviceBuffers& db, const double* scal, int phase, int world) {
-    hipLaunchKernelGGL(k_shard_unpack, dim3(1), dim3(64), 0, s, db, scal, phase, world);
-}
-void launch_clear_slots(hipStream_t s, const DeviceBuffers& db) { hipLaunchKernelGGL(k_clear_slots, dim3(1), dim3(64), 0, s, db); }
-void launch_shard_xnorm_finish(hipStream_t s, const DeviceBuffers& db) { hipLaunchKernelGGL(k_shard_xnorm_finish, dim3(1), dim3(64), 0, s, db); }
 
 // ------------------------------------------------------------------------------------------
 // kernel-level entry points used by the parity tests (C ABI: sfmba_problem_eval_*)

@@ -42,7 +42,7 @@ struct DcgSolveArgs {
     int* flags = nullptr;               // DenseSolver::flags: [0] done, [1] iterations, [2] x buffer (always 0 here)
     int* info = nullptr;                // linear-solver status word (set on breakdown)
     double tol = 1e-8; int anchor = 0; double cap = 1.0;
-    // non-null: the product is formed IMPLICITLY from the rank's own points (ba_kernels.hip, "Implicit Schur product") -- no block of S~
+    // non-null: the product is formed IMPLICITLY from the rank's own points (implicit_schur.hip) -- no block of S~
     // exists anywhere, `owned` is ignored and nothing of the reduced matrix was exchanged (options.shard_distributed_cg = 2)
     const ImplicitProduct* implicit = nullptr;
 };

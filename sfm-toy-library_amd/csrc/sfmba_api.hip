@@ -1646,7 +1646,7 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         // the CG without the redundant solve (dist_cg.h): reduce-scatter of the blocks, products from the owned blocks, one small
         // all-reduce per CG iteration
         // ... or WITHOUT any exchange of the reduced matrix (shard_distributed_cg = 2 / SFMBA_SHARD_DIST_CG=2): the product of a CG iteration is
-        // formed implicitly from every rank's own points (ba_kernels.hip, "Implicit Schur product"); duplicates live in diagonal blocks the
+        // formed implicitly from every rank's own points (implicit_schur.hip); duplicates live in diagonal blocks the
         // implicit form does not see: such a problem takes the explicit distributed form
         int dist_mode = o.shard_distributed_cg > 0 ? o.shard_distributed_cg : 0;
         if (const char* e = std::getenv("SFMBA_SHARD_DIST_CG")) dist_mode = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
