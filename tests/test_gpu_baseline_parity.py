@@ -4,7 +4,7 @@
          1e-8 tolerance (the library default the bench passes), and in the reference's own DENSE_SCHUR-equivalent mode
   cfg 4  all eight 25-camera sub-problems
   cfg 5  a cfg-5-SHAPED problem the oracle can afford: 1000 cameras (reduced dimension 6001, the real one) with 20k points
-         -- sixteen-lane pair pass (k_schur_pairs_sub), streaming CG, preconditioned matrix stored in fp32
+         -- sixteen-lane pair pass (k_schur_pairs_sub_f), streaming CG, preconditioned matrix stored in fp32
 
 Every case: same termination, same number of LM iterations, same accept/reject sequence, final cost within 1e-6 relative,
 final RMS reprojection error within the 1e-4 px bar of BASELINE.json, per-iteration cost within 1e-6 relative in fp64 mode.

@@ -18,7 +18,7 @@ CASES = {
     "small": (dict(name="small"), 0, 0, dict()),
     "cfg2": (dict(name="cfg2"), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
     # 230 cameras: reduced dimension 1381 > 1280 -> streaming CG (fp32-stored matrix in F32J mode); ~10 pairs per 6x6
-    # block -> the sixteen-lane pair pass k_schur_pairs_sub; sharded ranks transform the all-reduced system (k_pcg_transform)
+    # block -> the sixteen-lane pair pass k_schur_pairs_sub_f; sharded ranks transform the all-reduced system (k_pcg_transform)
     "wide": (dict(name="cfg3", n_cam=230, n_pt=6000, seed=77), 1, 1, dict()),
     # point counts that no world size of 2, 3 or 4 divides (5003 is prime, 6001 = 17 * 353): ranks hold shards of different sizes
     "cfg2_uneven": (dict(name="cfg2", n_pt=5003), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
