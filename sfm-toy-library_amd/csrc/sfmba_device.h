@@ -321,39 +321,22 @@ __device__ __forceinline__ void load_cam_g(const double* __restrict__ tab, int j
     for (int k = 0; k < 9; ++k) c.vt[k] = to_uniform((T)c.v[k]);
     c.small = tab[cam_tab_index(CT_SMALL, j_uniform, ncam)];
 }
-// The same row held PER LANE (vector registers): the small-block pair pass (k_schur_pairs_sub_f) gives every group of 16 lanes its own
-// column camera, so only the row camera of the wave can sit in scalar registers.
 template <typename T>
-struct CamGL {
-    double v[CT_K];          // R, t; (T) R is converted where it is used (nine registers fewer than a converted copy per lane)
-    bool small;
-};
-template <typename T>
-__device__ __forceinline__ void load_cam_gl(const double* __restrict__ tab, int j, int ncam, CamGL<T>& c) {
-#pragma unroll
-    for (int k = 0; k < CT_K; ++k) c.v[k] = tab[cam_tab_index(k, j, ncam)];
-    c.small = tab[cam_tab_index(CT_SMALL, j, ncam)] != 0.0;
-}
-template <typename T> __device__ __forceinline__ T cam_rot(const CamG<T>& c, int k) { return c.vt[k]; }
-template <typename T> __device__ __forceinline__ T cam_rot(const CamGL<T>& c, int k) { return (T)c.v[k]; }
-template <typename T> __device__ __forceinline__ bool cam_first_order(const CamG<T>& c) { return c.small != 0.0; }
-template <typename T> __device__ __forceinline__ bool cam_first_order(const CamGL<T>& c) { return c.small; }
-template <typename T, typename Cam>
-__device__ __forceinline__ void obs_factored(const Cam& cam, double focal, const double X[3], const T L[6], T g[GREC]) {
+__device__ __forceinline__ void obs_factored(const CamG<T>& cam, double focal, const double X[3], const T L[6], T g[GREC]) {
     const double rx = cam.v[CT_R + 0] * X[0] + cam.v[CT_R + 1] * X[1] + cam.v[CT_R + 2] * X[2];
     const double ry = cam.v[CT_R + 3] * X[0] + cam.v[CT_R + 4] * X[1] + cam.v[CT_R + 5] * X[2];
     const double rz = cam.v[CT_R + 6] * X[0] + cam.v[CT_R + 7] * X[1] + cam.v[CT_R + 8] * X[2];
     const double iz = fast_rcp(rz + cam.v[CT_T + 2]);
     const double xpd = (rx + cam.v[CT_T + 0]) * iz, ypd = (ry + cam.v[CT_T + 1]) * iz;
-    const bool first_order = cam_first_order(cam);        // (wave-uniform for a CamG)
+    const bool first_order = cam.small != 0.0;           // wave-uniform
     g[0] = (T)(first_order ? X[0] : rx); g[1] = (T)(first_order ? X[1] : ry); g[2] = (T)(first_order ? X[2] : rz);
     const T fz = (T)(focal * iz), xp = (T)xpd, yp = (T)ypd;
     g[3] = fz; g[4] = xp; g[5] = yp;
     T B[6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {                          // B = P R, the expressions of point_block
-        B[c] = fz * (cam_rot<T>(cam, c) - xp * cam_rot<T>(cam, 6 + c));
-        B[3 + c] = fz * (cam_rot<T>(cam, 3 + c) - yp * cam_rot<T>(cam, 6 + c));
+        B[c] = fz * (cam.vt[c] - xp * cam.vt[6 + c]);
+        B[3 + c] = fz * (cam.vt[3 + c] - yp * cam.vt[6 + c]);
     }
     const T l00 = L[0], l10 = L[1], l11 = L[2], l20 = L[3], l21 = L[4], l22 = L[5];
 #pragma unroll
