@@ -183,6 +183,7 @@ def main():
     if args.mode == "sharded":
         return main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear)
     sub = rank if world > 1 else None
+    globals()["PMC_WORKLOAD"] = args.workload
     prob = sfm.make_problem(args.workload, sub=sub)
     P = capi.Problem(prob, precision=precision, device=local_rank)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol)
@@ -480,6 +481,7 @@ PMC_KERNEL_NAMES = {"pcg_iter": "k_pcg_iter_fast", "schur_pairs": "k_schur_pairs
                     "chol_update": "k_chol_update"}
 
 
+PMC_WORKLOAD = "cfg3"  # set from --workload in main(): which committed summary the static fallback may read
 LIVE_PMC = None      # {kernel name as rocprofv3 prints it: (FETCH_SIZE KB, WRITE_SIZE KB) per launch}, filled by live_pmc_passes()
 
 
@@ -544,7 +546,8 @@ def pmc_traffic(kernel):
             # several instantiations of one kernel (k_schur_pairs<..., MODE, ...>): the one that moves the most is the per-iteration pass
             f, w = max(hits, key=lambda v: v[0] + v[1])
             return entry(f, w, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run (%.0f s)" % LIVE_PMC["seconds"], True)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.txt")))
+    # the committed summary must be of the SAME workload (r04_d_cfg3_pcg_pmc_traffic.txt / r04_d_cfg5_...): anything else is not this kernel's traffic
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pcg_pmc_traffic.txt" % PMC_WORKLOAD)))
     if not files:
         return None
     for line in open(files[-1]):
