@@ -1483,6 +1483,444 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_fast(int d, int ld, const do
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Segmented coarse space (d <= 1280): the gauge vectors restricted to SEGMENTS of the camera order.
+//
+// A reduced matrix that is sparsely filled is a camera graph of large diameter -- views along a path, tracks shared by neighbouring
+// cameras (what SfM.cpp:366-469 builds).  Block-Jacobi CG then needs hundreds of iterations, and the eight GLOBAL gauge vectors remove
+// only the eight smallest eigenvalues: the next few dozen are similarity transforms of PIECES of the path against each other
+// (tools/coarse_space_study.py on cfg3_banded: 187 iterations with block-Jacobi alone, 117 with the 8 global vectors, 33 with the seven
+// similarity vectors multiplied by eight hat functions along the cyclic camera order + the global focal/depth vector).  That coarse space,
+// 7 G + 1 = 57 vectors, is what this path uses.  Nothing new is stored per vector: with workgroup j = camera j (six rows; the last
+// workgroup = the focal row) and the hats a partition of unity with two non-zero hats per camera,
+//      W~_(g,k) = hat_g(camera) * W~_k        (W~_k: the 8 vectors k_finalize writes)
+//      W~_(g,k)^T q = sum_j hat_g(j) t_k(j),  t_k(j) = sum over camera j's rows of W~_k[row] q[row]
+// so a workgroup still publishes NINE partial sums per iteration (p_r . q and t_0 .. t_7) exactly like the 8-vector path; what changes is
+// how the next launch adds them up (per hat instead of over all workgroups), that the coarse state c, mu, p_mu (57 each) lives one entry
+// per lane in every wave, and that E^-1 is 57 x 57: each wave forms a quarter of E^-1 g, one LDS exchange completes it.
+// Set-up per linear solve: k_ml_aw (AW = S~ W~ for the 57 vectors, per-camera pieces of E and c_0), k_ml_e (E, c_0 summed per hat),
+// k_ml_invert (Jacobi-scaled Gauss-Jordan in one workgroup, 57 pivot steps with one barrier each; a vanishing pivot drops its vector).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ML_G = 8;                    // hat functions along the (cyclic) camera order
+constexpr int ML_NC = 7 * ML_G + 1;        // coarse vectors: (g, k) -> 7 g + k, the global focal/depth vector last
+constexpr int ML_N = 64;                   // padded: one coarse entry per lane
+constexpr int ML_MIN_CAMS = 4 * ML_G;      // below this the hats have too few cameras each: the 8-vector path
+constexpr int ML_LDS_TAIL = 96 + 7 * 256 + 2 * 4 * ML_N;     // doubles of LDS behind the search direction: red | tmp | gq | egq
+
+// cameras whose LOWER hat is a: [ml_first_cam(a), ml_first_cam(a + 1)); camera j there has weight 1 - frac in hat a and frac in hat
+// (a + 1) mod G, frac = (j G - a nc) / nc -- ONE formula for every place that needs a hat weight
+__device__ __forceinline__ int ml_first_cam(int a, int nc) { return (a * nc + ML_G - 1) / ML_G; }
+__device__ __forceinline__ double ml_frac(int j, int a, int nc, double inv_nc) { return (double)(j * ML_G - a * nc) * inv_nc; }
+
+// sum over the cameras of hat g of weight * f(camera): the two ranges (which_range 0: cameras whose lower hat is g - 1, weight frac; 1: lower hat
+// g, weight 1 - frac); `part` of `nparts` equal slices of the range.  Fixed order: deterministic.  MAXT bounds the terms of one slice: all of them
+// are fetched before the first is used (clamped, branch-free -- a loop of load / use pairs pays one memory round trip per term).
+template <int MAXT, typename Fn>
+__device__ __forceinline__ double ml_hat_sum(int g, int nc, double inv_nc, int which_range, int part, int nparts, Fn f) {
+    const int a = which_range == 0 ? (g + ML_G - 1) % ML_G : g;
+    const int lo = ml_first_cam(a, nc), hi = ml_first_cam(a + 1, nc);
+    const int len = hi - lo, chunk = (len + nparts - 1) / nparts;
+    const int j0 = lo + part * chunk, j1 = min(hi, j0 + chunk);
+    double s = 0.0;
+    for (int jb = j0; jb < j1; jb += MAXT) {
+        double val[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) val[t] = f(jb + t < j1 ? jb + t : j1 - 1);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const double fr = ml_frac(jb + t, a, nc, inv_nc);
+            s = fma(jb + t < j1 ? (which_range == 0 ? fr : 1.0 - fr) : 0.0, val[t], s);
+        }
+    }
+    return s;
+}
+
+// AW[row][64] = S~ W~ for the 57 vectors (own rows), V[wg][8][64] = sum over own rows of W~_k[row] AW[row][:], u[wg][8] = sum over own rows
+// of W~_k[row] b~[row].  Workgroup = camera (last: the focal row).  The camera's six rows of S~ and W~_0..7 (fp32: lossless) go to LDS in one
+// round trip; lane (g, k) of a wave then walks the cameras of hat g for the wave's two rows.
+constexpr int ML_ROWLEN = 64 * PCG_CPL;
+constexpr size_t ML_AW_LDS = sizeof(double) * 6 * ML_ROWLEN + sizeof(float) * PCG_NW * ML_ROWLEN + sizeof(double) * 4 * PCG_NW * ML_N;
+__global__ __launch_bounds__(256) void k_ml_aw(int d, int ld, const double* __restrict__ F, const double* __restrict__ W, const double* __restrict__ bt,
+                                               double* __restrict__ AW, double* __restrict__ V, double* __restrict__ U) {
+    extern __shared__ __align__(16) double sm[];
+    double* rows = sm;                                                   // [6][ML_ROWLEN]
+    float* wt = reinterpret_cast<float*>(rows + 6 * ML_ROWLEN);          // [8][ML_ROWLEN]
+    double* vbuf = reinterpret_cast<double*>(wt + PCG_NW * ML_ROWLEN);   // [4][8][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nc = (d - 1) / 6;
+    const double inv_nc = 1.0 / (double)nc;
+    const int row0 = 6 * blockIdx.x, row1 = min(d, row0 + 6);
+    {
+        double2 rv[6][3];
+        double wv[PCG_NW][PCG_EPT];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int c2 = tid + 256 * m;
+                const bool ok = row0 + r < row1 && 2 * c2 < d;
+                rv[r][m] = reinterpret_cast<const double2*>(F + (size_t)(row0 + r < row1 ? row0 + r : row0) * ld)[ok ? c2 : 0];
+                if (!ok) rv[r][m] = make_double2(0.0, 0.0);
+                if (2 * c2 + 1 >= d) rv[r][m].y = 0.0;
+            }
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k)
+#pragma unroll
+            for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; wv[k][m] = W[(size_t)k * ld + (e < d ? e : 0)]; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { const int c2 = tid + 256 * m; if (2 * c2 < ML_ROWLEN) reinterpret_cast<double2*>(rows + r * ML_ROWLEN)[c2] = rv[r][m]; }
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k)
+#pragma unroll
+            for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; wt[k * ML_ROWLEN + e] = e < d ? (float)wv[k][m] : 0.0f; }
+    }
+    __syncthreads();
+    const int g = lane / 7, k = lane - 7 * g;        // lanes 0..55: vector (g, k); lane 56: the global vector; beyond: nothing
+    const int ra = w, rb = w + 4;                    // this wave's rows (of the camera's six)
+    const bool have_a = row0 + ra < row1, have_b = row0 + rb < row1;
+    double awa = 0.0, awb = 0.0;
+    if (lane < 7 * ML_G) {
+        const float* wk = wt + k * ML_ROWLEN;
+        const double* Ra = rows + ra * ML_ROWLEN;
+        const double* Rb = rows + (have_b ? rb : ra) * ML_ROWLEN;
+        for (int range = 0; range < 2; ++range) {
+            const int a = range == 0 ? (g + ML_G - 1) % ML_G : g;
+            const int lo = ml_first_cam(a, nc), hi = ml_first_cam(a + 1, nc);
+            for (int j = lo; j < hi; ++j) {
+                const double fr = ml_frac(j, a, nc, inv_nc);
+                const double wgt = range == 0 ? fr : 1.0 - fr;
+                const float2 w01 = reinterpret_cast<const float2*>(wk + 6 * j)[0], w23 = reinterpret_cast<const float2*>(wk + 6 * j)[1], w45 = reinterpret_cast<const float2*>(wk + 6 * j)[2];
+                const double2 a0 = reinterpret_cast<const double2*>(Ra + 6 * j)[0], a1 = reinterpret_cast<const double2*>(Ra + 6 * j)[1], a2 = reinterpret_cast<const double2*>(Ra + 6 * j)[2];
+                const double2 b0 = reinterpret_cast<const double2*>(Rb + 6 * j)[0], b1 = reinterpret_cast<const double2*>(Rb + 6 * j)[1], b2 = reinterpret_cast<const double2*>(Rb + 6 * j)[2];
+                const double ta = fma(a0.x, (double)w01.x, fma(a0.y, (double)w01.y, fma(a1.x, (double)w23.x, fma(a1.y, (double)w23.y, fma(a2.x, (double)w45.x, a2.y * (double)w45.y)))));
+                const double tb = fma(b0.x, (double)w01.x, fma(b0.y, (double)w01.y, fma(b1.x, (double)w23.x, fma(b1.y, (double)w23.y, fma(b2.x, (double)w45.x, b2.y * (double)w45.y)))));
+                awa = fma(wgt, ta, awa);
+                awb = fma(wgt, tb, awb);
+            }
+        }
+    }
+    {   // the global vector: all d columns, the lanes stride them
+        double sa = 0.0, sb = 0.0;
+        const float* w7 = wt + (PCG_NW - 1) * ML_ROWLEN;
+        for (int c = lane; c < d; c += 64) { sa = fma(rows[ra * ML_ROWLEN + c], (double)w7[c], sa); sb = fma(rows[(have_b ? rb : ra) * ML_ROWLEN + c], (double)w7[c], sb); }
+        sa = wave_allsum(sa); sb = wave_allsum(sb);
+        if (lane == ML_NC - 1) { awa = sa; awb = sb; }
+    }
+    if (!have_a) awa = 0.0;
+    if (!have_b) awb = 0.0;
+    if (have_a) AW[(size_t)(row0 + ra) * ML_N + lane] = awa;
+    if (have_b) AW[(size_t)(row0 + rb) * ML_N + lane] = awb;
+#pragma unroll
+    for (int q = 0; q < PCG_NW; ++q) {
+        const double wa = have_a ? (double)wt[q * ML_ROWLEN + row0 + ra] : 0.0, wb = have_b ? (double)wt[q * ML_ROWLEN + row0 + rb] : 0.0;
+        vbuf[(w * PCG_NW + q) * ML_N + lane] = fma(wa, awa, wb * awb);
+    }
+    __syncthreads();
+    for (int e = tid; e < PCG_NW * ML_N; e += 256)
+        V[(size_t)blockIdx.x * PCG_NW * ML_N + e] = (vbuf[e] + vbuf[PCG_NW * ML_N + e]) + (vbuf[2 * PCG_NW * ML_N + e] + vbuf[3 * PCG_NW * ML_N + e]);
+    if (tid < PCG_NW) {
+        double s = 0.0;
+        for (int row = row0; row < row1; ++row) s = fma((double)wt[tid * ML_ROWLEN + row], bt[row], s);
+        U[(size_t)blockIdx.x * PCG_NW + tid] = s;
+    }
+}
+
+// E[i][:] and c_0[i]: row i = (g, k) is the hat-weighted sum of the cameras' pieces k; the last row the plain sum of piece 7 over all workgroups.
+// One workgroup per row, lane = column, the terms split over the four waves.
+__global__ __launch_bounds__(256) void k_ml_e(int d, const double* __restrict__ V, const double* __restrict__ U, double* __restrict__ E, double* __restrict__ c0) {
+    __shared__ double eq[4][ML_N], cq[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nc = (d - 1) / 6;
+    const double inv_nc = 1.0 / (double)nc;
+    double e = 0.0, c = 0.0;
+    if (i < 7 * ML_G) {
+        const int g = i / 7, k = i - 7 * g;
+        e = ml_hat_sum<16>(g, nc, inv_nc, w >> 1, w & 1, 2, [&](int j) { return V[((size_t)j * PCG_NW + k) * ML_N + lane]; });
+        c = ml_hat_sum<16>(g, nc, inv_nc, w >> 1, w & 1, 2, [&](int j) { return U[(size_t)j * PCG_NW + k]; });
+    } else {
+        for (int jb = w; jb <= nc; jb += 64) {          // wave w: workgroups w, w + 4, ...; sixteen loads in flight
+            double ve[16], vc[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = jb + 4 * t, jc = j <= nc ? j : nc;
+                ve[t] = V[((size_t)jc * PCG_NW + (PCG_NW - 1)) * ML_N + lane]; vc[t] = U[(size_t)jc * PCG_NW + (PCG_NW - 1)];
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const bool ok = jb + 4 * t <= nc; e += ok ? ve[t] : 0.0; c += ok ? vc[t] : 0.0; }
+        }
+    }
+    eq[w][lane] = e;
+    if (lane == 0) cq[w] = c;
+    __syncthreads();
+    if (tid < ML_N) E[(size_t)i * ML_N + tid] = (eq[0][tid] + eq[1][tid]) + (eq[2][tid] + eq[3][tid]);
+    if (tid == 0) c0[i] = (cq[0] + cq[1]) + (cq[2] + cq[3]);
+}
+
+// E^-1 (64 x 64, rows / columns beyond the 57 vectors and of dropped vectors zero): Jacobi scaling, then an in-place Gauss-Jordan sweep without
+// pivot search (E is symmetric positive definite).  Thread (row i = tid / 4, columns 16 (tid % 4) .. + 15) keeps its sixteen entries in registers;
+// per pivot p the row p and the column p go through LDS (double-buffered: one barrier per step).  The steps are unrolled sixteen at a time (the
+// register that holds column p is then a compile-time index) and that body runs four times: 57 unrolled steps do not fit the instruction cache
+// (measured: 74 us against ~15).  A pivot below 1e-10 of the unit diagonal means the vector depends on the earlier ones: its step is skipped and
+// its row and column of the result are zero.
+__global__ __launch_bounds__(256) void k_ml_invert(const double* __restrict__ E, double* __restrict__ einv, double* __restrict__ c0) {
+    __shared__ __align__(16) double rowbuf[2][ML_N];
+    __shared__ double colbuf[2][ML_N], sc[ML_N];
+    const int tid = threadIdx.x, i = tid >> 2, qd = tid & 3;
+    double ev[16], et[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { const int j = 16 * qd + c; ev[c] = E[(size_t)i * ML_N + j]; et[c] = E[(size_t)j * ML_N + i]; }
+    if (tid < ML_N) {
+        const double dii = tid < ML_NC ? E[(size_t)tid * ML_N + tid] : 0.0;
+        sc[tid] = (dii > 0.0 && dii <= 1.7e308) ? 1.0 / sqrt(dii) : 0.0;
+        if (tid >= ML_NC) c0[tid] = 0.0;
+    }
+    __syncthreads();
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = 16 * qd + c;
+        const bool in = i < ML_NC && j < ML_NC;
+        const double v = in ? 0.5 * (ev[c] + et[c]) * sc[i] * sc[j] : 0.0;
+        a[c] = (i == j) ? 1.0 : v;
+    }
+    unsigned long long dropped = 0ull;
+    for (int t = 0; t < ML_N; ++t) if (!(sc[t] > 0.0)) dropped |= 1ull << t;
+    for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int p = 16 * qq + c;
+            if (p >= ML_NC) break;
+            const int par = c & 1;
+            if (i == p) {
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) rowbuf[par][16 * qd + cc] = a[cc];
+            }
+            if (qd == qq) colbuf[par][i] = a[c];
+            __syncthreads();
+            const double piv = rowbuf[par][p];
+            const bool ok = !((dropped >> p) & 1ull) && piv > 1e-10;
+            if (!ok) { dropped |= 1ull << p; continue; }
+            const double ip = fast_rcp(piv);
+            const double f = colbuf[par][i] * ip;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const int j = 16 * qd + cc;
+                const double rp = rowbuf[par][j];
+                if (i == p) a[cc] = (j == p) ? ip : rp * ip;
+                else a[cc] = (j == p) ? -f : fma(-f, rp, a[cc]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = 16 * qd + c;
+        const bool gone = ((dropped >> i) & 1ull) || ((dropped >> j) & 1ull);
+        einv[(size_t)i * ML_N + j] = gone ? 0.0 : a[c] * sc[i] * sc[j];
+    }
+}
+
+// One CG iteration with the segmented coarse space: k_pcg_iter_fast's structure (every global load issued up front, one memory round trip per
+// launch), workgroup = camera.  LDS behind the search direction: red[96] | tmp[7][256] (the partials t_0..t_6 of every workgroup) |
+// gq[4][64] (quarter sums of W~^T q per wave) | egq[4][64] (quarter products of E^-1 g per wave).
+template <bool INIT>
+__global__ __launch_bounds__(256) void k_pcg_iter_ml(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
+                                                     const double* __restrict__ bt, double* __restrict__ part, double* __restrict__ scal,
+                                                     int* flags, double tol2, int in, int* info, int* mailbox, int anchor, double cap,
+                                                     const double* __restrict__ W, const double* __restrict__ AW, const double* __restrict__ einv,
+                                                     const double* __restrict__ c0, double* __restrict__ mlstate) {
+    extern __shared__ __align__(16) double sm[];
+    double* pl = sm;
+    double* red = sm + ld;
+    double* tmp = red + 96;
+    double* gq = tmp + 7 * 256;
+    double* egq = gq + 4 * ML_N;
+    const int seq = in >> 1;
+    in &= 1;
+    if (!INIT) { const int dn = flags[PF_DONE]; if (dn != 0 && seq >= dn) return; }
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), out = in ^ 1;
+    const int nc = (d - 1) / 6, nwg = (int)gridDim.x;
+    const double inv_nc = 1.0 / (double)nc;
+    const int row0 = 6 * blockIdx.x, row1 = min(d, row0 + 6);
+    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = INIT ? bt : pcg_vec(vec, 1, in, ld);
+    const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
+    double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld);
+    double* p_out = pcg_vec(vec, 2, out, ld); double* q_out = pcg_vec(vec, 3, out, ld);
+    const double* st_in = scal + PS_STATE + PS_STATE_LEN * in;
+    double* st_out = scal + PS_STATE + PS_STATE_LEN * out;
+    const double* ms_in = mlstate + 3 * ML_N * in;
+    double* ms_out = mlstate + 3 * ML_N * out;
+
+    // ---- all global loads of this iteration ----
+    double rv[PCG_EPT], qv[PCG_EPT], pv[PCG_EPT];
+#pragma unroll
+    for (int m = 0; m < PCG_EPT; ++m) {
+        const int e = tid + 256 * m;
+        const bool ok = e < d;
+        rv[m] = ok ? r_in[e] : 0.0; qv[m] = (ok && !INIT) ? q_in[e] : 0.0; pv[m] = (ok && !INIT) ? p_in[e] : 0.0;
+    }
+    double pp[PCG_NPART];                          // the nine partial sums workgroup `tid` published (clamped, branch-free)
+#pragma unroll
+    for (int v = 0; v < PCG_NPART; ++v) {
+        const double t = INIT ? 0.0 : pcg_part(part, in, v)[tid < nwg ? tid : nwg - 1];
+        pp[v] = tid < nwg ? t : 0.0;
+    }
+    double em[16];                                 // E^-1[16 w + jj][lane] (symmetric: = row `lane`, this wave's quarter of the columns)
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) em[jj] = einv[(size_t)(16 * w + jj) * ML_N + lane];
+    const double c_in = INIT ? c0[lane] : ms_in[lane];
+    const double mu_in = INIT ? 0.0 : ms_in[ML_N + lane];
+    const double pmu_in = INIT ? 0.0 : ms_in[2 * ML_N + lane];
+    const double rr0 = INIT ? 0.0 : scal[PS_RR0];
+    const double rz_in = INIT ? 0.0 : st_in[PS_RZ];
+    const int eo = row0 + (tid - 192);
+    const bool own = tid >= 192 && eo < row1;
+    double xo = 0.0, po = 0.0, ro = 0.0, qo = 0.0, wo[PCG_NW];
+    if (own) { ro = r_in[eo]; if (!INIT) { xo = x_in[eo]; po = p_in[eo]; qo = q_in[eo]; } }
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) wo[k] = (own && !INIT) ? W[(size_t)k * ld + eo] : 0.0;
+    double2 fv[PCG_RPW][PCG_CPL / 2];
+    double awv[PCG_RPW], wg8[PCG_RPW];             // AW[row][lane]; W~_(lane & 7)[row]
+#pragma unroll
+    for (int k = 0; k < PCG_RPW; ++k) {
+        const int row = row0 + w + 4 * k;
+        const bool have = row < row1;
+        const double2* Fr = reinterpret_cast<const double2*>(F + (size_t)(have ? row : row0) * ld);
+#pragma unroll
+        for (int m = 0; m < PCG_CPL / 2; ++m) {
+            const int c2 = lane + 64 * m;
+            double2 v = make_double2(0.0, 0.0);
+            if (have && 2 * c2 < d) v = Fr[c2];
+            if (2 * c2 + 1 >= d) v.y = 0.0;
+            fv[k][m] = v;
+        }
+        awv[k] = have ? AW[(size_t)row * ML_N + lane] : 0.0;
+        wg8[k] = have ? W[(size_t)(lane & 7) * ld + row] : 0.0;
+    }
+    double c_new, mu_new, pmu_new, rz_new;
+    if (INIT) {
+        // x0 = 0, r0 = b~, c0 = W~^T b~ (k_ml_e), mu0 = E^-1 c0, z0 = r0 + W~ mu0, p0 = z0
+        double rr = 0.0;
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) rr += rv[m] * rv[m];
+        rr = wave_allsum(rr);
+        if (lane == 0) red[16 + w] = rr;
+        double e = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) e = fma(em[jj], lane_bcast(c_in, 16 * w + jj), e);
+        egq[w * ML_N + lane] = e;
+        __syncthreads();
+        rr = red[16] + red[17] + red[18] + red[19];
+        c_new = c_in;
+        mu_new = (egq[lane] + egq[ML_N + lane]) + (egq[2 * ML_N + lane] + egq[3 * ML_N + lane]);
+        rz_new = rr + wave_allsum(c_new * mu_new);
+        pmu_new = mu_new;
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { const int e2 = tid + 256 * m; if (e2 < d) pl[e2] = rv[m]; }
+        if (own) { x_out[eo] = 0.0; r_out[eo] = ro; p_out[eo] = ro; }
+        if (blockIdx.x == 0 && tid == 0) {
+            scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
+            if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
+        }
+    } else {
+        // ---- p_r . q and t_7 over all workgroups (registers), t_0..t_6 per hat (through LDS) ----
+#pragma unroll
+        for (int v = 1; v < PCG_NW; ++v) tmp[(v - 1) * 256 + tid] = pp[v];
+        {
+            const double a = wave_allsum(pp[0]), b = wave_allsum(pp[PCG_NW]);
+            if (lane == 0) { red[w] = a; red[4 + w] = b; }
+        }
+        __syncthreads();
+        {
+            // wave 0, 1: the two halves of the hat's lower range (cameras whose lower hat is g - 1); wave 2, 3: of its upper range
+            double s = 0.0;
+            if (lane < 7 * ML_G) {
+                const int g = lane / 7, k = lane - 7 * g;
+                const double* tk = tmp + k * 256;
+                s = ml_hat_sum<8>(g, nc, inv_nc, w >> 1, w & 1, 2, [&](int j) { return tk[j]; });
+            }
+            gq[w * ML_N + lane] = s;
+        }
+        __syncthreads();
+        double g = (gq[lane] + gq[ML_N + lane]) + (gq[2 * ML_N + lane] + gq[3 * ML_N + lane]);
+        if (lane == ML_NC - 1) g = (red[4] + red[5]) + (red[6] + red[7]);
+        const double pq = (red[0] + red[1]) + (red[2] + red[3]) + wave_allsum(pmu_in * g);
+        const double alpha = rz_in * fast_rcp(pq);
+        {
+            double e = 0.0;                                // this wave's quarter of E^-1 g (independent of alpha)
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) e = fma(em[jj], lane_bcast(g, 16 * w + jj), e);
+            egq[w * ML_N + lane] = e;
+        }
+        double rrn = 0.0;
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
+        rrn = wave_allsum(rrn);
+        if (lane == 0) red[16 + w] = rrn;
+        if (w == 3) {                                      // x += alpha (p_r + W~ p_mu): this camera's two hats
+            const int jc = min((int)blockIdx.x, nc - 1);   // (the focal row: only W~_7 is non-zero there)
+            const int gl = (jc * ML_G) / nc, gh = gl + 1 == ML_G ? 0 : gl + 1;
+            const double fr = ml_frac(jc, gl, nc, inv_nc);
+            double wp = wo[PCG_NW - 1] * lane_bcast(pmu_in, ML_NC - 1);
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                wp = fma(wo[k], fma(fr, lane_bcast(pmu_in, 7 * gh + k), (1.0 - fr) * lane_bcast(pmu_in, 7 * gl + k)), wp);
+            if (own) x_out[eo] = xo + alpha * (po + wp);
+        }
+        __syncthreads();
+        const double Eg = (egq[lane] + egq[ML_N + lane]) + (egq[2 * ML_N + lane] + egq[3 * ML_N + lane]);
+        c_new = fma(-alpha, g, c_in);
+        mu_new = fma(-alpha, Eg, mu_in);
+        rrn = red[16] + red[17] + red[18] + red[19];
+        rz_new = rrn + wave_allsum(c_new * mu_new);
+        const bool broke = !(pq > 0.0) || !(rrn == rrn);
+        const bool done = rrn <= tol2 * rr0 || broke;
+        if (done) {
+            if (blockIdx.x == 0 && tid == 0) {
+                flags[PF_DONE] = seq + 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
+                if (broke) atomicCAS(info, 0, d + 1);
+                if (mailbox) pcg_post(mailbox, it, 1);
+            }
+            return;
+        }
+        const double beta = rz_new * fast_rcp(rz_in);
+        pmu_new = fma(beta, pmu_in, mu_new);
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; if (e < d) pl[e] = rv[m] + beta * pv[m]; }
+        if (own) { const double rn = ro - alpha * qo; r_out[eo] = rn; p_out[eo] = rn + beta * po; }
+        if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
+    }
+    if (blockIdx.x == 0 && w == 1) {
+        ms_out[lane] = c_new; ms_out[ML_N + lane] = mu_new; ms_out[2 * ML_N + lane] = pmu_new;
+        if (lane == 0) st_out[PS_RZ] = rz_new;
+    }
+    __syncthreads();
+    // ---- q = S~ p_r + AW p_mu for the rows of this camera ----
+    double pqp = 0.0, gacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < PCG_RPW; ++k) {
+        const int row = row0 + w + 4 * k;
+        double sacc = awv[k] * pmu_new, sacc2 = 0.0;
+#pragma unroll
+        for (int m = 0; m < PCG_CPL / 2; ++m) {
+            const int c2 = lane + 64 * m;
+            double2 pv2 = (2 * c2 < d) ? reinterpret_cast<const double2*>(pl)[c2] : make_double2(0.0, 0.0);
+            if (2 * c2 + 1 >= d) pv2.y = 0.0;
+            sacc = fma(fv[k][m].x, pv2.x, sacc);
+            sacc2 = fma(fv[k][m].y, pv2.y, sacc2);
+        }
+        sacc += sacc2;
+        sacc = wave_allsum(sacc);
+        if (lane == 0 && row < row1) { q_out[row] = sacc; pqp += pl[row] * sacc; }
+        if (lane >= PCG_NW && lane < 2 * PCG_NW && row < row1) gacc = fma(wg8[k], sacc, gacc);
+    }
+    if (lane == 0) red[40 + 9 * w] = pqp;
+    if (lane >= PCG_NW && lane < 2 * PCG_NW) red[40 + 9 * w + 1 + (lane - PCG_NW)] = gacc;
+    __syncthreads();
+    if (tid < PCG_NPART) pcg_part(part, out, tid)[blockIdx.x] = red[40 + tid] + red[49 + tid] + red[58 + tid] + red[67 + tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Persistent CG (d <= 1280, one workgroup per CU): the WHOLE solve in one launch.
 //
 // The launch-per-iteration kernel above costs one dependent-launch boundary (~1.4 us) plus one full re-read of S~ from
@@ -1673,7 +2111,10 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
     double* bt = ws->vec + (size_t)8 * ld;
     const int in = INIT ? 0 : (r.in | ((r.launched + 1) << 1));     // launch number 1.. of this solve, see k_pcg_iter
 #define CG_ARGS(Fptr) d, ld, Fptr, ws->vec, bt, ws->part, ws->scal, ws->flags, r.rows_per_wg, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->AW, ws->coarse
-    if (r.fast) {
+    if (r.ml) {
+        hipLaunchKernelGGL((k_pcg_iter_ml<INIT>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags, r.tol2, in, r.info,
+                           ws->d_mailbox, anchor, cap, ws->W, ws->mlAW, ws->mlEinv, ws->mlC0, ws->mlState);
+    } else if (r.fast) {
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
         else hipLaunchKernelGGL((k_pcg_iter_fast<INIT, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
     } else if (r.f32) {
@@ -1710,6 +2151,50 @@ void dense_pcg_note(DenseSolver* ws, int hist_key, int iters) {
 // cap of the anchored stopping rule: every solve at least max(tol, 1e-4) relative
 static double pcg_cap(double tol) { const double t2 = tol * tol; return t2 > 0.0 ? fmax(t2, 1e-8) / t2 : 1.0; }
 
+// the segmented coarse space needs the fast path's geometry with one workgroup per camera (d = 6 nc + 1) and enough cameras per hat
+bool dense_pcg_segments_applicable(const DenseSolver* ws) {
+    const int d = ws->d, nc = (d - 1) / 6;
+    return d == 6 * nc + 1 && nc >= ML_MIN_CAMS && nc + 1 <= PCG_MAXWG && d <= 256 * PCG_EPT && d <= 64 * PCG_CPL;
+}
+
+
+// DEBUG (SFMBA_ML_DEBUG): the set-up kernels' outputs against a host evaluation of the same definitions
+static void ml_debug_check(hipStream_t s, DenseSolver* ws, int nwg) {
+    (void)hipStreamSynchronize(s);
+    const int d = ws->d, ld = ws->ld, nc = (d - 1) / 6;
+    std::vector<double> F((size_t)d * ld), W((size_t)8 * ld), AW((size_t)d * 64), E(64 * 64), Ei(64 * 64), c0(64), bt(ld), V((size_t)nwg * 512);
+    (void)hipMemcpy(F.data(), ws->Sfull, sizeof(double) * F.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(W.data(), ws->W, sizeof(double) * W.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(AW.data(), ws->mlAW, sizeof(double) * AW.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(E.data(), ws->mlE, sizeof(double) * E.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(Ei.data(), ws->mlEinv, sizeof(double) * Ei.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(c0.data(), ws->mlC0, sizeof(double) * c0.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(bt.data(), ws->vec + (size_t)8 * ld, sizeof(double) * ld, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(V.data(), ws->mlV, sizeof(double) * V.size(), hipMemcpyDeviceToHost);
+    std::vector<double> Wt((size_t)57 * d, 0.0);
+    for (int j = 0; j < nc; ++j) {
+        const int gl = (j * 8) / nc, gh = (gl + 1) % 8;
+        const double fr = (double)(j * 8 - gl * nc) / (double)nc;
+        for (int k = 0; k < 7; ++k) for (int e = 0; e < 6; ++e) {
+            Wt[(size_t)(7 * gl + k) * d + 6 * j + e] += (1.0 - fr) * W[(size_t)k * ld + 6 * j + e];
+            Wt[(size_t)(7 * gh + k) * d + 6 * j + e] += fr * W[(size_t)k * ld + 6 * j + e];
+        }
+    }
+    for (int e = 0; e < d; ++e) Wt[(size_t)56 * d + e] = W[(size_t)7 * ld + e];
+    double eaw = 0, naw = 0, ee = 0, ne = 0, ec = 0, einv_err = 0;
+    std::vector<double> AWh((size_t)d * 57);
+    for (int r = 0; r < d; ++r) for (int i = 0; i < 57; ++i) {
+        double v = 0; for (int c = 0; c < d; ++c) v += F[(size_t)r * ld + c] * Wt[(size_t)i * d + c];
+        AWh[(size_t)r * 57 + i] = v; eaw = fmax(eaw, fabs(v - AW[(size_t)r * 64 + i])); naw = fmax(naw, fabs(v));
+    }
+    for (int i = 0; i < 57; ++i) {
+        for (int j = 0; j < 57; ++j) { double v = 0; for (int r = 0; r < d; ++r) v += Wt[(size_t)i * d + r] * AWh[(size_t)r * 57 + j]; ee = fmax(ee, fabs(v - E[i * 64 + j])); ne = fmax(ne, fabs(v)); }
+        double c = 0; for (int r = 0; r < d; ++r) c += Wt[(size_t)i * d + r] * bt[r]; ec = fmax(ec, fabs(c - c0[i]));
+    }
+    for (int i = 0; i < 57; ++i) for (int j = 0; j < 57; ++j) { double v = 0; for (int k = 0; k < 57; ++k) v += E[i * 64 + k] * Ei[k * 64 + j]; einv_err = fmax(einv_err, fabs(v - (i == j ? 1.0 : 0.0))); }
+    std::fprintf(stderr, "[ml debug] d %d: AW err %.3e (max %.3e)  E err %.3e (max %.3e)  c0 err %.3e  |E Einv - I| %.3e\n", d, eaw, naw, ee, ne, ec, einv_err);
+}
+
 // same path selection as dense_pcg_solve
 static void pcg_geometry(const DenseSolver* ws, bool* fast, bool* f32) {
     const int d = ws->d;
@@ -1733,7 +2218,7 @@ int dense_pcg_transform(hipStream_t s, DenseSolver* ws, double* S, double* rhs, 
 }
 
 int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, double tol, int max_iters, int* info_dev, Profiler* prof,
-                    bool finish, int hist_key, bool pretransformed, int anchor, bool no_wait, bool coarse) {
+                    bool finish, int hist_key, bool pretransformed, int anchor, bool no_wait, bool coarse, bool segments) {
     const double cap = pcg_cap(tol);
     const int ld = ws->ld, d = ws->d;
     if (dense_pcg_ensure_workspace(ws)) return -1;
@@ -1741,15 +2226,25 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
     const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && rows_per_wg <= 4 * PCG_RPW;
     if (!fast) rows_per_wg = std::max(8, ((d + PCG_MAXWG_BIG - 1) / PCG_MAXWG_BIG + 7) / 8 * 8);   // two rows per wave at a time
+    // segmented coarse space (7 x 8 hat-restricted gauge vectors + 1): workgroup = camera
+    const bool ml = segments && coarse && fast && dense_pcg_segments_applicable(ws) && ws->W && ws->mlAW;
+    if (ml) rows_per_wg = 6;
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
-    const size_t lds = sizeof(double) * (size_t)(ld + PCG_RED);
+    const size_t lds = sizeof(double) * (size_t)(ld + (ml ? ML_LDS_TAIL : PCG_RED));
     double* bt = ws->vec + (size_t)8 * ld;
     // fp32 storage of S~ on the streaming path whenever the caller asked for it (dense_pcg_want_f32 allocated the buffer)
     const bool f32 = !fast && ws->use_f32 && ws->Sfull32 != nullptr;
     if (!pretransformed) dense_pcg_transform(s, ws, S, rhs, info_dev, prof);
     // coarse space: the caller's linearisation wrote W~ (ws->W); AW, E^-1 and c_0 are formed here, one pass over S~
     coarse = coarse && ws->W && ws->AW && rows_per_wg <= 4 * CO_MAXROWS;
-    if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
+    if (ml) { ProfScope ps(prof, KID_PCG_SETUP, s, 3);
+      static bool ml_attr_set = false;
+      if (!ml_attr_set) { (void)hipFuncSetAttribute((const void*)k_ml_aw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ML_AW_LDS); ml_attr_set = true; }
+      hipLaunchKernelGGL(k_ml_aw, dim3(nwg), dim3(256), ML_AW_LDS, s, d, ld, ws->Sfull, ws->W, bt, ws->mlAW, ws->mlV, ws->mlU);
+      hipLaunchKernelGGL(k_ml_e, dim3(ML_NC), dim3(256), 0, s, d, ws->mlV, ws->mlU, ws->mlE, ws->mlC0);
+      hipLaunchKernelGGL(k_ml_invert, dim3(1), dim3(256), 0, s, ws->mlE, ws->mlEinv, ws->mlC0);
+      if (std::getenv("SFMBA_ML_DEBUG")) ml_debug_check(s, ws, nwg); }
+    else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
       else if (f32) hipLaunchKernelGGL(k_pcg_coarse<float>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
       else hipLaunchKernelGGL(k_pcg_coarse<double>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
@@ -1757,7 +2252,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       if (!fast) hipLaunchKernelGGL(k_pcg_coarse_invert, dim3(1), dim3(256), 0, s, nwg, ws->epart, ws->coarse); }
     volatile int* mb = ws->h_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }
-    ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32; ws->run.coarse = coarse;
+    ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32; ws->run.coarse = coarse; ws->run.ml = ml;
     ws->run.tol2 = tol * tol; ws->run.in = 1; ws->run.launched = 0; ws->run.max_iters = max_iters; ws->run.info = info_dev;
     { ProfScope ps(prof, KID_PCG_ITER, s);
       launch_cg_iteration<true>(s, ws, anchor, cap); }
@@ -1869,6 +2364,16 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
         if (ws_alloc(ws, &ws->epart, sizeof(double) * (size_t)(PCG_NW * PCG_NW + PCG_NW) * PCG_PART)) return -1;
         if (ws_alloc(ws, &ws->coarse, sizeof(double) * (size_t)(PCG_NW * PCG_NW + PCG_NW))) return -1;
     }
+    if (!ws->mlAW && dense_pcg_segments_applicable(ws)) {
+        const size_t nwg = (size_t)(ws->d - 1) / 6 + 1;
+        if (ws_alloc(ws, &ws->mlAW, sizeof(double) * (size_t)ws->ld * ML_N)) return -1;
+        if (ws_alloc(ws, &ws->mlV, sizeof(double) * nwg * PCG_NW * ML_N)) return -1;
+        if (ws_alloc(ws, &ws->mlU, sizeof(double) * nwg * PCG_NW)) return -1;
+        if (ws_alloc(ws, &ws->mlE, sizeof(double) * ML_N * ML_N)) return -1;
+        if (ws_alloc(ws, &ws->mlEinv, sizeof(double) * ML_N * ML_N)) return -1;
+        if (ws_alloc(ws, &ws->mlC0, sizeof(double) * ML_N)) return -1;
+        if (ws_alloc(ws, &ws->mlState, sizeof(double) * 2 * 3 * ML_N)) return -1;
+    }
     return 0;
 }
 
@@ -1914,6 +2419,7 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->AW) (void)hipFree(ws->AW);
         if (ws->epart) (void)hipFree(ws->epart);
         if (ws->coarse) (void)hipFree(ws->coarse);
+        for (double* q : { ws->mlAW, ws->mlV, ws->mlU, ws->mlE, ws->mlEinv, ws->mlC0, ws->mlState }) if (q) (void)hipFree(q);
     }
     if (!ws->pinned_external) {
         if (ws->h_flags) (void)hipHostFree(ws->h_flags);

@@ -217,6 +217,7 @@ struct sfmba_problem {
     int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_pwg_desc = nullptr;
     int2* d_pwg_chunk = nullptr; int* d_multi_slots = nullptr; int* d_build_counters = nullptr; int* d_pt_order = nullptr;
     double block_fill = 1.0;              // non-empty off-diagonal blocks of the reduced matrix / all of them
+    double block_band = 0.0;              // ... and the share of those that couple cameras within a quarter of the cyclic camera order
     int* d_blk_ptr = nullptr;
     int* d_cam_chunk_ptr = nullptr;
     bool deterministic = false;             // SFMBA_DETERMINISTIC=1 at build time
@@ -374,6 +375,12 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     const char* anchor_env = std::getenv("SFMBA_PCG_ANCHOR");
     // two-level preconditioner (8 gauge vectors as a coarse space, dense_solver.hip)
     const bool coarse_cg = option_switch(o.pcg_coarse_space, "SFMBA_PCG_COARSE", true);
+    // ... and for a sparsely filled reduced matrix (a camera graph of large diameter) the same vectors restricted to eight segments of the
+    // camera order (dense_solver.hip "Segmented coarse space"); SFMBA_PCG_SEGMENTS=0|1 forces it off / on wherever it applies
+    // -- where the structure says the camera order IS that path: a sparsely filled matrix whose blocks sit near the (cyclic) diagonal
+    // (options.pcg_coarse_space: 0 = by structure, 1 = the eight global vectors only, 2 = the segments wherever they apply)
+    const bool segments_cg = coarse_cg && dense_pcg_segments_applicable(&p->solver) &&
+                             option_switch(o.pcg_coarse_space == 2 ? 1 : o.pcg_coarse_space == 1 ? -1 : 0, "SFMBA_PCG_SEGMENTS", p->block_fill < 0.5 && p->block_band >= 0.9);
     // One persistent (cooperative) launch per CG solve: opt-in only.  It used to win below d = 640 where the
     // solve is launch-bound; with the gauge coarse space the launch-per-iteration path needs half the iterations and is as fast or
     // faster at every size measured (cfg 4, d = 151: 4990 vs 4820 LM it/s; cfg 2: 6300 vs 6220; 7 views: 6170 vs 6380), and it has
@@ -405,6 +412,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // (views along a path, tracks of neighbouring cameras: SfM.cpp:366-469 builds exactly that) -- block-Jacobi CG then needs hundreds of
     // iterations per linearisation (cfg3_banded, fill 0.29: ~160 at 1e-12) and the factorisation is the cheaper way to the DENSE_SCHUR
     // result from the first linearisation on.  A property of the problem, not of the call history: deterministic.
+    // (With the segmented coarse space the CG needs ~49 iterations per linearisation at 1e-12 on cfg3_banded: 1 566 LM iterations/s against the
+    // factorisation's 1 639 -- the factorisation stays AUTO's choice there; the PCG mode is where the segments pay: 1 224 -> 2 220.)
     if (exact_pcg && p->block_fill < 0.5) auto_prefers_cholesky = true;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
@@ -451,7 +460,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 // not wait for the linear solve.  If the batch was too short k_lm_control says so and more is enqueued.
                 pcg_gated = gated_cg;
                 const int it = dense_pcg_solve(p->stream, &p->solver, p->db.S, p->db.rhs, cg_tol, cg_max_iters, p->d_info, prof,
-                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/pcg_gated, /*coarse=*/coarse_cg);
+                                               /*finish=*/false, /*hist_key=*/host_iter, /*pretransformed=*/true, anchor, /*no_wait=*/pcg_gated, /*coarse=*/coarse_cg, /*segments=*/segments_cg);
                 if (it < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
                 if (!pcg_gated) { sum.linear_iters += it; lin_hist.push_back(it); }
             }
@@ -833,7 +842,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             HIP_TRY(dev_alloc(&p->d_pwg_chunk, pair_slot_cap));
             HIP_TRY(dev_alloc(&p->d_multi_slots, pwg_blocks.size() + 1));
         }
-        HIP_TRY(dev_alloc(&p->d_build_counters, (size_t)2));
+        HIP_TRY(dev_alloc(&p->d_build_counters, (size_t)4));
         HIP_TRY(dev_alloc(&p->d_dup_blocks, (size_t)ncam));
         return SFMBA_OK;
     };
@@ -932,11 +941,11 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     // diagonal blocks that contain pairs (the same camera observing a point twice; handled by a separate pass).  The number of
     // those and the device's own pair total come back through host-mapped memory and are read after the one wait below.
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
-    volatile int* build_report = reinterpret_cast<volatile int*>(p->kit.pinned + 1536);      // [1536, 1552) of the mailbox slice
+    volatile int* build_report = reinterpret_cast<volatile int*>(p->kit.pinned + 1536);      // [1536, 1568) of the mailbox slice
     build_report[0] = -1;
     int* d_report = reinterpret_cast<int*>(p->d_pinned + 1536);
-    build_report[1] = -1; build_report[4] = -1; build_report[5] = -1;
-    HIP_TRY(hipMemsetAsync(p->d_build_counters, 0, 2 * sizeof(int), p->stream));
+    build_report[1] = -1; build_report[4] = -1; build_report[5] = -1; build_report[6] = -1;
+    HIP_TRY(hipMemsetAsync(p->d_build_counters, 0, 4 * sizeof(int), p->stream));
     if (pair_lpb == 64) {
         const int crc = build_pair_chunks(p->stream, &staging, (int)pwg_blocks.size(), SFMBA_PAIR_CHUNK, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr,
                                           p->d_pwg_desc, p->d_pwg_chunk, p->d_multi_slots, p->d_build_counters, d_report);
@@ -948,7 +957,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         launch_row_order(p->stream, ncam, pair_lpb, p->d_blk_ptr, d_perm);
         launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, d_perm, p->d_pwg_desc);
     }
-    launch_block_fill(p->stream, nblock, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
+    launch_block_fill(p->stream, nblock, ncam, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
     launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, d_report);
     HIP_TRY(hipGetLastError());
     p->focal0 = p->focal = focal;
@@ -1051,6 +1060,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     }
     // fill of the reduced matrix: non-empty off-diagonal blocks / all of them (what SFMBA_LINEAR_AUTO reads the co-visibility from)
     p->block_fill = ncam > 1 ? (double)std::max((int)build_report[1], 0) / ((double)ncam * (ncam - 1) / 2.0) : 1.0;
+    p->block_band = build_report[1] > 0 ? (double)std::max((int)build_report[6], 0) / (double)build_report[1] : 0.0;
     bt_mark("wait for device");
     return sfmba_problem_reset(p);
 }

@@ -375,16 +375,23 @@ __global__ void k_chunk_report(int nwg, const int* __restrict__ off, const int* 
     report[5] = counters[0];
     __threadfence_system();
 }
-// number of off-diagonal blocks of the upper triangle that hold at least one pair -> report[1] (the fill of the reduced matrix: what
+// number of off-diagonal blocks of the upper triangle that hold at least one pair -> report[1], those close to the diagonal -> report[6] (the fill of the reduced matrix: what
 // SFMBA_LINEAR_AUTO reads the co-visibility structure from)
-__global__ __launch_bounds__(256) void k_block_fill(int nblock, const int2* __restrict__ blk_cams, const int* __restrict__ blk_ptr, int* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_block_fill(int nblock, int ncam, const int2* __restrict__ blk_cams, const int* __restrict__ blk_ptr, int* __restrict__ counters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    int has = 0;
-    if (b < nblock) { const int2 cj = blk_cams[b]; has = cj.x != cj.y && blk_ptr[b + 1] > blk_ptr[b]; }
-    const unsigned long long m = __ballot(has);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[1], __popcll(m));
+    int has = 0, near = 0;
+    if (b < nblock) {
+        const int2 cj = blk_cams[b];
+        has = cj.x != cj.y && blk_ptr[b + 1] > blk_ptr[b];
+        // ... and how many of them couple cameras that are close in the (cyclic) camera order: within a quarter of it.  A camera graph laid out
+        // along its index -- views registered one after the other -- has all of its blocks there, a random one half of them.
+        const int dist = cj.y - cj.x, cyc = dist < ncam - dist ? dist : ncam - dist;
+        near = has && 4 * cyc <= ncam;
+    }
+    const unsigned long long m = __ballot(has), mn = __ballot(near);
+    if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&counters[1], __popcll(m)); if (mn) atomicAdd(&counters[2], __popcll(mn)); }
 }
-__global__ void k_fill_report(const int* __restrict__ counters, int* __restrict__ report) { report[1] = counters[1]; __threadfence_system(); }
+__global__ void k_fill_report(const int* __restrict__ counters, int* __restrict__ report) { report[1] = counters[1]; report[6] = counters[2]; __threadfence_system(); }
 }  // namespace
 
 int build_pair_chunks(hipStream_t s, DeviceArena* scratch, int nwg, int chunk, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr,
@@ -405,8 +412,8 @@ int build_pair_chunks(hipStream_t s, DeviceArena* scratch, int nwg, int chunk, c
     hipLaunchKernelGGL(k_chunk_report, dim3(1), dim3(1), 0, s, nwg, off, counters, report);
     return (int)hipGetLastError();
 }
-void launch_block_fill(hipStream_t s, int nblock, const int2* blk_cams, const int* blk_ptr, int* counters, int* report) {
-    if (nblock > 0) hipLaunchKernelGGL(k_block_fill, dim3((nblock + 255) / 256), dim3(256), 0, s, nblock, blk_cams, blk_ptr, counters);
+void launch_block_fill(hipStream_t s, int nblock, int ncam, const int2* blk_cams, const int* blk_ptr, int* counters, int* report) {
+    if (nblock > 0) hipLaunchKernelGGL(k_block_fill, dim3((nblock + 255) / 256), dim3(256), 0, s, nblock, ncam, blk_cams, blk_ptr, counters);
     hipLaunchKernelGGL(k_fill_report, dim3(1), dim3(1), 0, s, counters, report);
 }
 

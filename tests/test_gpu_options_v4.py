@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SWITCH_ENVS = ["SFMBA_PCG_COARSE", "SFMBA_PCG_PERSISTENT", "SFMBA_PCG_F32_MATRIX", "SFMBA_EARLY_LINEARISE", "SFMBA_SHARD_TWO_PHASE",
-               "SFMBA_SHARD_F32_EXCHANGE", "SFMBA_DETERMINISTIC", "SFMBA_SHARD_DIST_CG"]
+               "SFMBA_SHARD_F32_EXCHANGE", "SFMBA_DETERMINISTIC", "SFMBA_SHARD_DIST_CG", "SFMBA_PCG_SEGMENTS"]
 
 
 @pytest.fixture(autouse=True)

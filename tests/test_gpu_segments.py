@@ -1,0 +1,105 @@
+"""The segmented coarse space of the reduced-system CG (dense_solver.hip "Segmented coarse space"): the seven similarity vectors restricted to
+eight overlapping segments of the camera order + the global focal/depth vector.  A preconditioner only -- the solve must land where the
+oracle's does whatever the coarse space; what it buys is CG iterations on camera graphs laid out along a path."""
+import numpy as np
+import pytest
+
+from test_gpu_baseline_parity import assert_same_solve
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def clean_env(monkeypatch):
+    for e in ("SFMBA_PCG_COARSE", "SFMBA_PCG_SEGMENTS"):
+        monkeypatch.delenv(e, raising=False)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from sfm_toy_library_amd import capi as c
+    assert c.device_count() >= 1
+    return c
+
+
+@pytest.fixture(scope="module")
+def banded60(sfm):
+    return sfm.make_problem("cfg3_banded", n_cam=60, n_pt=8000)
+
+
+@pytest.fixture(scope="module")
+def banded60_oracle(sfm, oracle, banded60):
+    return oracle.solve(banded60, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_segments_same_solve_fewer_iterations(capi, banded60, banded60_oracle, precision):
+    """d = 361: forced on (pcg_coarse_space = 2) against the eight global vectors (= 1) and against the oracle."""
+    res = {}
+    for mode in (1, 2):
+        with capi.Problem(banded60, precision=precision) as P:
+            s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=precision, linear_solver=1, pcg_coarse_space=mode))
+            cam, pt, f = P.get_params()
+            res[mode] = (cam, pt, f, s, tr)
+        assert_same_solve(banded60, res[mode], banded60_oracle, param_atol=1e-7 if precision == 0 else 5e-5, trace_rtol=1e-6 if precision == 0 else 5e-5,
+                          point_atol=1e-6 if precision == 0 else 5e-3)
+    it1 = [r["linear_iters"] for r in res[1][4][1:]]
+    it2 = [r["linear_iters"] for r in res[2][4][1:]]
+    assert all(b < a for a, b in zip(it1, it2)) and sum(it2) <= 0.7 * sum(it1), (it1, it2)
+    assert np.abs(res[1][0] - res[2][0]).max() < (1e-8 if precision == 0 else 2e-6)
+
+
+def test_segments_on_dense_covisibility_and_smallest_size(capi, sfm, oracle):
+    """Forced where the structure would not choose them: every camera sees every part of the scene (no path in the camera order), and the
+    smallest camera count the path accepts (32: four cameras per hat).  Still the same solve."""
+    for prob in (sfm.make_problem("cfg2", n_cam=48, n_pt=4000), sfm.make_problem("cfg3_banded", n_cam=32, n_pt=3000)):
+        want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+        got = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=2))
+        assert_same_solve(prob, got, want, param_atol=1e-7, cost_rtol=1e-9, point_atol=1e-6)
+        assert sum(r["linear_iters"] for r in got[4][1:]) > 0
+
+
+def test_segments_not_applicable_is_silent(capi, sfm):
+    """31 cameras (below four per hat) and 214 cameras (d = 1285: beyond the one-round-trip CG kernels): the request falls back to the eight
+    global vectors, same result as asking for those."""
+    for n_cam, n_pt in ((31, 2500), (214, 6000)):
+        prob = sfm.make_problem("cfg3_banded", n_cam=n_cam, n_pt=n_pt)
+        a = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=2))
+        b = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=1))
+        # (the same path twice: the iteration counts may differ by the summation order of the accumulating passes, nothing more)
+        assert all(abs(x["linear_iters"] - y["linear_iters"]) <= 2 for x, y in zip(a[4], b[4])), ([r["linear_iters"] for r in a[4]], [r["linear_iters"] for r in b[4]])
+        assert abs(a[3]["final_cost"] - b[3]["final_cost"]) <= 1e-10 * b[3]["final_cost"]
+
+
+def test_segments_bitwise_repeatable(capi, sfm, banded60):
+    """Everything the segments add is summed in a fixed order (no atomics): a deterministic handle repeats bit for bit."""
+    opt = capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_coarse_space=2)
+    runs = []
+    with capi.Problem(banded60, precision=1, flags=sfm.CREATE_DETERMINISTIC) as P:
+        for rep in range(3):
+            P.reset()
+            s, tr = P.solve(opt)
+            runs.append((P.get_params(), s["final_cost"], [r["linear_iters"] for r in tr]))
+    for (cam, pt, f), cost, lin in runs[1:]:
+        assert lin == runs[0][2] and cost == runs[0][1]
+        assert np.array_equal(cam, runs[0][0][0]) and np.array_equal(pt, runs[0][0][1]) and f == runs[0][0][2]
+
+
+def test_structure_chooses_segments_on_the_banded_baseline_shape(capi, sfm):
+    """cfg3_banded (fill 0.29, every block within a quarter of the cyclic camera order): the default coarse space IS the segmented one --
+    a third of the CG iterations of the eight global vectors; cfg3 (every camera sees everything) keeps the global vectors."""
+    prob = sfm.make_problem("cfg3_banded")
+    its = {}
+    with capi.Problem(prob, precision=1) as P:
+        for mode in (0, 1, 2):
+            P.reset()
+            s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_coarse_space=mode))
+            its[mode] = [r["linear_iters"] for r in tr[1:]]
+    assert its[0] == its[2] and sum(its[0]) <= 0.4 * sum(its[1]), its
+    prob = sfm.make_problem("cfg3", n_pt=20000)
+    with capi.Problem(prob, precision=1) as P:
+        for mode in (0, 1):
+            P.reset()
+            s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_coarse_space=mode))
+            its[mode] = [r["linear_iters"] for r in tr[1:]]
+    assert its[0] == its[1]
