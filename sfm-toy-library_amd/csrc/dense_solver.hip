@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 #include <cstdlib>
 
@@ -1587,7 +1588,8 @@ __global__ __launch_bounds__(256) void k_ml_aw(int d, int ld, const double* __re
         for (int range = 0; range < 2; ++range) {
             const int a = range == 0 ? (g + ML_G - 1) % ML_G : g;
             const int lo = ml_first_cam(a, nc), hi = ml_first_cam(a + 1, nc);
-            for (int j = lo; j < hi; ++j) {
+#pragma unroll 3
+            for (int j = lo; j < hi; ++j) {               // (three cameras' LDS reads in flight)
                 const double fr = ml_frac(j, a, nc, inv_nc);
                 const double wgt = range == 0 ? fr : 1.0 - fr;
                 const float2 w01 = reinterpret_cast<const float2*>(wk + 6 * j)[0], w23 = reinterpret_cast<const float2*>(wk + 6 * j)[1], w45 = reinterpret_cast<const float2*>(wk + 6 * j)[2];
@@ -1665,7 +1667,7 @@ __global__ __launch_bounds__(256) void k_ml_e(int d, const double* __restrict__ 
 // its row and column of the result are zero.
 __global__ __launch_bounds__(256) void k_ml_invert(const double* __restrict__ E, double* __restrict__ einv, double* __restrict__ c0) {
     __shared__ __align__(16) double rowbuf[2][ML_N];
-    __shared__ double colbuf[2][ML_N], sc[ML_N];
+    __shared__ double colbuf[2][ML_N], sc[ML_N], diagbuf[2];
     const int tid = threadIdx.x, i = tid >> 2, qd = tid & 3;
     double ev[16], et[16];
 #pragma unroll
@@ -1686,31 +1688,41 @@ __global__ __launch_bounds__(256) void k_ml_invert(const double* __restrict__ E,
     }
     unsigned long long dropped = 0ull;
     for (int t = 0; t < ML_N; ++t) if (!(sc[t] > 0.0)) dropped |= 1ull << t;
-    for (int qq = 0; qq < 4; ++qq) {
+    // the pivot of the NEXT step and its reciprocal are formed by every thread during this step's update (from the published row, column and
+    // the next diagonal entry): the reciprocal's dependent chain is off the barrier-to-barrier path
+    double piv = 1.0, ip = 1.0;                      // unit diagonal after the scaling
+    auto step = [&](int qq, auto cconst) {
+        constexpr int c = decltype(cconst)::value;   // (a compile-time register index, whatever the optimiser thinks of unrolling the loop)
+        const int p = 16 * qq + c;
+        if (p >= ML_NC) return;                      // uniform
+        constexpr int par = c & 1;
+        if (i == p) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int p = 16 * qq + c;
-            if (p >= ML_NC) break;
-            const int par = c & 1;
-            if (i == p) {
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) rowbuf[par][16 * qd + cc] = a[cc];
-            }
-            if (qd == qq) colbuf[par][i] = a[c];
-            __syncthreads();
-            const double piv = rowbuf[par][p];
-            const bool ok = !((dropped >> p) & 1ull) && piv > 1e-10;
-            if (!ok) { dropped |= 1ull << p; continue; }
-            const double ip = fast_rcp(piv);
-            const double f = colbuf[par][i] * ip;
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) {
-                const int j = 16 * qd + cc;
-                const double rp = rowbuf[par][j];
-                if (i == p) a[cc] = (j == p) ? ip : rp * ip;
-                else a[cc] = (j == p) ? -f : fma(-f, rp, a[cc]);
-            }
+            for (int cc = 0; cc < 16; ++cc) rowbuf[par][16 * qd + cc] = a[cc];
         }
+        if (qd == qq) colbuf[par][i] = a[c];
+        if (i == p + 1 && qd == qq + (c == 15 ? 1 : 0)) diagbuf[par] = a[(c + 1) & 15];
+        __syncthreads();
+        const bool ok = !((dropped >> p) & 1ull) && piv > 1e-10;
+        double dn = diagbuf[par];
+        if (ok) {
+            // a_ij -= (a_ip / piv) a_pj everywhere -- the pivot row itself with the multiplier 1 - 1/piv (a_pj - (1 - 1/piv) a_pj = a_pj / piv:
+            // no select per entry) --, then the pivot column is set: -a_ip / piv, and 1 / piv on the diagonal
+            const double fc = colbuf[par][i] * ip;
+            const double f = i == p ? 1.0 - ip : fc;
+            dn = fma(-colbuf[par][(p + 1) & (ML_N - 1)] * ip, rowbuf[par][(p + 1) & (ML_N - 1)], dn);
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) a[cc] = fma(-f, rowbuf[par][16 * qd + cc], a[cc]);
+            if (qd == qq) a[c] = i == p ? ip : -fc;
+        } else dropped |= 1ull << p;
+        piv = dn;
+        ip = fast_rcp(dn);
+    };
+    for (int qq = 0; qq < 4; ++qq) {
+#define ML_STEP(C) step(qq, std::integral_constant<int, C>())
+        ML_STEP(0); ML_STEP(1); ML_STEP(2); ML_STEP(3); ML_STEP(4); ML_STEP(5); ML_STEP(6); ML_STEP(7);
+        ML_STEP(8); ML_STEP(9); ML_STEP(10); ML_STEP(11); ML_STEP(12); ML_STEP(13); ML_STEP(14); ML_STEP(15);
+#undef ML_STEP
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -2158,7 +2170,7 @@ bool dense_pcg_segments_applicable(const DenseSolver* ws) {
 }
 
 
-// DEBUG (SFMBA_ML_DEBUG): the set-up kernels' outputs against a host evaluation of the same definitions
+// SFMBA_ML_DEBUG=1 (tools/segments_check.py): the set-up kernels' outputs against a host evaluation of the same definitions, printed per linear solve
 static void ml_debug_check(hipStream_t s, DenseSolver* ws, int nwg) {
     (void)hipStreamSynchronize(s);
     const int d = ws->d, ld = ws->ld, nc = (d - 1) / 6;
@@ -2243,7 +2255,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       hipLaunchKernelGGL(k_ml_aw, dim3(nwg), dim3(256), ML_AW_LDS, s, d, ld, ws->Sfull, ws->W, bt, ws->mlAW, ws->mlV, ws->mlU);
       hipLaunchKernelGGL(k_ml_e, dim3(ML_NC), dim3(256), 0, s, d, ws->mlV, ws->mlU, ws->mlE, ws->mlC0);
       hipLaunchKernelGGL(k_ml_invert, dim3(1), dim3(256), 0, s, ws->mlE, ws->mlEinv, ws->mlC0);
-      if (std::getenv("SFMBA_ML_DEBUG")) ml_debug_check(s, ws, nwg); }
+      static const bool ml_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;      // (read once per process)
+      if (ml_debug) ml_debug_check(s, ws, nwg); }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
       else if (f32) hipLaunchKernelGGL(k_pcg_coarse<float>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
