@@ -807,20 +807,49 @@ constexpr int CO_MAXROWS = 4;             // rows per wave k_pcg_coarse can hold
 
 __device__ __forceinline__ double* pcg_part(double* part, int parity, int v) { return part + ((size_t)parity * PCG_NPART + v) * PCG_PART; }
 
-template <typename FT>
+// four consecutive matrix entries, loaded with 16-byte loads
+template <typename FT> struct Quad;
+template <> struct Quad<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ double get(int i) const { return (double)(i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w); }
+};
+template <> struct Quad<double> {
+    double2 a, b;
+    __device__ __forceinline__ void load(const double* p) { a = reinterpret_cast<const double2*>(p)[0]; b = reinterpret_cast<const double2*>(p)[1]; }
+    __device__ __forceinline__ double get(int i) const { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? b.x : b.y; }
+};
+
+// NR: rows per wave held at a time (2 for rows_per_wg <= 8 -- BASELINE config 5 --, else NR)
+template <typename FT, int NR>
 __global__ __launch_bounds__(256) void k_pcg_coarse(int d, int ld, const FT* __restrict__ F, const double* __restrict__ W, const double* __restrict__ bt,
                                                     double* __restrict__ AW, double* __restrict__ epart, int rows_per_wg) {
-    __shared__ float wt[PCG_NW][CO_TILE];
+    __shared__ __align__(16) float wt[PCG_NW][CO_TILE];
     __shared__ double awrow[4][PCG_NW];
     __shared__ double esum[4][PCG_NW * PCG_NW + PCG_NW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row0 = blockIdx.x * rows_per_wg, row1 = min(d, row0 + rows_per_wg);
-    double acc[CO_MAXROWS][PCG_NW];
+    double acc[NR][PCG_NW];
 #pragma unroll
-    for (int r = 0; r < CO_MAXROWS; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) acc[r][k] = 0.0;
     for (int t0 = 0; t0 < d; t0 += CO_TILE) {
+        // The wave's rows of this tile first, 16 bytes per load and ALL of them in flight before anything waits (a lane takes four consecutive
+        // columns of each 256-column chunk): with one 4-byte load per row and chunk, as this loop used to be written, a wave of cfg 5 (two rows)
+        // had 32 bytes per lane in flight and the pass ran at 1.3 TB/s (112 us for the 144 MB of the fp32 matrix).  They do not depend on the
+        // staging of W~ below and overlap it.
+        Quad<FT> f[NR][CO_TILE / 256];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int row = row0 + w + 4 * r;
+            const FT* Fr = F + (size_t)(row < row1 ? row : row0) * ld + t0;
+#pragma unroll
+            for (int q = 0; q < CO_TILE / 256; ++q) {
+                const int c = 256 * q + 4 * lane;
+                f[r][q].load(Fr + ((row < row1 && t0 + c < d) ? c : 0));
+            }
+        }
         __syncthreads();
         // (eight loads in flight per thread: left as one load per loop iteration the staging was a chain of L2 round trips per tile and
         // cost more than the pass over the matrix it serves)
@@ -834,36 +863,29 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(int d, int ld, const FT* __r
             for (int k = 0; k < PCG_NW; ++k) wt[k][c] = (t0 + c < d) ? (float)wv[k] : 0.0f;       // W~ holds fp32-representable values: lossless
         }
         __syncthreads();
-        // column chunks outermost: a lane's eight W~ values of a column are read from LDS (and widened) ONCE and used by all of the wave's
-        // rows (they used to be re-read per row: 8 LDS reads + 8 conversions per matrix element, more than the eight FMAs they feed)
-        for (int c0 = 0; c0 < CO_TILE && t0 + c0 < d; c0 += 256) {
-            FT f[CO_MAXROWS][4];
+        // a lane's W~ values of its four columns are read from LDS (and widened) ONCE per chunk and used by all of the wave's rows
 #pragma unroll
-            for (int r = 0; r < CO_MAXROWS; ++r) {
-                const int row = row0 + w + 4 * r;
-                const FT* Fr = F + (size_t)(row < row1 ? row : row0) * ld + t0;
+        for (int q = 0; q < CO_TILE / 256; ++q) {
+            const int c = 256 * q + 4 * lane;
+            if (t0 + 256 * q >= d) break;                            // wave-uniform
+            float4 wq[PCG_NW];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int c = c0 + 64 * u + lane; f[r][u] = (row < row1 && t0 + c < d) ? Fr[c] : (FT)0; }
-            }
+            for (int k = 0; k < PCG_NW; ++k) wq[k] = *reinterpret_cast<const float4*>(&wt[k][c]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + 64 * u + lane;
-                double wk[PCG_NW];
+            for (int r = 0; r < NR; ++r) {
+                if (row0 + w + 4 * r >= row1) continue;              // wave-uniform
+                // columns beyond d hold padding: never multiply garbage (W~ is zero there, 0 x NaN is not)
+                const double f0 = t0 + c + 0 < d ? f[r][q].get(0) : 0.0, f1 = t0 + c + 1 < d ? f[r][q].get(1) : 0.0;
+                const double f2 = t0 + c + 2 < d ? f[r][q].get(2) : 0.0, f3 = t0 + c + 3 < d ? f[r][q].get(3) : 0.0;
 #pragma unroll
-                for (int k = 0; k < PCG_NW; ++k) wk[k] = (double)wt[k][c];
-#pragma unroll
-                for (int r = 0; r < CO_MAXROWS; ++r) {
-                    if (row0 + w + 4 * r >= row1) continue;          // wave-uniform
-                    const double fv = (double)f[r][u];
-#pragma unroll
-                    for (int k = 0; k < PCG_NW; ++k) acc[r][k] = fma(fv, wk[k], acc[r][k]);
-                }
+                for (int k = 0; k < PCG_NW; ++k)
+                    acc[r][k] = fma(f0, (double)wq[k].x, fma(f1, (double)wq[k].y, fma(f2, (double)wq[k].z, fma(f3, (double)wq[k].w, acc[r][k]))));
             }
         }
     }
     double e_acc = 0.0, c_acc = 0.0;
 #pragma unroll
-    for (int r = 0; r < CO_MAXROWS; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int row = row0 + w + 4 * r;
         if (row >= row1) continue;                        // wave-uniform
 #pragma unroll
@@ -2259,8 +2281,10 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       if (ml_debug) ml_debug_check(s, ws, nwg); }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
-      else if (f32) hipLaunchKernelGGL(k_pcg_coarse<float>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
-      else hipLaunchKernelGGL(k_pcg_coarse<double>, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
+      else if (f32) { if (rows_per_wg <= 8) hipLaunchKernelGGL((k_pcg_coarse<float, 2>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
+                      else hipLaunchKernelGGL((k_pcg_coarse<float, CO_MAXROWS>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg); }
+      else { if (rows_per_wg <= 8) hipLaunchKernelGGL((k_pcg_coarse<double, 2>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
+             else hipLaunchKernelGGL((k_pcg_coarse<double, CO_MAXROWS>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg); }
       // fast path: the first CG launch sums the partials and inverts E itself (one launch fewer per LM iteration)
       if (!fast) hipLaunchKernelGGL(k_pcg_coarse_invert, dim3(1), dim3(256), 0, s, nwg, ws->epart, ws->coarse); }
     volatile int* mb = ws->h_mailbox;
