@@ -1053,11 +1053,28 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
     const double* st_in = scal + PS_STATE + PS_STATE_LEN * in;
     double* st_out = scal + PS_STATE + PS_STATE_LEN * out;
     if (COARSE && tid < PCG_NW * PCG_NW) red[80 + tid] = coarse[tid];
+    // fp32 matrix: the first 16-byte batch of this wave's first two rows is requested NOW -- the vector phase below (three syncs, the
+    // vectors from L2) then runs under the matrix's first memory round trip instead of in front of it
+    float4 pre_a[4], pre_b[4];
+    const bool pre = sizeof(FT) == 4 && row0 + w < row1 && lane + 192 < (d >> 2);
+    if (sizeof(FT) == 4) {
+        const int rowa = row0 + w < row1 ? row0 + w : row0, rowb = rowa + 4 < row1 ? rowa + 4 : rowa;
+        const float4* Fa = reinterpret_cast<const float4*>(F + (size_t)rowa * ld);
+        const float4* Fb = reinterpret_cast<const float4*>(F + (size_t)rowb * ld);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { pre_a[m] = Fa[pre ? lane + 64 * m : 0]; pre_b[m] = Fb[pre ? lane + 64 * m : 0]; }
+    }
     double c_new[PCG_NW], mu_new[PCG_NW], pmu_new[PCG_NW], pmu_in[PCG_NW];
     double rz_new = 0.0;
     if (INIT) {
         double rr = 0.0;
-        for (int e = tid; e < d; e += 256) { const double v = bt[e]; pl[e] = v; rr += v * v; }
+        for (int e0 = tid; e0 < d; e0 += 256 * 8) {
+            double bv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; bv8[u] = bt[e < d ? e : d - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < d) { pl[e] = bv8[u]; rr += bv8[u] * bv8[u]; } }
+        }
         rr = wave_allsum(rr);
         if (lane == 0) red[16 + w] = rr;
         __syncthreads();
@@ -1108,7 +1125,14 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
         for (int k = 0; k < PCG_NW; ++k) { c_new[k] = fma(-alpha, g[k], c_in[k]); mu_new[k] = fma(-alpha, Eg[k], mu_in[k]); }
         const double cmu = COARSE ? dot8(c_new, mu_new) : 0.0;
         double rrn = 0.0;
-        for (int e = tid; e < d; e += 256) { const double v = r_in[e] - alpha * q_in[e]; pl[e] = v; rrn += v * v; }
+        // (eight elements' loads in flight: one load / use pair per loop iteration is a chain of d / 256 cache round trips)
+        for (int e0 = tid; e0 < d; e0 += 256 * 8) {
+            double rv8[8], qv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u, ec = e < d ? e : d - 1; rv8[u] = r_in[ec]; qv8[u] = q_in[ec]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < d) { const double v = rv8[u] - alpha * qv8[u]; pl[e] = v; rrn += v * v; } }
+        }
         rrn = wave_allsum(rrn);
         if (lane == 0) red[16 + w] = rrn;
         // x += alpha p  with p = p_r + W~ p_mu, own rows
@@ -1137,7 +1161,13 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
         for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = fma(beta, pmu_in[k], mu_new[k]);
         for (int e = row0 + tid; e < row1; e += 256) r_out[e] = pl[e];      // pl holds r_new
         __syncthreads();
-        for (int e = tid; e < d; e += 256) pl[e] = pl[e] + beta * p_in[e];
+        for (int e0 = tid; e0 < d; e0 += 256 * 8) {
+            double pv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; pv8[u] = p_in[e < d ? e : d - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < d) pl[e] = pl[e] + beta * pv8[u]; }
+        }
         __syncthreads();
         for (int e = row0 + tid; e < row1; e += 256) p_out[e] = pl[e];
         if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
@@ -1191,8 +1221,14 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
             int c = lane;
             for (; c + 192 < nd4; c += 256) {
                 float4 a[4], b[4];
+                const bool first = pre && row == row0 + w && c == lane;       // (wave-uniform) the batch requested before the vector phase
+                if (first) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
+                    for (int m = 0; m < 4; ++m) { a[m] = pre_a[m]; b[m] = pre_b[m]; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const double2 p0 = reinterpret_cast<const double2*>(pl)[2 * (c + 64 * m)], p1 = reinterpret_cast<const double2*>(pl)[2 * (c + 64 * m) + 1];
