@@ -412,6 +412,23 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
             iters += summ["iterations"]
         barrier()
         dt = time.perf_counter() - t0
+        # one rank: the same loop WITHOUT a communicator (the C loop then issues no collective call; pack / unpack kernels and the rest of
+        # the sharded machinery stay) -- separates the loop's own overhead from what RCCL's one-rank all-reduce launches (two fills and a
+        # copy per call in the r04_d kernel statistics)
+        no_comm = None
+        if world == 1:
+            for _ in range(2):
+                be.reset(); sharded.solve_sharded_native(be, opt, comm=None)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            it2 = 0
+            for _ in range(steps):
+                be.reset()
+                it2 += sharded.solve_sharded_native(be, opt, comm=None)["iterations"]
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            no_comm = {"value": it2 / dt2, "unit": "LM iterations/s", "ms_per_step": 1e3 * dt2 / steps,
+                       "note": "one rank, no communicator call: pack / unpack kernels and loop bookkeeping only"}
         # the exchange step on its own, K back-to-back all-reduces of the large block.  CG path (csrc/ba_kernels.hip, k_shard_diag /
         # k_shard_offdiag): (A) diagonal blocks + vectors + scalars, (B) the off-diagonal blocks of the preconditioned matrix, (C) 80 scalars
         L = be.L
@@ -446,6 +463,7 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
                 "distributed_cg_exchange": dist_note,
                 "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
                 "ms_per_step": 1e3 * g_dt / steps, "lm_iterations_per_step": iters / steps,
+                "one_rank_without_collective": no_comm,
                 "allreduce_bytes_per_lm_iteration": int(sum(ex_bytes)),
                 # one rank: the "all-reduce" is a no-op of the communicator, its time says nothing about xGMI
                 "allreduce_ms": 1e3 * g_ar if world > 1 else None,
