@@ -907,29 +907,30 @@ __global__ __launch_bounds__(256) void k_pcg_coarse(int d, int ld, const FT* __r
     if (tid < PCG_NW * PCG_NW + PCG_NW) epart[(size_t)tid * PCG_PART + blockIdx.x] = esum[0][tid] + esum[1][tid] + esum[2][tid] + esum[3][tid];
 }
 
-// E and c_0 = sums of the per-workgroup partials of k_pcg_coarse*: 18 values per wave, their lane-partials reduced in lock
-// step; tot[0 .. 72) (LDS) is complete after the caller's next __syncthreads().  All 256 threads.
+// E and c_0 = sums of the per-workgroup partials of k_pcg_coarse*: NPW values per wave (18: E and c_0; 20: W~^T S~ b~ behind them, fast
+// path), their lane-partials reduced in lock step; tot[0 .. 4 NPW) (LDS) is complete after the caller's next __syncthreads().  All 256 threads.
+template <int NPW = 18>
 __device__ __forceinline__ void coarse_sum_partials(int nwg, const double* __restrict__ epart, double* tot) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double part[18];
+    double part[NPW];
 #pragma unroll
-    for (int m = 0; m < 18; ++m) part[m] = 0.0;
-    for (int i0 = 0; i0 < nwg; i0 += 128) {               // 36 independent loads per lane and pass (clamped, branch-free)
-        double t[18][2];
+    for (int m = 0; m < NPW; ++m) part[m] = 0.0;
+    for (int i0 = 0; i0 < nwg; i0 += 128) {               // 2 NPW independent loads per lane and pass (clamped, branch-free)
+        double t[NPW][2];
 #pragma unroll
-        for (int m = 0; m < 18; ++m)
+        for (int m = 0; m < NPW; ++m)
 #pragma unroll
             for (int i = 0; i < 2; ++i) { const int wg = i0 + lane + 64 * i; t[m][i] = epart[(size_t)(w + 4 * m) * PCG_PART + (wg < nwg ? wg : nwg - 1)]; }
 #pragma unroll
-        for (int m = 0; m < 18; ++m)
+        for (int m = 0; m < NPW; ++m)
 #pragma unroll
             for (int i = 0; i < 2; ++i) part[m] += (i0 + lane + 64 * i < nwg) ? t[m][i] : 0.0;
     }
 #pragma unroll
-    for (int m = 0; m < 18; ++m) part[m] = wave_allsum(part[m]);
+    for (int m = 0; m < NPW; ++m) part[m] = wave_allsum(part[m]);
     if (lane == 0) {
 #pragma unroll
-        for (int m = 0; m < 18; ++m) tot[w + 4 * m] = part[m];
+        for (int m = 0; m < NPW; ++m) tot[w + 4 * m] = part[m];
     }
 }
 
@@ -1021,8 +1022,8 @@ __device__ __forceinline__ void einv_apply(const double* einv_s, const double (&
 
 // LDS scratch of the CG kernels behind the search direction: [0..9) partial totals, [16..20) rrn per wave,
 // [32..40) p_mu of this iteration, [40..76) end-of-kernel partials per wave (4 x 9), [80..144) E^-1; first launch of the fast
-// path only: [144..216) E and c_0 summed from the partials, [216..344) work space of the 8 x 8 inversion
-constexpr int PCG_RED = 344;
+// path only: [144..224) E, c_0 and W~^T S~ b~ summed from the partials, [224..352) work space of the 8 x 8 inversion
+constexpr int PCG_RED = 352;
 
 // Generic path of one CG iteration (any d).  Vector phase as in the fast path but looped; the matvec streams two rows
 // of S~ per wave with 16-byte loads, four deep, so that a wave keeps 128 B per lane in flight (the rows are HBM/MALL
@@ -1274,7 +1275,12 @@ constexpr int PCG_EPT = 5;    // vector elements per thread  (256 * 5 >= d)
 constexpr int PCG_RPW = 2;    // rows of S~ per wave         (rows_per_wg <= 8)
 constexpr int PCG_CPL = 20;   // columns per lane            (64 * 20 >= d)
 
-template <bool INIT, bool COARSE>
+// MODE 0: an iteration.  MODE 1: the first launch of a solve without a coarse space (x0 = 0, r0 = p0 = b~, the product).  MODE 2: the first launch
+// WITH the coarse space, which is also the first ITERATION: k_pcg_coarse_fast left t = S~ b~ (in the q buffer), AW, and the partials of E, c_0 and
+// W~^T t; with p_r0 = b~ and p_mu0 = E^-1 c_0 the first product is q_0 = t + AW p_mu0 and W~^T q_0 = W~^T t + E p_mu0 -- nothing of it needs a pass
+// over S~, so the launch that used to do only the initialisation and that product (10.7 us) is gone and this one (E^-1 by one wave, then a regular
+// iteration) takes its place.
+template <int MODE, bool COARSE>
 __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const double* __restrict__ F, double* __restrict__ vec,
                                                        const double* __restrict__ bt, double* __restrict__ part, double* __restrict__ scal,
                                                        int* flags, int rows_per_wg, double tol2, int in, int* info, int* mailbox, int anchor, double cap,
@@ -1286,19 +1292,22 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
     // `in` = (launch number << 1) | parity.  PF_DONE holds the first launch number that has nothing left to do: a launch must not act
     // on the flag its own workgroup 0 raises (workgroups that start late, e.g. behind another process's kernels, would skip the
     // converging iteration's x update).
+    constexpr bool INIT = MODE == 1, FIRST = MODE == 2;
+    static_assert(!FIRST || COARSE, "the merged first launch exists for the coarse space only");
     const int seq = in >> 1;
     in &= 1;
-    if (!INIT) { const int dn = flags[PF_DONE]; if (dn != 0 && seq >= dn) return; }
+    if (MODE == 0) { const int dn = flags[PF_DONE]; if (dn != 0 && seq >= dn) return; }
     constexpr int NV = COARSE ? PCG_NPART : 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
     // first launch of a solve: E^-1 and c_0 from the partials k_pcg_coarse_fast left behind -- formed by EVERY workgroup for
     // itself (no launch of its own: the 8 x 8 inversion is ~3 us of one wave), published by workgroup 0 for the launches that follow
     if (INIT && COARSE) coarse_sum_partials((int)gridDim.x, epart, red + 144);
+    if (FIRST) coarse_sum_partials<20>((int)gridDim.x, epart, red + 144);
     const int row0 = blockIdx.x * rows_per_wg;
     const int row1 = min(d, row0 + rows_per_wg);
     const int nwg = (int)gridDim.x;
-    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = INIT ? bt : pcg_vec(vec, 1, in, ld);
-    const double* p_in = pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
+    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = (INIT || FIRST) ? bt : pcg_vec(vec, 1, in, ld);
+    const double* p_in = FIRST ? bt : pcg_vec(vec, 2, in, ld); const double* q_in = pcg_vec(vec, 3, in, ld);
     double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld);
     double* p_out = pcg_vec(vec, 2, out, ld); double* q_out = pcg_vec(vec, 3, out, ld);
     const double* st_in = scal + PS_STATE + PS_STATE_LEN * in;
@@ -1310,13 +1319,13 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
     for (int m = 0; m < PCG_EPT; ++m) {
         const int e = tid + 256 * m;
         const bool ok = e < d;
-        rv[m] = ok ? r_in[e] : 0.0; qv[m] = (ok && !INIT) ? q_in[e] : 0.0; pv[m] = (ok && !INIT) ? p_in[e] : 0.0;
+        rv[m] = ok ? r_in[e] : 0.0; qv[m] = (ok && !INIT) ? q_in[e] : 0.0; pv[m] = FIRST ? rv[m] : (ok && !INIT) ? p_in[e] : 0.0;      // (first launch: p_r0 = r_0 = b~)
     }
     double mine[3] = { 0.0, 0.0, 0.0 };           // partial sums of the previous launch: wave w owns values w, w + 4, w + 8
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int v = w + 4 * j;
-        if (!INIT && 4 * j < NV) {
+        if (MODE == 0 && 4 * j < NV) {
             // branch-free, clamped: a conditional `+= load` makes the compiler wait for every load in turn (measured: twelve
             // dependent memory round trips, +3 us per iteration)
             const double* pp = pcg_part(part, in, v < NV ? v : 0);
@@ -1327,23 +1336,35 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             for (int i = 0; i < 4; ++i) mine[j] += (lane + 64 * i < nwg && v < NV) ? t[i] : 0.0;
         }
     }
-    const double einv_mine = (COARSE && !INIT && tid < PCG_NW * PCG_NW) ? coarse[tid] : 0.0;
-    const double rr0 = INIT ? 0.0 : scal[PS_RR0];
-    const double rz_in = INIT ? 0.0 : st_in[PS_RZ];
+    const double einv_mine = (COARSE && MODE == 0 && tid < PCG_NW * PCG_NW) ? coarse[tid] : 0.0;
+    double rr0 = MODE == 0 ? scal[PS_RR0] : 0.0;
+    double rz_in = MODE == 0 ? st_in[PS_RZ] : 0.0;
+    const double rrf = (FIRST && anchor == 2) ? scal[PS_RRF] : 0.0;
     double c_in[PCG_NW], mu_in[PCG_NW], pmu_in[PCG_NW];
 #pragma unroll
     for (int k = 0; k < PCG_NW; ++k) {
-        c_in[k] = (COARSE && !INIT) ? st_in[PS_C + k] : 0.0;
-        mu_in[k] = (COARSE && !INIT) ? st_in[PS_MU + k] : 0.0;
-        pmu_in[k] = (COARSE && !INIT) ? st_in[PS_PMU + k] : 0.0;
+        c_in[k] = (COARSE && MODE == 0) ? st_in[PS_C + k] : 0.0;
+        mu_in[k] = (COARSE && MODE == 0) ? st_in[PS_MU + k] : 0.0;
+        pmu_in[k] = (COARSE && MODE == 0) ? st_in[PS_PMU + k] : 0.0;
     }
     // own rows (the last wave's lanes < rows): what the x update and the stores of r, p_r need
     const int eo = row0 + (tid - 192);
     const bool own = tid >= 192 && eo < row1;
     double xo = 0.0, po = 0.0, ro = 0.0, qo = 0.0, wo[PCG_NW];
-    if (own) { ro = r_in[eo]; if (!INIT) { xo = x_in[eo]; po = p_in[eo]; qo = q_in[eo]; } }
+    if (own) { ro = r_in[eo]; if (MODE == 0) { xo = x_in[eo]; po = p_in[eo]; qo = q_in[eo]; } if (FIRST) { po = ro; qo = q_in[eo]; } }
 #pragma unroll
     for (int k = 0; k < PCG_NW; ++k) wo[k] = (COARSE && own && !INIT) ? W[(size_t)k * ld + eo] : 0.0;
+    double aw5[FIRST ? PCG_EPT : 1][PCG_NW], awo[PCG_NW];     // first launch: AW[e][:] for q_0 = t + AW p_mu0
+    if (FIRST) {
+#pragma unroll
+        for (int m = 0; m < PCG_EPT; ++m) {
+            const int e = tid + 256 * m;
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) { const double v = AW[(size_t)(e < d ? e : 0) * PCG_NW + k]; aw5[m][k] = e < d ? v : 0.0; }
+        }
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) awo[k] = own ? AW[(size_t)eo * PCG_NW + k] : 0.0;
+    }
     double2 fv[PCG_RPW][PCG_CPL / 2];          // 16-byte loads: lane takes columns 2*(lane + 64 m), +1
     double awv[PCG_RPW];                       // lanes 0..7: AW[row][lane]; lanes 8..15: W~[lane - 8][row]
 #pragma unroll
@@ -1361,14 +1382,14 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         awv[k] = 0.0;
         if (COARSE && row < row1 && lane < 2 * PCG_NW) awv[k] = lane < PCG_NW ? AW[(size_t)row * PCG_NW + lane] : W[(size_t)(lane - PCG_NW) * ld + row];
     }
-    if (COARSE && !INIT && tid < PCG_NW * PCG_NW) red[80 + tid] = einv_mine;
+    if (COARSE && MODE == 0 && tid < PCG_NW * PCG_NW) red[80 + tid] = einv_mine;
     double c_new[PCG_NW], mu_new[PCG_NW], pmu_new[PCG_NW];
     double rz_new;
     if (INIT) {
         if (COARSE) {
             __syncthreads();                              // E, c_0 complete in red[144 ..)
             if (w == 0) {
-                const double e = coarse_invert_wave(red + 144, red + 216, red + 280);
+                const double e = coarse_invert_wave(red + 144, red + 224, red + 288);
                 red[80 + lane] = e;
                 if (blockIdx.x == 0) { coarse[lane] = e; if (lane < PCG_NW) coarse[PCG_NW * PCG_NW + lane] = red[144 + PCG_NW * PCG_NW + lane]; }
             }
@@ -1395,12 +1416,62 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
             if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
         }
     } else {
-        reduce_partials<NV>(mine, red);
-        __syncthreads();
         double g[PCG_NW], Eg[PCG_NW];
+        double pq;
+        if (FIRST) {
+            __syncthreads();                              // E, c_0, W~^T t complete in red[144 .. 224)
+            if (w == 0) {
+                const double e = coarse_invert_wave(red + 144, red + 224, red + 288);
+                red[80 + lane] = e;
+                if (blockIdx.x == 0) { coarse[lane] = e; if (lane < PCG_NW) coarse[PCG_NW * PCG_NW + lane] = red[144 + PCG_NW * PCG_NW + lane]; }
+            }
+            double rr = 0.0;
 #pragma unroll
-        for (int k = 0; k < PCG_NW; ++k) { g[k] = COARSE ? red[1 + k] : 0.0; Eg[k] = 0.0; }
-        const double pq = red[0] + (COARSE ? dot8(pmu_in, g) : 0.0);
+            for (int m = 0; m < PCG_EPT; ++m) rr += rv[m] * rv[m];
+            rr = wave_allsum(rr);
+            if (lane == 0) red[16 + w] = rr;
+            __syncthreads();                              // E^-1 in red[80 .. 144), |b~|^2
+            rr = red[16] + red[17] + red[18] + red[19];
+            if (rr == 0.0) {                              // b~ = 0: x = 0 is the solution
+                if (own) x_out[eo] = 0.0;
+                if (blockIdx.x == 0 && tid == 0) {
+                    scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = seq + 1; flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
+                    if (mailbox) pcg_post(mailbox, 0, 1);
+                }
+                return;
+            }
+            // c_0, mu_0 = E^-1 c_0 = p_mu0; q_0 = t + AW p_mu0; W~^T q_0 = W~^T t + E p_mu0; r_0 . z_0 = |b~|^2 + c_0 . mu_0
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) { c_in[k] = red[144 + PCG_NW * PCG_NW + k]; mu_in[k] = 0.0; }
+            einv_apply(red + 80, c_in, mu_in);
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) pmu_in[k] = mu_in[k];
+            rz_in = rr + dot8(c_in, mu_in);
+            rr0 = anchor == 2 ? fmin(fmax(rr, rrf), cap * rr) : rr;          // pcg_threshold_base, without its store
+            if (blockIdx.x == 0 && tid == 0) scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap);
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) {
+                double erow[PCG_NW];
+#pragma unroll
+                for (int j = 0; j < PCG_NW; ++j) erow[j] = red[144 + PCG_NW * k + j];
+                g[k] = red[144 + PCG_NW * PCG_NW + PCG_NW + k] + dot8(erow, pmu_in);
+                Eg[k] = 0.0;
+            }
+            double pqr = 0.0;
+#pragma unroll
+            for (int m = 0; m < PCG_EPT; ++m) { qv[m] += dot8(aw5[m], pmu_in); pqr = fma(pv[m], qv[m], pqr); }     // (elements beyond d: all zero)
+            qo += dot8(awo, pmu_in);
+            pqr = wave_allsum(pqr);
+            if (lane == 0) red[20 + w] = pqr;
+            __syncthreads();
+            pq = (red[20] + red[21]) + (red[22] + red[23]) + dot8(pmu_in, g);
+        } else {
+            reduce_partials<NV>(mine, red);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) { g[k] = COARSE ? red[1 + k] : 0.0; Eg[k] = 0.0; }
+            pq = red[0] + (COARSE ? dot8(pmu_in, g) : 0.0);
+        }
         const double alpha = rz_in * fast_rcp(pq);       // rcp + 2 Newton steps: the generic fp64 division is a ~15-deep dependent chain on the critical path
         if (COARSE) einv_apply(red + 80, g, Eg);          // independent of alpha: overlaps the reciprocal
 #pragma unroll
@@ -1421,7 +1492,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
         const bool done = rrn <= tol2 * rr0 || broke;
         if (done) {
             if (blockIdx.x == 0 && tid == 0) {
-                flags[PF_DONE] = seq + 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
+                flags[PF_DONE] = seq + 1; flags[PF_XBUF] = out; const int it = FIRST ? 1 : flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
                 if (broke) atomicCAS(info, 0, d + 1);
                 if (mailbox) pcg_post(mailbox, it, 1);
             }
@@ -1433,7 +1504,10 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
 #pragma unroll
         for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; if (e < d) pl[e] = rv[m] + beta * pv[m]; }
         if (own) { const double rn = ro - alpha * qo; r_out[eo] = rn; p_out[eo] = rn + beta * po; }
-        if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
+        if (blockIdx.x == 0 && tid == 0) {
+            const int it = FIRST ? 1 : flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (FIRST) flags[PF_DONE] = 0;
+            if (mailbox) pcg_post(mailbox, it, 0);
+        }
     }
     if (blockIdx.x == 0 && tid == 64) {
         st_out[PS_RZ] = rz_new;
@@ -1470,12 +1544,16 @@ __global__ __launch_bounds__(256) void k_pcg_iter_fast(int d, int ld, const doub
 // AW = S~ W~, E = W~^T AW, c_0 = W~^T b~ for d <= 1280, same workgroup geometry as k_pcg_iter_fast: the rows of S~ and this
 // thread's share of W~ are loaded up front, W~ goes to LDS in fp32 (its values are fp32-representable: lossless).
 __global__ __launch_bounds__(256) void k_pcg_coarse_fast(int d, int ld, const double* __restrict__ F, const double* __restrict__ W,
-                                                         const double* __restrict__ bt, double* __restrict__ AW, double* __restrict__ epart, int rows_per_wg) {
+                                                         const double* __restrict__ bt, double* __restrict__ AW, double* __restrict__ epart, int rows_per_wg,
+                                                         double* __restrict__ t_out) {
     __shared__ __align__(16) float wt[PCG_NW][64 * PCG_CPL];
-    __shared__ double esum[4][PCG_NW * PCG_NW + PCG_NW];
+    __shared__ double esum[4][PCG_NW * PCG_NW + 2 * PCG_NW];
+    __shared__ __align__(16) double bl[64 * PCG_CPL];            // b~ (t = S~ b~ for the first CG launch)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row0 = blockIdx.x * rows_per_wg, row1 = min(d, row0 + rows_per_wg);
-    double wreg[PCG_NW][PCG_EPT];
+    double wreg[PCG_NW][PCG_EPT], breg[PCG_EPT];
+#pragma unroll
+    for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; breg[m] = bt[e < d ? e : 0]; }
 #pragma unroll
     for (int k = 0; k < PCG_NW; ++k)
 #pragma unroll
@@ -1504,15 +1582,22 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_fast(int d, int ld, const do
     for (int k = 0; k < PCG_NW; ++k)
 #pragma unroll
         for (int m = 0; m < PCG_EPT; ++m) wt[k][tid + 256 * m] = (tid + 256 * m < d) ? (float)wreg[k][m] : 0.0f;
-    __syncthreads();
-    double acc[PCG_RPW][PCG_NW];
 #pragma unroll
-    for (int r = 0; r < PCG_RPW; ++r)
+    for (int m = 0; m < PCG_EPT; ++m) bl[tid + 256 * m] = (tid + 256 * m < d) ? breg[m] : 0.0;
+    __syncthreads();
+    double acc[PCG_RPW][PCG_NW], tacc[PCG_RPW];
+#pragma unroll
+    for (int r = 0; r < PCG_RPW; ++r) {
+        tacc[r] = 0.0;
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) acc[r][k] = 0.0;
+    }
 #pragma unroll
     for (int m = 0; m < PCG_CPL / 2; ++m) {
         const int c2 = lane + 64 * m;
+        const double2 bv = reinterpret_cast<const double2*>(bl)[c2];
+#pragma unroll
+        for (int r = 0; r < PCG_RPW; ++r) tacc[r] = fma(fv[r][m].x, bv.x, fma(fv[r][m].y, bv.y, tacc[r]));
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) {
             const float2 wv = reinterpret_cast<const float2*>(&wt[k][0])[c2];
@@ -1524,10 +1609,13 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_fast(int d, int ld, const do
     for (int r = 0; r < PCG_RPW; ++r)
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) acc[r][k] = wave_allsum(acc[r][k]);
-    double e_acc = 0.0, c_acc = 0.0;
+    double e_acc = 0.0, c_acc = 0.0, t_acc = 0.0;
 #pragma unroll
     for (int r = 0; r < PCG_RPW; ++r) {
         const int row = row0 + w + 4 * r;
+        const double tr = wave_allsum(tacc[r]);          // (S~ b~)[row]: the first CG launch's q = S~ p_r with p_r = b~
+        if (lane == 0 && row < row1) t_out[row] = tr;
+        t_acc = fma(wcol[r], tr, t_acc);                 // W~^T S~ b~ (lanes 0..7; rows beyond row1: wcol = 0)
         double mine = 0.0;                               // AW[row][lane & 7]
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) mine = ((lane & 7) == k) ? acc[r][k] : mine;
@@ -1536,9 +1624,9 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_fast(int d, int ld, const do
         c_acc = fma(wcol[r], btr[r], c_acc);
     }
     esum[w][lane] = e_acc;
-    if (lane < PCG_NW) esum[w][PCG_NW * PCG_NW + lane] = c_acc;
+    if (lane < PCG_NW) { esum[w][PCG_NW * PCG_NW + lane] = c_acc; esum[w][PCG_NW * PCG_NW + PCG_NW + lane] = t_acc; }
     __syncthreads();
-    if (tid < PCG_NW * PCG_NW + PCG_NW) epart[(size_t)tid * PCG_PART + blockIdx.x] = esum[0][tid] + esum[1][tid] + esum[2][tid] + esum[3][tid];
+    if (tid < PCG_NW * PCG_NW + 2 * PCG_NW) epart[(size_t)tid * PCG_PART + blockIdx.x] = esum[0][tid] + esum[1][tid] + esum[2][tid] + esum[3][tid];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2185,8 +2273,9 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
         hipLaunchKernelGGL((k_pcg_iter_ml<INIT>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags, r.tol2, in, r.info,
                            ws->d_mailbox, anchor, cap, ws->W, ws->mlAW, ws->mlEinv, ws->mlC0, ws->mlState);
     } else if (r.fast) {
-        if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
-        else hipLaunchKernelGGL((k_pcg_iter_fast<INIT, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
+        // (with the coarse space the first launch is also the first iteration: MODE 2, see k_pcg_iter_fast)
+        if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT ? 2 : 0, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
+        else hipLaunchKernelGGL((k_pcg_iter_fast<INIT ? 1 : 0, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
     } else if (r.f32) {
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter<INIT, float, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
         else hipLaunchKernelGGL((k_pcg_iter<INIT, float, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
@@ -2316,7 +2405,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       static const bool ml_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;      // (read once per process)
       if (ml_debug) ml_debug_check(s, ws, nwg); }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
-      if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
+      if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg, ws->vec + (size_t)(2 * 3 + 0) * ld);      // t -> the q buffer of parity 0 (pcg_vec)
       else if (f32) { if (rows_per_wg <= 8) hipLaunchKernelGGL((k_pcg_coarse<float, 2>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
                       else hipLaunchKernelGGL((k_pcg_coarse<float, CO_MAXROWS>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg); }
       else { if (rows_per_wg <= 8) hipLaunchKernelGGL((k_pcg_coarse<double, 2>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
@@ -2329,12 +2418,13 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     ws->run.tol2 = tol * tol; ws->run.in = 1; ws->run.launched = 0; ws->run.max_iters = max_iters; ws->run.info = info_dev;
     { ProfScope ps(prof, KID_PCG_ITER, s);
       launch_cg_iteration<true>(s, ws, anchor, cap); }
+    if (fast && coarse && !ml) ws->run.launched = 1;       // the merged first launch IS iteration 1 (max_iters counts it)
     int batch = 24;
     static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 1; }();
     // history + 1 (was + 2; +0.6 % on the headline): a solve that needs two more iterations than last time costs a host round trip, a surplus (early-exit) launch ~2 us
     // (run to 1e-12 -- AUTO -- a solve takes 13 +- 1 iterations from one call to the next, the atomics' summation order is enough: a batch one
     // launch short costs a host round trip of ~50 us, a surplus launch ~2: one more in reserve there)
-    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra + (tol < 1e-10 ? 1 : 0);
+    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra + (tol < 1e-10 ? 1 : 0) - ((fast && coarse && !ml) ? 1 : 0);     // (the merged first launch is iteration 1)
     if (no_wait) return dense_pcg_more(s, ws, batch, prof);
     bool done = false;
     while (!done) {
@@ -2434,7 +2524,7 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
     if (!ws->W) {
         if (ws_alloc(ws, &ws->W, sizeof(double) * (size_t)PCG_NW * ws->ld)) return -1;
         if (ws_alloc(ws, &ws->AW, sizeof(double) * (size_t)PCG_NW * ws->ld)) return -1;
-        if (ws_alloc(ws, &ws->epart, sizeof(double) * (size_t)(PCG_NW * PCG_NW + PCG_NW) * PCG_PART)) return -1;
+        if (ws_alloc(ws, &ws->epart, sizeof(double) * (size_t)(PCG_NW * PCG_NW + 2 * PCG_NW) * PCG_PART)) return -1;
         if (ws_alloc(ws, &ws->coarse, sizeof(double) * (size_t)(PCG_NW * PCG_NW + PCG_NW))) return -1;
     }
     if (!ws->mlAW && dense_pcg_segments_applicable(ws)) {
