@@ -1688,7 +1688,8 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             // the streaming CG path stores S~ in fp32: with a single-precision all-reduce the partial blocks are exchanged in fp32 and
             // the sum is the CG's matrix (what the camera pass and the pair epilogue write directly -- diagonal blocks, focal column --
             // goes to the fp32 matrix as on one GPU); otherwise everything is summed in fp64 and narrowed after the sum
-            const bool x32 = F32 != nullptr && p->allreduce_f32 != nullptr && allreduce != nullptr && !exchange_f32_off;
+            // (one rank without a communicator: nothing is exchanged, the blocks stay in the CG's own precision)
+            const bool x32 = F32 != nullptr && !exchange_f32_off && ((p->allreduce_f32 != nullptr && allreduce != nullptr) || (p->shard_world == 1 && allreduce == nullptr));
             p->db.pcg_F32 = x32 ? F32 : nullptr;
             p->shard_exchange[0] = 8 * shard_diag_len(p->ds); p->shard_exchange[1] = (x32 ? 4 : 8) * shard_offdiag_len(p->ds);
             p->shard_exchange[2] = 8 * SFMBA_SHARD_SCALARS; p->shard_exchange[3] = x32 ? 1 : 0;
@@ -1749,7 +1750,7 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 1); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 1);
             p->db.shard_blocks = nullptr; p->db.shard_blocks32 = nullptr;
             if (x32) {
-                const int arc = p->allreduce_f32(ctx, p->d_red, shard_offdiag_len(p->ds), (void*)p->stream);
+                const int arc = allreduce ? p->allreduce_f32(ctx, p->d_red, shard_offdiag_len(p->ds), (void*)p->stream) : 0;
                 if (arc != 0) return fail(SFMBA_ERR_HIP, "all-reduce (fp32) failed (rc " + std::to_string(arc) + ")");
                 launch_shard_offdiag_f32(p->stream, p->ds, F32, reinterpret_cast<const float*>(p->d_red));
             } else {
