@@ -414,7 +414,7 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
         dt = time.perf_counter() - t0
         # one rank: the same loop WITHOUT a communicator (the C loop then issues no collective call; pack / unpack kernels and the rest of
         # the sharded machinery stay) -- separates the loop's own overhead from what RCCL's one-rank all-reduce launches (two fills and a
-        # copy per call in the r04_d kernel statistics)
+        # copy per call in the r04_f kernel statistics)
         no_comm = None
         if world == 1:
             for _ in range(2):
@@ -564,7 +564,7 @@ def pmc_traffic(kernel):
             # several instantiations of one kernel (k_schur_pairs<..., MODE, ...>): the one that moves the most is the per-iteration pass
             f, w = max(hits, key=lambda v: v[0] + v[1])
             return entry(f, w, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run (%.0f s)" % LIVE_PMC["seconds"], True)
-    # the committed summary must be of the SAME workload (r04_d_cfg3_pcg_pmc_traffic.txt / r04_d_cfg5_...): anything else is not this kernel's traffic
+    # the committed summary must be of the SAME workload (r04_f_cfg3_pcg_pmc_traffic.txt / r04_f_cfg5_...): anything else is not this kernel's traffic
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pcg_pmc_traffic.txt" % PMC_WORKLOAD)))
     if not files:
         return None
