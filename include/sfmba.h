@@ -123,7 +123,8 @@ typedef struct sfmba_options {
                                          matrix is sparsely filled (< 1/2 of its blocks) with >= 90 % of the blocks within a quarter of the cyclic camera
                                          order -- views registered along a path --, d <= 1280 and >= 32 cameras, the seven similarity vectors are used
                                          restricted to eight overlapping SEGMENTS of the camera order (57 vectors: 3 - 4x fewer CG iterations there).
-                                         1 = the eight global vectors only, 2 = the segments wherever they apply (SFMBA_PCG_SEGMENTS=0|1 likewise) */
+                                         1 = the eight global vectors only, 2 = the segments wherever they apply (SFMBA_PCG_SEGMENTS=0|1 likewise).
+                                         The sharded solve keeps the eight global vectors (the choice would have to be agreed between the ranks). */
     int    pcg_persistent;            /* SFMBA_PCG_PERSISTENT     default off: whole CG solve in one cooperative launch (d <= 1280) */
     int    pcg_f32_matrix;            /* SFMBA_PCG_F32_MATRIX     default on : F32J + streaming CG (d > 1280) store S~ in fp32 */
     int    early_linearise;           /* SFMBA_EARLY_LINEARISE    default on : next linearisation enqueued before the host reads the verdict */
