@@ -103,3 +103,21 @@ def test_structure_chooses_segments_on_the_banded_baseline_shape(capi, sfm):
             s, tr = P.solve(capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_coarse_space=mode))
             its[mode] = [r["linear_iters"] for r in tr[1:]]
     assert its[0] == its[1]
+
+
+@pytest.mark.parametrize("n_cam", [32, 33, 47, 64, 101, 150, 213])
+def test_segments_any_camera_count(capi, sfm, n_cam):
+    """Hat boundaries that fall between cameras (camera counts no multiple of eight), the largest count the one-round-trip CG kernels take
+    (213: d = 1279), both co-visibility shapes: forced segments against the eight global vectors -- the same LM trajectory and minimum."""
+    for views, n_pt in (("banded", 60 * n_cam), (None, 40 * n_cam)):
+        kw = dict(n_cam=n_cam, n_pt=n_pt, seed=900 + n_cam)
+        prob = sfm.make_problem("cfg3_banded", **kw) if views else sfm.make_problem("cfg3", **kw)
+        res = {}
+        for mode in (1, 2):
+            res[mode] = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=mode, pcg_tolerance=1e-10))
+        a, b = res[1], res[2]
+        assert a[3]["termination_name"] == b[3]["termination_name"] == "CONVERGENCE"
+        assert a[3]["iterations"] == b[3]["iterations"]
+        assert abs(a[3]["final_cost"] - b[3]["final_cost"]) <= 1e-9 * a[3]["final_cost"]
+        assert np.abs(a[0] - b[0]).max() < 1e-6 and np.abs(a[1] - b[1]).max() < 1e-5
+        assert all(r["linear_iters"] > 0 for r in b[4][1:])
