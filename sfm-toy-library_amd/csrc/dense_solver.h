@@ -19,7 +19,7 @@ struct DenseSolver {
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
     float* Sfull32 = nullptr; // fp32 copy for the streaming path (allocated by dense_pcg_want_f32)
     // launch parameters of the running CG solve (dense_pcg_solve ... dense_pcg_more)
-    struct CgRun { int nwg = 0, rows_per_wg = 0; size_t lds = 0; bool fast = false, f32 = false, coarse = false, ml = false; double tol2 = 0.0; int in = 1, launched = 0, max_iters = 0; int* info = nullptr; } run;
+    struct CgRun { int nwg = 0, rows_per_wg = 0; size_t lds = 0; bool fast = false, f32 = false, coarse = false, ml = false, sg = false; double tol2 = 0.0; int in = 1, launched = 0, max_iters = 0; int* info = nullptr; } run;
     bool use_f32 = false;     // set by the caller per solve: the preconditioned matrix of THIS solve lives in Sfull32
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][9][1024] per-workgroup partial sums of one iteration (p_r.q, W~^T q), by iteration parity
@@ -36,6 +36,8 @@ struct DenseSolver {
     double* mlEinv = nullptr; // [64][64] E^-1 (rows / columns of dropped vectors zero)
     double* mlC0 = nullptr;   // [64] c_0 = W~^T b~
     double* mlState = nullptr;// [2][3][64] c, mu, p_mu by iteration parity
+    // ... on the streaming path (d > 1280): per-camera pieces of E, E, E^-1 (192 x 192), per-camera W~_k . r, |r|^2 partials, {r.z, p.q} by parity
+    double *sgV = nullptr, *sgE = nullptr, *sgEinv = nullptr, *sgT = nullptr, *sgRR = nullptr, *sgState = nullptr;
     int last_iters = 0;       // CG iterations of the previous solve
     std::vector<int> hist;    // CG iterations of the previous call per caller key (LM iteration index): sizes the first launch batch
     double* binv = nullptr;   // [ld*6] inverses of the 6x6 diagonal blocks (+1x1 focal)
@@ -76,6 +78,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
                     bool no_wait = false, bool coarse = false, bool segments = false);
 // segments = true (with coarse): the segmented coarse space where it applies (dense_pcg_segments_applicable: d = 6 nc + 1 <= 1280, nc >= 32)
 bool dense_pcg_segments_applicable(const DenseSolver* ws);
+// ... or its streaming-path form (1280 < d <= 8192): classical PCG in three launches per iteration, up to 27 hats
+bool dense_pcg_segments_streaming_applicable(const DenseSolver* ws);
 // dense_pcg_transform: the block-Jacobi transform on its own (block factors -> ws->binv, S~ -> ws->Sfull / Sfull32, b~), for callers that
 // need the factors before the solve (sharded path: gauge vectors are formed from them); follow with dense_pcg_solve(pretransformed = true).
 int dense_pcg_transform(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof = nullptr);

@@ -2079,6 +2079,455 @@ __global__ __launch_bounds__(256) void k_pcg_iter_ml(int d, int ld, const double
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Segmented coarse space on the STREAMING path (d > 1280: long camera paths -- 600 cameras of a path need 314 .. 396 CG iterations per
+// linearisation with the eight global vectors, tools/large_banded_check.py).  Same coarse space as above with G = cameras / 25 hats (at most 20:
+// 7 G + 1 <= 141 vectors), but a coarse operator of that size cannot ride in every workgroup of a fused launch (E^-1 is 166 KB), and the search
+// direction need not be kept split: classical PCG with M^-1 = I + W~ E^-1 W~^T in THREE launches per iteration --
+//   k_sg_q   q = S~ p for the rows of a workgroup (the streaming product of k_pcg_iter), per-workgroup partials of p . q
+//   k_sg_u   alpha; x += alpha p, r -= alpha q on the rows of a workgroup's cameras; per camera t_k = sum of W~_k[row] r[row]; partials of |r|^2
+//   k_sg_p   |r|^2 (the stopping test), c = W~^T r from the t_k per hat, mu = E^-1 c, r . z = |r|^2 + c . mu, beta, p = r + W~ mu + beta p
+// (the coarse solve is formed by each of the SG_UWG workgroups of k_sg_p for itself).  Set-up per linear solve: k_sg_v (per camera: the pieces of E
+// and c_0, AW is never stored), k_sg_e (E, hat sums), k_sg_invert (Gauss-Jordan in the registers of one workgroup -- what limits the hats to 20,
+// see there).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SG_MAXG = 20;
+constexpr int SG_NCP = 144;                 // padded coarse dimension: 7 SG_MAXG + 1 = 141 vectors
+constexpr int SG_CB = 36;                   // columns per part of the E^-1 c product (SG_NCP / 4)
+constexpr int SG_UWG = 16;                  // workgroups of the vector kernels
+constexpr int SG_UT = 1024;                 // ... and their threads
+constexpr int SG_TC = 128;                  // cameras per column tile of k_sg_v
+constexpr size_t SG_V_LDS = sizeof(double) * 6 * 6 * SG_TC + sizeof(float) * PCG_NW * 6 * SG_TC + sizeof(double) * 4 * SG_NCP;
+enum { SGS_RZ = 0, SGS_PQ = 1, SGS_LEN = 4 };     // per-parity scalars of the running solve (sg_state)
+
+__device__ __forceinline__ int sg_first_cam(int a, int nc, int G) { return (a * nc + G - 1) / G; }
+__device__ __forceinline__ double sg_frac(int j, int a, int nc, int G, double inv_nc) { return (double)(j * G - a * nc) * inv_nc; }
+__host__ __device__ __forceinline__ int sg_hats(int nc) { const int g = nc / 25; return g < ML_G ? ML_G : g > SG_MAXG ? SG_MAXG : g; }
+
+// per camera j (workgroup; the last one: the focal row): V[j][8][SG_NCP] = sum over the camera's rows of W~_k[row] (S~ W~)[row][:].  Column tiles of SG_TC cameras: the camera's six rows of the tile and W~_0..7 (fp32) in LDS, lane + 64 pass = coarse vector.
+template <typename FT>
+__global__ __launch_bounds__(256) void k_sg_v(int d, int ld, int G, const FT* __restrict__ F, const double* __restrict__ W,
+                                              double* __restrict__ V) {
+    extern __shared__ __align__(16) double sm[];
+    double* rows = sm;                                                   // [6][6 SG_TC]
+    float* wt = reinterpret_cast<float*>(rows + 6 * 6 * SG_TC);          // [8][6 SG_TC]
+    double* vbuf = reinterpret_cast<double*>(wt + PCG_NW * 6 * SG_TC);   // [4][SG_NCP]
+    constexpr int TW = 6 * SG_TC;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nc = (d - 1) / 6, NC = 7 * G + 1;
+    const double inv_nc = 1.0 / (double)nc;
+    const int row0 = 6 * blockIdx.x, row1 = min(d, row0 + 6);
+    const int ra = w, rb = w + 4;
+    const bool have_a = row0 + ra < row1, have_b = row0 + rb < row1;
+    double acc[2][3], gs[2] = { 0.0, 0.0 };
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) acc[r][p] = 0.0;
+    for (int c0 = 0; c0 < nc; c0 += SG_TC) {
+        const int col0 = 6 * c0, ncol = min(6 * nc - col0, TW);
+        // all loads of the tile first (18 + 24 per thread, clamped, branch-free), then the LDS stores: a loop of load / store pairs is a chain of
+        // 42 memory round trips per tile (measured: 289 us for this kernel)
+        FT fr_[6 * TW / 256];
+        double wr_[PCG_NW * TW / 256];
+#pragma unroll
+        for (int u = 0; u < 6 * TW / 256; ++u) {
+            const int e = tid + 256 * u, r = e / TW, c = e - TW * r;
+            const bool ok = row0 + r < row1 && c < ncol;
+            fr_[u] = F[(size_t)(ok ? row0 + r : row0) * ld + col0 + (ok ? c : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < PCG_NW * TW / 256; ++u) {
+            const int e = tid + 256 * u, k = e / TW, c = e - TW * k;
+            wr_[u] = W[(size_t)k * ld + col0 + (c < ncol ? c : 0)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 6 * TW / 256; ++u) {
+            const int e = tid + 256 * u, r = e / TW, c = e - TW * r;
+            rows[e] = (row0 + r < row1 && c < ncol) ? (double)fr_[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < PCG_NW * TW / 256; ++u) {
+            const int e = tid + 256 * u, c = e % TW;
+            wt[e] = c < ncol ? (float)wr_[u] : 0.0f;
+        }
+        __syncthreads();
+        const int c1 = min(nc, c0 + SG_TC);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int v = lane + 64 * p;
+            if (v < NC - 1) {
+                const int g = v / 7, k = v - 7 * g;
+                const float* wk = wt + k * TW;
+                for (int range = 0; range < 2; ++range) {
+                    const int a = range == 0 ? (g + G - 1) % G : g;
+                    const int lo = max(sg_first_cam(a, nc, G), c0), hi = min(sg_first_cam(a + 1, nc, G), c1);
+                    for (int j = lo; j < hi; ++j) {
+                        const double fr = sg_frac(j, a, nc, G, inv_nc);
+                        const double wgt = range == 0 ? fr : 1.0 - fr;
+                        const int o = 6 * (j - c0);
+                        double ta = 0.0, tb = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) { const double wv = (double)wk[o + e]; ta = fma(rows[ra * TW + o + e], wv, ta); tb = fma(rows[(have_b ? rb : ra) * TW + o + e], wv, tb); }
+                        acc[0][p] = fma(wgt, ta, acc[0][p]);
+                        acc[1][p] = fma(wgt, tb, acc[1][p]);
+                    }
+                }
+            }
+        }
+        // the global (focal / depth) vector: every column of the tile
+        for (int c = lane; c < ncol; c += 64) {
+            const double wv = (double)wt[(PCG_NW - 1) * TW + c];
+            gs[0] = fma(rows[ra * TW + c], wv, gs[0]);
+            gs[1] = fma(rows[(have_b ? rb : ra) * TW + c], wv, gs[1]);
+        }
+    }
+    gs[0] = wave_allsum(gs[0]); gs[1] = wave_allsum(gs[1]);
+    {   // the focal column
+        const double wf = W[(size_t)(PCG_NW - 1) * ld + d - 1];
+        if (have_a) gs[0] = fma((double)F[(size_t)(row0 + ra) * ld + d - 1], wf, gs[0]);
+        if (have_b) gs[1] = fma((double)F[(size_t)(row0 + rb) * ld + d - 1], wf, gs[1]);
+    }
+    if (!have_a) { gs[0] = 0.0; acc[0][0] = acc[0][1] = acc[0][2] = 0.0; }
+    if (!have_b) { gs[1] = 0.0; acc[1][0] = acc[1][1] = acc[1][2] = 0.0; }
+    if (lane + 128 == NC - 1) { acc[0][2] = gs[0]; acc[1][2] = gs[1]; }        // (NC - 1 = 7 G lies in the third pass for G >= 19, else below:)
+    if (lane + 64 == NC - 1) { acc[0][1] = gs[0]; acc[1][1] = gs[1]; }
+    if (lane == NC - 1) { acc[0][0] = gs[0]; acc[1][0] = gs[1]; }
+    // V[k][:] = sum over the camera's rows of W~_k[row] AW[row][:], wave partials summed through LDS, one k at a time
+    double wab[PCG_NW][2];
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) { wab[k][0] = have_a ? W[(size_t)k * ld + row0 + ra] : 0.0; wab[k][1] = have_b ? W[(size_t)k * ld + row0 + rb] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) {
+        const double wa = wab[k][0], wb = wab[k][1];
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 3; ++p) if (lane + 64 * p < SG_NCP) vbuf[w * SG_NCP + lane + 64 * p] = fma(wa, acc[0][p], wb * acc[1][p]);
+        __syncthreads();
+        if (tid < SG_NCP) V[((size_t)blockIdx.x * PCG_NW + k) * SG_NCP + tid] = (vbuf[tid] + vbuf[SG_NCP + tid]) + (vbuf[2 * SG_NCP + tid] + vbuf[3 * SG_NCP + tid]);
+    }
+}
+
+// E[i][:]: one workgroup per coarse vector, 3 x SG_NCP threads (a third of the terms each)
+__global__ __launch_bounds__(3 * SG_NCP) void k_sg_e(int d, int G, const double* __restrict__ V, double* __restrict__ E) {
+    __shared__ double eq[3][SG_NCP];
+    const int i = blockIdx.x, tid = threadIdx.x, v = tid % SG_NCP, part = tid / SG_NCP;
+    const int nc = (d - 1) / 6, NC = 7 * G + 1;
+    const double inv_nc = 1.0 / (double)nc;
+    double e = 0.0;
+    if (i < NC - 1) {
+        const int g = i / 7, k = i - 7 * g;
+        for (int range = 0; range < 2; ++range) {
+            const int a = range == 0 ? (g + G - 1) % G : g;
+            const int lo = sg_first_cam(a, nc, G), hi = sg_first_cam(a + 1, nc, G);
+            for (int j = lo + part; j < hi; j += 3) {
+                const double fr = sg_frac(j, a, nc, G, inv_nc);
+                const double wgt = range == 0 ? fr : 1.0 - fr;
+                e = fma(wgt, V[((size_t)j * PCG_NW + k) * SG_NCP + v], e);
+            }
+        }
+    } else {
+        for (int j = part; j <= nc; j += 3) e += V[((size_t)j * PCG_NW + (PCG_NW - 1)) * SG_NCP + v];
+    }
+    eq[part][v] = e;
+    __syncthreads();
+    if (tid < SG_NCP) E[(size_t)i * SG_NCP + tid] = (eq[0][tid] + eq[1][tid]) + eq[2][tid];
+}
+
+// E^-1 (SG_NCP x SG_NCP; rows / columns beyond the NC vectors and of dropped vectors zero): k_ml_invert's scheme -- Jacobi scaling, in-place Gauss-Jordan
+// without pivot search, one barrier per pivot, the next pivot's reciprocal formed during the current update -- on 1008 threads: thread (row i, columns
+// SG_ICB q .. + SG_ICB - 1), seven column blocks of 21: the 42 registers of matrix per thread and the 42 of the pivot row fit the 128 of four waves per
+// SIMD.  (27 hats -- 192 rows, 48 or 40 columns per thread -- spilled two dozen doubles per thread in every step whatever the scheduling hints: 1.3 ms.
+// Hence the limit of 20 hats.)
+constexpr int SG_ICB = 21, SG_INB = 7, SG_IW = SG_ICB * SG_INB;       // 147 >= SG_NCP columns
+__global__ __launch_bounds__(SG_INB * SG_NCP) void k_sg_invert(int NC, const double* __restrict__ E, double* __restrict__ einv) {
+    __shared__ double rowbuf[2][SG_IW + 1], colbuf[2][SG_NCP], sc[SG_NCP], diagbuf[2];
+    __shared__ unsigned char drop[SG_IW + 1];
+    const int tid = threadIdx.x, i = tid % SG_NCP, qd = tid / SG_NCP;
+    if (tid <= SG_IW) drop[tid] = 1;
+    __syncthreads();
+    if (tid < SG_NCP) {
+        const double dii = tid < NC ? E[(size_t)tid * SG_NCP + tid] : 0.0;
+        const bool ok = dii > 0.0 && dii <= 1.7e308;
+        sc[tid] = ok ? 1.0 / sqrt(dii) : 0.0;
+        drop[tid] = ok ? 0 : 1;
+    }
+    __syncthreads();
+    double a[SG_ICB];
+#pragma unroll
+    for (int c = 0; c < SG_ICB; ++c) {
+        const int j = SG_ICB * qd + c;
+        const bool in = i < NC && j < NC;
+        const int jc = j < SG_NCP ? j : 0;
+        const double v = in ? 0.5 * (E[(size_t)i * SG_NCP + jc] + E[(size_t)jc * SG_NCP + i]) * sc[i] * sc[jc] : 0.0;
+        a[c] = (i == j) ? 1.0 : v;
+    }
+    double piv = 1.0, ip = 1.0;
+    auto step = [&](int qq, auto cconst) __attribute__((always_inline)) {
+        constexpr int c = decltype(cconst)::value;
+        const int p = SG_ICB * qq + c;
+        if (p >= NC) return;                         // uniform
+        const int par = p & 1;                       // (SG_ICB is odd: the parity of c does not alternate across a block boundary)
+        if (i == p) {
+#pragma unroll
+            for (int cc = 0; cc < SG_ICB; ++cc) rowbuf[par][SG_ICB * qd + cc] = a[cc];
+        }
+        if (qd == qq) colbuf[par][i] = a[c];
+        if (i == p + 1 && qd == qq + (c == SG_ICB - 1 ? 1 : 0)) diagbuf[par] = a[(c + 1) % SG_ICB];
+        __syncthreads();
+        const bool ok = !drop[p] && piv > 1e-10;
+        double dn = diagbuf[par];
+        if (ok) {
+            const double fc = colbuf[par][i] * ip;
+            const double f = i == p ? 1.0 - ip : fc;
+            dn = fma(-colbuf[par][p + 1 < SG_NCP ? p + 1 : 0] * ip, rowbuf[par][p + 1], dn);
+#pragma unroll
+            for (int cc = 0; cc < SG_ICB; ++cc) a[cc] = fma(-f, rowbuf[par][SG_ICB * qd + cc], a[cc]);
+            if (qd == qq) a[c] = i == p ? ip : -fc;
+        } else if (tid == 0) drop[p] = 1;
+        piv = dn;
+        ip = fast_rcp(dn);
+    };
+    for (int qq = 0; qq < SG_INB; ++qq) {
+#define SG_STEP(C) step(qq, std::integral_constant<int, C>())
+        SG_STEP(0); SG_STEP(1); SG_STEP(2); SG_STEP(3); SG_STEP(4); SG_STEP(5); SG_STEP(6); SG_STEP(7); SG_STEP(8); SG_STEP(9); SG_STEP(10);
+        SG_STEP(11); SG_STEP(12); SG_STEP(13); SG_STEP(14); SG_STEP(15); SG_STEP(16); SG_STEP(17); SG_STEP(18); SG_STEP(19); SG_STEP(20);
+#undef SG_STEP
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < SG_ICB; ++c) {
+        const int j = SG_ICB * qd + c;
+        if (j < SG_NCP) einv[(size_t)i * SG_NCP + j] = (drop[i] || drop[j]) ? 0.0 : a[c] * sc[i] * sc[j];
+    }
+}
+
+// q = S~ p for the rows of this workgroup (eight; two per wave at a time), partial of p . q
+template <typename FT>
+__global__ __launch_bounds__(256) void k_sg_q(int d, int ld, const FT* __restrict__ F, const double* __restrict__ p, double* __restrict__ q,
+                                              double* __restrict__ pqpart, const int* __restrict__ flags, int rows_per_wg) {
+    extern __shared__ __align__(16) double sm[];
+    double* pl = sm;
+    __shared__ double red[4];
+    if (flags[PF_DONE] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = blockIdx.x * rows_per_wg, row1 = min(d, row0 + rows_per_wg);
+    for (int e0 = tid; e0 < ld; e0 += 256 * 8) {
+        double pv8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; pv8[u] = p[e < d ? e : d - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < ld) pl[e] = e < d ? pv8[u] : 0.0; }
+    }
+    __syncthreads();
+    double pqp = 0.0;
+    const int nd2 = d >> 1, nd4 = d >> 2;
+    for (int row = row0 + w; row < row1; row += 8) {
+        const int rowb = (row + 4 < row1) ? row + 4 : row;
+        double sa = 0.0, sb = 0.0;
+        if (sizeof(FT) == 8) {
+            const double2* pl2 = reinterpret_cast<const double2*>(pl);
+            const double2* Fa = reinterpret_cast<const double2*>(F + (size_t)row * ld);
+            const double2* Fb = reinterpret_cast<const double2*>(F + (size_t)rowb * ld);
+            int c = lane;
+            for (; c + 192 < nd2; c += 256) {
+                double2 a[4], b[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { const double2 pv = pl2[c + 64 * m]; sa += a[m].x * pv.x + a[m].y * pv.y; sb += b[m].x * pv.x + b[m].y * pv.y; }
+            }
+            for (; c < nd2; c += 64) { const double2 a = Fa[c], b = Fb[c], pv = pl2[c]; sa += a.x * pv.x + a.y * pv.y; sb += b.x * pv.x + b.y * pv.y; }
+            if ((d & 1) && lane == 0) { sa += (double)F[(size_t)row * ld + d - 1] * pl[d - 1]; sb += (double)F[(size_t)rowb * ld + d - 1] * pl[d - 1]; }
+        } else {
+            const float4* Fa = reinterpret_cast<const float4*>(F + (size_t)row * ld);
+            const float4* Fb = reinterpret_cast<const float4*>(F + (size_t)rowb * ld);
+            int c = lane;
+            for (; c + 192 < nd4; c += 256) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { a[m] = Fa[c + 64 * m]; b[m] = Fb[c + 64 * m]; }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double2 p0 = reinterpret_cast<const double2*>(pl)[2 * (c + 64 * m)], p1 = reinterpret_cast<const double2*>(pl)[2 * (c + 64 * m) + 1];
+                    sa += (double)a[m].x * p0.x + (double)a[m].y * p0.y + (double)a[m].z * p1.x + (double)a[m].w * p1.y;
+                    sb += (double)b[m].x * p0.x + (double)b[m].y * p0.y + (double)b[m].z * p1.x + (double)b[m].w * p1.y;
+                }
+            }
+            for (; c < nd4; c += 64) {
+                const float4 a = Fa[c], b = Fb[c];
+                const double2 p0 = reinterpret_cast<const double2*>(pl)[2 * c], p1 = reinterpret_cast<const double2*>(pl)[2 * c + 1];
+                sa += (double)a.x * p0.x + (double)a.y * p0.y + (double)a.z * p1.x + (double)a.w * p1.y;
+                sb += (double)b.x * p0.x + (double)b.y * p0.y + (double)b.z * p1.x + (double)b.w * p1.y;
+            }
+            if (lane == 0) for (int cc = 4 * nd4; cc < d; ++cc) { sa += (double)F[(size_t)row * ld + cc] * pl[cc]; sb += (double)F[(size_t)rowb * ld + cc] * pl[cc]; }
+        }
+        sa = wave_allsum(sa); sb = wave_allsum(sb);
+        if (lane == 0) {
+            q[row] = sa; pqp += pl[row] * sa;
+            if (rowb != row) { q[rowb] = sb; pqp += pl[rowb] * sb; }
+        }
+    }
+    if (lane == 0) red[w] = pqp;
+    __syncthreads();
+    if (tid == 0) pqpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// block sum over SG_UT threads (every thread gets the total); scratch: 16 doubles
+__device__ __forceinline__ double sg_block_sum(double v, double* scratch) {
+    v = wave_allsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < SG_UT / 64; ++k) s += scratch[k];
+    return s;
+}
+// cameras (and the focal pseudo-camera nc) of vector workgroup g: [sg_cam0(g), sg_cam0(g + 1)) of nc + 1
+__device__ __forceinline__ int sg_cam0(int g, int nc) { return (int)(((long long)g * (nc + 1)) / SG_UWG); }
+
+// INIT: x = 0, r = b~.  Else: alpha = r.z / p.q; x += alpha p; r -= alpha q.  Both: t_k per camera, the workgroup's share of |r|^2.
+template <bool INIT>
+__global__ __launch_bounds__(SG_UT) void k_sg_u(int d, int ld, int nwgq, const double* __restrict__ bt, double* __restrict__ x, double* __restrict__ r,
+                                                const double* __restrict__ p, const double* __restrict__ q, const double* __restrict__ W,
+                                                const double* __restrict__ pqpart, double* __restrict__ tcam, double* __restrict__ rrpart,
+                                                double* __restrict__ state, const int* __restrict__ flags, int in) {
+    __shared__ double scratch[16];
+    __shared__ double rl[6 * 64 + 8];                 // the workgroup's rows of the new r (at most ceil(1001 / 16) = 63 cameras)
+    if (!INIT && flags[PF_DONE] != 0) return;
+    const int tid = threadIdx.x;
+    const int nc = (d - 1) / 6;
+    const int j0 = sg_cam0(blockIdx.x, nc), j1 = sg_cam0(blockIdx.x + 1, nc);
+    const int r0 = 6 * j0, r1 = min(d, 6 * j1), nrows = r1 - r0;
+    double alpha = 0.0;
+    if (!INIT) {
+        double s = 0.0;
+        for (int wg = tid; wg < nwgq; wg += SG_UT) s += pqpart[wg];
+        const double pq = sg_block_sum(s, scratch);
+        alpha = state[SGS_LEN * in + SGS_RZ] / pq;
+        if (blockIdx.x == 0 && tid == 0) state[SGS_LEN * in + SGS_PQ] = pq;
+    }
+    double rr = 0.0;
+    if (tid < nrows) {
+        const int row = r0 + tid;
+        double rn;
+        if (INIT) { rn = bt[row]; x[row] = 0.0; }
+        else { x[row] += alpha * p[row]; rn = r[row] - alpha * q[row]; }
+        r[row] = rn;
+        rl[tid] = rn;
+        rr = rn * rn;
+    }
+    rr = sg_block_sum(rr, scratch);                   // (also the barrier behind rl)
+    if (tid == 0) rrpart[blockIdx.x] = rr;
+    if (tid < PCG_NW * (j1 - j0)) {
+        const int jl = tid / PCG_NW, k = tid - PCG_NW * jl, j = j0 + jl;
+        double t = 0.0;
+        if (j < nc) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) t = fma(W[(size_t)k * ld + 6 * j + e], rl[6 * jl + e], t);
+        } else t = W[(size_t)k * ld + d - 1] * rl[6 * jl];          // the focal row
+        tcam[(size_t)j * PCG_NW + k] = t;
+    }
+}
+
+// |r|^2 and the stopping test; c = W~^T r (hat sums of the t_k), mu = E^-1 c, r . z = |r|^2 + c . mu, beta; p = r + W~ mu + beta p on the workgroup's rows
+template <bool INIT>
+__global__ __launch_bounds__(SG_UT) void k_sg_p(int d, int ld, int G, const double* __restrict__ r, double* __restrict__ p, const double* __restrict__ W,
+                                                const double* __restrict__ tcam, const double* __restrict__ rrpart, const double* __restrict__ einv,
+                                                double* __restrict__ state, double* __restrict__ scal, int* __restrict__ flags, int* info, int* mailbox,
+                                                double tol2, int in, int anchor, double cap) {
+    __shared__ double scratch[16];
+    __shared__ double cl[SG_NCP], ml[SG_NCP], mp[4][SG_NCP];
+    if (!INIT && flags[PF_DONE] != 0) return;
+    const int tid = threadIdx.x, out = in ^ 1;
+    const int nc = (d - 1) / 6, NC = 7 * G + 1;
+    const double inv_nc = 1.0 / (double)nc;
+    double rr = 0.0;
+#pragma unroll
+    for (int k = 0; k < SG_UWG; ++k) rr += rrpart[k];
+    if (INIT) {
+        if (blockIdx.x == 0 && tid == 0) {
+            scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = 0;
+            if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
+        }
+        if (rr == 0.0) return;
+    } else {
+        const double pq = state[SGS_LEN * in + SGS_PQ];
+        const bool broke = !(pq > 0.0) || !(rr == rr);
+        if (rr <= tol2 * scal[PS_RR0] || broke) {
+            if (blockIdx.x == 0 && tid == 0) {
+                flags[PF_XBUF] = 0; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
+                if (broke) atomicCAS(info, 0, d + 1);
+                __threadfence();
+                flags[PF_DONE] = 1;
+                if (mailbox) pcg_post(mailbox, it, 1);
+            }
+            return;
+        }
+    }
+    // c: vector i = tid % SG_NCP, a quarter of its hat's cameras per part = tid / SG_NCP (eight loads in flight); the global vector by a block sum
+    {
+        double t7 = 0.0;
+        for (int j = tid; j <= nc; j += SG_UT) t7 += tcam[(size_t)j * PCG_NW + (PCG_NW - 1)];
+        t7 = sg_block_sum(t7, scratch);
+        double c = 0.0;
+        const int i = tid % SG_NCP, part = tid / SG_NCP;
+        if (part < 4 && i < NC - 1) {
+            const int g = i / 7, k = i - 7 * g;
+            const int a = (part >> 1) == 0 ? (g + G - 1) % G : g;
+            const int lo = sg_first_cam(a, nc, G), hi = sg_first_cam(a + 1, nc, G);
+            const int half = (hi - lo + 1) >> 1;
+            const int jb0 = (part & 1) ? lo + half : lo, jb1 = (part & 1) ? hi : min(hi, lo + half);
+            for (int jb = jb0; jb < jb1; jb += 8) {
+                double val[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) val[t] = tcam[(size_t)(jb + t < jb1 ? jb + t : jb1 - 1) * PCG_NW + k];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const double fr = sg_frac(jb + t, a, nc, G, inv_nc);
+                    c = fma(jb + t < jb1 ? ((part >> 1) == 0 ? fr : 1.0 - fr) : 0.0, val[t], c);
+                }
+            }
+        }
+        if (part < 4) mp[part][i] = c;
+        __syncthreads();
+        if (tid < SG_NCP) cl[tid] = tid < NC - 1 ? (mp[0][tid] + mp[1][tid]) + (mp[2][tid] + mp[3][tid]) : tid == NC - 1 ? t7 : 0.0;
+    }
+    __syncthreads();
+    if (tid < 4 * SG_NCP) {
+        const int i = tid % SG_NCP, part = tid / SG_NCP;
+        double s = 0.0;
+#pragma unroll 8
+        for (int jj = 0; jj < SG_CB; ++jj) { const int j = SG_CB * part + jj; s = fma(einv[(size_t)j * SG_NCP + i], cl[j], s); }
+        mp[part][i] = s;
+    }
+    __syncthreads();
+    if (tid < SG_NCP) ml[tid] = (mp[0][tid] + mp[1][tid]) + (mp[2][tid] + mp[3][tid]);
+    __syncthreads();
+    const double cmu = sg_block_sum(tid < SG_NCP ? cl[tid] * ml[tid] : 0.0, scratch);
+    const double rz_new = rr + cmu;
+    const double beta = INIT ? 0.0 : rz_new / state[SGS_LEN * in + SGS_RZ];
+    // p on the rows of this workgroup's cameras
+    const int j0 = sg_cam0(blockIdx.x, nc), j1 = sg_cam0(blockIdx.x + 1, nc);
+    const int r0 = 6 * j0, r1 = min(d, 6 * j1);
+    if (r0 + tid < r1) {
+        const int row = r0 + tid;
+        const int j = min(row / 6, nc - 1);           // (the focal row: W~_0..6 are zero there)
+        const int gl = (j * G) / nc, gh = gl + 1 == G ? 0 : gl + 1;
+        const double fr = sg_frac(j, gl, nc, G, inv_nc);
+        double z = fma(W[(size_t)(PCG_NW - 1) * ld + row], ml[NC - 1], r[row]);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) z = fma(W[(size_t)k * ld + row], fma(fr, ml[7 * gh + k], (1.0 - fr) * ml[7 * gl + k]), z);
+        p[row] = INIT ? z : fma(beta, p[row], z);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        state[SGS_LEN * out + SGS_RZ] = rz_new;
+        if (!INIT) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; if (mailbox) pcg_post(mailbox, it, 0); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Persistent CG (d <= 1280, one workgroup per CU): the WHOLE solve in one launch.
 //
 // The launch-per-iteration kernel above costs one dependent-launch boundary (~1.4 us) plus one full re-read of S~ from
@@ -2269,7 +2718,20 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
     double* bt = ws->vec + (size_t)8 * ld;
     const int in = INIT ? 0 : (r.in | ((r.launched + 1) << 1));     // launch number 1.. of this solve, see k_pcg_iter
 #define CG_ARGS(Fptr) d, ld, Fptr, ws->vec, bt, ws->part, ws->scal, ws->flags, r.rows_per_wg, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->AW, ws->coarse
-    if (r.ml) {
+    if (r.sg) {
+        const int G = sg_hats((d - 1) / 6);
+        double *x = ws->vec, *rv = ws->vec + (size_t)2 * ld, *pv = ws->vec + (size_t)4 * ld, *qv = ws->vec + (size_t)6 * ld;      // the parity-0 buffers of pcg_vec
+        const int par = INIT ? 0 : r.in;
+        if (INIT) {
+            hipLaunchKernelGGL((k_sg_u<true>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, r.nwg, bt, x, rv, pv, qv, ws->W, ws->part, ws->sgT, ws->sgRR, ws->sgState, ws->flags, par);
+            hipLaunchKernelGGL((k_sg_p<true>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, G, rv, pv, ws->W, ws->sgT, ws->sgRR, ws->sgEinv, ws->sgState, ws->scal, ws->flags, r.info, ws->d_mailbox, r.tol2, par, anchor, cap);
+        } else {
+            if (r.f32) hipLaunchKernelGGL((k_sg_q<float>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull32, pv, qv, ws->part, ws->flags, r.rows_per_wg);
+            else hipLaunchKernelGGL((k_sg_q<double>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, pv, qv, ws->part, ws->flags, r.rows_per_wg);
+            hipLaunchKernelGGL((k_sg_u<false>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, r.nwg, bt, x, rv, pv, qv, ws->W, ws->part, ws->sgT, ws->sgRR, ws->sgState, ws->flags, par);
+            hipLaunchKernelGGL((k_sg_p<false>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, G, rv, pv, ws->W, ws->sgT, ws->sgRR, ws->sgEinv, ws->sgState, ws->scal, ws->flags, r.info, ws->d_mailbox, r.tol2, par, anchor, cap);
+        }
+    } else if (r.ml) {
         hipLaunchKernelGGL((k_pcg_iter_ml<INIT>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, ws->vec, bt, ws->part, ws->scal, ws->flags, r.tol2, in, r.info,
                            ws->d_mailbox, anchor, cap, ws->W, ws->mlAW, ws->mlEinv, ws->mlC0, ws->mlState);
     } else if (r.fast) {
@@ -2354,6 +2816,45 @@ static void ml_debug_check(hipStream_t s, DenseSolver* ws, int nwg) {
     std::fprintf(stderr, "[ml debug] d %d: AW err %.3e (max %.3e)  E err %.3e (max %.3e)  c0 err %.3e  |E Einv - I| %.3e\n", d, eaw, naw, ee, ne, ec, einv_err);
 }
 
+
+// SFMBA_ML_DEBUG=1: E and E^-1 of the streaming-path segments against a host evaluation
+static void sg_debug_check(hipStream_t s, DenseSolver* ws, bool f32) {
+    (void)hipStreamSynchronize(s);
+    const int d = ws->d, ld = ws->ld, nc = (d - 1) / 6, G = sg_hats(nc), NC = 7 * G + 1;
+    std::vector<double> F((size_t)d * ld), W((size_t)8 * ld), E((size_t)SG_NCP * SG_NCP), Ei((size_t)SG_NCP * SG_NCP);
+    if (f32) { std::vector<float> F32((size_t)d * ld); (void)hipMemcpy(F32.data(), ws->Sfull32, sizeof(float) * F32.size(), hipMemcpyDeviceToHost); for (size_t e = 0; e < F.size(); ++e) F[e] = F32[e]; }
+    else (void)hipMemcpy(F.data(), ws->Sfull, sizeof(double) * F.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(W.data(), ws->W, sizeof(double) * W.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(E.data(), ws->sgE, sizeof(double) * E.size(), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(Ei.data(), ws->sgEinv, sizeof(double) * Ei.size(), hipMemcpyDeviceToHost);
+    std::vector<double> Wt((size_t)NC * d, 0.0);
+    for (int j = 0; j < nc; ++j) {
+        const int gl = (j * G) / nc, gh = (gl + 1) % G;
+        const double fr = (double)(j * G - gl * nc) / (double)nc;
+        for (int k = 0; k < 7; ++k) for (int e = 0; e < 6; ++e) {
+            Wt[(size_t)(7 * gl + k) * d + 6 * j + e] += (1.0 - fr) * (double)(float)W[(size_t)k * ld + 6 * j + e];
+            Wt[(size_t)(7 * gh + k) * d + 6 * j + e] += fr * (double)(float)W[(size_t)k * ld + 6 * j + e];
+        }
+    }
+    for (int e = 0; e < d; ++e) Wt[(size_t)(NC - 1) * d + e] = W[(size_t)7 * ld + e];
+    std::vector<double> AW((size_t)d * NC, 0.0);
+    for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) { const double f = F[(size_t)r * ld + c]; if (f != 0.0) for (int i = 0; i < NC; ++i) AW[(size_t)r * NC + i] += f * Wt[(size_t)i * d + c]; }
+    double ee = 0, ne = 0, inv_err = 0;
+    for (int i = 0; i < NC; ++i) for (int j = 0; j < NC; ++j) {
+        double v = 0; for (int r = 0; r < d; ++r) v += Wt[(size_t)i * d + r] * AW[(size_t)r * NC + j];
+        ee = fmax(ee, fabs(v - E[(size_t)i * SG_NCP + j])); ne = fmax(ne, fabs(v));
+    }
+    for (int i = 0; i < NC; ++i) for (int j = 0; j < NC; ++j) { double v = 0; for (int k = 0; k < NC; ++k) v += E[(size_t)i * SG_NCP + k] * Ei[(size_t)k * SG_NCP + j]; inv_err = fmax(inv_err, fabs(v - (i == j ? 1.0 : 0.0))); }
+    std::fprintf(stderr, "[sg debug] d %d, %d hats, %d vectors: E err %.3e (max %.3e)  |E Einv - I| %.3e\n", d, G, NC, ee, ne, inv_err);
+}
+
+// ... and its streaming-path form: beyond the one-round-trip kernels, eight rows per workgroup of the product (d <= 8192)
+bool dense_pcg_segments_streaming_applicable(const DenseSolver* ws) {
+    const int d = ws->d, nc = (d - 1) / 6;
+    const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL;
+    return d == 6 * nc + 1 && nc >= ML_MIN_CAMS && !fast && (d + 7) / 8 <= PCG_PART && nc + 1 <= 64 * SG_UWG - SG_UWG;
+}
+
 // same path selection as dense_pcg_solve
 static void pcg_geometry(const DenseSolver* ws, bool* fast, bool* f32) {
     const int d = ws->d;
@@ -2388,8 +2889,11 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     // segmented coarse space (7 x 8 hat-restricted gauge vectors + 1): workgroup = camera
     const bool ml = segments && coarse && fast && dense_pcg_segments_applicable(ws) && ws->W && ws->mlAW;
     if (ml) rows_per_wg = 6;
+    // ... its streaming-path form (d > 1280): classical PCG, three launches per iteration
+    const bool sg = segments && coarse && !fast && dense_pcg_segments_streaming_applicable(ws) && ws->W && ws->sgV;
+    if (sg) rows_per_wg = 8;
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
-    const size_t lds = sizeof(double) * (size_t)(ld + (ml ? ML_LDS_TAIL : PCG_RED));
+    const size_t lds = sizeof(double) * (size_t)(ld + (ml ? ML_LDS_TAIL : sg ? 0 : PCG_RED));
     double* bt = ws->vec + (size_t)8 * ld;
     // fp32 storage of S~ on the streaming path whenever the caller asked for it (dense_pcg_want_f32 allocated the buffer)
     const bool f32 = !fast && ws->use_f32 && ws->Sfull32 != nullptr;
@@ -2404,6 +2908,20 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       hipLaunchKernelGGL(k_ml_invert, dim3(1), dim3(256), 0, s, ws->mlE, ws->mlEinv, ws->mlC0);
       static const bool ml_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;      // (read once per process)
       if (ml_debug) ml_debug_check(s, ws, nwg); }
+    else if (sg) { ProfScope ps(prof, KID_PCG_SETUP, s, 3);
+      static bool sg_attr_set = false;
+      if (!sg_attr_set) {
+          (void)hipFuncSetAttribute((const void*)k_sg_v<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SG_V_LDS);
+          (void)hipFuncSetAttribute((const void*)k_sg_v<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SG_V_LDS);
+          sg_attr_set = true;
+      }
+      const int nc = (d - 1) / 6, G = sg_hats(nc), NC = 7 * G + 1;
+      if (f32) hipLaunchKernelGGL((k_sg_v<float>), dim3(nc + 1), dim3(256), SG_V_LDS, s, d, ld, G, ws->Sfull32, ws->W, ws->sgV);
+      else hipLaunchKernelGGL((k_sg_v<double>), dim3(nc + 1), dim3(256), SG_V_LDS, s, d, ld, G, ws->Sfull, ws->W, ws->sgV);
+      hipLaunchKernelGGL(k_sg_e, dim3(NC), dim3(3 * SG_NCP), 0, s, d, G, ws->sgV, ws->sgE);
+      hipLaunchKernelGGL(k_sg_invert, dim3(1), dim3(SG_INB * SG_NCP), 0, s, NC, ws->sgE, ws->sgEinv);
+      static const bool sg_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;
+      if (sg_debug) sg_debug_check(s, ws, f32); }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg, ws->vec + (size_t)(2 * 3 + 0) * ld);      // t -> the q buffer of parity 0 (pcg_vec)
       else if (f32) { if (rows_per_wg <= 8) hipLaunchKernelGGL((k_pcg_coarse<float, 2>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
@@ -2414,7 +2932,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       if (!fast) hipLaunchKernelGGL(k_pcg_coarse_invert, dim3(1), dim3(256), 0, s, nwg, ws->epart, ws->coarse); }
     volatile int* mb = ws->h_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }
-    ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32; ws->run.coarse = coarse; ws->run.ml = ml;
+    ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32; ws->run.coarse = coarse; ws->run.ml = ml; ws->run.sg = sg;
     ws->run.tol2 = tol * tol; ws->run.in = 1; ws->run.launched = 0; ws->run.max_iters = max_iters; ws->run.info = info_dev;
     { ProfScope ps(prof, KID_PCG_ITER, s);
       launch_cg_iteration<true>(s, ws, anchor, cap); }
@@ -2424,7 +2942,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     // history + 1 (was + 2; +0.6 % on the headline): a solve that needs two more iterations than last time costs a host round trip, a surplus (early-exit) launch ~2 us
     // (run to 1e-12 -- AUTO -- a solve takes 13 +- 1 iterations from one call to the next, the atomics' summation order is enough: a batch one
     // launch short costs a host round trip of ~50 us, a surplus launch ~2: one more in reserve there)
-    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra + (tol < 1e-10 ? 1 : 0) - ((fast && coarse && !ml) ? 1 : 0);     // (the merged first launch is iteration 1)
+    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra + (tol < 1e-10 ? 1 : 0) - ((fast && coarse && !ml && !sg) ? 1 : 0);     // (the merged first launch is iteration 1)
     if (no_wait) return dense_pcg_more(s, ws, batch, prof);
     bool done = false;
     while (!done) {
@@ -2537,6 +3055,15 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
         if (ws_alloc(ws, &ws->mlC0, sizeof(double) * ML_N)) return -1;
         if (ws_alloc(ws, &ws->mlState, sizeof(double) * 2 * 3 * ML_N)) return -1;
     }
+    if (!ws->sgV && dense_pcg_segments_streaming_applicable(ws)) {
+        const size_t ncp1 = (size_t)(ws->d - 1) / 6 + 1;
+        if (ws_alloc(ws, &ws->sgV, sizeof(double) * ncp1 * PCG_NW * SG_NCP)) return -1;
+        if (ws_alloc(ws, &ws->sgE, sizeof(double) * SG_NCP * SG_NCP)) return -1;
+        if (ws_alloc(ws, &ws->sgEinv, sizeof(double) * SG_NCP * SG_NCP)) return -1;
+        if (ws_alloc(ws, &ws->sgT, sizeof(double) * ncp1 * PCG_NW)) return -1;
+        if (ws_alloc(ws, &ws->sgRR, sizeof(double) * SG_UWG)) return -1;
+        if (ws_alloc(ws, &ws->sgState, sizeof(double) * 2 * SGS_LEN)) return -1;
+    }
     return 0;
 }
 
@@ -2582,7 +3109,7 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->AW) (void)hipFree(ws->AW);
         if (ws->epart) (void)hipFree(ws->epart);
         if (ws->coarse) (void)hipFree(ws->coarse);
-        for (double* q : { ws->mlAW, ws->mlV, ws->mlU, ws->mlE, ws->mlEinv, ws->mlC0, ws->mlState }) if (q) (void)hipFree(q);
+        for (double* q : { ws->mlAW, ws->mlV, ws->mlU, ws->mlE, ws->mlEinv, ws->mlC0, ws->mlState, ws->sgV, ws->sgE, ws->sgEinv, ws->sgT, ws->sgRR, ws->sgState }) if (q) (void)hipFree(q);
     }
     if (!ws->pinned_external) {
         if (ws->h_flags) (void)hipHostFree(ws->h_flags);

@@ -379,7 +379,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // camera order (dense_solver.hip "Segmented coarse space"); SFMBA_PCG_SEGMENTS=0|1 forces it off / on wherever it applies
     // -- where the structure says the camera order IS that path: a sparsely filled matrix whose blocks sit near the (cyclic) diagonal
     // (options.pcg_coarse_space: 0 = by structure, 1 = the eight global vectors only, 2 = the segments wherever they apply)
-    const bool segments_cg = coarse_cg && dense_pcg_segments_applicable(&p->solver) &&
+    const bool segments_cg = coarse_cg && (dense_pcg_segments_applicable(&p->solver) || dense_pcg_segments_streaming_applicable(&p->solver)) &&
                              option_switch(o.pcg_coarse_space == 2 ? 1 : o.pcg_coarse_space == 1 ? -1 : 0, "SFMBA_PCG_SEGMENTS", p->block_fill < 0.5 && p->block_band >= 0.9);
     // One persistent (cooperative) launch per CG solve: opt-in only.  It used to win below d = 640 where the
     // solve is launch-bound; with the gauge coarse space the launch-per-iteration path needs half the iterations and is as fast or
@@ -414,7 +414,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // result from the first linearisation on.  A property of the problem, not of the call history: deterministic.
     // (With the segmented coarse space the CG needs ~49 iterations per linearisation at 1e-12 on cfg3_banded: 1 566 LM iterations/s against the
     // factorisation's 1 639 -- the factorisation stays AUTO's choice there; the PCG mode is where the segments pay: 1 224 -> 2 220.)
-    if (exact_pcg && p->block_fill < 0.5) auto_prefers_cholesky = true;
+    // On the streaming path (d > 1280) it is the other way round: a 600-camera path costs 4.5 ms per factorisation against ~1.7 ms for the
+    // segmented CG run to 1e-12 (tools/large_banded_check.py) -- AUTO keeps the CG there.
+    if (exact_pcg && p->block_fill < 0.5 && !(segments_cg && dense_pcg_segments_streaming_applicable(&p->solver))) auto_prefers_cholesky = true;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }

@@ -60,9 +60,9 @@ def test_segments_on_dense_covisibility_and_smallest_size(capi, sfm, oracle):
 
 
 def test_segments_not_applicable_is_silent(capi, sfm):
-    """31 cameras (below four per hat) and 214 cameras (d = 1285: beyond the one-round-trip CG kernels): the request falls back to the eight
-    global vectors, same result as asking for those."""
-    for n_cam, n_pt in ((31, 2500), (214, 6000)):
+    """31 cameras (below four per hat): the request falls back to the eight global vectors, same result as asking for those.  (214 cameras and
+    more -- beyond the one-round-trip CG kernels -- take the streaming form: test_segments_streaming_path_long_camera_path.)"""
+    for n_cam, n_pt in ((31, 2500),):
         prob = sfm.make_problem("cfg3_banded", n_cam=n_cam, n_pt=n_pt)
         a = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=2))
         b = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=1))
@@ -121,3 +121,23 @@ def test_segments_any_camera_count(capi, sfm, n_cam):
         assert abs(a[3]["final_cost"] - b[3]["final_cost"]) <= 1e-9 * a[3]["final_cost"]
         assert np.abs(a[0] - b[0]).max() < 1e-6 and np.abs(a[1] - b[1]).max() < 1e-5
         assert all(r["linear_iters"] > 0 for r in b[4][1:])
+
+
+def test_segments_streaming_path_long_camera_path(capi, sfm, oracle):
+    """Beyond 213 cameras (d > 1280) the segments run as a classical PCG on the streaming kernels (three launches per iteration, up to 20 hats):
+    240 cameras on a path, against the oracle and against the eight global vectors."""
+    prob = sfm.make_problem("cfg3_banded", n_cam=240, n_pt=24000, seed=77)
+    want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    res = {}
+    for mode in (1, 2):
+        res[mode] = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=mode))
+        assert_same_solve(prob, res[mode], want, param_atol=1e-7, trace_rtol=1e-6, point_atol=1e-6)
+    it1 = [r["linear_iters"] for r in res[1][4][1:]]
+    it2 = [r["linear_iters"] for r in res[2][4][1:]]
+    assert sum(it2) <= 0.5 * sum(it1), (it1, it2)
+    # F32J (the fp32 copy of the preconditioned matrix), chosen by structure (pcg_coarse_space = 0)
+    a = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1))
+    b = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_coarse_space=1))
+    assert [r["linear_iters"] for r in a[4][1:]] != [r["linear_iters"] for r in b[4][1:]] and a[3]["linear_iters"] < 0.5 * b[3]["linear_iters"]
+    assert a[3]["termination_name"] == "CONVERGENCE" and abs(a[3]["final_cost"] - b[3]["final_cost"]) <= 1e-7 * b[3]["final_cost"]      # (F32J, CG at 1e-8)
+    assert_same_solve(prob, a, want, param_atol=5e-5, trace_rtol=5e-5, point_atol=5e-3)
