@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 #include <chrono>
 #include <cstdlib>
 
@@ -1805,77 +1806,94 @@ __global__ __launch_bounds__(256) void k_ml_e(int d, const double* __restrict__ 
     if (tid == 0) c0[i] = (cq[0] + cq[1]) + (cq[2] + cq[3]);
 }
 
-// E^-1 (64 x 64, rows / columns beyond the 57 vectors and of dropped vectors zero): Jacobi scaling, then an in-place Gauss-Jordan sweep without
-// pivot search (E is symmetric positive definite).  Thread (row i = tid / 4, columns 16 (tid % 4) .. + 15) keeps its sixteen entries in registers;
-// per pivot p the row p and the column p go through LDS (double-buffered: one barrier per step).  The steps are unrolled sixteen at a time (the
-// register that holds column p is then a compile-time index) and that body runs four times: 57 unrolled steps do not fit the instruction cache
-// (measured: 74 us against ~15).  A pivot below 1e-10 of the unit diagonal means the vector depends on the earlier ones: its step is skipped and
-// its row and column of the result are zero.
-__global__ __launch_bounds__(256) void k_ml_invert(const double* __restrict__ E, double* __restrict__ einv, double* __restrict__ c0) {
-    __shared__ __align__(16) double rowbuf[2][ML_N];
-    __shared__ double colbuf[2][ML_N], sc[ML_N], diagbuf[2];
-    const int tid = threadIdx.x, i = tid >> 2, qd = tid & 3;
-    double ev[16], et[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) { const int j = 16 * qd + c; ev[c] = E[(size_t)i * ML_N + j]; et[c] = E[(size_t)j * ML_N + i]; }
-    if (tid < ML_N) {
-        const double dii = tid < ML_NC ? E[(size_t)tid * ML_N + tid] : 0.0;
-        sc[tid] = (dii > 0.0 && dii <= 1.7e308) ? 1.0 / sqrt(dii) : 0.0;
-        if (tid >= ML_NC) c0[tid] = 0.0;
+// In-place Gauss-Jordan inverse of the Jacobi-scaled N x N matrix E (symmetric positive definite, no pivot search) in the registers of ONE workgroup:
+// thread (tr, tc) holds the TR x TC tile of rows TR tr .., columns TC tc .. -- per pivot it needs TR entries of the pivot column and TC of the pivot row
+// from LDS (a column-per-thread layout reads a whole row slice per thread: the kernel was bound by that LDS traffic).  One barrier per pivot (row, column
+// and the next diagonal entry double-buffered by pivot parity); the next pivot's reciprocal is formed during the current update; L = lcm(TR, TC)
+// steps are instantiated with compile-time register indices and that body loops.  A pivot below 1e-10 of the unit diagonal: the vector depends on the
+// earlier ones, its step is skipped and its row and column of the result are zero.  Rows / columns >= NC: zero.
+template <typename F, int... S>
+__device__ __forceinline__ void gj_steps(F& step, int m, std::integer_sequence<int, S...>) { (step(m, std::integral_constant<int, S>()), ...); }
+template <int N, int TR, int TC, int L>
+__device__ __forceinline__ void gj_invert_tiled(int NC, const double* __restrict__ E, double* __restrict__ einv,
+                                                double* rowbuf, double* colbuf, double* sc, double* diagbuf, unsigned char* drop) {
+    static_assert(N % TR == 0 && N % TC == 0 && L % TR == 0 && L % TC == 0, "tile geometry");
+    constexpr int NTC = N / TC;
+    const int tid = threadIdx.x, tr = tid / NTC, tc = tid % NTC;
+    for (int t = tid; t <= N; t += blockDim.x) {
+        const double dii = t < NC ? E[(size_t)t * N + t] : 0.0;
+        const bool ok = dii > 0.0 && dii <= 1.7e308;
+        if (t < N) sc[t] = ok ? 1.0 / sqrt(dii) : 0.0;
+        drop[t] = ok ? 0 : 1;
     }
     __syncthreads();
-    double a[16];
+    double a[TR][TC];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int j = 16 * qd + c;
-        const bool in = i < ML_NC && j < ML_NC;
-        const double v = in ? 0.5 * (ev[c] + et[c]) * sc[i] * sc[j] : 0.0;
-        a[c] = (i == j) ? 1.0 : v;
-    }
-    unsigned long long dropped = 0ull;
-    for (int t = 0; t < ML_N; ++t) if (!(sc[t] > 0.0)) dropped |= 1ull << t;
-    // the pivot of the NEXT step and its reciprocal are formed by every thread during this step's update (from the published row, column and
-    // the next diagonal entry): the reciprocal's dependent chain is off the barrier-to-barrier path
-    double piv = 1.0, ip = 1.0;                      // unit diagonal after the scaling
-    auto step = [&](int qq, auto cconst) {
-        constexpr int c = decltype(cconst)::value;   // (a compile-time register index, whatever the optimiser thinks of unrolling the loop)
-        const int p = 16 * qq + c;
-        if (p >= ML_NC) return;                      // uniform
-        constexpr int par = c & 1;
-        if (i == p) {
+    for (int rr = 0; rr < TR; ++rr)
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) rowbuf[par][16 * qd + cc] = a[cc];
+        for (int cc = 0; cc < TC; ++cc) {
+            const int i = TR * tr + rr, j = TC * tc + cc;
+            const bool in = i < NC && j < NC;
+            const double v = in ? 0.5 * (E[(size_t)i * N + j] + E[(size_t)j * N + i]) * sc[i] * sc[j] : 0.0;
+            a[rr][cc] = (i == j) ? 1.0 : v;
         }
-        if (qd == qq) colbuf[par][i] = a[c];
-        if (i == p + 1 && qd == qq + (c == 15 ? 1 : 0)) diagbuf[par] = a[(c + 1) & 15];
+    double piv = 1.0, ip = 1.0;                      // unit diagonal after the scaling
+    auto step = [&](int m, auto sconst) __attribute__((always_inline)) {
+        constexpr int sidx = decltype(sconst)::value, rr0 = sidx % TR, cc0 = sidx % TC, rr1 = (sidx + 1) % TR, cc1 = (sidx + 1) % TC;
+        const int p = L * m + sidx;
+        if (p >= NC) return;                         // uniform
+        const int rg = p / TR, cg = p / TC, par = p & 1;
+        if (tr == rg) {
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) rowbuf[par * N + TC * tc + cc] = a[rr0][cc];
+        }
+        if (tc == cg) {
+#pragma unroll
+            for (int rr = 0; rr < TR; ++rr) colbuf[par * N + TR * tr + rr] = a[rr][cc0];
+        }
+        if (tr == (p + 1) / TR && tc == (p + 1) / TC) diagbuf[par] = a[rr1][cc1];
         __syncthreads();
-        const bool ok = !((dropped >> p) & 1ull) && piv > 1e-10;
+        const bool ok = !drop[p] && piv > 1e-10;
         double dn = diagbuf[par];
         if (ok) {
-            // a_ij -= (a_ip / piv) a_pj everywhere -- the pivot row itself with the multiplier 1 - 1/piv (a_pj - (1 - 1/piv) a_pj = a_pj / piv:
-            // no select per entry) --, then the pivot column is set: -a_ip / piv, and 1 / piv on the diagonal
-            const double fc = colbuf[par][i] * ip;
-            const double f = i == p ? 1.0 - ip : fc;
-            dn = fma(-colbuf[par][(p + 1) & (ML_N - 1)] * ip, rowbuf[par][(p + 1) & (ML_N - 1)], dn);
+            // a_ij -= (a_ip / piv) a_pj everywhere -- the pivot row itself with the multiplier 1 - 1/piv --, then the pivot column is set
+            double fc[TR], f[TR], rv[TC];
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) a[cc] = fma(-f, rowbuf[par][16 * qd + cc], a[cc]);
-            if (qd == qq) a[c] = i == p ? ip : -fc;
-        } else dropped |= 1ull << p;
+            for (int rr = 0; rr < TR; ++rr) { fc[rr] = colbuf[par * N + TR * tr + rr] * ip; f[rr] = (TR * tr + rr == p) ? 1.0 - ip : fc[rr]; }
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) rv[cc] = rowbuf[par * N + TC * tc + cc];
+            const int q = p + 1 < N ? p + 1 : N - 1;
+            dn = fma(-colbuf[par * N + q] * ip, rowbuf[par * N + q], dn);
+#pragma unroll
+            for (int rr = 0; rr < TR; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < TC; ++cc) a[rr][cc] = fma(-f[rr], rv[cc], a[rr][cc]);
+            if (tc == cg) {
+#pragma unroll
+                for (int rr = 0; rr < TR; ++rr) a[rr][cc0] = (TR * tr + rr == p) ? ip : -fc[rr];
+            }
+        } else if (tid == 0) drop[p] = 1;
         piv = dn;
         ip = fast_rcp(dn);
     };
-    for (int qq = 0; qq < 4; ++qq) {
-#define ML_STEP(C) step(qq, std::integral_constant<int, C>())
-        ML_STEP(0); ML_STEP(1); ML_STEP(2); ML_STEP(3); ML_STEP(4); ML_STEP(5); ML_STEP(6); ML_STEP(7);
-        ML_STEP(8); ML_STEP(9); ML_STEP(10); ML_STEP(11); ML_STEP(12); ML_STEP(13); ML_STEP(14); ML_STEP(15);
-#undef ML_STEP
-    }
+    for (int m = 0; m * L < NC; ++m) gj_steps(step, m, std::make_integer_sequence<int, L>());
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int j = 16 * qd + c;
-        const bool gone = ((dropped >> i) & 1ull) || ((dropped >> j) & 1ull);
-        einv[(size_t)i * ML_N + j] = gone ? 0.0 : a[c] * sc[i] * sc[j];
-    }
+    for (int rr = 0; rr < TR; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < TC; ++cc) {
+            const int i = TR * tr + rr, j = TC * tc + cc;
+            einv[(size_t)i * N + j] = (drop[i] || drop[j]) ? 0.0 : a[rr][cc] * sc[i] * sc[j];
+        }
+}
+
+// E^-1 (64 x 64, rows / columns beyond the 57 vectors and of dropped vectors zero): 4 x 4 tiles on 256 threads.  (History: the compiler REFUSED a 57-step
+// `#pragma unroll` -- "loop not unrolled", dynamic register indices, 74 us; a column slice per thread with compile-time indices took 32 us.)
+__global__ __launch_bounds__(256) void k_ml_invert(const double* __restrict__ E, double* __restrict__ einv, double* __restrict__ c0) {
+    __shared__ double rowbuf[2 * ML_N], colbuf[2 * ML_N], sc[ML_N], diagbuf[2];
+    __shared__ unsigned char drop[ML_N + 1];
+    if (threadIdx.x >= ML_NC && threadIdx.x < ML_N) c0[threadIdx.x] = 0.0;
+    gj_invert_tiled<ML_N, 4, 4, 4>(ML_NC, E, einv, rowbuf, colbuf, sc, diagbuf, drop);
 }
 
 // One CG iteration with the segmented coarse space: k_pcg_iter_fast's structure (every global load issued up front, one memory round trip per
@@ -2234,72 +2252,14 @@ __global__ __launch_bounds__(3 * SG_NCP) void k_sg_e(int d, int G, const double*
     if (tid < SG_NCP) E[(size_t)i * SG_NCP + tid] = (eq[0][tid] + eq[1][tid]) + eq[2][tid];
 }
 
-// E^-1 (SG_NCP x SG_NCP; rows / columns beyond the NC vectors and of dropped vectors zero): k_ml_invert's scheme -- Jacobi scaling, in-place Gauss-Jordan
-// without pivot search, one barrier per pivot, the next pivot's reciprocal formed during the current update -- on 1008 threads: thread (row i, columns
-// SG_ICB q .. + SG_ICB - 1), seven column blocks of 21: the 42 registers of matrix per thread and the 42 of the pivot row fit the 128 of four waves per
-// SIMD.  (27 hats -- 192 rows, 48 or 40 columns per thread -- spilled two dozen doubles per thread in every step whatever the scheduling hints: 1.3 ms.
-// Hence the limit of 20 hats.)
-constexpr int SG_ICB = 21, SG_INB = 7, SG_IW = SG_ICB * SG_INB;       // 147 >= SG_NCP columns
-__global__ __launch_bounds__(SG_INB * SG_NCP) void k_sg_invert(int NC, const double* __restrict__ E, double* __restrict__ einv) {
-    __shared__ double rowbuf[2][SG_IW + 1], colbuf[2][SG_NCP], sc[SG_NCP], diagbuf[2];
-    __shared__ unsigned char drop[SG_IW + 1];
-    const int tid = threadIdx.x, i = tid % SG_NCP, qd = tid / SG_NCP;
-    if (tid <= SG_IW) drop[tid] = 1;
-    __syncthreads();
-    if (tid < SG_NCP) {
-        const double dii = tid < NC ? E[(size_t)tid * SG_NCP + tid] : 0.0;
-        const bool ok = dii > 0.0 && dii <= 1.7e308;
-        sc[tid] = ok ? 1.0 / sqrt(dii) : 0.0;
-        drop[tid] = ok ? 0 : 1;
-    }
-    __syncthreads();
-    double a[SG_ICB];
-#pragma unroll
-    for (int c = 0; c < SG_ICB; ++c) {
-        const int j = SG_ICB * qd + c;
-        const bool in = i < NC && j < NC;
-        const int jc = j < SG_NCP ? j : 0;
-        const double v = in ? 0.5 * (E[(size_t)i * SG_NCP + jc] + E[(size_t)jc * SG_NCP + i]) * sc[i] * sc[jc] : 0.0;
-        a[c] = (i == j) ? 1.0 : v;
-    }
-    double piv = 1.0, ip = 1.0;
-    auto step = [&](int qq, auto cconst) __attribute__((always_inline)) {
-        constexpr int c = decltype(cconst)::value;
-        const int p = SG_ICB * qq + c;
-        if (p >= NC) return;                         // uniform
-        const int par = p & 1;                       // (SG_ICB is odd: the parity of c does not alternate across a block boundary)
-        if (i == p) {
-#pragma unroll
-            for (int cc = 0; cc < SG_ICB; ++cc) rowbuf[par][SG_ICB * qd + cc] = a[cc];
-        }
-        if (qd == qq) colbuf[par][i] = a[c];
-        if (i == p + 1 && qd == qq + (c == SG_ICB - 1 ? 1 : 0)) diagbuf[par] = a[(c + 1) % SG_ICB];
-        __syncthreads();
-        const bool ok = !drop[p] && piv > 1e-10;
-        double dn = diagbuf[par];
-        if (ok) {
-            const double fc = colbuf[par][i] * ip;
-            const double f = i == p ? 1.0 - ip : fc;
-            dn = fma(-colbuf[par][p + 1 < SG_NCP ? p + 1 : 0] * ip, rowbuf[par][p + 1], dn);
-#pragma unroll
-            for (int cc = 0; cc < SG_ICB; ++cc) a[cc] = fma(-f, rowbuf[par][SG_ICB * qd + cc], a[cc]);
-            if (qd == qq) a[c] = i == p ? ip : -fc;
-        } else if (tid == 0) drop[p] = 1;
-        piv = dn;
-        ip = fast_rcp(dn);
-    };
-    for (int qq = 0; qq < SG_INB; ++qq) {
-#define SG_STEP(C) step(qq, std::integral_constant<int, C>())
-        SG_STEP(0); SG_STEP(1); SG_STEP(2); SG_STEP(3); SG_STEP(4); SG_STEP(5); SG_STEP(6); SG_STEP(7); SG_STEP(8); SG_STEP(9); SG_STEP(10);
-        SG_STEP(11); SG_STEP(12); SG_STEP(13); SG_STEP(14); SG_STEP(15); SG_STEP(16); SG_STEP(17); SG_STEP(18); SG_STEP(19); SG_STEP(20);
-#undef SG_STEP
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < SG_ICB; ++c) {
-        const int j = SG_ICB * qd + c;
-        if (j < SG_NCP) einv[(size_t)i * SG_NCP + j] = (drop[i] || drop[j]) ? 0.0 : a[c] * sc[i] * sc[j];
-    }
+// E^-1 (SG_NCP x SG_NCP): gj_invert_tiled with 6 x 4 tiles on 864 threads (24 entries per thread).  (History: 27 hats -- 192 rows, a slice of 48 or 40
+// columns per thread -- spilled two dozen doubles per thread in every step whatever the scheduling hints: 1.3 ms; hence the limit of 20 hats.  21
+// columns per thread on 1008 threads: 219 us, bound by the LDS reads of the pivot row.)
+constexpr int SG_ITR = 6, SG_ITC = 4, SG_ITHREADS = (SG_NCP / SG_ITR) * (SG_NCP / SG_ITC);
+__global__ __launch_bounds__(SG_ITHREADS) void k_sg_invert(int NC, const double* __restrict__ E, double* __restrict__ einv) {
+    __shared__ double rowbuf[2 * SG_NCP], colbuf[2 * SG_NCP], sc[SG_NCP], diagbuf[2];
+    __shared__ unsigned char drop[SG_NCP + 1];
+    gj_invert_tiled<SG_NCP, SG_ITR, SG_ITC, 12>(NC, E, einv, rowbuf, colbuf, sc, diagbuf, drop);
 }
 
 // q = S~ p for the rows of this workgroup (eight; two per wave at a time), partial of p . q
@@ -2919,7 +2879,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       if (f32) hipLaunchKernelGGL((k_sg_v<float>), dim3(nc + 1), dim3(256), SG_V_LDS, s, d, ld, G, ws->Sfull32, ws->W, ws->sgV);
       else hipLaunchKernelGGL((k_sg_v<double>), dim3(nc + 1), dim3(256), SG_V_LDS, s, d, ld, G, ws->Sfull, ws->W, ws->sgV);
       hipLaunchKernelGGL(k_sg_e, dim3(NC), dim3(3 * SG_NCP), 0, s, d, G, ws->sgV, ws->sgE);
-      hipLaunchKernelGGL(k_sg_invert, dim3(1), dim3(SG_INB * SG_NCP), 0, s, NC, ws->sgE, ws->sgEinv);
+      hipLaunchKernelGGL(k_sg_invert, dim3(1), dim3(SG_ITHREADS), 0, s, NC, ws->sgE, ws->sgEinv);
       static const bool sg_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;
       if (sg_debug) sg_debug_check(s, ws, f32); }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
