@@ -2113,23 +2113,25 @@ constexpr int SG_NCP = 144;                 // padded coarse dimension: 7 SG_MAX
 constexpr int SG_CB = 36;                   // columns per part of the E^-1 c product (SG_NCP / 4)
 constexpr int SG_UWG = 16;                  // workgroups of the vector kernels
 constexpr int SG_UT = 1024;                 // ... and their threads
-constexpr int SG_TC = 128;                  // cameras per column tile of k_sg_v
-constexpr size_t SG_V_LDS = sizeof(double) * 6 * 6 * SG_TC + sizeof(float) * PCG_NW * 6 * SG_TC + sizeof(double) * 4 * SG_NCP;
+constexpr int SG_TC = 64;                   // cameras per column tile of k_sg_v
 enum { SGS_RZ = 0, SGS_PQ = 1, SGS_LEN = 4 };     // per-parity scalars of the running solve (sg_state)
 
 __device__ __forceinline__ int sg_first_cam(int a, int nc, int G) { return (a * nc + G - 1) / G; }
 __device__ __forceinline__ double sg_frac(int j, int a, int nc, int G, double inv_nc) { return (double)(j * G - a * nc) * inv_nc; }
 __host__ __device__ __forceinline__ int sg_hats(int nc) { const int g = nc / 25; return g < ML_G ? ML_G : g > SG_MAXG ? SG_MAXG : g; }
 
-// per camera j (workgroup; the last one: the focal row): V[j][8][SG_NCP] = sum over the camera's rows of W~_k[row] (S~ W~)[row][:].  Column tiles of SG_TC cameras: the camera's six rows of the tile and W~_0..7 (fp32) in LDS, lane + 64 pass = coarse vector.
+// per camera j (workgroup; the last one: the focal row): V[j][8][SG_NCP] = sum over the camera's rows of W~_k[row] (S~ W~)[row][:].  Column tiles of
+// SG_TC cameras, two phases per tile through LDS: (1) T[row][camera][k] = the 6-term product of the camera's row entries with W~_k, one item per thread
+// and step -- k = 7 is the global vector's share --, (2) lane + 64 pass = coarse vector (g, k) adds hat_g(camera) T over the cameras of its hat inside the
+// tile.  (With the 6-term products inside phase 2, every wave ran as long as its busiest lane's hat: 187 us.)
 template <typename FT>
 __global__ __launch_bounds__(256) void k_sg_v(int d, int ld, int G, const FT* __restrict__ F, const double* __restrict__ W,
                                               double* __restrict__ V) {
-    extern __shared__ __align__(16) double sm[];
-    double* rows = sm;                                                   // [6][6 SG_TC]
-    float* wt = reinterpret_cast<float*>(rows + 6 * 6 * SG_TC);          // [8][6 SG_TC]
-    double* vbuf = reinterpret_cast<double*>(wt + PCG_NW * 6 * SG_TC);   // [4][SG_NCP]
     constexpr int TW = 6 * SG_TC;
+    __shared__ __align__(16) double rows[6 * TW];               // [6][TW]
+    __shared__ __align__(16) float wt[PCG_NW * TW];             // [8][TW]
+    __shared__ double T[6 * SG_TC * PCG_NW];                    // [6][SG_TC][8]
+    __shared__ double vbuf[4 * SG_NCP];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nc = (d - 1) / 6, NC = 7 * G + 1;
     const double inv_nc = 1.0 / (double)nc;
@@ -2143,8 +2145,7 @@ __global__ __launch_bounds__(256) void k_sg_v(int d, int ld, int G, const FT* __
         for (int p = 0; p < 3; ++p) acc[r][p] = 0.0;
     for (int c0 = 0; c0 < nc; c0 += SG_TC) {
         const int col0 = 6 * c0, ncol = min(6 * nc - col0, TW);
-        // all loads of the tile first (18 + 24 per thread, clamped, branch-free), then the LDS stores: a loop of load / store pairs is a chain of
-        // 42 memory round trips per tile (measured: 289 us for this kernel)
+        // all loads of the tile first (9 + 12 per thread, clamped, branch-free), then the LDS stores
         FT fr_[6 * TW / 256];
         double wr_[PCG_NW * TW / 256];
 #pragma unroll
@@ -2158,7 +2159,7 @@ __global__ __launch_bounds__(256) void k_sg_v(int d, int ld, int G, const FT* __
             const int e = tid + 256 * u, k = e / TW, c = e - TW * k;
             wr_[u] = W[(size_t)k * ld + col0 + (c < ncol ? c : 0)];
         }
-        __syncthreads();
+        __syncthreads();                                         // (the previous tile's phase 2 is done with T, rows, wt)
 #pragma unroll
         for (int u = 0; u < 6 * TW / 256; ++u) {
             const int e = tid + 256 * u, r = e / TW, c = e - TW * r;
@@ -2170,35 +2171,40 @@ __global__ __launch_bounds__(256) void k_sg_v(int d, int ld, int G, const FT* __
             wt[e] = c < ncol ? (float)wr_[u] : 0.0f;
         }
         __syncthreads();
+        // (1) T[r][camera][k]
+#pragma unroll
+        for (int u = 0; u < 6 * SG_TC * PCG_NW / 256; ++u) {
+            const int item = tid + 256 * u, r = item / (SG_TC * PCG_NW), rem = item - (SG_TC * PCG_NW) * r, cam = rem / PCG_NW, k = rem - PCG_NW * cam;
+            const double* rp = rows + r * TW + 6 * cam;
+            const float* wk = wt + k * TW + 6 * cam;
+            double t = 0.0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) t = fma(rp[e], (double)wk[e], t);
+            T[item] = t;
+        }
+        __syncthreads();
+        // (2) hat sums
         const int c1 = min(nc, c0 + SG_TC);
+        const double* Ta = T + (size_t)ra * SG_TC * PCG_NW;
+        const double* Tb = T + (size_t)(have_b ? rb : ra) * SG_TC * PCG_NW;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int v = lane + 64 * p;
             if (v < NC - 1) {
                 const int g = v / 7, k = v - 7 * g;
-                const float* wk = wt + k * TW;
                 for (int range = 0; range < 2; ++range) {
                     const int a = range == 0 ? (g + G - 1) % G : g;
                     const int lo = max(sg_first_cam(a, nc, G), c0), hi = min(sg_first_cam(a + 1, nc, G), c1);
                     for (int j = lo; j < hi; ++j) {
                         const double fr = sg_frac(j, a, nc, G, inv_nc);
                         const double wgt = range == 0 ? fr : 1.0 - fr;
-                        const int o = 6 * (j - c0);
-                        double ta = 0.0, tb = 0.0;
-#pragma unroll
-                        for (int e = 0; e < 6; ++e) { const double wv = (double)wk[o + e]; ta = fma(rows[ra * TW + o + e], wv, ta); tb = fma(rows[(have_b ? rb : ra) * TW + o + e], wv, tb); }
-                        acc[0][p] = fma(wgt, ta, acc[0][p]);
-                        acc[1][p] = fma(wgt, tb, acc[1][p]);
+                        acc[0][p] = fma(wgt, Ta[(j - c0) * PCG_NW + k], acc[0][p]);
+                        acc[1][p] = fma(wgt, Tb[(j - c0) * PCG_NW + k], acc[1][p]);
                     }
                 }
             }
         }
-        // the global (focal / depth) vector: every column of the tile
-        for (int c = lane; c < ncol; c += 64) {
-            const double wv = (double)wt[(PCG_NW - 1) * TW + c];
-            gs[0] = fma(rows[ra * TW + c], wv, gs[0]);
-            gs[1] = fma(rows[(have_b ? rb : ra) * TW + c], wv, gs[1]);
-        }
+        if (c0 + lane < c1) { gs[0] += Ta[lane * PCG_NW + (PCG_NW - 1)]; gs[1] += Tb[lane * PCG_NW + (PCG_NW - 1)]; }     // the global (focal / depth) vector
     }
     gs[0] = wave_allsum(gs[0]); gs[1] = wave_allsum(gs[1]);
     {   // the focal column
@@ -2208,7 +2214,7 @@ __global__ __launch_bounds__(256) void k_sg_v(int d, int ld, int G, const FT* __
     }
     if (!have_a) { gs[0] = 0.0; acc[0][0] = acc[0][1] = acc[0][2] = 0.0; }
     if (!have_b) { gs[1] = 0.0; acc[1][0] = acc[1][1] = acc[1][2] = 0.0; }
-    if (lane + 128 == NC - 1) { acc[0][2] = gs[0]; acc[1][2] = gs[1]; }        // (NC - 1 = 7 G lies in the third pass for G >= 19, else below:)
+    if (lane + 128 == NC - 1) { acc[0][2] = gs[0]; acc[1][2] = gs[1]; }
     if (lane + 64 == NC - 1) { acc[0][1] = gs[0]; acc[1][1] = gs[1]; }
     if (lane == NC - 1) { acc[0][0] = gs[0]; acc[1][0] = gs[1]; }
     // V[k][:] = sum over the camera's rows of W~_k[row] AW[row][:], wave partials summed through LDS, one k at a time
@@ -2869,15 +2875,9 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       static const bool ml_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;      // (read once per process)
       if (ml_debug) ml_debug_check(s, ws, nwg); }
     else if (sg) { ProfScope ps(prof, KID_PCG_SETUP, s, 3);
-      static bool sg_attr_set = false;
-      if (!sg_attr_set) {
-          (void)hipFuncSetAttribute((const void*)k_sg_v<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SG_V_LDS);
-          (void)hipFuncSetAttribute((const void*)k_sg_v<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SG_V_LDS);
-          sg_attr_set = true;
-      }
       const int nc = (d - 1) / 6, G = sg_hats(nc), NC = 7 * G + 1;
-      if (f32) hipLaunchKernelGGL((k_sg_v<float>), dim3(nc + 1), dim3(256), SG_V_LDS, s, d, ld, G, ws->Sfull32, ws->W, ws->sgV);
-      else hipLaunchKernelGGL((k_sg_v<double>), dim3(nc + 1), dim3(256), SG_V_LDS, s, d, ld, G, ws->Sfull, ws->W, ws->sgV);
+      if (f32) hipLaunchKernelGGL((k_sg_v<float>), dim3(nc + 1), dim3(256), 0, s, d, ld, G, ws->Sfull32, ws->W, ws->sgV);
+      else hipLaunchKernelGGL((k_sg_v<double>), dim3(nc + 1), dim3(256), 0, s, d, ld, G, ws->Sfull, ws->W, ws->sgV);
       hipLaunchKernelGGL(k_sg_e, dim3(NC), dim3(3 * SG_NCP), 0, s, d, G, ws->sgV, ws->sgE);
       hipLaunchKernelGGL(k_sg_invert, dim3(1), dim3(SG_ITHREADS), 0, s, NC, ws->sgE, ws->sgEinv);
       static const bool sg_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;
