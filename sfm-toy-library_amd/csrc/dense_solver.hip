@@ -2244,14 +2244,26 @@ __global__ __launch_bounds__(3 * SG_NCP) void k_sg_e(int d, int G, const double*
         for (int range = 0; range < 2; ++range) {
             const int a = range == 0 ? (g + G - 1) % G : g;
             const int lo = sg_first_cam(a, nc, G), hi = sg_first_cam(a + 1, nc, G);
-            for (int j = lo + part; j < hi; j += 3) {
-                const double fr = sg_frac(j, a, nc, G, inv_nc);
-                const double wgt = range == 0 ? fr : 1.0 - fr;
-                e = fma(wgt, V[((size_t)j * PCG_NW + k) * SG_NCP + v], e);
+            for (int jb = lo + part; jb < hi; jb += 3 * 8) {               // eight loads in flight (clamped, branch-free)
+                double val[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { const int j = jb + 3 * t; val[t] = V[((size_t)(j < hi ? j : lo) * PCG_NW + k) * SG_NCP + v]; }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int j = jb + 3 * t;
+                    const double fr = sg_frac(j, a, nc, G, inv_nc);
+                    e = fma(j < hi ? (range == 0 ? fr : 1.0 - fr) : 0.0, val[t], e);
+                }
             }
         }
     } else {
-        for (int j = part; j <= nc; j += 3) e += V[((size_t)j * PCG_NW + (PCG_NW - 1)) * SG_NCP + v];
+        for (int jb = part; jb <= nc; jb += 3 * 16) {                       // the plain sum over all workgroups: sixteen loads in flight
+            double val[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { const int j = jb + 3 * t; val[t] = V[((size_t)(j <= nc ? j : nc) * PCG_NW + (PCG_NW - 1)) * SG_NCP + v]; }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) e += (jb + 3 * t <= nc) ? val[t] : 0.0;
+        }
     }
     eq[part][v] = e;
     __syncthreads();
