@@ -122,7 +122,7 @@ typedef struct sfmba_options {
     int    pcg_coarse_space;          /* SFMBA_PCG_COARSE         default on : two-level CG preconditioner (8 gauge vectors).  Where the reduced
                                          matrix is sparsely filled (< 1/2 of its blocks) with >= 90 % of the blocks within a quarter of the cyclic camera
                                          order -- views registered along a path -- and >= 32 cameras, the seven similarity vectors are used restricted to
-                                         overlapping SEGMENTS of the camera order (eight up to 213 cameras, cameras / 25 <= 20 up to 1365: 3 - 15x fewer CG
+                                         overlapping SEGMENTS of the camera order (eight up to 213 cameras, cameras / 25 <= 20 up to 1007: 3 - 15x fewer CG
                                          iterations there; AUTO keeps that CG above 213 cameras instead of factorising).
                                          1 = the eight global vectors only, 2 = the segments wherever they apply (SFMBA_PCG_SEGMENTS=0|1 likewise).
                                          The sharded solve keeps the eight global vectors (the choice would have to be agreed between the ranks). */
