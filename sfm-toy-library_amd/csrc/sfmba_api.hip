@@ -785,6 +785,40 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         // 75 over all blocks -- runs the wave-per-chunk pass 627 -> 370 us faster than sixteen lanes per block (tools/large_banded_check.py).
         const double mean_pairs = (double)npair_total / std::max(1.0, p->block_fill * (double)std::max(1, nblock - ncam));
         pair_lpb = mean_pairs >= 128.0 ? 64 : 16;
+        // A FIRST build does not know the fill.  Where the plain mean says "sixteen lanes" for a problem with many cameras, a sample decides: the
+        // pairs of ~1000 points (every 2^s-th slot), their blocks sorted, m_b sampled pairs in block b -- pairs of one point never share a block, so
+        // sum_b m_b (m_b - 1) estimates q^2 sum_b n_b^2 (q: the sampled share of the points) and  sum n_b^2 / sum n_b = C2 / (q * keys) + 1  is the
+        // number of pairs in the block an average PAIR lives in: mean + 1 for uniform co-visibility, ~800 on the 600-camera path (mean 75).
+        if (pair_lpb == 16 && src.n_old == 0 && ncam > 64 && nn > 100000 && mean_pairs >= 8.0) {
+            int shift = 0;
+            while ((npt >> shift) > 1024) ++shift;
+            const int mask = (1 << shift) - 1;
+            std::vector<std::pair<int, int>> smp;
+            { std::mutex mu;
+              parallel_for((int)nn, [&](int k0, int k1) {
+                  std::vector<std::pair<int, int>> loc;
+                  for (int k = k0; k < k1; ++k) if ((h_pt[(size_t)k] & mask) == 0) loc.emplace_back(h_pt[(size_t)k], h_cam[(size_t)k]);
+                  std::lock_guard<std::mutex> lk(mu);
+                  smp.insert(smp.end(), loc.begin(), loc.end());
+              }); }
+            std::sort(smp.begin(), smp.end());
+            std::vector<int> keys;
+            size_t npts_s = 0;
+            for (size_t a = 0; a < smp.size();) {
+                size_t b = a;
+                while (b < smp.size() && smp[b].first == smp[a].first) ++b;
+                ++npts_s;
+                for (size_t u = a; u < b; ++u)
+                    for (size_t v = u + 1; v < b; ++v) if (smp[u].second != smp[v].second) keys.push_back(block_of(std::min(smp[u].second, smp[v].second), std::max(smp[u].second, smp[v].second)));
+                a = b;
+            }
+            std::sort(keys.begin(), keys.end());
+            double c2 = 0.0;
+            for (size_t a = 0; a < keys.size();) { size_t b = a; while (b < keys.size() && keys[b] == keys[a]) ++b; c2 += (double)(b - a) * (double)(b - a - 1); a = b; }
+            const double q = (double)npts_s / (double)std::max(1, npt);
+            const double weighted = (keys.empty() || q <= 0.0) ? mean_pairs : c2 / (q * (double)keys.size()) + 1.0;
+            if (weighted >= 4.0 * 128.0) pair_lpb = 64;         // (well beyond the uniform crossover: the empty blocks of such a structure cost a wave each)
+        }
         if (const char* e = std::getenv("SFMBA_PAIR_LPB")) { const int v = std::atoi(e); if (v == 64 || v == 16) pair_lpb = v; }
         blocks_per_wg = pair_lpb == 64 ? 1 : 64 / pair_lpb;
         {
