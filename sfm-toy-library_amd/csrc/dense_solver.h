@@ -36,7 +36,7 @@ struct DenseSolver {
     double* mlEinv = nullptr; // [64][64] E^-1 (rows / columns of dropped vectors zero)
     double* mlC0 = nullptr;   // [64] c_0 = W~^T b~
     double* mlState = nullptr;// [2][3][64] c, mu, p_mu by iteration parity
-    // ... on the streaming path (d > 1280): per-camera pieces of E, E, E^-1 (192 x 192), per-camera W~_k . r, |r|^2 partials, {r.z, p.q} by parity
+    // ... on the streaming path (d > 1280): per-camera pieces of E, E, E^-1 (144 x 144), per-camera W~_k . r, |r|^2 partials, {r.z, p.q} by parity
     double *sgV = nullptr, *sgE = nullptr, *sgEinv = nullptr, *sgT = nullptr, *sgRR = nullptr, *sgState = nullptr;
     int last_iters = 0;       // CG iterations of the previous solve
     std::vector<int> hist;    // CG iterations of the previous call per caller key (LM iteration index): sizes the first launch batch
@@ -78,7 +78,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
                     bool no_wait = false, bool coarse = false, bool segments = false);
 // segments = true (with coarse): the segmented coarse space where it applies (dense_pcg_segments_applicable: d = 6 nc + 1 <= 1280, nc >= 32)
 bool dense_pcg_segments_applicable(const DenseSolver* ws);
-// ... or its streaming-path form (1280 < d <= 8192): classical PCG in three launches per iteration, up to 27 hats
+// ... or its streaming-path form (1280 < d <= 8192): classical PCG in three launches per iteration, up to 20 hats (at most 1007 cameras)
 bool dense_pcg_segments_streaming_applicable(const DenseSolver* ws);
 // dense_pcg_transform: the block-Jacobi transform on its own (block factors -> ws->binv, S~ -> ws->Sfull / Sfull32, b~), for callers that
 // need the factors before the solve (sharded path: gauge vectors are formed from them); follow with dense_pcg_solve(pretransformed = true).
