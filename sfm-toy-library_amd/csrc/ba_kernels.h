@@ -248,6 +248,7 @@ void launch_row_order(hipStream_t s, int ncam, int lpb, const int* blk_ptr, int*
 int build_pair_chunks(hipStream_t s, DeviceArena* scratch, int nwg, int chunk, const int2* pwg_blocks, const int2* blk_cams, const int* blk_ptr,
                       int4* desc, int2* info, int* multi, int* counters, int* report);
 void launch_block_fill(hipStream_t s, int nblock, int ncam, const int2* blk_cams, const int* blk_ptr, int* counters, int* report);
+void launch_block_mask(hipStream_t s, int ncam, const int* blk_ptr, unsigned* mask);       // per camera: the cameras it shares a non-empty block with (bit mask)
 void launch_dup_blocks(hipStream_t s, int ncam, const int* blk_ptr, const long long* pair_total, int2* dup, int* report);
 
 // triangulate.hip: two-view DLT triangulation + reprojection filter (SfMStereoUtilities::triangulateViews), device pointers

@@ -38,6 +38,8 @@ struct DenseSolver {
     double* mlState = nullptr;// [2][3][64] c, mu, p_mu by iteration parity
     // ... on the streaming path (d > 1280): per-camera pieces of E, E, E^-1 (144 x 144), per-camera W~_k . r, |r|^2 partials, {r.z, p.q} by parity
     double *sgV = nullptr, *sgE = nullptr, *sgEinv = nullptr, *sgT = nullptr, *sgRR = nullptr, *sgState = nullptr;
+    const unsigned* blk_mask = nullptr;   // [ncam][(ncam + 31) / 32] per camera: cameras with a non-empty block in common (set by the caller; null: dense product)
+    double blk_fill = 1.0;    // non-empty off-diagonal blocks / all (set by the caller)
     int last_iters = 0;       // CG iterations of the previous solve
     std::vector<int> hist;    // CG iterations of the previous call per caller key (LM iteration index): sizes the first launch batch
     double* binv = nullptr;   // [ld*6] inverses of the 6x6 diagonal blocks (+1x1 focal)

@@ -2351,6 +2351,74 @@ __global__ __launch_bounds__(256) void k_sg_q(int d, int ld, const FT* __restric
     if (tid == 0) pqpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The same product for a SPARSELY FILLED S~ (a long camera path: 6 % of the blocks hold anything): workgroup = camera (six rows; the last workgroup: the
+// focal row, dense), the cameras it shares a non-empty block with come from the structure build's bit mask (k_block_mask; the camera itself included:
+// S~_jj = I), compacted into LDS; lanes walk (neighbour, entry) pairs -- six consecutive lanes read the 24 / 48 contiguous bytes of a block row -- and
+// read p from L2.  Empty blocks of S~ are exact zeros (the pair pass writes them), so this IS the dense product.
+template <typename FT>
+__global__ __launch_bounds__(256) void k_sg_q_sparse(int d, int ld, const FT* __restrict__ F, const double* __restrict__ p, double* __restrict__ q,
+                                                     double* __restrict__ pqpart, const int* __restrict__ flags, const unsigned* __restrict__ mask) {
+    __shared__ int list[1024];
+    __shared__ int wcount[4], nn_s;
+    __shared__ double red[4];
+    if (flags[PF_DONE] != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nc = (d - 1) / 6, words = (nc + 31) / 32, ja = blockIdx.x;
+    double pqp = 0.0;
+    if (ja < nc) {
+        // compact the set bits of mask[ja] into list (ascending): ballot + popcount per wave, wave offsets through LDS
+        int base = 0;
+        for (int c0 = 0; c0 < nc; c0 += 256) {
+            const int c = c0 + tid;
+            const bool on = c < nc && ((mask[(size_t)ja * words + (c >> 5)] >> (c & 31)) & 1u);
+            const unsigned long long bal = __ballot(on);
+            if (lane == 0) wcount[w] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int k = 0; k < w; ++k) off += wcount[k];
+            if (on) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+            base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+            __syncthreads();
+        }
+        if (tid == 0) nn_s = base;
+        __syncthreads();
+        const int nn = nn_s;
+        const double pf = p[d - 1];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = w + 4 * rr;
+            if (r < 6) {
+                const int row = 6 * ja + r;
+                const FT* Fr = F + (size_t)row * ld;
+                double s = 0.0;
+                for (int idx0 = lane; idx0 < 6 * nn; idx0 += 64 * 4) {          // four gathers in flight
+                    double fv[4], pv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = idx0 + 64 * u, ic = idx < 6 * nn ? idx : 0;
+                        const int col = 6 * list[ic / 6] + ic % 6;
+                        fv[u] = (double)Fr[col]; pv[u] = p[col];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s = fma(idx0 + 64 * u < 6 * nn ? fv[u] : 0.0, pv[u], s);
+                }
+                if (lane == 0) s = fma((double)Fr[d - 1], pf, s);
+                s = wave_allsum(s);
+                if (lane == 0) { q[row] = s; pqp += p[row] * s; }
+            }
+        }
+    } else if (w == 0) {                             // the focal row: dense
+        const FT* Fr = F + (size_t)(d - 1) * ld;
+        double s = 0.0;
+        for (int c = lane; c < d; c += 64) s = fma((double)Fr[c], p[c], s);
+        s = wave_allsum(s);
+        if (lane == 0) { q[d - 1] = s; pqp = p[d - 1] * s; }
+    }
+    if (lane == 0) red[w] = pqp;
+    __syncthreads();
+    if (tid == 0) pqpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // block sum over SG_UT threads (every thread gets the total); scratch: 16 doubles
 __device__ __forceinline__ double sg_block_sum(double v, double* scratch) {
     v = wave_allsum(v);
@@ -2704,9 +2772,15 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
             hipLaunchKernelGGL((k_sg_u<true>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, r.nwg, bt, x, rv, pv, qv, ws->W, ws->part, ws->sgT, ws->sgRR, ws->sgState, ws->flags, par);
             hipLaunchKernelGGL((k_sg_p<true>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, G, rv, pv, ws->W, ws->sgT, ws->sgRR, ws->sgEinv, ws->sgState, ws->scal, ws->flags, r.info, ws->d_mailbox, r.tol2, par, anchor, cap);
         } else {
-            if (r.f32) hipLaunchKernelGGL((k_sg_q<float>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull32, pv, qv, ws->part, ws->flags, r.rows_per_wg);
+            // (a reduced matrix filled below a quarter: the block-sparse product, one workgroup per camera)
+            const bool sparse = ws->blk_mask != nullptr && ws->blk_fill < 0.25 && (d - 1) / 6 + 1 <= PCG_PART;
+            const int nwgq = sparse ? (d - 1) / 6 + 1 : r.nwg;
+            if (sparse) {
+                if (r.f32) hipLaunchKernelGGL((k_sg_q_sparse<float>), dim3(nwgq), dim3(256), 0, s, d, ld, ws->Sfull32, pv, qv, ws->part, ws->flags, ws->blk_mask);
+                else hipLaunchKernelGGL((k_sg_q_sparse<double>), dim3(nwgq), dim3(256), 0, s, d, ld, ws->Sfull, pv, qv, ws->part, ws->flags, ws->blk_mask);
+            } else if (r.f32) hipLaunchKernelGGL((k_sg_q<float>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull32, pv, qv, ws->part, ws->flags, r.rows_per_wg);
             else hipLaunchKernelGGL((k_sg_q<double>), dim3(r.nwg), dim3(256), r.lds, s, d, ld, ws->Sfull, pv, qv, ws->part, ws->flags, r.rows_per_wg);
-            hipLaunchKernelGGL((k_sg_u<false>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, r.nwg, bt, x, rv, pv, qv, ws->W, ws->part, ws->sgT, ws->sgRR, ws->sgState, ws->flags, par);
+            hipLaunchKernelGGL((k_sg_u<false>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, nwgq, bt, x, rv, pv, qv, ws->W, ws->part, ws->sgT, ws->sgRR, ws->sgState, ws->flags, par);
             hipLaunchKernelGGL((k_sg_p<false>), dim3(SG_UWG), dim3(SG_UT), 0, s, d, ld, G, rv, pv, ws->W, ws->sgT, ws->sgRR, ws->sgEinv, ws->sgState, ws->scal, ws->flags, r.info, ws->d_mailbox, r.tol2, par, anchor, cap);
         }
     } else if (r.ml) {

@@ -219,6 +219,7 @@ struct sfmba_problem {
     double block_fill = 1.0;              // non-empty off-diagonal blocks of the reduced matrix / all of them
     double block_band = 0.0;              // ... and the share of those that couple cameras within a quarter of the cyclic camera order
     int* d_blk_ptr = nullptr;
+    unsigned* d_blk_mask = nullptr;       // per camera: cameras with a non-empty block in common (block-sparse CG product)
     int* d_cam_chunk_ptr = nullptr;
     bool deterministic = false;             // SFMBA_DETERMINISTIC=1 at build time
     bool cam_identity = false, pt_identity = false;   // slot == caller index for every camera / point (arrays copied as they are)
@@ -997,6 +998,11 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, d_perm, p->d_pwg_desc);
     }
     launch_block_fill(p->stream, nblock, ncam, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
+    p->d_blk_mask = nullptr;
+    if (6 * ncam + 1 > 1280 && !sharded) {       // (the streaming CG kernels: a sparsely filled reduced matrix is multiplied block-sparse there)
+        HIP_TRY(dev_alloc(&p->d_blk_mask, (size_t)ncam * (size_t)((ncam + 31) / 32)));
+        launch_block_mask(p->stream, ncam, p->d_blk_ptr, p->d_blk_mask);
+    }
     launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, d_report);
     HIP_TRY(hipGetLastError());
     p->focal0 = p->focal = focal;
@@ -1083,6 +1089,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.trace = nullptr; db.trace_cap = 0; p->trace_mapped = false;
     dense_solver_destroy(&p->solver);
     if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
+    p->solver.blk_mask = p->d_blk_mask;
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
     HIP_TRY(dev_alloc(&db.pair_G, (size_t)36 * std::max(ncam, 1)));
@@ -1100,6 +1107,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     // fill of the reduced matrix: non-empty off-diagonal blocks / all of them (what SFMBA_LINEAR_AUTO reads the co-visibility from)
     p->block_fill = ncam > 1 ? (double)std::max((int)build_report[1], 0) / ((double)ncam * (ncam - 1) / 2.0) : 1.0;
     p->block_band = build_report[1] > 0 ? (double)std::max((int)build_report[6], 0) / (double)build_report[1] : 0.0;
+    p->solver.blk_fill = p->block_fill;
     bt_mark("wait for device");
     return sfmba_problem_reset(p);
 }

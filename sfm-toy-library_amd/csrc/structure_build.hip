@@ -412,6 +412,26 @@ int build_pair_chunks(hipStream_t s, DeviceArena* scratch, int nwg, int chunk, c
     hipLaunchKernelGGL(k_chunk_report, dim3(1), dim3(1), 0, s, nwg, off, counters, report);
     return (int)hipGetLastError();
 }
+// Per camera j the set of cameras c whose block (min, max) of the reduced matrix holds a pair -- and j itself --, as a bit mask of `words` 32-bit words:
+// what a block-sparse product of the CG needs (dense_solver.hip, k_sg_q_sparse).  One thread per (camera, word).
+__global__ __launch_bounds__(256) void k_block_mask(int ncam, int words, const int* __restrict__ blk_ptr, unsigned* __restrict__ mask) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncam * words) return;
+    const int j = t / words, wd = t - words * j;
+    unsigned m = 0;
+    for (int bit = 0; bit < 32; ++bit) {
+        const int c = 32 * wd + bit;
+        if (c >= ncam) break;
+        const int ja = j < c ? j : c, jb = j < c ? c : j;
+        const long long b = (long long)ja * ncam - (long long)ja * (ja - 1) / 2 + (jb - ja);
+        if (c == j || blk_ptr[b + 1] > blk_ptr[b]) m |= 1u << bit;
+    }
+    mask[t] = m;
+}
+void launch_block_mask(hipStream_t s, int ncam, const int* blk_ptr, unsigned* mask) {
+    const int words = (ncam + 31) / 32;
+    if (ncam > 0) hipLaunchKernelGGL(k_block_mask, dim3((ncam * words + 255) / 256), dim3(256), 0, s, ncam, words, blk_ptr, mask);
+}
 void launch_block_fill(hipStream_t s, int nblock, int ncam, const int2* blk_cams, const int* blk_ptr, int* counters, int* report) {
     if (nblock > 0) hipLaunchKernelGGL(k_block_fill, dim3((nblock + 255) / 256), dim3(256), 0, s, nblock, ncam, blk_cams, blk_ptr, counters);
     hipLaunchKernelGGL(k_fill_report, dim3(1), dim3(1), 0, s, counters, report);
