@@ -243,7 +243,8 @@ def banded_oracle(sfm, oracle, banded):
 
 def test_banded_visibility_bench_mode_and_default_match_oracle(capi, sfm, banded, banded_oracle):
     """cfg3_banded: 200 cameras / 100k points / ~1M observations, banded reduced system with a few very heavy blocks (up to ~10^4 pairs:
-    the fp64 flush of the pair pass) and ~90 CG iterations per LM iteration.  Bench mode (F32J, two-level PCG 1e-8 anchored), the library
+    the fp64 flush of the pair pass) and ~90 CG iterations per LM iteration with the eight global gauge vectors -- 16 .. 33 with the segmented coarse
+    space the structure build chooses here (tests/test_gpu_segments.py).  Bench mode (F32J, two-level PCG 1e-8 anchored), the library
     default (AUTO: starts on the CG, sees that a linearisation costs more CG iterations than a factorisation and factorises from there on)
     and the exact fp64 configuration.  Points: a track of two NEIGHBOURING cameras (baseline 0.16 at depth 5) leaves the point's depth almost
     free, so the fp32 Jacobian rounding shows up as up to ~1e-3 in such a point while cost, cameras and every well-observed point agree
