@@ -61,6 +61,12 @@ def set_num_threads(n):
     lib().sfmba_oracle_set_num_threads(C.c_int(int(n)))
 
 
+def set_minimizer_variant(v):
+    """0: the >= 1.12 TrustRegionMinimizer ordering (default); 1: the candidate of the terminating iteration is accepted before the
+    function-tolerance exit; 2: strict '<' in the function-tolerance test (sfmba_oracle.c, g_minimizer_variant)."""
+    lib().sfmba_oracle_set_minimizer_variant(C.c_int(int(v)))
+
+
 def rotation_matrix_to_angle_axis_f(R):
     """R: 3x3 (row-major numpy) -> float32 angle-axis, float arithmetic (BA.cpp:126)."""
     Rcm = np.ascontiguousarray(np.asarray(R, dtype=np.float32).T)   # column-major bytes of R

@@ -214,3 +214,34 @@ def test_adjust_bundle_marshalling(oracle, sfm):
     p3, K3, pts3, summ3 = oracle.adjust_bundle(poses, K, pts, views, feats, sfm.SfmbaOptions.defaults(max_seconds=0.0, max_iters=1))
     assert summ3["termination_name"] == "NO_CONVERGENCE"
     assert np.array_equal(p3, poses) and np.array_equal(K3, K) and np.array_equal(pts3, pts)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "crazyhorse_like", "cfg2"])
+def test_final_rms_is_insensitive_to_the_upstream_minimizer_ordering(oracle, sfm, name):
+    """VERDICT r4 (Next round 2c).  The reference links an un-pinned Ceres (CMakeLists.txt:30); the restatement follows the >= 1.12
+    TrustRegionMinimizer.  The upstream orderings of the function-tolerance exit we know of -- the candidate of the terminating
+    iteration accepted BEFORE the exit (variant 1: the final x is one tiny step further), and the strict comparison of the older
+    sources (variant 2) -- move the final RMS by less than 1e-6 px on every fixture: two orders of magnitude inside north_star's
+    1e-4 px bar, so the (unpinned) solver parity does not hinge on which release the reference was built against."""
+    prob = sfm.make_problem(name)
+    opt = sfm.SfmbaOptions.defaults(max_seconds=0.0)
+    try:
+        out = {}
+        for v in (0, 1, 2):
+            oracle.set_minimizer_variant(v)
+            cam, pt, f, s, tr = oracle.solve(prob, opt)
+            out[v] = (np.sqrt(2.0 * s["final_cost"] / prob.n_obs), s, cam, pt, f)
+    finally:
+        oracle.set_minimizer_variant(0)
+    rms0, s0 = out[0][0], out[0][1]
+    assert s0["termination_name"] == "CONVERGENCE"
+    for v in (1, 2):
+        rms, s = out[v][0], out[v][1]
+        assert s["termination_name"] == "CONVERGENCE" and s["iterations"] == s0["iterations"]
+        assert abs(rms - rms0) < 1e-6, (name, v, rms, rms0)
+    # variant 1 really is a different final point whenever the exit was the function tolerance and the last candidate a descent step
+    if "Function tolerance" in s0["message"]:
+        assert out[1][1]["final_cost"] <= s0["final_cost"]
+        assert out[1][1]["successful_steps"] in (s0["successful_steps"], s0["successful_steps"] + 1)
+    # variant 2 differs from 0 only on a measure-zero tie (the oracle's OpenMP reductions are not bitwise repeatable: 1e-12)
+    assert abs(out[2][1]["final_cost"] - s0["final_cost"]) <= 1e-12 * s0["final_cost"] and np.allclose(out[2][2], out[0][2], rtol=0, atol=1e-10)
