@@ -54,6 +54,11 @@ def parse():
                          "of the reduced camera system: 1 = yes, 0 = no, -1 (default) = only when N > 1")
     ap.add_argument("--distributed-cg", action="store_true", help="--mode sharded: the CG without the redundant solve (reduce-scatter + one small all-reduce per CG iteration)")
     ap.add_argument("--implicit-cg", action="store_true", help="--mode sharded: the CG with the product formed implicitly from every rank's own points (no exchange of the reduced matrix at all)")
+    ap.add_argument("--row-sharded", action="store_true", help="--mode sharded: block ROWS of the reduced matrix per rank (every rank holds the whole problem; per-point table all-gathered; "
+                                                              "multi-workgroup distributed CG on the owned rows)")
+    ap.add_argument("--extra-workloads", type=int, default=-1,
+                    help="after the timed region also run the other BASELINE configurations (cfg 2 in fp64 with the reference's solver, cfg 3 in all-fp64, cfg3_banded, cfg 5) and hold "
+                         "each to the oracle's stored final cost: 1 = yes, 0 = no, -1 (default) = at N = 1 with the default workload")
     ap.add_argument("--extras-timeout", type=int, default=300, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -147,6 +152,9 @@ def cpu_baseline(prob_name, seed_sub, args, gpu_rms):
 
 
 SOLVER_NAMES = {0: "DENSE_SCHUR-equivalent Cholesky", 1: "two-level block-Jacobi PCG", 2: "AUTO (CG to 1e-12, Cholesky fallback)"}
+# what is summed in which precision in SFMBA_PRECISION_F32J (include/sfmba.h; csrc/ba_kernels.hip pair_block_reduce / k_point_build / cam_diag_finish)
+DTYPE_F32J = ("f32 Jacobian blocks and observation coordinates; a lane's own partial sum (<= 8 pair products of a block, ceil(track / 4) point-block products of a "
+              "point) in f32, every sum across lanes, chunks, points and ranks in f64; residuals, cost, reduced system and solve in f64")
 
 
 def _cpu_model():
@@ -248,7 +256,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if precision == 0 else "f32 Jacobian blocks, f64 residual/accumulate/solve",
+            "dtype": "f64" if precision == 0 else DTYPE_F32J,
             "data": "synthetic",
             "config": {"workload": "%s: %d cams / %d pts / %d obs, shared focal, %s, one independent problem per GPU"
                                    % (args.workload, n_cam, n_pt, n_obs, SOLVER_NAMES[linear]),
@@ -313,6 +321,12 @@ def main():
         line["default_solver_auto"] = {"value": it2 / da, "unit": "LM iterations/s", "ms_per_step": 1e3 * da / args.steps,
                                        "cg_iterations_per_step": li2 / args.steps, "cholesky_fallbacks": fb2,
                                        "final_cost": s2["final_cost"], "note": "same problem, sfmba_options_default (SFMBA_LINEAR_AUTO)"}
+    if rank == 0 and world == 1 and not os.environ.get("SFMBA_BENCH_PMC_CHILD") and \
+            (args.extra_workloads == 1 or (args.extra_workloads == -1 and args.workload == "cfg3" and linear == 1 and precision == 1)):
+        try:
+            line["extra_workloads"] = extra_workloads(args, torch, sfm, capi)
+        except Exception as e:                                  # never lose the headline line to the extras
+            line["extra_workloads"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and linear == 1 and world == 1 and args.pcg_tol < 1e-3:
         # Inexact Newton: the same solver with the CG stopped at 1e-3 relative (Ceres' own default for its iterative Schur solvers is
         # eta = 1e-1, the reference sets eta = 1e-2, BA.cpp:173) -- NOT the headline: the headline keeps the 1e-8 of rounds 1 / 2, which
@@ -364,11 +378,11 @@ def main():
             os._exit(0)
         old_term = signal.signal(signal.SIGTERM, on_term)
         for wl in (["cfg3", "cfg5"] if args.workload == "cfg3" else [args.workload]):
-            for variant in ("replicated_cg", "distributed_cg", "implicit_schur_cg"):          # the three forms of the reduced-system solve
+            for variant in ("replicated_cg", "distributed_cg", "implicit_schur_cg", "row_sharded_cg"):          # the four forms of the reduced-system solve
                 key = wl if variant == "replicated_cg" else wl + "_" + variant
                 try:
                     sh[key] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)),
-                                          distributed={"replicated_cg": 0, "distributed_cg": 1, "implicit_schur_cg": 2}[variant])
+                                          distributed={"replicated_cg": 0, "distributed_cg": 1, "implicit_schur_cg": 2, "row_sharded_cg": 3}[variant])
                 except Exception as e:                       # never lose the headline line to the extras
                     sh[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         watchdog.cancel()
@@ -382,13 +396,69 @@ def main():
         dist.destroy_process_group()
 
 
+def extra_workloads(args, torch, sfm, capi):
+    """The other BASELINE configurations under the same clock as the headline, untimed extras of the default run: each
+    problem resident, 2 warm-up solves, K timed solves bracketed by synchronisations; LM iterations, final cost and RMS held to the ORACLE's
+    stored result (tests/golden/oracle_final_costs.json, regenerated by tests/golden/make_oracle_final_costs.py) -- `parity_ok`."""
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_final_costs.json")) as f:
+        want = json.load(f)
+    runs = [
+        # key, workload, precision, linear solver, options, timed solves
+        ("cfg2_f64_dense_schur", "cfg2", 0, 0, {}, 20),                       # BASELINE config 2: fp64, the reference's solver (BA.cpp:172)
+        ("cfg2_f64_default", "cfg2", 0, 2, {}, 20),
+        ("cfg3_f64_pcg", "cfg3", 0, 1, {"pcg_tolerance": args.pcg_tol}, 10),  # the headline's problem and solver in the reference's own arithmetic
+        ("cfg3_f64_default", "cfg3", 0, 2, {}, 10),
+        ("cfg3_banded_pcg", "cfg3_banded", 1, 1, {"pcg_tolerance": args.pcg_tol}, 10),      # realistic co-visibility (cameras on a path)
+        ("cfg3_banded_default", "cfg3_banded", 1, 2, {}, 10),
+        ("cfg5_pcg", "cfg5", 1, 1, {"pcg_tolerance": args.pcg_tol}, 4),       # BASELINE config 5's problem on ONE GPU
+    ]
+    out = {}
+    cache = {}
+    for key, wl, prec, lin, okw, steps in runs:
+        try:
+            if wl not in cache:
+                cache.clear()
+                cache[wl] = sfm.make_problem(wl)
+            prob = cache[wl]
+            with capi.Problem(prob, precision=prec, device=torch.cuda.current_device()) as P:
+                opt = capi.default_options(max_seconds=0.0, precision=prec, linear_solver=lin, **okw)
+                for _ in range(2):
+                    P.reset(); P.solve(opt)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                iters = lin_it = 0
+                for _ in range(steps):
+                    P.reset()
+                    s, _ = P.solve(opt)
+                    iters += s["iterations"]; lin_it += s["linear_iters"]
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            w = want[wl]
+            rms = float(np.sqrt(2.0 * s["final_cost"] / prob.n_obs))
+            rel = abs(s["final_cost"] - w["final_cost"]) / w["final_cost"]
+            # the bar: fp64 with a factorised (or 1e-12) solve 1e-9 relative, anything inexact or F32J north_star's 1e-6 cost / 1e-4 px
+            tol = 1e-9 if (prec == 0 and lin != 1) else 1e-6
+            ok = (s["termination_name"] == w["termination"] and s["iterations"] == w["iterations"] and rel <= tol and abs(rms - w["final_rms_px"]) < 1e-4)
+            out[key] = {"workload": "%s: %d cams / %d pts / %d obs" % (wl, prob.n_cam, prob.n_pt, prob.n_obs), "dtype": "f64" if prec == 0 else DTYPE_F32J,
+                        "linear_solver": SOLVER_NAMES[lin], "steps": steps, "value": iters / dt, "unit": "LM iterations/s", "ms_per_step": 1e3 * dt / steps,
+                        "lm_iterations_per_step": iters / steps, "cg_iterations_per_step": lin_it / steps, "termination": s["termination_name"],
+                        "final_cost": s["final_cost"], "final_rms_px": rms, "oracle_final_cost": w["final_cost"], "oracle_iterations": w["iterations"],
+                        "rel_cost_diff_vs_oracle": rel, "rms_diff_vs_oracle_px": rms - w["final_rms_px"], "parity_tolerance_rel_cost": tol, "parity_ok": bool(ok)}
+            assert ok, "%s: result differs from the oracle's stored one: %r" % (key, out[key])
+        except AssertionError as e:
+            out.setdefault(key, {})["error"] = str(e)
+        except Exception as e:
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps, distributed=False):
     """ONE problem, points sharded over the ranks; the LM loop runs inside the C library (sfmba_problem_solve_sharded) with
     ncclAllReduce on the solver's stream (sharded.RcclComm); every rank times the same K solves.  Returns the result dict."""
     from sfm_toy_library_amd import sharded
     import ctypes as C
     prob = sfm.make_problem(workload)
-    be = sharded.HipShardBackend(prob, rank, world, device=local_rank, precision=precision)
+    be = (sharded.HipRowShardBackend if int(distributed) == 3 else sharded.HipShardBackend)(prob, rank, world, device=local_rank, precision=precision)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol,
                                shard_distributed_cg=int(distributed))
     comm = sharded.RcclComm(dist, rank, world, device=local_rank)
@@ -450,7 +520,12 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         g_dt, g_ar = [float(v) for v in tmax.tolist()]
         dist_note = None
-        if summ.get("implicit_schur_cg"):
+        if summ.get("row_sharded"):
+            dist_note = ("block ROWS of the preconditioned reduced matrix per rank: every rank holds the whole problem, eliminates its own range of points, the per-point table "
+                         "is all-gathered (%d bytes received per rank and linearisation), the pair pass forms the rank's own block rows from all their pairs (no partial block "
+                         "crosses a rank), per CG iteration ONE all-reduce of %d + 16 (cameras / 4 + 1) doubles (partial product + its partial dot products); "
+                         "vector updates multi-workgroup, replicated" % (ex_bytes[1], ld))
+        elif summ.get("implicit_schur_cg"):
             dist_note = ("no exchange of the reduced matrix: per CG iteration every rank applies its own points' W V^-1 W^T to the vector (two passes over "
                          "its observations) and ONE all-reduce of %d doubles sums the partial products; vector updates replicated" % ld)
         elif summ.get("distributed_cg"):
@@ -458,7 +533,8 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
                          "receives 1 / %d of it), then per CG iteration ONE all-reduce of %d doubles (the partial product from the owned blocks); "
                          "vector updates replicated" % (ex_bytes[1], world, ld))
         return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
-                "reduced_system_solve": ("implicit Schur CG (no reduced matrix formed or exchanged)" if summ.get("implicit_schur_cg") else
+                "reduced_system_solve": ("row-sharded: distributed CG on the rank's own block rows, formed from all their pairs" if summ.get("row_sharded") else
+                                         "implicit Schur CG (no reduced matrix formed or exchanged)" if summ.get("implicit_schur_cg") else
                                          "distributed CG (no redundant solve)" if summ.get("distributed_cg") else "every rank runs the CG on the summed matrix (redundant)"),
                 "distributed_cg_exchange": dist_note,
                 "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
@@ -480,12 +556,13 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
 
 def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear):
     """--mode sharded: the sharded run IS the headline line (strong scaling)."""
-    r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps, distributed=2 if args.implicit_cg else 1 if args.distributed_cg else 0)
+    r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps,
+                    distributed=3 if args.row_sharded else 2 if args.implicit_cg else 1 if args.distributed_cg else 0)
     if rank == 0:
         print(json.dumps({
             "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64" if precision == 0 else "f32 Jacobian blocks, f64 residual/accumulate/solve",
+            "vs_baseline": None, "dtype": "f64" if precision == 0 else DTYPE_F32J,
             "data": "synthetic", "config": {"workload": r["workload"], "step": "one full LM solve to ceres CONVERGENCE",
                                             "lm_iterations_per_step": r["lm_iterations_per_step"], "collective": r["collective"]},
             "sharded": r, "final_rms_px": r["final_rms_px"], "final_cost": r["final_cost"], "termination": r["termination"]}), flush=True)

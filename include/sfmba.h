@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SFMBA_ABI_VERSION 4
+#define SFMBA_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define SFMBA_API __attribute__((visibility("default")))
@@ -138,11 +138,36 @@ typedef struct sfmba_options {
                                          2 (SFMBA_SHARD_DIST_CG=2): the same CG with the product formed IMPLICITLY -- no pair pass, no
                                          exchange (B) at all: per CG iteration every rank applies its own points' W V^-1 W^T to the
                                          all-reduced vector (two passes over its observations) and the ranks all-reduce ld doubles
-                                         (needs no reduce-scatter; a problem with duplicate (camera, point) observations runs as 1) */
+                                         (needs no reduce-scatter; duplicate (camera, point) observations are part of the implicit
+                                         product: their cross terms are then NOT added to the diagonal blocks, which stay a preconditioner).
+                                         3 (ABI v5; implied by a problem created with SFMBA_CREATE_ROW_SHARDED): block ROWS of S~ per rank.
+                                         Every rank holds the whole problem; it eliminates its own range of points, the per-point table is
+                                         ALL-GATHERED (88 bytes per point in F32J: 44 MB at 500k points), the camera-diagonal sums of the
+                                         rank's share of the camera-major list go through exchange (A) as before, and the pair pass then
+                                         forms the blocks of the rank's OWN block rows from ALL their pairs -- at one-GPU efficiency, no
+                                         partial block ever crosses a rank, no exchange (B), no unpack.  The CG runs on the owned rows:
+                                         per iteration one product launch, ONE all-reduce of ld + 16 (cameras / 4 + 1) doubles (the partial
+                                         product and its partial dot products) and one update launch, all multi-workgroup. */
 } sfmba_options;
 
 /* Flags of sfmba_problem_create_ex (ABI v4; were environment variables read at create time). */
-enum { SFMBA_CREATE_DETERMINISTIC = 1 };  /* SFMBA_DETERMINISTIC=1 forces it on: every workgroup owns its accumulator slot and multi-chunk
+enum { SFMBA_CREATE_DETERMINISTIC = 1,
+       SFMBA_CREATE_NO_PAIR_LIST = 4,     /* ABI v5: do not build the list of observation pairs (4 bytes per pair of observations of one point: O(sum of squared
+                                             track lengths) memory, and 2^31 pairs at most) and never form the reduced camera matrix: sfmba_problem_solve then runs the
+                                             two-level CG with the matrix applied IMPLICITLY from the observations -- per CG iteration two passes over them, memory
+                                             O(observations) whatever the track lengths.  A problem with 2^31 or more pairs (100 cameras that all see 440 000 points:
+                                             the reference adds a residual block per (view, point) with no bound on the track length, BA.cpp:142-166) takes this path
+                                             by itself -- no problem the reference's solver accepts is refused for its size.  Every linear_solver setting is served by
+                                             that CG: SFMBA_LINEAR_PCG at pcg_tolerance, SFMBA_LINEAR_AUTO / _CHOLESKY at a relative residual of 1e-12 (the DENSE_SCHUR
+                                             result to ~1e-10, not bit for bit); max_seconds is not applied; sfmba_problem_build_reduced and sfmba_problem_append are
+                                             refused.  Slower than the formed matrix wherever that fits (~8x per CG iteration at BASELINE config 5). */
+       SFMBA_CREATE_ROW_SHARDED = 2 };    /* ABI v5, sfmba_problem_create_ex only: EVERY rank passes the WHOLE problem (all observations) with its rank / world;
+                                             cam_active may be NULL.  The rank owns the points of a contiguous range of point slots (ceil(n / world) each), a
+                                             contiguous share of the camera-major list and a balanced range of block rows of the reduced matrix
+                                             (sfmba_options.shard_distributed_cg = 3).  Solved with sfmba_problem_solve_sharded (needs sfmba_problem_set_allgather
+                                             when world > 1); always through the CG (SFMBA_LINEAR_CHOLESKY is treated as SFMBA_LINEAR_AUTO: CG to 1e-12).  After
+                                             a solve every rank holds ALL parameters (the final points are all-gathered): sfmba_problem_get_params returns the
+                                             whole solution on every rank. */  /* SFMBA_DETERMINISTIC=1 forces it on: every workgroup owns its accumulator slot and multi-chunk
                                              sums are added in a fixed order, so results do not depend on the order fp64 atomics arrive in
                                              (bitwise reproducible run to run; ~30 % slower).  Sharded problems included (ABI v4). */
 
@@ -366,8 +391,15 @@ SFMBA_API int  sfmba_problem_set_allreduce_f32(sfmba_problem* p, sfmba_allreduce
 typedef int (*sfmba_reduce_scatter_fn)(void* ctx, void* send_buf, void* recv_buf, int64_t n_values, int is_f32, void* hip_stream);
 SFMBA_API int  sfmba_comm_reduce_scatter(void* comm /* sfmba_comm* */, void* send_buf, void* recv_buf, int64_t n_values, int is_f32, void* hip_stream);   /* an sfmba_reduce_scatter_fn: ncclReduceScatter */
 SFMBA_API int  sfmba_problem_set_reduce_scatter(sfmba_problem* p, sfmba_reduce_scatter_fn reduce_scatter);     /* NULL: none */
+/* All-gather of the ROW-SHARDED solve (SFMBA_CREATE_ROW_SHARDED): in place -- buf holds `world` slices of bytes_per_rank bytes, slice `rank` is this
+ * rank's contribution; after the call, stream-ordered, every slice holds its owner's bytes.  Called twice per linearisation (the two halves of the
+ * per-point table) and once at the end of a solve (the final points). */
+typedef int (*sfmba_allgather_fn)(void* ctx, void* buf, int64_t bytes_per_rank, void* hip_stream);
+SFMBA_API int  sfmba_comm_allgather(void* comm /* sfmba_comm* */, void* buf, int64_t bytes_per_rank, void* hip_stream);   /* an sfmba_allgather_fn: ncclAllGather */
+SFMBA_API int  sfmba_problem_set_allgather(sfmba_problem* p, sfmba_allgather_fn allgather);     /* NULL: none */
 /* what the last sfmba_problem_solve_sharded() exchanged per linearisation: out = { bytes of (A), bytes of (B), bytes of (C), flags: bit 0 = (B) was fp32, bit 1 = distributed CG (then (B) = the bytes of the whole
- * reduce-scatter buffer, of which a rank receives 1 / world, and every CG iteration adds 8 ld bytes of all-reduce) } */
+ * reduce-scatter buffer, of which a rank receives 1 / world, and every CG iteration adds 8 ld bytes of all-reduce),
+ * bit 2 = implicit Schur CG, bit 3 = row-sharded (then (B) = the bytes of the per-point table a rank RECEIVES through the all-gather) } */
 SFMBA_API int  sfmba_shard_last_exchange(const sfmba_problem* p, int64_t out[4]);
 
 /*

@@ -73,6 +73,8 @@ struct TraceRow {   // same layout as sfmba_iteration
 // Static structure of a problem, all device pointers (built once on the host, see sfmba_api.cpp).
 struct DeviceStructure {
     int ncam, npt, nobs;      // active cameras / points, observations
+    int pt_base;              // first point slot of the passes that walk the points in slot order without pt_order (k_xnorm): 0, or the first own slot of a
+                              // row-sharded rank (whose point passes see npt = its own points through pt_order)
     int d, ld;                // reduced dim 6*ncam+1, padded leading dimension (multiple of 64)
     const int* pt_ptr;        // [npt+1] point-major CSR
     const int* pt_order;      // [npt] point slots sorted by number of observations (lane-group point passes: the quads of a wave loop alike); null = slot order

@@ -16,6 +16,7 @@
 #include "ba_common.h"
 #include "../../include/sfmba.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace sfmba {
 
@@ -127,7 +128,7 @@ __global__ void k_xnorm(DeviceStructure ds, DeviceBuffers db) {
     const int nc = 6 * ds.ncam, np = 3 * ds.npt;
     double s = 0.0;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nc + np; e += gridDim.x * blockDim.x) {
-        const double v = e < nc ? cam[e] : pts[e - nc];
+        const double v = e < nc ? cam[e] : pts[(size_t)3 * ds.pt_base + (e - nc)];
         s += (e < nc ? db.shared_weight : 1.0) * v * v;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { const double f = db.st->focal[cur]; s += db.shared_weight * f * f; }
@@ -218,7 +219,7 @@ void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const 
 }
 void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int f32, bool clear_udiag) {
     if (clear_udiag) (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
-    if (!jacobi) return;
+    if (!jacobi || ds.nchunk_coarse <= 0) return;
     if (f32) hipLaunchKernelGGL(k_colnorm_cams<float>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
     else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
 }
@@ -445,7 +446,8 @@ __global__ PB_BOUNDS void k_point_build(DeviceStructure ds, DeviceBuffers db, in
 // Sum of N per-lane values over the lanes that differ in the bits OFF, OFF/2, ..., 1: at every level a lane keeps one half of
 // the values and sends the other half to its partner, so the whole reduction moves N/2 + N/4 + ... values instead of N per level.
 // On return v[0 .. len) of this lane are the sums of values base .. base + len - 1 (len may be <= 0).
-template <typename V, int N, int OFF>
+// VALU64: fp64 values exchanged in the VALU as well (two 32-bit halves per value: DPP / permlane swaps) -- the pair pass's block sums
+template <typename V, int N, int OFF, bool VALU64 = false>
 struct HalvingReduceT {
     static __device__ __forceinline__ void run(V* v, int lane, int& base, int& len) {
         constexpr int H = (N + 1) / 2;
@@ -454,7 +456,7 @@ struct HalvingReduceT {
         for (int k = 0; k < H; ++k) {
             const V lo = v[k];
             const V hi = (H + k < N) ? v[H + k] : (V)0;
-            if constexpr (sizeof(V) == 8) {
+            if constexpr (sizeof(V) == 8 && !VALU64) {
                 // fp64 (camera pass: 24 doubles): through the LDS pipe as before.  The permlane / DPP forms cost that pass its occupancy
                 // (62 -> 144 registers: two registers in and two out per swapped word), and it is bound by loads in flight, not by issue.
                 const V send = up ? lo : hi;
@@ -470,14 +472,75 @@ struct HalvingReduceT {
         }
         base += up ? H : 0;
         len = up ? len - H : (len < H ? len : H);
-        HalvingReduceT<V, H, OFF / 2>::run(v, lane, base, len);
+        HalvingReduceT<V, H, OFF / 2, VALU64>::run(v, lane, base, len);
     }
 };
-template <typename V, int N>
-struct HalvingReduceT<V, N, 0> {
+template <typename V, int N, bool VALU64>
+struct HalvingReduceT<V, N, 0, VALU64> {
     static __device__ __forceinline__ void run(V*, int, int&, int&) {}
 };
+// The block sums of the pair passes: the lane's own sums (at most eight pair products each in the wave-per-chunk pass) are WIDENED to fp64
+// before the first cross-lane step, so that everything summed across lanes, chunks and ranks is summed in fp64 ("fp32 Jacobian blocks,
+// fp64 accumulation", BASELINE config 3).  The first halving level converts on the fly: only N / 2 doubles are ever live.
+//   SFMBA_PAIR_ACC = 0: the round-4 form (lane sums AND butterfly in T; fp64 from the chunk boundary on)
+//                    1: lane sums in T, butterfly in fp64 (default)
+//                    2: fp64 lane accumulators as well (every pair product widened before it is added)
+#ifndef SFMBA_PAIR_ACC
+#define SFMBA_PAIR_ACC 1
+#endif
+template <typename T> struct PairAccSel { typedef T type; };
+#if SFMBA_PAIR_ACC == 2
+template <> struct PairAccSel<float> { typedef double type; };
+#endif
+template <typename T> using PairAcc = typename PairAccSel<T>::type;
+template <typename T, int N, int OFF>
+__device__ __forceinline__ double pair_block_reduce(T (&acc)[N], int lane, int& base, int& len) {
+    if constexpr (sizeof(T) == 8 || SFMBA_PAIR_ACC == 0) {
+        HalvingReduceT<T, N, OFF, SFMBA_PAIR_ACC == 2>::run(acc, lane, base, len);
+        return len >= 1 ? (double)acc[0] : 0.0;
+    } else {
+        constexpr int H = (N + 1) / 2;
+        const bool up = (lane & OFF) != 0;
+        double w[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double lo = (double)acc[k];
+            const double hi = (H + k < N) ? (double)acc[H + k] : 0.0;
+            if constexpr (OFF >= 16) w[k] = xlane_pairsum<OFF>(lo, hi);
+            else { const double send = up ? lo : hi, keep = up ? hi : lo; w[k] = keep + xlane_get<OFF>(send); }
+        }
+        base += up ? H : 0;
+        len = up ? len - H : (len < H ? len : H);
+        HalvingReduceT<double, H, OFF / 2, true>::run(w, lane, base, len);
+        return len >= 1 ? w[0] : 0.0;
+    }
+}
 template <int N, int OFF> using HalvingReduce = HalvingReduceT<double, N, OFF>;
+
+// the same for a lane GROUP of LPB lanes (sixteen-lane pair pass): the group's lanes end up with up to three sums each (own[0 .. len))
+template <typename T, int LPB>
+__device__ __forceinline__ void pair_group_reduce(T (&acc)[36], int lane, int& base, int& len, double (&own)[3]) {
+    if constexpr (sizeof(T) == 8 || SFMBA_PAIR_ACC == 0) {
+        HalvingReduceT<T, 36, LPB / 2, SFMBA_PAIR_ACC == 2>::run(acc, lane, base, len);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) own[k] = (double)acc[k];
+    } else {
+        constexpr int OFF = LPB / 2, H = 18;
+        const bool up = (lane & OFF) != 0;
+        double w[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double lo = (double)acc[k], hi = (double)acc[H + k];
+            const double send = up ? lo : hi, keep = up ? hi : lo;
+            w[k] = keep + xlane_get<OFF>(send);
+        }
+        base += up ? H : 0;
+        len = up ? len - H : (len < H ? len : H);
+        HalvingReduceT<double, H, OFF / 2, true>::run(w, lane, base, len);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) own[k] = w[k];
+    }
+}
 
 // one pair of observations: acc += A_a^T (C_a C_b^T) A_b   (unscaled; the camera scales are applied once at the end)
 template <typename T>
@@ -570,9 +633,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(De
         return;     // pairs inside diagonal blocks (duplicates) were added by k_schur_dups before k_finalize
     }
     const int s = lane & 3, g = lane >> 2;
-    T acc[36];
+    PairAcc<T> acc[36];
 #pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+    for (int e = 0; e < 36; ++e) acc[e] = (PairAcc<T>)0;
     {
         const LMState* st = db.st;
         const int cur = st->cur;
@@ -592,14 +655,13 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(De
             obs_factored<T>(ca, focal, pa.X, pa.L, ga);
             obs_factored<T>(cb, focal, pa.X, pa.L, gb);
             if (p0 + mine >= p1) ga[3] = (T)0;      // this lane's pair lies beyond the chunk: contribute nothing (N carries f_a / p_z)
-            pair_product_factored<T>(ga, gb, acc);
+            pair_product_factored<T, PairAcc<T>>(ga, gb, acc);
         }
     }
     // Sum of the 36 entries over the 64 lanes by a halving butterfly: afterwards lane `base` -- 36 of the 64 lanes -- owns ONE
     // entry of the 6x6 block.
     int base = 0, len = 36;
-    HalvingReduceT<T, 36, 32>::run(acc, lane, base, len);
-    const double total = len >= 1 ? (double)acc[0] : 0.0;
+    const double total = pair_block_reduce<PairAcc<T>, 36, 32>(acc, lane, base, len);
     if (chunk.y > 1) {                              // one of several chunks: the partial sums of this one
         if (len >= 1) db.pair_partial[(size_t)blockIdx.x * 36 + base] = -total;
         return;
@@ -740,9 +802,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? SFMBA_SUBF_WPS : 2)) void k_s
     const bool fo_b = tab[cam_tab_index(CT_SMALL, work ? cj.y : 0, ds.ncam)] != 0.0;
     const T focal_t = (T)focal;
     const PtRecA<T>* PA = reinterpret_cast<const PtRecA<T>*>(db.PA);
-    T acc[36];
+    PairAcc<T> acc[36];
 #pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+    for (int e = 0; e < 36; ++e) acc[e] = (PairAcc<T>)0;
     int p0 = work ? dsc.z : 0;
     const int p1 = work ? dsc.w : 0;
     // the point slot of a round's pair is fetched one round ahead (a round then costs one dependent memory level: the point-table entry);
@@ -760,18 +822,19 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? SFMBA_SUBF_WPS : 2)) void k_s
         obs_factored_t<T>(Ra, fo_a, focal_t, X0, X1, X2, pa.L, ga);
         obs_factored_t<T>(Rb, fo_b, focal_t, X0, X1, X2, pa.L, gb);
         if (!mine) ga[3] = (T)0;                       // (N carries f_a / p_z)
-        pair_product_factored<T>(ga, gb, acc);
+        pair_product_factored<T, PairAcc<T>>(ga, gb, acc);
         p0 += LPB;
     }
     if (!nonempty) {                                   // never had a pair: whatever point 0 gave under these two cameras (0 x inf) is not a sum
 #pragma unroll
-        for (int e = 0; e < 36; ++e) acc[e] = (T)0;
+        for (int e = 0; e < 36; ++e) acc[e] = (PairAcc<T>)0;
     }
     int base = 0, len = 36;
-    HalvingReduceT<T, 36, LPB / 2>::run(acc, lane, base, len);          // afterwards lane li owns entries base .. base + len - 1 (len <= 3)
+    double own[3];                                     // afterwards lane li owns entries base .. base + len - 1 (len <= 3)
+    pair_group_reduce<PairAcc<T>, LPB>(acc, lane, base, len, own);
     if (work) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if (k < len) tile[sub][base + k] = -(double)acc[k];
+        for (int k = 0; k < 3; ++k) if (k < len) tile[sub][base + k] = -own[k];
     }
     wave_lds_fence();
     if (work) {
@@ -944,7 +1007,8 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
 template <typename T>
 void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int ps_mode) {
     const int per_wg = WPB * (64 / PB_LPP);
-    hipLaunchKernelGGL(k_point_build<T>, dim3((ds.npt + per_wg - 1) / per_wg), dim3(PBK), 0, s, ds, db, ps_mode);
+    // (at least one workgroup: the launch also clears what the camera pass accumulates -- a row-sharded rank may own no point)
+    hipLaunchKernelGGL(k_point_build<T>, dim3(std::max(1, (ds.npt + per_wg - 1) / per_wg)), dim3(PBK), 0, s, ds, db, ps_mode);
 }
 template void launch_point_build<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
 template void launch_point_build<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int);
@@ -988,6 +1052,7 @@ __global__ void k_pair_factors(DeviceStructure ds, DeviceBuffers db) {
 template <typename T>
 void launch_schur_pairs(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int mode) {
     const dim3 grid(ds.npairwg);
+    if (mode != 2 && ds.npairwg <= 0) return;      // (a row-sharded rank without a block row)
     if (mode == 2) {
         if (ds.ndupwg > 0) hipLaunchKernelGGL(k_schur_dups<T>, dim3(ds.ndupwg), dim3(64), 0, s, ds, db);
         return;
@@ -1010,7 +1075,7 @@ template void launch_schur_pairs<double>(hipStream_t, const DeviceStructure&, co
 
 template <typename T>
 void launch_cam_diag(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
-    hipLaunchKernelGGL(k_cam_diag_f<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
+    if (ds.nchunk > 0) hipLaunchKernelGGL(k_cam_diag_f<T>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, db);
 }
 template void launch_cam_diag<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_cam_diag<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
@@ -1544,8 +1609,9 @@ __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, Dev
 #pragma unroll
     for (int c = 0; c < 3; ++c) SFMBA_QUADSUM(zacc[c])
     SFMBA_QUADSUM(ur) SFMBA_QUADSUM(uu)
+    double Gd[6];            // (the lane's own sum in the precision of C, across the quad in fp64 like every cross-lane sum)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) SFMBA_QUADSUM(G[c])
+    for (int c = 0; c < 6; ++c) { Gd[c] = (double)G[c]; SFMBA_QUADSUM(Gd[c]) }
 #undef SFMBA_QUADSUM
     // (the point's t and M: loaded here, behind the sweep -- in front of it they cost the sweep its fourth wave per SIMD)
     double tp[3], Mp[6];
@@ -1566,7 +1632,7 @@ __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, Dev
             xn2 += Xn[c] * Xn[c];
             db.pts[nxt][3 * i + c] = Xn[c];
         }
-        const double zGz = (double)G[0] * z0 * z0 + (double)G[3] * z1 * z1 + (double)G[5] * z2 * z2 + 2.0 * ((double)G[1] * z0 * z1 + (double)G[2] * z0 * z2 + (double)G[4] * z1 * z2);
+        const double zGz = Gd[0] * z0 * z0 + Gd[3] * z1 * z1 + Gd[5] * z2 * z2 + 2.0 * (Gd[1] * z0 * z1 + Gd[2] * z0 * z2 + Gd[4] * z1 * z2);
         model += ur + (z0 * tp[0] + z1 * tp[1] + z2 * tp[2]) - 0.5 * uu - (z0 * zacc[0] + z1 * zacc[1] + z2 * zacc[2]) - 0.5 * zGz;
     }
     {
@@ -1607,7 +1673,7 @@ void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuf
 template <typename T>
 void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     const int per_wg = WPB * (64 / PB_LPP);
-    hipLaunchKernelGGL(k_point_update<T>, dim3((ds.npt + per_wg - 1) / per_wg), dim3(PBK), 0, s, ds, db);
+    hipLaunchKernelGGL(k_point_update<T>, dim3(std::max(1, (ds.npt + per_wg - 1) / per_wg)), dim3(PBK), 0, s, ds, db);
 }
 template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);

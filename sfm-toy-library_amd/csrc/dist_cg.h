@@ -20,9 +20,12 @@ struct DistCg {
     int* d_row_shift = nullptr;          // [ncam] block offset to ADD to a block's upper-triangle list position (pair pass -> reduce-scatter layout)
     double *qa = nullptr, *qb = nullptr; // [ld] row part / transposed part of the partial product
     double* qred = nullptr;              // [9 * ld] the all-reduce buffer: partial products (one per CG iteration; eight at the coarse setup)
-    double *x = nullptr, *r = nullptr, *p = nullptr;   // [ld] each, replicated (x: the caller's buffer -- DenseSolver::vec, where k_cam_update looks)
+    double *x = nullptr, *r = nullptr, *p = nullptr;   // [ld] each ([2][ld] for r: by launch parity), replicated (x: the caller's buffer -- DenseSolver::vec, where k_cam_update looks)
     double* AW = nullptr;                // [8][ld] S~ W~
     double* scal = nullptr;              // [128] rz, thresholds, E^-1 (64), ...
+    double* state = nullptr;             // [2][16] {r.z, c = W~^T r} by launch parity (multi-workgroup form)
+    int np = 0;                          // workgroups of the product kernels (four cameras each + one for the focal entry): rows of partial dots in the all-reduce
+    int launched = 0;                    // CG launches of the running solve (a launch compares the done flag with its own number)
     bool ready = false;
 };
 

@@ -2,6 +2,8 @@
 // streams 1/N of the matrix per rank, the rest is O(d) work in one workgroup; what a CG iteration costs at N > 1 is its collective.
 #include "dist_cg.h"
 #include "sfmba_device.h"
+#include "coarse_inverse.h"
+#include <algorithm>
 
 namespace sfmba {
 
@@ -267,6 +269,371 @@ __global__ __launch_bounds__(STEP_T) void k_dcg_step(int d, int ld, const double
     if (tid == 0) { scal[DS_RZ] = rzn[0]; flags[PF_ITERS] = flags[PF_ITERS] + 1; }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The multi-workgroup form (round 5): TWO launches and ONE all-reduce per CG iteration, none of them a single
+// workgroup.  k_dcg_init / k_dcg_step / k_dcg_comb above -- one workgroup over the whole vector, two or three dependent block
+// reductions each: 120 / 19 / 8 us at d = 6001 -- are what sank the distributed forms of round 4; they stay for the implicit product.
+//   k_dcg_prod   a WAVE per camera c: row part (blocks (c, J), J > c, if the rank owns row c) and transposed part (blocks (I, c) of the
+//                owned rows I < c) of the rank's partial product, straight into the all-reduce buffer (no qa / qb, no combine launch);
+//                per workgroup the partial dot products p . out and W~^T out -- LINEAR in the partial product, so they ride through
+//                the same all-reduce and arrive summed over the ranks
+//   all-reduce   q (ld doubles) | the partial dots (16 doubles per product workgroup)
+//   k_dcg_upd    every workgroup sums the partial dots (fixed order: identical on every rank), forms alpha, c = c - alpha W~^T q,
+//                mu = E^-1 c, |r - alpha q|^2 over the WHOLE vector (96 KB from L2, redundantly: cheaper than a second launch boundary),
+//                beta, and updates ITS slice of x, r, p.  The stopping test is taken by every workgroup from the same numbers.
+// r is double-buffered by launch parity (a workgroup's redundant norm reads what another one's slice update writes), the scalar state
+// {r.z, c} likewise.  The done flag holds the NUMBER of the first launch with nothing left to do (a launch compares it with its own
+// number: it must never act on a flag its own first workgroup raises, DESIGN.md section 4 "LM loop").
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int CPW = 4;                 // cameras per workgroup of the product kernels (a wave each)
+constexpr int LIN_STRIDE = 16;         // doubles per product workgroup in the iteration's all-reduce tail (9 used: p . out, W~^T out)
+constexpr int LIN8_STRIDE = 64;        // ... in the set-up's (the workgroup's part of E = W~^T (S~ W~))
+constexpr int UPD_MAXWG = 32;
+enum { ST_RZ = 0, ST_C = 1, ST_LEN = 16 };     // scalar state by launch parity: r.z, c = W~^T r
+
+__device__ __forceinline__ bool dcg_done(const int* flags, int launch_no) { const int dn = flags[PF_DONE]; return dn != 0 && dn <= launch_no; }
+
+// block (row I, column J > I) of the owned list: 36 values, row-major
+template <typename FT> __device__ __forceinline__ void load_block36(const FT* __restrict__ B, double (&b)[36]) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) b[e] = (double)B[e];
+}
+
+template <typename FT, typename FF>
+__global__ __launch_bounds__(256) void k_dcg_prod(int d, int ld, int ncam, int row0, int row1, int rank, const FT* __restrict__ owned,
+                                                  const FF* __restrict__ focal_row, const double* __restrict__ p, const double* __restrict__ W,
+                                                  double* __restrict__ out, const int* __restrict__ flags, int launch_no) {
+    if (dcg_done(flags, launch_no)) return;
+    __shared__ double sh[4][9];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fo = d - 1;
+    double* lin = out + ld + (size_t)blockIdx.x * LIN_STRIDE;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the focal entry: known on every rank from exchange (A) -- rank 0 contributes it
+        double fd = 0.0;
+        if (rank == 0) { for (int i = tid; i < fo; i += 256) fd = fma((double)focal_row[i], p[i], fd); }
+        fd = wave_allsum(fd);
+        if (lane == 0) sh[w][0] = fd;
+        __syncthreads();
+        const double v = rank == 0 ? p[fo] + (sh[0][0] + sh[1][0] + sh[2][0] + sh[3][0]) : 0.0;
+        if (tid == 0) out[fo] = v;
+        if (tid < 9) lin[tid] = tid == 0 ? p[fo] * v : (W ? W[(size_t)(tid - 1) * ld + fo] * v : 0.0);
+        return;
+    }
+    const int c = blockIdx.x * CPW + w;
+    double mine = 0.0;
+    if (c < ncam) {
+        const long long base = first_of_row(row0, ncam);
+        double acc[6] = { 0, 0, 0, 0, 0, 0 };
+        if (c >= row0 && c < row1) {
+            const long long rowpos = first_of_row(c, ncam) - base;
+            for (int J = c + 1 + lane; J < ncam; J += 64) {
+                double b[36], pj[6];
+                load_block36(owned + (size_t)(rowpos + (J - c - 1)) * 36, b);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) pj[e] = p[6 * J + e];
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) acc[r] = fma(b[6 * r + e], pj[e], acc[r]);
+            }
+        }
+        if (c > row0) {
+            const int iend = row1 < c ? row1 : c;
+            for (int I = row0 + lane; I < iend; I += 64) {
+                double b[36], pi[6];
+                load_block36(owned + (size_t)(first_of_row(I, ncam) - base + (c - I - 1)) * 36, b);
+#pragma unroll
+                for (int r = 0; r < 6; ++r) pi[r] = p[6 * I + r];
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) acc[e] = fma(b[6 * r + e], pi[r], acc[e]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = wave_allsum(acc[k]);       // (every lane holds all six)
+        if (rank == 0) {
+            const double pf = p[fo];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += p[6 * c + k] + (double)focal_row[6 * c + k] * pf;
+        }
+        if (lane < 6) {
+            double v = acc[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) v = lane == k ? acc[k] : v;
+            out[6 * c + lane] = v;
+        }
+        if (lane < 9) {           // lane 0: p . out of this camera; lanes 1 .. 8: W~_k . out
+            const double* u = lane == 0 ? p : (W ? W + (size_t)(lane - 1) * ld : nullptr);
+            if (u) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) mine = fma(u[6 * c + k], acc[k], mine);
+            }
+        }
+    }
+    if (lane < 9) sh[w][lane] = mine;
+    __syncthreads();
+    if (tid < 9) lin[tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+}
+
+// the same product for the EIGHT gauge vectors at once (set-up of a solve: S~ W~, read from the blocks once), with the workgroup's part of
+// E[k][l] = sum_i W~_k[i] (S~ W~_l)[i] behind it
+template <typename FT, typename FF>
+__global__ __launch_bounds__(256) void k_dcg_prod8(int d, int ld, int ncam, int row0, int row1, int rank, const FT* __restrict__ owned,
+                                                   const FF* __restrict__ focal_row, const double* __restrict__ W, double* __restrict__ out) {
+    __shared__ double sh[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fo = d - 1;
+    double* lin = out + (size_t)NW * ld + (size_t)blockIdx.x * LIN8_STRIDE;
+    if (blockIdx.x == gridDim.x - 1) {
+        double fd[NW];
+#pragma unroll
+        for (int l = 0; l < NW; ++l) fd[l] = 0.0;
+        if (rank == 0) {
+            for (int i = tid; i < fo; i += 256) {
+                const double f = (double)focal_row[i];
+#pragma unroll
+                for (int l = 0; l < NW; ++l) fd[l] = fma(f, W[(size_t)l * ld + i], fd[l]);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NW; ++l) fd[l] = wave_allsum(fd[l]);
+        if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < NW; ++l) sh[w][l] = fd[l];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int k = tid >> 3, l = tid & 7;
+            const double v = rank == 0 ? W[(size_t)l * ld + fo] + (sh[0][l] + sh[1][l] + sh[2][l] + sh[3][l]) : 0.0;
+            if (k == 0) out[(size_t)l * ld + fo] = v;
+            lin[tid] = W[(size_t)k * ld + fo] * v;
+        }
+        return;
+    }
+    const int c = blockIdx.x * CPW + w;
+    double e_kl = 0.0;
+    if (c < ncam) {
+        const long long base = first_of_row(row0, ncam);
+        double acc[NW][6];
+#pragma unroll
+        for (int l = 0; l < NW; ++l)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[l][k] = 0.0;
+        if (c >= row0 && c < row1) {
+            const long long rowpos = first_of_row(c, ncam) - base;
+            for (int J = c + 1 + lane; J < ncam; J += 64) {
+                double b[36];
+                load_block36(owned + (size_t)(rowpos + (J - c - 1)) * 36, b);
+#pragma unroll
+                for (int l = 0; l < NW; ++l) {
+                    double pj[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) pj[e] = W[(size_t)l * ld + 6 * J + e];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) acc[l][r] = fma(b[6 * r + e], pj[e], acc[l][r]);
+                }
+            }
+        }
+        if (c > row0) {
+            const int iend = row1 < c ? row1 : c;
+            for (int I = row0 + lane; I < iend; I += 64) {
+                double b[36];
+                load_block36(owned + (size_t)(first_of_row(I, ncam) - base + (c - I - 1)) * 36, b);
+#pragma unroll
+                for (int l = 0; l < NW; ++l) {
+                    double pi[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) pi[r] = W[(size_t)l * ld + 6 * I + r];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) acc[l][e] = fma(b[6 * r + e], pi[r], acc[l][e]);
+                }
+            }
+        }
+        const int kk = lane >> 3, ll = lane & 7;
+        double wk[6], mine_l[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { wk[e] = W[(size_t)kk * ld + 6 * c + e]; mine_l[e] = 0.0; }
+#pragma unroll
+        for (int l = 0; l < NW; ++l) {
+            const double wf = rank == 0 ? W[(size_t)l * ld + fo] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                double v = wave_allsum(acc[l][e]);
+                if (rank == 0) v += W[(size_t)l * ld + 6 * c + e] + (double)focal_row[6 * c + e] * wf;
+                if (lane == l * 8 + e) out[(size_t)l * ld + 6 * c + e] = v;
+                mine_l[e] = ll == l ? v : mine_l[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) e_kl = fma(wk[e], mine_l[e], e_kl);
+    }
+    sh[w][lane] = e_kl;
+    __syncthreads();
+    if (tid < 64) lin[tid] = sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid];
+}
+
+__device__ __forceinline__ double block_sum_all256(double v, double* sh4) {      // sum over a workgroup of 256 threads, in every thread
+    v = wave_allsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
+
+// start of a solve behind the all-reduce of [S~ W~ | E partials]: E^-1, c_0 = W~^T b~ and |b~|^2 (formed by every workgroup itself: 9 d
+// reads from L2), mu_0, then the workgroup's slice of x = 0, r = b~, p = z = r + W~ mu_0; thresholds, flags, scalar state (workgroup 0)
+__global__ __launch_bounds__(256) void k_dcg_start(int d, int ld, int np, const double* __restrict__ buf, const double* __restrict__ bt,
+                                                   const double* __restrict__ W, double* __restrict__ x, double* __restrict__ r0, double* __restrict__ p,
+                                                   double* __restrict__ state, double* __restrict__ scal, int* __restrict__ flags, int anchor, double cap) {
+    __shared__ double tot[NW * NW], sa[NW * NW], sb[NW * NW], s_einv[NW * NW], sh4[4];
+    const int tid = threadIdx.x;
+    double mu[NW], c0[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { mu[k] = 0.0; c0[k] = 0.0; }
+    double rr = 0.0;
+    if (W) {
+        const double* lin = buf + (size_t)NW * ld;
+        if (tid < NW * NW) {
+            double e = 0.0;
+            for (int i = 0; i < np; ++i) e += lin[(size_t)i * LIN8_STRIDE + tid];       // fixed order: the same on every rank
+            tot[tid] = e;
+        }
+        __syncthreads();
+        if (tid < 64) s_einv[tid] = coarse_invert_wave(tot, sa, sb);
+        double v[NW + 1];
+#pragma unroll
+        for (int k = 0; k <= NW; ++k) v[k] = 0.0;
+        for (int i = tid; i < d; i += 256) {
+            const double b = bt[i];
+            v[NW] = fma(b, b, v[NW]);
+#pragma unroll
+            for (int k = 0; k < NW; ++k) v[k] = fma(W[(size_t)k * ld + i], b, v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) c0[k] = block_sum_all256(v[k], sh4);
+        rr = block_sum_all256(v[NW], sh4);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            double m = 0.0;
+#pragma unroll
+            for (int l = 0; l < NW; ++l) m = fma(s_einv[k * NW + l], c0[l], m);
+            mu[k] = m;
+        }
+    } else {
+        double v = 0.0;
+        for (int i = tid; i < d; i += 256) { const double b = bt[i]; v = fma(b, b, v); }
+        rr = block_sum_all256(v, sh4);
+    }
+    double rz = rr;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) rz = fma(c0[k], mu[k], rz);
+    const int per = (d + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(d, i0 + per);
+    for (int i = i0 + tid; i < i1; i += 256) {
+        const double b = bt[i];
+        double z = b;
+        if (W) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) z = fma(W[(size_t)k * ld + i], mu[k], z);
+        }
+        x[i] = 0.0; r0[i] = b; p[i] = z;
+    }
+    if (blockIdx.x == 0) {
+        if (W && tid < NW * NW) scal[DS_EINV + tid] = s_einv[tid];
+        if (tid < NW) state[ST_C + tid] = c0[tid];
+        if (tid == 0) {
+            double base = rr;
+            if (anchor == 1) scal[DS_RRF] = rr;
+            else if (anchor == 2) base = fmin(fmax(rr, scal[DS_RRF]), cap * rr);
+            scal[DS_RR0] = base;
+            state[ST_RZ] = rz;
+            flags[PF_DONE] = (rr == 0.0) ? 1 : 0; flags[PF_ITERS] = 0; flags[PF_XBUF] = 0;
+        }
+    }
+}
+
+// one CG iteration behind the all-reduce of [q | partial dots]
+__global__ __launch_bounds__(256) void k_dcg_upd(int d, int ld, int np, const double* __restrict__ qbuf, const double* __restrict__ W,
+                                                 double* __restrict__ x, const double* __restrict__ r_in, double* __restrict__ r_out, double* __restrict__ p,
+                                                 double* __restrict__ state, const double* __restrict__ scal, int* __restrict__ flags, double tol2, int* info,
+                                                 int launch_no) {
+    if (dcg_done(flags, launch_no)) return;
+    __shared__ double tot[12], s_einv[NW * NW], sh4[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const double* q = qbuf;
+    const double* lin = qbuf + ld;
+    {   // the nine partial dots summed over the product workgroups: wave w takes values w, w + 4, w + 8, lane-strided (fixed order)
+        double m[3] = { 0.0, 0.0, 0.0 };
+        for (int i = lane; i < np; i += 64) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (w + 4 * j < 9) m[j] += lin[(size_t)i * LIN_STRIDE + w + 4 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m[j] = wave_allsum(m[j]);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (w + 4 * j < 9) tot[w + 4 * j] = m[j];
+        }
+    }
+    if (W && tid < NW * NW) s_einv[tid] = scal[DS_EINV + tid];
+    const double* st_in = state + (size_t)((launch_no - 1) & 1) * ST_LEN;
+    double* st_out = state + (size_t)(launch_no & 1) * ST_LEN;
+    __syncthreads();
+    const double pq = tot[0], rz = st_in[ST_RZ];
+    const bool broke = !(pq > 0.0);
+    const double alpha = broke ? 0.0 : rz / pq;
+    double rr = 0.0;
+    for (int i = tid; i < d; i += 256) { const double rn = fma(-alpha, q[i], r_in[i]); rr = fma(rn, rn, rr); }
+    rr = block_sum_all256(rr, sh4);
+    double c[NW], mu[NW];
+    double rzn = rr;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { c[k] = 0.0; mu[k] = 0.0; }
+    if (W) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) c[k] = fma(-alpha, tot[1 + k], st_in[ST_C + k]);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            double m = 0.0;
+#pragma unroll
+            for (int l = 0; l < NW; ++l) m = fma(s_einv[k * NW + l], c[l], m);
+            mu[k] = m;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) rzn = fma(c[k], mu[k], rzn);
+    }
+    const bool done = broke || !(rr == rr) || rr <= tol2 * scal[DS_RR0];
+    const double beta = rzn / rz;
+    const int per = (d + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(d, i0 + per);
+    for (int i = i0 + tid; i < i1; i += 256) {
+        const double rn = fma(-alpha, q[i], r_in[i]);
+        const double pi = p[i];
+        r_out[i] = rn;
+        x[i] = fma(alpha, pi, x[i]);
+        if (!done) {
+            double z = rn;
+            if (W) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) z = fma(W[(size_t)k * ld + i], mu[k], z);
+            }
+            p[i] = fma(beta, pi, z);
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (tid < NW) st_out[ST_C + tid] = c[tid];
+        if (tid == 0) {
+            st_out[ST_RZ] = rzn;
+            flags[PF_ITERS] = launch_no;
+            if (done) { flags[PF_DONE] = launch_no + 1; if (broke || !(rr == rr)) atomicCAS(info, 0, d + 1); }
+        }
+    }
+}
 }  // namespace
 
 void dcg_partition(int ncam, int world, std::vector<int>* rows, long long* chunk_blocks) {
@@ -301,14 +668,19 @@ int dcg_create(DistCg* g, int d, int ld, int ncam, int rank, int world, DeviceAr
     // all or nothing: a workspace that fails half way leaves nothing behind in *g (the arena keeps the bytes until the problem goes)
     int* d_row_shift = arena->alloc_n<int>(shift.size());
     double* qa = arena->alloc_n<double>((size_t)ld); double* qb = arena->alloc_n<double>((size_t)ld);
-    double* qred = arena->alloc_n<double>((size_t)9 * ld);
-    double* r = arena->alloc_n<double>((size_t)ld); double* pp = arena->alloc_n<double>((size_t)ld);
+    // all-reduce buffer: [8][ld] S~ W~ (set-up) | [ld] the iteration's product | the partial dots of the product workgroups behind either
+    g->np = (ncam + CPW - 1) / CPW + 1;
+    const size_t qred_len = (size_t)9 * ld + (size_t)g->np * LIN8_STRIDE;
+    double* qred = arena->alloc_n<double>(qred_len);
+    double* r = arena->alloc_n<double>((size_t)2 * ld); double* pp = arena->alloc_n<double>((size_t)ld);
     double* scal = arena->alloc_n<double>(128);
-    if (!d_row_shift || !qa || !qb || !qred || !r || !pp || !scal) return -1;
+    double* state = arena->alloc_n<double>((size_t)2 * ST_LEN);
+    if (!d_row_shift || !qa || !qb || !qred || !r || !pp || !scal || !state) return -1;
     if (hipMemcpy(d_row_shift, shift.data(), sizeof(int) * shift.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
     // the collectives carry ld doubles per vector, the kernels write d of them: the padding is zero once and for all
-    if (hipMemset(qred, 0, sizeof(double) * (size_t)9 * ld) != hipSuccess) return -1;
-    g->d_row_shift = d_row_shift; g->qa = qa; g->qb = qb; g->qred = qred; g->r = r; g->p = pp; g->scal = scal;
+    if (hipMemset(qred, 0, sizeof(double) * qred_len) != hipSuccess) return -1;
+    if (hipMemset(state, 0, sizeof(double) * 2 * ST_LEN) != hipSuccess) return -1;
+    g->d_row_shift = d_row_shift; g->qa = qa; g->qb = qb; g->qred = qred; g->r = r; g->p = pp; g->scal = scal; g->state = state;
     g->AW = g->qred;                  // slots 0..7 of the all-reduce buffer ARE S~ W~ after the setup; slot 8 carries the iterations' products
     g->ready = true;
     return 0;
@@ -325,21 +697,56 @@ static void launch_product(hipStream_t s, const DistCg* g, const DcgSolveArgs& a
     else hipLaunchKernelGGL(k_dcg_comb<double>, dim3(1), dim3(STEP_T), 0, s, g->d, g->ncam, g->row0, g->row1, g->rank, g->qa, g->qb, p, a.focal_row, out, flags);
 }
 
+static int upd_grid(int d) { return std::max(1, std::min(UPD_MAXWG, (d + 255) / 256)); }
+
 int dcg_begin(hipStream_t s, DistCg* g, const DcgSolveArgs& a, dcg_allreduce_fn ar, void* ctx) {
-    if (a.W) {
-        for (int k = 0; k < NW; ++k) launch_product(s, g, a, a.W + (size_t)k * g->ld, g->qred + (size_t)k * g->ld, nullptr);
-        if (ar) { const int rc = ar(ctx, g->qred, (long long)NW * g->ld, s); if (rc) return rc; }
+    g->launched = 0;
+    if (a.implicit) {
+        // the implicit product forms whole vectors in launches of its own: the single-workgroup update kernels of round 4
+        if (a.W) {
+            for (int k = 0; k < NW; ++k) launch_product(s, g, a, a.W + (size_t)k * g->ld, g->qred + (size_t)k * g->ld, nullptr);
+            if (ar) { const int rc = ar(ctx, g->qred, (long long)NW * g->ld, s); if (rc) return rc; }
+        }
+        hipLaunchKernelGGL(k_dcg_init, dim3(1), dim3(STEP_T), 0, s, g->d, g->ld, a.bt, a.W, g->AW, g->x, g->r, g->p, g->scal, a.flags, a.anchor, a.cap);
+        return 0;
     }
-    hipLaunchKernelGGL(k_dcg_init, dim3(1), dim3(STEP_T), 0, s, g->d, g->ld, a.bt, a.W, g->AW, g->x, g->r, g->p, g->scal, a.flags, a.anchor, a.cap);
+    if (a.W) {
+        const dim3 grid(g->np);
+#define SFMBA_DCG_PROD8(FT, FF, fr) hipLaunchKernelGGL((k_dcg_prod8<FT, FF>), grid, dim3(256), 0, s, g->d, g->ld, g->ncam, g->row0, g->row1, g->rank, \
+                                                       static_cast<const FT*>(a.owned), fr, a.W, g->qred)
+        if (a.owned_f32) { if (a.focal_row32) SFMBA_DCG_PROD8(float, float, a.focal_row32); else SFMBA_DCG_PROD8(float, double, a.focal_row); }
+        else { if (a.focal_row32) SFMBA_DCG_PROD8(double, float, a.focal_row32); else SFMBA_DCG_PROD8(double, double, a.focal_row); }
+#undef SFMBA_DCG_PROD8
+        if (ar) { const int rc = ar(ctx, g->qred, (long long)NW * g->ld + (long long)g->np * LIN8_STRIDE, s); if (rc) return rc; }
+    }
+    hipLaunchKernelGGL(k_dcg_start, dim3(upd_grid(g->d)), dim3(256), 0, s, g->d, g->ld, g->np, g->qred, a.bt, a.W, g->x, g->r, g->p, g->state, g->scal,
+                       a.flags, a.anchor, a.cap);
     return 0;
 }
 
 int dcg_iterate(hipStream_t s, DistCg* g, const DcgSolveArgs& a, int n, dcg_allreduce_fn ar, void* ctx) {
     double* q = g->qred + (size_t)NW * g->ld;
+    if (a.implicit) {
+        for (int it = 0; it < n; ++it) {
+            launch_product(s, g, a, g->p, q, a.flags);
+            if (ar) { const int rc = ar(ctx, q, (long long)g->ld, s); if (rc) return rc; }
+            hipLaunchKernelGGL(k_dcg_step, dim3(1), dim3(STEP_T), 0, s, g->d, g->ld, q, a.W, g->x, g->r, g->p, g->scal, a.flags, a.tol * a.tol, a.info);
+        }
+        return 0;
+    }
+    const dim3 grid(g->np);
     for (int it = 0; it < n; ++it) {
-        launch_product(s, g, a, g->p, q, a.flags);
-        if (ar) { const int rc = ar(ctx, q, (long long)g->ld, s); if (rc) return rc; }
-        hipLaunchKernelGGL(k_dcg_step, dim3(1), dim3(STEP_T), 0, s, g->d, g->ld, q, a.W, g->x, g->r, g->p, g->scal, a.flags, a.tol * a.tol, a.info);
+        const int no = ++g->launched;
+#define SFMBA_DCG_PROD(FT, FF, fr) hipLaunchKernelGGL((k_dcg_prod<FT, FF>), grid, dim3(256), 0, s, g->d, g->ld, g->ncam, g->row0, g->row1, g->rank, \
+                                                      static_cast<const FT*>(a.owned), fr, g->p, a.W, q, a.flags, no)
+        if (a.owned_f32) { if (a.focal_row32) SFMBA_DCG_PROD(float, float, a.focal_row32); else SFMBA_DCG_PROD(float, double, a.focal_row); }
+        else { if (a.focal_row32) SFMBA_DCG_PROD(double, float, a.focal_row32); else SFMBA_DCG_PROD(double, double, a.focal_row); }
+#undef SFMBA_DCG_PROD
+        if (ar) { const int rc = ar(ctx, q, (long long)g->ld + (long long)g->np * LIN_STRIDE, s); if (rc) return rc; }
+        double* r_in = g->r + (size_t)((no - 1) & 1) * g->ld;
+        double* r_out = g->r + (size_t)(no & 1) * g->ld;
+        hipLaunchKernelGGL(k_dcg_upd, dim3(upd_grid(g->d)), dim3(256), 0, s, g->d, g->ld, g->np, q, a.W, g->x, r_in, r_out, g->p, g->state, g->scal,
+                           a.flags, a.tol * a.tol, a.info, no);
     }
     return 0;
 }

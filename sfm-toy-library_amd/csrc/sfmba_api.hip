@@ -253,6 +253,15 @@ struct sfmba_problem {
     int64_t shard_exchange[4] = { 0, 0, 0, 0 };       // bytes of exchanges (A), (B), (C) per linearisation of the last sharded solve; (B) in fp32?
     sfmba_allreduce_f32_fn allreduce_f32 = nullptr;   // optional: exchange (B) in fp32 where the CG stores S~ in fp32
     sfmba_reduce_scatter_fn reduce_scatter = nullptr; // optional: the distributed CG's exchange (B)
+    // row-sharded problem (SFMBA_CREATE_ROW_SHARDED: every rank holds the whole problem; options.shard_distributed_cg = 3)
+    // no pair list (SFMBA_CREATE_NO_PAIR_LIST, or more pairs of observations than a list can hold): sfmba_problem_solve runs the CG with the
+    // reduced matrix applied implicitly (implicit_schur.hip) -- O(observations) memory whatever the track lengths
+    bool no_pairs = false;
+    bool row_sharded = false;
+    int own_pt0 = 0, own_pt1 = 0, own_pt_stride = 0;  // own range of point slots; slots per rank (the per-point arrays are padded to world * stride)
+    int own_chunk0 = 0, own_chunk1 = 0;               // own share of the camera-major chunks (k_cam_diag_f) ...
+    int own_coarse0 = 0, own_coarse1 = 0;             // ... and of the coarse ones (column norms)
+    sfmba_allgather_fn allgather = nullptr;
     DistCg dcg;                                       // distributed CG workspace (created by the first solve that asks for it)
     double *imp_dtab = nullptr, *imp_spt = nullptr, *imp_acc = nullptr;   // implicit Schur product workspace (shard_distributed_cg = 2; allocated by the first solve that asks)
     long long shard_blocks_off = 0;                   // doubles: where the block region of d_red starts (behind the region of exchange (A))
@@ -269,6 +278,27 @@ int check_device(int device) {
         return fail(SFMBA_ERR_NO_DEVICE, "no HIP device available: the MI355X back end has no CPU fallback");
     if (device < 0 || device >= n) return fail(SFMBA_ERR_INVALID_ARG, "device index out of range");
     return SFMBA_OK;
+}
+
+// What the passes of a ROW-SHARDED rank see (include/sfmba.h, SFMBA_CREATE_ROW_SHARDED): the point passes its own points (pt_order lists
+// them), the camera-major passes its share of the chunks; everything else the whole problem.
+DeviceStructure ds_points(const sfmba_problem* p) {
+    DeviceStructure ds = p->ds;
+    if (p->row_sharded) { ds.npt = p->own_pt1 - p->own_pt0; ds.pt_base = p->own_pt0; }
+    return ds;
+}
+DeviceStructure ds_cams(const sfmba_problem* p) {
+    DeviceStructure ds = p->ds;
+    if (p->row_sharded) {
+        ds.chunks += p->own_chunk0; ds.nchunk = p->own_chunk1 - p->own_chunk0;
+        ds.chunks_coarse += p->own_coarse0; ds.nchunk_coarse = p->own_coarse1 - p->own_coarse0;
+    }
+    return ds;
+}
+DeviceBuffers db_cams(const sfmba_problem* p) {
+    DeviceBuffers db = p->db;
+    if (p->row_sharded && db.cd_part) db.cd_part += (size_t)p->own_chunk0 * 48;      // (a chunk's slot is its GLOBAL index: k_cd_fold walks all of them, the others' stay zero)
+    return db;
 }
 
 void init_state(sfmba_problem* p, LMState& st, const sfmba_options& o) {
@@ -646,10 +676,12 @@ int sfmba_problem_create(int device, int precision, int n_cam, const double* cam
 int sfmba_problem_create_ex(int device, int precision, int flags, int n_cam, const double* cam6, const unsigned char* cam_active, int n_pt,
                             const double* pt3, int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
                             double focal, int rank, int world, sfmba_problem** out) {
-    if (flags & ~SFMBA_CREATE_DETERMINISTIC) return fail(SFMBA_ERR_INVALID_ARG, "unknown create flag");
-    if (cam_active && (world < 1 || rank < 0 || rank >= world || world > SFMBA_SHARD_SCALARS - 16)) return fail(SFMBA_ERR_INVALID_ARG, "bad rank/world");
+    if (flags & ~(SFMBA_CREATE_DETERMINISTIC | SFMBA_CREATE_ROW_SHARDED | SFMBA_CREATE_NO_PAIR_LIST)) return fail(SFMBA_ERR_INVALID_ARG, "unknown create flag");
+    if ((flags & SFMBA_CREATE_NO_PAIR_LIST) && (cam_active || (flags & SFMBA_CREATE_ROW_SHARDED))) return fail(SFMBA_ERR_INVALID_ARG, "SFMBA_CREATE_NO_PAIR_LIST applies to unsharded problems");
+    const bool sharded = cam_active != nullptr || (flags & SFMBA_CREATE_ROW_SHARDED) != 0;
+    if (sharded && (world < 1 || rank < 0 || rank >= world || world > SFMBA_SHARD_SCALARS - 16)) return fail(SFMBA_ERR_INVALID_ARG, "bad rank/world");
     return create_impl(device, precision, flags, n_cam, cam6, cam_active, n_pt, pt3, n_obs, obs_cam, obs_pt, obs_xy, focal,
-                       cam_active ? rank : 0, cam_active ? world : 1, out);
+                       sharded ? rank : 0, sharded ? world : 1, out);
 }
 
 int sfmba_problem_create_sharded(int device, int precision, int n_cam, const double* cam6, const unsigned char* cam_active,
@@ -731,6 +763,19 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         });
     }
     bt_mark("counts");
+    // row-sharded: this rank's range of point slots (ceil(n / world) each: the per-point arrays are padded so that the table goes through an
+    // in-place all-gather of equal slices) and its block rows of the reduced matrix (the partition of the distributed CG)
+    const bool rowsh = p->row_sharded && sharded;
+    int own0 = 0, own1 = npt, pt_stride = npt, brow0 = 0, brow1 = ncam;
+    if (rowsh) {
+        pt_stride = (npt + p->shard_world - 1) / p->shard_world;
+        own0 = std::min(npt, p->shard_rank * pt_stride); own1 = std::min(npt, own0 + pt_stride);
+        std::vector<int> rows; long long chunk_blocks = 0;
+        dcg_partition(ncam, p->shard_world, &rows, &chunk_blocks);
+        brow0 = rows[(size_t)p->shard_rank]; brow1 = rows[(size_t)p->shard_rank + 1];
+    }
+    p->own_pt0 = own0; p->own_pt1 = own1; p->own_pt_stride = pt_stride;
+    const size_t npt_alloc = rowsh ? (size_t)pt_stride * (size_t)p->shard_world : (size_t)npt;
     PointMajor pm;
     const int64_t nblock64 = (int64_t)ncam * (ncam + 1) / 2;
     if (nblock64 >= ((int64_t)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many cameras");
@@ -750,10 +795,17 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     std::vector<char> blob;
     int pair_lpb = 64, blocks_per_wg = 1;
     size_t pair_slot_cap = 0;
+    // (SFMBA_PAIR_LIMIT: a test hook that lowers the threshold so that the matrix-free path runs at test size; read when a problem is built)
+    long long pair_limit = (long long)1 << 31;
+    if (const char* e = std::getenv("SFMBA_PAIR_LIMIT")) { const long long v = std::atoll(e); if (v > 0 && v < pair_limit) pair_limit = v; }
     auto host_half = [&]() -> int {
         for (int i = 0; i < npt; ++i) { const long long m = p->h_pt_cnt[(size_t)i]; pt_ptr[(size_t)i + 1] = pt_ptr[(size_t)i] + (int)m; npair_total += m * (m - 1) / 2; }
         for (int j = 0; j < ncam; ++j) cam_ptr[(size_t)j + 1] = cam_ptr[(size_t)j] + p->h_cam_cnt[(size_t)j];
-        const bool counts_ok = pt_ptr[(size_t)npt] == nobs && cam_ptr[(size_t)ncam] == nobs && npair_total < ((long long)1 << 31);
+        // More pairs of observations than a pair list can hold (32-bit positions; 16 bytes of sort workspace each) -- a hundred cameras that all
+        // see 440k points, say; the reference adds a residual block per (view, point) without any bound on the track length, BA.cpp:142-166 --
+        // or a caller that asked for it: no pair list is built and the solve applies the reduced matrix implicitly (include/sfmba.h).
+        if (!sharded && npair_total >= pair_limit) p->no_pairs = true;
+        const bool counts_ok = pt_ptr[(size_t)npt] == nobs && cam_ptr[(size_t)ncam] == nobs && (p->no_pairs || npair_total < ((long long)1 << 31));
         counts_state.store(counts_ok ? 1 : -1, std::memory_order_release);
         if (!counts_ok) return SFMBA_OK;         // (reported by the other half)
         // ---- launch descriptors (from the CSR pointer arrays) ----
@@ -790,7 +842,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         // pairs of ~1000 points (every 2^s-th slot), their blocks sorted, m_b sampled pairs in block b -- pairs of one point never share a block, so
         // sum_b m_b (m_b - 1) estimates q^2 sum_b n_b^2 (q: the sampled share of the points) and  sum n_b^2 / sum n_b = C2 / (q * keys) + 1  is the
         // number of pairs in the block an average PAIR lives in: mean + 1 for uniform co-visibility, ~800 on the 600-camera path (mean 75).
-        if (pair_lpb == 16 && src.n_old == 0 && ncam > 64 && nn > 100000 && mean_pairs >= 8.0) {
+        if (!p->no_pairs && pair_lpb == 16 && src.n_old == 0 && ncam > 64 && nn > 100000 && mean_pairs >= 8.0) {
             int shift = 0;
             while ((npt >> shift) > 1024) ++shift;
             const int mask = (1 << shift) - 1;
@@ -824,7 +876,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         blocks_per_wg = pair_lpb == 64 ? 1 : 64 / pair_lpb;
         {
             std::vector<std::vector<int2>> per_xcd(8);
-            for (int ja = 0; ja < ncam; ++ja) {
+            for (int ja = brow0; ja < (p->no_pairs ? brow0 : brow1); ++ja) {       // (a row-sharded rank: its own block rows only -- all pairs of each of their blocks; no pair list: no pair pass)
                 const int b0 = block_of(ja, ja), nb = ncam - ja;
                 for (int o = 0; o < nb; o += blocks_per_wg) { int2 w; w.x = b0 + o; w.y = std::min(blocks_per_wg, nb - o); per_xcd[ja % 8].push_back(w); }
             }
@@ -844,13 +896,14 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             constexpr int NB = 18;                 // rounds 1 .. 16, > 16 in one bucket (+ the empty bucket 0)
             int cnt_b[NB + 1] = {};
             auto bucket = [&](int i) { const int k = pt_ptr[(size_t)i + 1] - pt_ptr[i]; return std::min((k + 3) / 4, NB - 1); };
-            for (int i = 0; i < npt; ++i) ++cnt_b[bucket(i) + 1];
+            // (a row-sharded rank: the list of its OWN points -- always materialised, position and slot differ)
+            for (int i = own0; i < own1; ++i) ++cnt_b[bucket(i) + 1];
             int used = 0;
             for (int b = 0; b < NB; ++b) used += cnt_b[b + 1] > 0;
-            if (used > 1) {
+            if (used > 1 || rowsh) {
                 for (int b = 0; b < NB; ++b) cnt_b[b + 1] += cnt_b[b];
-                pt_order.resize((size_t)npt);
-                for (int i = 0; i < npt; ++i) pt_order[(size_t)cnt_b[bucket(i)]++] = i;
+                pt_order.resize((size_t)std::max(own1 - own0, 1));
+                for (int i = own0; i < own1; ++i) pt_order[(size_t)cnt_b[bucket(i)]++] = i;
             }
         }
         // upload: ONE synchronous copy on the NULL stream (the problem's stream is non-blocking: it runs beside the sorts) of the
@@ -876,7 +929,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             p->d_pt_order = pt_order.empty() ? nullptr : reinterpret_cast<int*>(d_blob + o_pto);
         }
         // (wave-per-block pass: one descriptor per chunk of SFMBA_PAIR_CHUNK pairs -- as many as the pair total allows at most)
-        pair_slot_cap = pair_lpb == 64 ? pwg_blocks.size() + (size_t)(npair_total / SFMBA_PAIR_CHUNK) + 1 : pwg_blocks.size() * (size_t)blocks_per_wg;
+        pair_slot_cap = p->no_pairs ? 1 : pair_lpb == 64 ? pwg_blocks.size() + (size_t)(npair_total / SFMBA_PAIR_CHUNK) + 1 : std::max<size_t>(pwg_blocks.size() * (size_t)blocks_per_wg, 1);
         HIP_TRY(dev_alloc(&p->d_pwg_desc, pair_slot_cap));
         if (pair_lpb == 64) {
             HIP_TRY(dev_alloc(&p->d_pwg_chunk, pair_slot_cap));
@@ -926,13 +979,18 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     while (counts_state.load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
     if (counts_state.load() < 0) {
         helper.wait();
-        if (npair_total >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs");
+        if (npair_total >= ((long long)1 << 31)) return fail(SFMBA_ERR_INVALID_ARG, "too many observation pairs for a sharded problem (2^31: the matrix-free path is unsharded)");
         return fail(SFMBA_ERR_HIP, "observation counts out of step with the observation list");
     }
+    const bool no_pairs = p->no_pairs;      // (decided by the host half before it published the counts)
     // camera-pair lists: for every point, every pair of its observations (qa < qb, cameras ascending; the self pairs are folded
     // into the camera-diagonal pass) goes to block (ja, jb) of the upper triangle of S -- listed as the pair's POINT, which is all the
     // re-evaluating pair pass reads per pair
-    {
+    if (no_pairs) {
+        p->d_blk_ptr = p->arena.alloc_n<int>((size_t)nblock + 1);          // (all empty: the arena hands out zeroed memory)
+        p->d_pair_pt = p->arena.alloc_n<int>(1);
+        if (!p->d_blk_ptr || !p->d_pair_pt) { helper.wait(); return fail(SFMBA_ERR_ALLOC, "device allocation failed"); }
+    } else {
         const int brc = build_pair_lists(p->stream, &p->arena, &staging, npt, nobs, ncam, nblock, p->d_pt_ptr, p->d_obs_pt, p->d_obs_cam, pm.pair_off, npair_total,
                                          &p->d_blk_ptr, &p->d_pair_pt);
         if (brc) { helper.wait(); return fail(SFMBA_ERR_HIP, std::string("pair-list build: ") + hipGetErrorString((hipError_t)brc)); }
@@ -986,7 +1044,9 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     int* d_report = reinterpret_cast<int*>(p->d_pinned + 1536);
     build_report[1] = -1; build_report[4] = -1; build_report[5] = -1; build_report[6] = -1;
     HIP_TRY(hipMemsetAsync(p->d_build_counters, 0, 4 * sizeof(int), p->stream));
-    if (pair_lpb == 64) {
+    if (pwg_blocks.empty()) {
+        build_report[4] = 0; build_report[5] = 0;      // (a row-sharded rank without a block row, or no pair list: no pair pass)
+    } else if (pair_lpb == 64) {
         const int crc = build_pair_chunks(p->stream, &staging, (int)pwg_blocks.size(), SFMBA_PAIR_CHUNK, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr,
                                           p->d_pwg_desc, p->d_pwg_chunk, p->d_multi_slots, p->d_build_counters, d_report);
         if (crc) return fail(SFMBA_ERR_HIP, std::string("pair-chunk descriptors: ") + hipGetErrorString((hipError_t)crc));
@@ -999,7 +1059,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     }
     launch_block_fill(p->stream, nblock, ncam, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
     p->d_blk_mask = nullptr;
-    if (6 * ncam + 1 > 1280 && !sharded) {       // (the streaming CG kernels: a sparsely filled reduced matrix is multiplied block-sparse there)
+    if (6 * ncam + 1 > 1280 && !sharded && !no_pairs) {       // (the streaming CG kernels: a sparsely filled reduced matrix is multiplied block-sparse there)
         HIP_TRY(dev_alloc(&p->d_blk_mask, (size_t)ncam * (size_t)((ncam + 31) / 32)));
         launch_block_mask(p->stream, ncam, p->d_blk_ptr, p->d_blk_mask);
     }
@@ -1014,6 +1074,13 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     ds.ld = dense_padded_dim(ds.d);
     ds.pt_ptr = p->d_pt_ptr; ds.pt_order = p->d_pt_order; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
     ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt; ds.cam_obs_xy = p->d_cam_obs_xy;
+    // row-sharded: a contiguous, equally sized share of the camera-major chunks per rank (every chunk is <= 256 entries of one camera)
+    p->own_chunk0 = 0; p->own_chunk1 = (int)chunks.size(); p->own_coarse0 = 0; p->own_coarse1 = (int)chunks_coarse.size();
+    if (rowsh) {
+        const long long nc_ = (long long)chunks.size(), ncc = (long long)chunks_coarse.size(), r_ = p->shard_rank, w_ = p->shard_world;
+        p->own_chunk0 = (int)(nc_ * r_ / w_); p->own_chunk1 = (int)(nc_ * (r_ + 1) / w_);
+        p->own_coarse0 = (int)(ncc * r_ / w_); p->own_coarse1 = (int)(ncc * (r_ + 1) / w_);
+    }
     ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
     ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
     ds.obs_pt = p->d_obs_pt;
@@ -1027,7 +1094,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db = DeviceBuffers{};
     for (int b = 0; b < 2; ++b) {
         HIP_TRY(dev_alloc(&db.cam[b], (size_t)6 * ncam));
-        HIP_TRY(dev_alloc(&db.pts[b], (size_t)3 * npt));
+        HIP_TRY(dev_alloc(&db.pts[b], (size_t)3 * npt_alloc));
         HIP_TRY(dev_alloc(&db.camtab[b], (size_t)CT_STRIDE * ncam));
     }
     HIP_TRY(dev_alloc(&db.steptab, (size_t)ST_STRIDE * ncam));
@@ -1036,14 +1103,21 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     // Nothing is stored per observation: the reduced-system passes and the back-substitution re-evaluate every observation from the
     // camera row and a per-point table (PA / PB, 64 + 24 bytes per point in fp32-Jacobian mode) plus a camera-major copy of the
     // observation coordinates (rounds 1 - 3 kept a 64-byte record per observation: 64 MB at BASELINE config 3).
-    db.PA = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecA<float>) : sizeof(PtRecA<double>)));
-    db.PB = p->arena.alloc((size_t)std::max(npt, 1) * (f32 ? sizeof(PtRecB<float>) : sizeof(PtRecB<double>)));
+    db.PA = p->arena.alloc(std::max<size_t>(npt_alloc, 1) * (f32 ? sizeof(PtRecA<float>) : sizeof(PtRecA<double>)));
+    db.PB = p->arena.alloc(std::max<size_t>(npt_alloc, 1) * (f32 ? sizeof(PtRecB<float>) : sizeof(PtRecB<double>)));
     if (!db.PA || !db.PB) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
     HIP_TRY(dev_alloc(&db.pt_t, (size_t)3 * npt));
     HIP_TRY(dev_alloc(&db.pt_M, (size_t)6 * npt));
     const size_t sys_len = (size_t)ds.ld * ds.ld + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
     HIP_TRY(dev_alloc(&p->d_sys, sys_len));
     p->d_red = nullptr;
+    if (no_pairs) {
+        // the matrix-free solve runs the CG loop of the sharded path on one rank: the buffer of exchange (A)
+        p->shard_blocks_off = (shard_diag_len(ds) + 63) / 64 * 64;
+        HIP_TRY(dev_alloc(&p->d_red, (size_t)p->shard_blocks_off));
+        p->dcg = DistCg(); p->dcg_last_f32 = -1;
+        p->imp_dtab = p->imp_spt = p->imp_acc = nullptr;
+    }
     if (sharded) {
         // the all-reduce buffer: packed triangle of S + tail (exact solver), or the two blocks of the CG path (ba_kernels.hip, k_shard_diag)
         const size_t tri = (size_t)ds.ld * (ds.ld + 1) / 2 + 3 * (size_t)ds.ld + SFMBA_SHARD_SCALARS;
@@ -1093,13 +1167,13 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
     HIP_TRY(dev_alloc(&db.pair_G, (size_t)36 * std::max(ncam, 1)));
-    if (pair_lpb == 64) HIP_TRY(dev_alloc(&db.pair_partial, (size_t)36 * pair_slot_cap));
+    if (pair_lpb == 64 && !no_pairs) HIP_TRY(dev_alloc(&db.pair_partial, (size_t)36 * pair_slot_cap));
     bt_mark("alloc buffers");
     // the one wait of the build: sorts, lists and descriptors are in place; the staging arena and the host vectors may go
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (build_report[0] < 0 || (((long long)build_report[3] << 32) | (unsigned)build_report[2]) != npair_total)
         return fail(SFMBA_ERR_HIP, "structure build: the device's pair count differs from the host's");
-    ds.ndupwg = build_report[0];
+    ds.ndupwg = no_pairs ? 0 : build_report[0];
     if (pair_lpb == 64) {
         if (build_report[4] < 0 || (size_t)build_report[4] > pair_slot_cap || build_report[5] < 0) return fail(SFMBA_ERR_HIP, "structure build: pair-chunk descriptors out of range");
         ds.npairwg = build_report[4]; ds.nmulti = build_report[5];
@@ -1107,6 +1181,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     // fill of the reduced matrix: non-empty off-diagonal blocks / all of them (what SFMBA_LINEAR_AUTO reads the co-visibility from)
     p->block_fill = ncam > 1 ? (double)std::max((int)build_report[1], 0) / ((double)ncam * (ncam - 1) / 2.0) : 1.0;
     p->block_band = build_report[1] > 0 ? (double)std::max((int)build_report[6], 0) / (double)build_report[1] : 0.0;
+    if (no_pairs) { p->block_fill = 1.0; p->block_band = 0.0; }      // (unknown without the list)
     p->solver.blk_fill = p->block_fill;
     bt_mark("wait for device");
     return sfmba_problem_reset(p);
@@ -1132,7 +1207,9 @@ static int create_impl(int device, int precision, int flags, int n_cam, const do
     p->n_cam_full = n_cam; p->n_pt_full = n_pt; p->n_obs = n_obs;
     p->focal0 = p->focal = focal;
     p->shard_rank = rank; p->shard_world = world;
-    p->sharded = cam_active != nullptr;
+    p->no_pairs = (flags & SFMBA_CREATE_NO_PAIR_LIST) != 0;
+    p->row_sharded = (flags & SFMBA_CREATE_ROW_SHARDED) != 0;
+    p->sharded = cam_active != nullptr || p->row_sharded;
     // create flag, or the environment override (kept across appends: the structure is rebuilt in the same mode)
     { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e ? e[0] == '1' : (flags & SFMBA_CREATE_DETERMINISTIC) != 0; }
     struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
@@ -1164,7 +1241,7 @@ static int create_impl(int device, int precision, int flags, int n_cam, const do
     p->arena.set_ordering_stream(p->stream);          // zeroing of its chunks: ordered in front of the stream's work, not waited for
     p->h_state = reinterpret_cast<LMState*>(p->kit.pinned);                        // [0, 1024)
     p->h_lm_mail = reinterpret_cast<volatile int*>(p->kit.pinned + 1024);          // [1024, 1088)
-    if (n_obs == 0 && !cam_active) {
+    if (n_obs == 0 && !p->sharded) {
         p->empty = true;
         guard.p = nullptr;
         *out = p;
@@ -1184,6 +1261,7 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
     if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
     if (p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "a sharded problem cannot grow in place");
+    if (p->no_pairs) return fail(SFMBA_ERR_INVALID_ARG, "a problem without a pair list cannot grow in place: create it anew");
     if (n_cam < p->n_cam_full || n_pt < p->n_pt_full || n_obs_new < 0 || p->n_obs + n_obs_new >= (int64_t)1 << 31)
         return fail(SFMBA_ERR_INVALID_ARG, "bad sizes: cameras and points can only be added at the end");
     if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs_new > 0 && (!obs_cam || !obs_pt || !obs_xy)))
@@ -1307,12 +1385,16 @@ int sfmba_problem_get_params(sfmba_problem* p, double* cam6, double* pt3, double
     return SFMBA_OK;
 }
 
+static int solve_matrix_free(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, sfmba_iteration* trace, int trace_cap, int* trace_len);
+
 int sfmba_problem_solve(sfmba_problem* p, const sfmba_options* opt, sfmba_summary* summary,
                         sfmba_iteration* trace, int trace_cap, int* trace_len) {
     if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
     if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
+    if (p->row_sharded) return fail(SFMBA_ERR_INVALID_ARG, "a row-sharded problem is solved with sfmba_problem_solve_sharded only");
     sfmba_options o;
     if (opt) o = *opt; else sfmba_options_default(&o);
+    if (p->no_pairs && !p->empty) return solve_matrix_free(p, o, summary, trace, trace_cap, trace_len);
     if (p->precision == SFMBA_PRECISION_F32J) return run_solve<float>(p, o, summary, trace, trace_cap, trace_len);
     return run_solve<double>(p, o, summary, trace, trace_cap, trace_len);
 }
@@ -1421,6 +1503,8 @@ int sfmba_problem_eval_jacobian(sfmba_problem* p, double* jc, double* jp, double
 int sfmba_problem_build_reduced(sfmba_problem* p, const sfmba_options* opt, double radius, double* S, double* rhs, double* scale) {
     if (p && !p->poisoned) { const int frc = flush_reset(p); if (frc) return frc; }
     if (!p || p->empty || p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, p && p->poisoned ? "poisoned problem (a failed sfmba_problem_append): destroy it" : "NULL or empty problem");
+    if (p->row_sharded) return fail(SFMBA_ERR_INVALID_ARG, "a row-sharded problem is solved with sfmba_problem_solve_sharded only");
+    if (p->no_pairs) return fail(SFMBA_ERR_INVALID_ARG, "this problem has no pair list (SFMBA_CREATE_NO_PAIR_LIST / too many pairs): its reduced matrix is never formed");
     sfmba_options o;
     if (opt) o = *opt; else sfmba_options_default(&o);
     HIP_TRY(hipSetDevice(p->device));
@@ -1523,12 +1607,13 @@ static int shard_begin_impl(sfmba_problem* p, const sfmba_options* opt, bool fus
     LMState st;
     init_state(p, st, p->shard_opt);
     const int f32 = p->precision == SFMBA_PRECISION_F32J;
+    if (p->row_sharded && !fused) return fail(SFMBA_ERR_INVALID_ARG, "a row-sharded problem runs the loop of sfmba_problem_solve_sharded only");
     if (fused) {
         *p->h_state = st;
         launch_begin(p->stream, p->ds, p->db, st, p->reset_pending ? p->d_cam0 : nullptr, p->reset_pending ? p->d_pts0 : nullptr);
         p->reset_pending = false;
-        launch_xnorm(p->stream, p->ds, p->db);
-        launch_colnorm_cams_only(p->stream, p->ds, p->db, p->shard_opt.jacobi_scaling, f32, /*clear_udiag=*/false);
+        launch_xnorm(p->stream, ds_points(p), p->db);
+        launch_colnorm_cams_only(p->stream, ds_cams(p), p->db, p->shard_opt.jacobi_scaling, f32, /*clear_udiag=*/false);
     } else {
         if ((rc = flush_reset(p))) return rc;
         rc = upload_state(p, st);
@@ -1661,9 +1746,36 @@ int sfmba_shard_end(sfmba_problem* p, sfmba_summary* summary) {
 }
 
 // ---- the sharded LM loop in one call: collectives through a callback (RCCL below, or the caller's) ----
+static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx, sfmba_summary* summary);
+
 int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx, sfmba_summary* summary) {
     if (!p || p->empty || p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, p && p->poisoned ? "poisoned problem (a failed sfmba_problem_append): destroy it" : "NULL or empty problem");
     if (!p->sharded) return fail(SFMBA_ERR_INVALID_ARG, "not a sharded problem (sfmba_problem_create_sharded)");
+    return solve_sharded_impl(p, opt, allreduce, ctx, summary);
+}
+
+// The matrix-free solve of an UNSHARDED problem without a pair list (include/sfmba.h, SFMBA_CREATE_NO_PAIR_LIST): the CG loop of the sharded
+// path on one rank with the reduced matrix applied implicitly (implicit_schur.hip) -- two passes over the observations per CG iteration,
+// nothing of size (pairs) or (cameras^2) is ever formed.  The trace rows are the ones k_lm_control wrote.
+static int solve_matrix_free(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, sfmba_iteration* trace, int trace_cap, int* trace_len) {
+    if (trace_len) *trace_len = 0;
+    if (p->poisoned) return fail(SFMBA_ERR_INVALID_ARG, "poisoned problem (a failed sfmba_problem_append): destroy it");
+    sfmba_summary sum;
+    const int rc = solve_sharded_impl(p, &o, nullptr, nullptr, &sum);
+    if (rc) return rc;
+    const int rows = std::min(sum.iterations + 1, p->db.trace_cap);
+    if (rows > 0 && (trace || trace_len)) {
+        std::vector<TraceRow> tr((size_t)rows);
+        if (p->trace_mapped) std::memcpy(tr.data(), p->kit.pinned + 4096, sizeof(TraceRow) * (size_t)rows);
+        else HIP_TRY(hipMemcpy(tr.data(), p->db.trace, sizeof(TraceRow) * (size_t)rows, hipMemcpyDeviceToHost));
+        if (trace && trace_cap > 0) std::memcpy(trace, tr.data(), sizeof(TraceRow) * (size_t)std::min(rows, trace_cap));
+        if (trace_len) *trace_len = trace ? std::min(rows, std::max(trace_cap, 0)) : rows;
+    }
+    if (summary) *summary = sum;
+    return SFMBA_OK;
+}
+
+static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx, sfmba_summary* summary) {
     if (p->shard_world > 1 && !allreduce) return fail(SFMBA_ERR_INVALID_ARG, "world > 1 needs an all-reduce");
     auto reduce = [&](void* buf, int64_t n) -> int {
         if (!allreduce) return SFMBA_OK;          // (a communicator of one rank is still called: the RCCL path is exercised on a one-GPU box)
@@ -1672,8 +1784,10 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
     };
     sfmba_options o_in;
     if (opt) o_in = *opt; else sfmba_options_default(&o_in);
-    const bool two_phase = (o_in.linear_solver == SFMBA_LINEAR_PCG || (o_in.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) &&
-                           option_switch(o_in.shard_two_phase, "SFMBA_SHARD_TWO_PHASE", true);
+    // (a row-sharded problem: always the CG loop -- a rank holds all observations, the single all-reduce of partial systems does not apply)
+    const bool two_phase = p->row_sharded || p->no_pairs || ((o_in.linear_solver == SFMBA_LINEAR_PCG || (o_in.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) &&
+                                              option_switch(o_in.shard_two_phase, "SFMBA_SHARD_TWO_PHASE", true));
+    if (p->row_sharded && p->shard_world > 1 && !p->allgather) return fail(SFMBA_ERR_INVALID_ARG, "a row-sharded solve with world > 1 needs sfmba_problem_set_allgather");
     // fail-stop rule (include/sfmba.h): everything the loop allocates is allocated before this rank's first collective
     if (two_phase) {
         if (dense_pcg_ensure_workspace(&p->solver)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
@@ -1698,7 +1812,7 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         const bool exchange_f32_off = !option_switch(o.shard_f32_exchange, "SFMBA_SHARD_F32_EXCHANGE", true);
         // AUTO here = the CG run to a plain relative 1e-12 (no Cholesky fallback in the sharded loop: the factorisation would need the
         // unpreconditioned matrix exchanged as well; at max_iters the step is forced, as with PCG)
-        const bool exact_pcg = o.linear_solver == SFMBA_LINEAR_AUTO;
+        const bool exact_pcg = o.linear_solver != SFMBA_LINEAR_PCG;
         const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : auto_cg_tol(), auto_cg_tol()) : o.pcg_tolerance;
         // the CG without the redundant solve (dist_cg.h): reduce-scatter of the blocks, products from the owned blocks, one small
         // all-reduce per CG iteration
@@ -1706,10 +1820,24 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
         // formed implicitly from every rank's own points (implicit_schur.hip); duplicates live in diagonal blocks the
         // implicit form does not see: such a problem takes the explicit distributed form
         int dist_mode = o.shard_distributed_cg > 0 ? o.shard_distributed_cg : 0;
-        if (const char* e = std::getenv("SFMBA_SHARD_DIST_CG")) dist_mode = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
-        if (dist_mode == 2 && p->ds.ndupwg > 0) dist_mode = 1;
+        if (const char* e = std::getenv("SFMBA_SHARD_DIST_CG")) dist_mode = e[0] == '0' ? 0 : e[0] == '2' ? 2 : e[0] == '3' ? 3 : 1;
+        // ... or with the block ROWS of S~ sharded (shard_distributed_cg = 3): a property of the problem handle -- every rank was given the whole problem
+        if (p->no_pairs) dist_mode = 2;          // no pair list: the implicit product is the only one there is
+        else if (p->row_sharded) dist_mode = 3;
+        else if (dist_mode == 3) return fail(SFMBA_ERR_INVALID_ARG, "shard_distributed_cg = 3 needs a problem created with SFMBA_CREATE_ROW_SHARDED");
+        // (duplicate (camera, point) observations: the implicit product sums over ALL pairs of a point's observations, those of one camera
+        // included, so in that form their cross terms are simply not added to the diagonal blocks -- which stay what they are for: a
+        // preconditioner.  Nothing is decided from a rank's own duplicate count: every rank takes the form the options name)
         const bool implicit_cg = dist_mode == 2;
-        const bool dist_cg = dist_mode > 0 && (implicit_cg || p->shard_world == 1 || p->reduce_scatter != nullptr);
+        const bool row_cg = dist_mode == 3;
+        const bool dist_cg = dist_mode > 0 && (implicit_cg || row_cg || p->shard_world == 1 || p->reduce_scatter != nullptr);
+        const DeviceStructure dsp = ds_points(p), dsc = ds_cams(p);
+        const size_t pa_bytes = f32 ? sizeof(PtRecA<float>) : sizeof(PtRecA<double>), pb_bytes = f32 ? sizeof(PtRecB<float>) : sizeof(PtRecB<double>);
+        auto gather = [&](void* buf, size_t bytes_per_rank) -> int {
+            if (!p->allgather) return SFMBA_OK;       // (one rank; a communicator of one rank is still called)
+            const int grc = p->allgather(ctx, buf, (int64_t)bytes_per_rank, (void*)p->stream);
+            return grc == 0 ? SFMBA_OK : fail(SFMBA_ERR_HIP, "all-gather failed (rc " + std::to_string(grc) + ")");
+        };
         struct ArCtx { sfmba_allreduce_fn fn; void* ctx; } arctx{ allreduce, ctx };
         auto ar_thunk = [](void* c, void* buf, long long n, hipStream_t st) -> int { ArCtx* a = static_cast<ArCtx*>(c); return a->fn ? a->fn(a->ctx, buf, (int64_t)n, (void*)st) : 0; };
         int dcg_launched = 0, dcg_max = o.pcg_max_iters > 0 ? o.pcg_max_iters : 4 * p->ds.d;
@@ -1736,14 +1864,20 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             // the sum is the CG's matrix (what the camera pass and the pair epilogue write directly -- diagonal blocks, focal column --
             // goes to the fp32 matrix as on one GPU); otherwise everything is summed in fp64 and narrowed after the sum
             // (one rank without a communicator: nothing is exchanged, the blocks stay in the CG's own precision)
-            const bool x32 = F32 != nullptr && !exchange_f32_off && ((p->allreduce_f32 != nullptr && allreduce != nullptr) || (p->shard_world == 1 && allreduce == nullptr));
+            const bool x32 = F32 != nullptr && !exchange_f32_off && (row_cg || (p->allreduce_f32 != nullptr && allreduce != nullptr) || (p->shard_world == 1 && allreduce == nullptr));
             p->db.pcg_F32 = x32 ? F32 : nullptr;
             p->shard_exchange[0] = 8 * shard_diag_len(p->ds); p->shard_exchange[1] = (x32 ? 4 : 8) * shard_offdiag_len(p->ds);
             p->shard_exchange[2] = 8 * SFMBA_SHARD_SCALARS; p->shard_exchange[3] = x32 ? 1 : 0;
-            if (!build_enqueued) { if (f32) launch_point_build<float>(p->stream, p->ds, p->db, first_build); else launch_point_build<double>(p->stream, p->ds, p->db, first_build); }
+            if (!build_enqueued) { if (f32) launch_point_build<float>(p->stream, dsp, p->db, first_build); else launch_point_build<double>(p->stream, dsp, p->db, first_build); }
             build_enqueued = false;
-            if (f32) { launch_cam_diag<float>(p->stream, p->ds, p->db); launch_schur_pairs<float>(p->stream, p->ds, p->db, 2); }
-            else { launch_cam_diag<double>(p->stream, p->ds, p->db); launch_schur_pairs<double>(p->stream, p->ds, p->db, 2); }
+            if (row_cg) {
+                // the per-point table of every rank's points: what the camera pass and the pair pass re-evaluate the observations from
+                if ((rc = gather(p->db.PA, (size_t)p->own_pt_stride * pa_bytes))) return rc;
+                if ((rc = gather(p->db.PB, (size_t)p->own_pt_stride * pb_bytes))) return rc;
+            }
+            { const DeviceBuffers dbc = db_cams(p); if (f32) launch_cam_diag<float>(p->stream, dsc, dbc); else launch_cam_diag<double>(p->stream, dsc, dbc); }
+            // pairs inside diagonal blocks: part of the implicit product; a row-sharded rank holds ALL of them -- rank 0 adds them
+            if (!implicit_cg && (!row_cg || p->shard_rank == 0)) { if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 2); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 2); }
             first_build = 0;
             launch_cd_fold(p->stream, p->ds, p->db);       // deterministic mode: chunk sums in chunk order, before the exchange
             launch_shard_diag(p->stream, p->ds, p->db, p->d_red, /*unpack=*/false, p->shard_rank, p->shard_world);
@@ -1762,6 +1896,8 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                 da.implicit = &ip;
                 p->shard_exchange[1] = 0; p->shard_exchange[3] = 2 | 4;
               } else {
+                // row-sharded: the glue for ALL cameras on its own (the pair pass below only visits the diagonal blocks of the rank's rows)
+                if (row_cg) launch_pcg_glue(p->stream, p->ds, p->db);
                 // ... in the reduce-scatter layout (`world` equal chunks of whole block rows behind the region of exchange (A); padding zero)
                 double* blocks = p->d_red + p->shard_blocks_off;
                 const long long cv = dcg_chunk_values(p->dcg), total = cv * p->shard_world;
@@ -1771,11 +1907,13 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                 if (f32) launch_schur_pairs<float>(p->stream, p->ds, p->db, 1); else launch_schur_pairs<double>(p->stream, p->ds, p->db, 1);
                 p->db.shard_blocks = nullptr; p->db.shard_blocks32 = nullptr; p->db.shard_row_shift = nullptr;
                 char* mine = reinterpret_cast<char*>(blocks) + (size_t)p->shard_rank * (size_t)cv * (x32 ? 4 : 8);
-                if (p->shard_world > 1) {
+                if (p->shard_world > 1 && !row_cg) {
                     const int rrc = p->reduce_scatter(ctx, blocks, mine, (int64_t)cv, x32 ? 1 : 0, (void*)p->stream);
                     if (rrc != 0) return fail(SFMBA_ERR_HIP, "reduce-scatter failed (rc " + std::to_string(rrc) + ")");
                 }
                 p->shard_exchange[1] = (x32 ? 4 : 8) * total; p->shard_exchange[3] = (x32 ? 1 : 0) | 2;
+                // (row-sharded: the rank's blocks are complete as they leave the pair pass -- what crosses the ranks is the per-point table)
+                if (row_cg) { p->shard_exchange[1] = (long long)(p->shard_world - 1) * p->own_pt_stride * (long long)(pa_bytes + pb_bytes); p->shard_exchange[3] = (x32 ? 1 : 0) | 2 | 8; }
                 da.owned = mine; da.owned_f32 = x32;
                 if (p->db.pcg_F32) da.focal_row32 = p->db.pcg_F32 + (size_t)fo * p->ds.ld; else da.focal_row = p->solver.Sfull + (size_t)fo * p->ds.ld;
               }
@@ -1817,7 +1955,7 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
             volatile int* mb = p->h_lm_mail;
             for (;;) {
                 launch_cam_update(p->stream, p->ds, dbu);
-                if (f32) launch_point_update<float>(p->stream, p->ds, dbu); else launch_point_update<double>(p->stream, p->ds, dbu);
+                if (f32) launch_point_update<float>(p->stream, dsp, dbu); else launch_point_update<double>(p->stream, dsp, dbu);
                 launch_shard_pack(p->stream, p->db, p->d_scal, 2, p->shard_rank);
                 if ((rc = reduce(sfmba_shard_scalars_buf(p), SFMBA_SHARD_SCALARS))) return rc;
                 dbu.shard_scal = p->d_scal;        // k_lm_control reads the sums from the all-reduced block
@@ -1827,7 +1965,7 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                 // the next linearisation's first kernel before the host waits for the verdict, as in the one-GPU loop (run_solve): it
                 // looks at the LM state itself and returns at once if the solve ended or the iteration wants more CG first
                 if (speculate && p->shard_host_iter + 2 <= o.max_iters) {
-                    if (f32) launch_point_build<float>(p->stream, p->ds, p->db, 4); else launch_point_build<double>(p->stream, p->ds, p->db, 4);
+                    if (f32) launch_point_build<float>(p->stream, dsp, p->db, 4); else launch_point_build<double>(p->stream, dsp, p->db, 4);
                     build_enqueued = true;
                 }
                 if (wait_mailbox(mb, controls, p->stream) != 0) {
@@ -1861,6 +1999,11 @@ int sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmb
                 std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(MSG_MAX_ITERS));
                 break;
             }
+        }
+        if (row_cg) {
+            // every rank has moved its own points only: the final points of all ranks, so that the handle holds the whole solution
+            if ((rc = download_state(p))) return rc;
+            if ((rc = gather(p->db.pts[p->h_state->cur], (size_t)p->own_pt_stride * 3 * sizeof(double)))) return rc;
         }
         return sfmba_shard_end(p, summary);
     }
@@ -1995,6 +2138,21 @@ int sfmba_comm_reduce_scatter(void* comm, void* send_buf, void* recv_buf, int64_
     if (!c || !a || !a->ReduceScatter) return -1;
     const ncclResult_t r = a->ReduceScatter(send_buf, recv_buf, (size_t)n_values, is_f32 ? ncclFloat : ncclDouble, ncclSum, c->comm, static_cast<hipStream_t>(hip_stream));
     return r == ncclSuccess ? 0 : (int)r;
+}
+
+int sfmba_comm_allgather(void* comm, void* buf, int64_t bytes_per_rank, void* hip_stream) {
+    sfmba_comm* c = static_cast<sfmba_comm*>(comm);
+    RcclApi* a = rccl();
+    if (!c || !a || !a->AllGather) return -1;
+    const ncclResult_t r = a->AllGather(static_cast<char*>(buf) + (size_t)c->rank * (size_t)bytes_per_rank, buf, (size_t)bytes_per_rank, ncclChar, c->comm,
+                                        static_cast<hipStream_t>(hip_stream));
+    return r == ncclSuccess ? 0 : (int)r;
+}
+
+int sfmba_problem_set_allgather(sfmba_problem* p, sfmba_allgather_fn allgather) {
+    if (!p) return fail(SFMBA_ERR_INVALID_ARG, "NULL problem");
+    p->allgather = allgather;
+    return SFMBA_OK;
 }
 
 int sfmba_problem_set_reduce_scatter(sfmba_problem* p, sfmba_reduce_scatter_fn reduce_scatter) {

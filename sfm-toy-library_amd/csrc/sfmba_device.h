@@ -380,8 +380,9 @@ __device__ __forceinline__ void obs_factored_t(const T (&Rt)[12], bool first_ord
 }
 // acc += G_a^T N G_b  (6 x 6 row-major; rows: camera a, columns: camera b; the first three of each are the rotation part)
 //   = [[ -[X_a]x N [X_b]x ,  [X_a]x N ],  [ -N [X_b]x ,  N ]]   with  v [X]x = v x X  and  [X]x v = X x v
-template <typename T>
-__device__ __forceinline__ void pair_product_factored(const T ga[GREC], const T gb[GREC], T acc[36]) {
+// (A: the type the lane's sums are kept in -- T, or double with the products widened one by one)
+template <typename T, typename A = T>
+__device__ __forceinline__ void pair_product_factored(const T ga[GREC], const T gb[GREC], A acc[36]) {
     const T ff = ga[3] * gb[3];
     const T m00 = ff * (ga[6] * gb[6] + ga[7] * gb[7] + ga[8] * gb[8]);
     const T m01 = ff * (ga[6] * gb[9] + ga[7] * gb[10] + ga[8] * gb[11]);
@@ -404,15 +405,15 @@ __device__ __forceinline__ void pair_product_factored(const T ga[GREC], const T 
     for (int r = 0; r < 3; ++r) {
         const T t0 = Tm[3 * r], t1 = Tm[3 * r + 1], t2 = Tm[3 * r + 2];
         // -(T[r, :] [X_b]x) = X_b x T[r, :]
-        acc[6 * r + 0] += b1 * t2 - b2 * t1;
-        acc[6 * r + 1] += b2 * t0 - b0 * t2;
-        acc[6 * r + 2] += b0 * t1 - b1 * t0;
-        acc[6 * r + 3] += t0; acc[6 * r + 4] += t1; acc[6 * r + 5] += t2;
+        acc[6 * r + 0] += (A)(b1 * t2 - b2 * t1);
+        acc[6 * r + 1] += (A)(b2 * t0 - b0 * t2);
+        acc[6 * r + 2] += (A)(b0 * t1 - b1 * t0);
+        acc[6 * r + 3] += (A)t0; acc[6 * r + 4] += (A)t1; acc[6 * r + 5] += (A)t2;
         const T n0 = N[3 * r], n1 = N[3 * r + 1], n2 = N[3 * r + 2];
-        acc[6 * (3 + r) + 0] += b1 * n2 - b2 * n1;
-        acc[6 * (3 + r) + 1] += b2 * n0 - b0 * n2;
-        acc[6 * (3 + r) + 2] += b0 * n1 - b1 * n0;
-        acc[6 * (3 + r) + 3] += n0; acc[6 * (3 + r) + 4] += n1; acc[6 * (3 + r) + 5] += n2;
+        acc[6 * (3 + r) + 0] += (A)(b1 * n2 - b2 * n1);
+        acc[6 * (3 + r) + 1] += (A)(b2 * n0 - b0 * n2);
+        acc[6 * (3 + r) + 2] += (A)(b0 * n1 - b1 * n0);
+        acc[6 * (3 + r) + 3] += (A)n0; acc[6 * (3 + r) + 4] += (A)n1; acc[6 * (3 + r) + 5] += (A)n2;
     }
 }
 

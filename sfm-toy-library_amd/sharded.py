@@ -110,7 +110,41 @@ class HipShardBackend:
             self._h = C.c_void_p()
 
 
+class HipRowShardBackend(HipShardBackend):
+    """Rank-local half of the ROW-SHARDED solve (SFMBA_CREATE_ROW_SHARDED, options.shard_distributed_cg = 3): every rank is given the
+    WHOLE problem and owns a range of points, a share of the camera-major list and a range of block rows of the reduced matrix; after
+    a solve every rank holds the whole solution.  Driven by solve_sharded_native only."""
+
+    CREATE_ROW_SHARDED = 2
+
+    def __init__(self, full_prob, rank, world, device=0, precision=1, flags=0):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.device = rank, world, device
+        self._point_range = (0, full_prob.n_pt)
+        self._template = (np.ascontiguousarray(full_prob.cam6, np.float64).copy(), np.ascontiguousarray(full_prob.pt3, np.float64).copy())
+        cam6, pt3 = self._template
+        oc = np.ascontiguousarray(full_prob.obs_cam, np.int32)
+        op = np.ascontiguousarray(full_prob.obs_pt, np.int32)
+        oxy = np.ascontiguousarray(full_prob.obs_xy, np.float64)
+        self._h = C.c_void_p()
+        L = capi.lib()
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        capi._check(L.sfmba_problem_create_ex(
+            C.c_int(device), C.c_int(precision), C.c_int(flags | self.CREATE_ROW_SHARDED), C.c_int(full_prob.n_cam), cam6.ctypes.data_as(dp),
+            C.cast(None, C.POINTER(C.c_ubyte)), C.c_int(full_prob.n_pt), pt3.ctypes.data_as(dp), C.c_int64(full_prob.n_obs),
+            oc.ctypes.data_as(ip), op.ctypes.data_as(ip), oxy.ctypes.data_as(dp), C.c_double(full_prob.focal),
+            C.c_int(rank), C.c_int(world), C.byref(self._h)))
+        self.L = L
+        self.stream = torch.cuda.ExternalStream(L.sfmba_problem_stream(self._h), device=torch.device("cuda", device))
+        dev = "cuda:%d" % device
+        self.reduce_t = torch.as_tensor(_DevicePtr(L.sfmba_shard_reduce_buf(self._h), L.sfmba_shard_reduce_len(self._h)), device=dev)
+        self.setup_t = torch.as_tensor(_DevicePtr(L.sfmba_shard_setup_buf(self._h), L.sfmba_shard_setup_len(self._h)), device=dev)
+        self.scalars_t = torch.as_tensor(_DevicePtr(L.sfmba_shard_scalars_buf(self._h), 80), device=dev)
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 REDUCE_SCATTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 
@@ -148,10 +182,12 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
     keep = None
     fn32 = None
     rs = None
+    ag = None
     if comm is not None:
         fn, ctx = C.cast(L.sfmba_comm_allreduce, ALLREDUCE_FN), comm._h
         fn32 = C.cast(L.sfmba_comm_allreduce_f32, ALLREDUCE_FN)
         rs = C.cast(L.sfmba_comm_reduce_scatter, REDUCE_SCATTER_FN)
+        ag = C.cast(L.sfmba_comm_allgather, ALLGATHER_FN)
     elif dist is not None and backend.world > 1:
         by_ptr = {int(L.sfmba_shard_setup_buf(backend._h)): "setup", int(L.sfmba_shard_reduce_buf(backend._h)): "reduce",
                   int(L.sfmba_shard_scalars_buf(backend._h)): "scalars"}
@@ -191,16 +227,28 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
                 return 0
             except Exception:
                 return 1
+        def _ag(_ctx, buf, nbytes, _stream):
+            # gloo has no all-gather of device tensors: one broadcast per slice (bytes, no arithmetic)
+            try:
+                t = backend.torch.as_tensor(_DevicePtrT(buf, int(nbytes) * backend.world, "|u1"), device="cuda:%d" % backend.device)
+                with backend.torch.cuda.stream(backend.stream):
+                    for r in range(backend.world):
+                        dist.broadcast(t[r * int(nbytes):(r + 1) * int(nbytes)], src=r, group=group)
+                return 0
+            except Exception:
+                return 1
         fn = ALLREDUCE_FN(_cb_generic)
         fn32 = ALLREDUCE_FN(_cb32)
         rs = REDUCE_SCATTER_FN(_rs)
-        keep = (fn, fn32, rs)
+        ag = ALLGATHER_FN(_ag)
+        keep = (fn, fn32, rs, ag)
         ctx = None
     else:
         fn, ctx = C.cast(None, ALLREDUCE_FN), None
     # the single-precision all-reduce is optional (exchange (B) in fp32 where the CG stores the matrix in fp32, include/sfmba.h)
     capi._check(L.sfmba_problem_set_allreduce_f32(backend._h, fn32 if fn32 is not None else C.cast(None, ALLREDUCE_FN)))
     capi._check(L.sfmba_problem_set_reduce_scatter(backend._h, rs if rs is not None else C.cast(None, REDUCE_SCATTER_FN)))
+    capi._check(L.sfmba_problem_set_allgather(backend._h, ag if ag is not None else C.cast(None, ALLGATHER_FN)))
     capi._check(L.sfmba_problem_solve_sharded(backend._h, C.byref(opt), fn, ctx, C.byref(summ)))
     del keep
     out = summ.as_dict()
@@ -210,6 +258,7 @@ def solve_sharded_native(backend, opt, comm=None, dist=None, group=None):
     out["exchange_b_fp32"] = bool(ex[3] & 1)
     out["distributed_cg"] = bool(ex[3] & 2)
     out["implicit_schur_cg"] = bool(ex[3] & 4)
+    out["row_sharded"] = bool(ex[3] & 8)
     return out
 
 

@@ -6,6 +6,8 @@ TERMINATION_NAMES = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
 LINEAR_CHOLESKY, LINEAR_PCG, LINEAR_AUTO = 0, 1, 2
 PRECISION_F64, PRECISION_F32J = 0, 1
 CREATE_DETERMINISTIC = 1
+CREATE_ROW_SHARDED = 2      # every rank holds the whole problem (sharded.HipRowShardBackend)
+CREATE_NO_PAIR_LIST = 4     # matrix-free solve: no list of observation pairs, the reduced matrix is never formed
 
 
 class SfmbaOptions(C.Structure):

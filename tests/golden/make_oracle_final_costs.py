@@ -1,0 +1,22 @@
+"""Regenerates tests/golden/oracle_final_costs.json: iterations and final cost of oracle/sfmba_oracle.c (the CPU restatement of the reference's
+ceres::Solve, reference options BA.cpp:171-177 without the 10 s limit) on the BASELINE configurations -- what bench.py's `extra_workloads` and the
+full-size GPU tests hold the HIP path to.  cfg5 takes ~3 minutes on 16 threads.     python tests/golden/make_oracle_final_costs.py [names...]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import sfm_toy_library_amd as sfm
+from oracle import oracle_py as oracle
+
+path = os.path.join(ROOT, "tests", "golden", "oracle_final_costs.json")
+out = json.load(open(path)) if os.path.exists(path) else {}
+for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg3_banded", "cfg5"]):
+    prob = sfm.make_problem(name)
+    s = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))[3]
+    out[name] = {"n_cam": prob.n_cam, "n_pt": prob.n_pt, "n_obs": prob.n_obs, "iterations": s["iterations"], "termination": s["termination_name"],
+                 "initial_cost": s["initial_cost"], "final_cost": s["final_cost"], "final_rms_px": float(np.sqrt(2 * s["final_cost"] / prob.n_obs))}
+    print(name, out[name])
+json.dump(out, open(path, "w"), indent=1, sort_keys=True)

@@ -190,25 +190,26 @@ def test_sharded_switches_and_deterministic_sharded(capi, sfm, mid):
     assert abs(runs[0][1] - ref[3]["final_cost"]) <= 1e-9 * ref[3]["final_cost"] and np.abs(runs[0][0][0] - ref[0]).max() < 2e-6
 
 
-def test_implicit_schur_cg_steps_aside_for_duplicate_observations(capi, sfm, mid):
-    """shard_distributed_cg = 2 applies the off-diagonal part of the reduced matrix implicitly, from pairs of observations of DIFFERENT cameras on
-    a point; pairs of one camera on a point (duplicate observations, which the C ABI allows) live in the diagonal blocks.  A problem that has
-    them must run as form 1 (blocks reduce-scattered) -- and give the unsharded solve's result either way."""
+def test_implicit_schur_cg_with_duplicate_observations(capi, sfm, mid):
+    """shard_distributed_cg = 2 applies the reduced matrix implicitly, from ALL pairs of observations of a point -- pairs of ONE camera on a
+    point (duplicate observations, which the C ABI allows) included.  Round 4 made such a problem step aside to form 1, decided from the
+    rank's OWN duplicate count: ranks could disagree on the form and issue different collectives (ADVICE r4).  Now the duplicates' cross
+    terms are simply not added to the diagonal blocks in this form (they stay a preconditioner) and the implicit product carries them:
+    every rank takes the form the options name, and the result is the unsharded solve's."""
     from sfm_toy_library_amd.sharded import HipShardBackend, solve_sharded_native
     extra = np.arange(0, mid.n_obs, 7)
     dup = sfm.BAProblem(mid.cam6, mid.pt3, mid.focal, np.concatenate([mid.obs_cam, mid.obs_cam[extra]]),
                         np.concatenate([mid.obs_pt, mid.obs_pt[extra]]), np.concatenate([mid.obs_xy, mid.obs_xy[extra] + 0.25]))
     opt = capi.default_options(max_seconds=0.0, linear_solver=1, precision=0, pcg_tolerance=1e-12, pcg_anchored=0)
-    ref = capi.solve(dup, opt)
-    for prob, implicit in ((dup, False), (mid, True)):
+    for prob in (dup, mid):
+        ref = capi.solve(prob, opt)
         be = HipShardBackend(prob, 0, 1, device=0, precision=0)
         try:
             s = solve_sharded_native(be, capi.default_options(max_seconds=0.0, linear_solver=1, precision=0, pcg_tolerance=1e-12, pcg_anchored=0,
                                                               shard_distributed_cg=2), comm=None)
-            assert s["distributed_cg"] and s["implicit_schur_cg"] == implicit and s["termination_name"] == "CONVERGENCE"
-            if prob is dup:
-                assert s["iterations"] == ref[3]["iterations"] and abs(s["final_cost"] - ref[3]["final_cost"]) <= 1e-9 * ref[3]["final_cost"]
-                assert np.abs(be.get_params()[0] - ref[0]).max() < 1e-7
+            assert s["distributed_cg"] and s["implicit_schur_cg"] and s["termination_name"] == "CONVERGENCE"
+            assert s["iterations"] == ref[3]["iterations"] and abs(s["final_cost"] - ref[3]["final_cost"]) <= 1e-9 * ref[3]["final_cost"]
+            assert np.abs(be.get_params()[0] - ref[0]).max() < 1e-7
         finally:
             be.close()
 

@@ -39,10 +39,18 @@ CASES = {
     "dist_imp_wide": (dict(name="cfg3", n_cam=230, n_pt=6001, seed=78), 1, 1, dict(shard_distributed_cg=2)),
     "dist_imp_auto": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 0, 2, dict(shard_distributed_cg=2)),
     "dist_imp_plain": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 1, 1, dict(shard_distributed_cg=2, pcg_coarse_space=-1)),
+    # ... and with the block ROWS of the reduced matrix sharded (SFMBA_CREATE_ROW_SHARDED: every rank holds the whole problem,
+    # the per-point table is all-gathered, the pair pass forms the rank's own block rows from all their pairs, the multi-workgroup distributed CG
+    # runs on them) -- fp64 blocks, fp32 blocks (d = 1381, F32J), the library default (AUTO), plain block-Jacobi, the reference's solver choice
+    "row_cfg2": (dict(name="cfg2", n_pt=5003), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
+    "row_wide": (dict(name="cfg3", n_cam=230, n_pt=6001, seed=78), 1, 1, dict()),
+    "row_auto": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 0, 2, dict()),
+    "row_plain": (dict(name="cfg3", n_cam=60, n_pt=8003, seed=5), 1, 1, dict(pcg_coarse_space=-1)),
+    "row_chol": (dict(name="cfg2", n_pt=5003), 0, 0, dict()),
 }
 
 
-def _worker(rank, world, port, case, out, native=False, n_repeats=12):
+def _worker(rank, world, port, case, out, native=False, n_repeats=12, flags=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -51,10 +59,10 @@ def _worker(rank, world, port, case, out, native=False, n_repeats=12):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sfm_toy_library_amd as sfm
     from sfm_toy_library_amd import capi
-    from sfm_toy_library_amd.sharded import HipShardBackend, solve_sharded, solve_sharded_native
+    from sfm_toy_library_amd.sharded import HipShardBackend, HipRowShardBackend, solve_sharded, solve_sharded_native
     kw, precision, linear, okw = CASES[case]
     prob = sfm.make_problem(**kw)
-    backend = HipShardBackend(prob, rank, world, device=0, precision=precision)
+    backend = (HipRowShardBackend if case.startswith("row_") else HipShardBackend)(prob, rank, world, device=0, precision=precision, flags=flags)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw)
     summ = solve_sharded_native(backend, opt, dist=dist) if native else solve_sharded(backend, dist, opt)
     cam, pt, f = backend.get_params()
@@ -213,3 +221,98 @@ def test_multi_rank_uneven_sharded_hip_solve(sfm, oracle, world, case):
     atol = 1e-7 if exact else 5e-6
     assert np.abs(cam0 - cam_o).max() <= atol and np.isclose(f0, f_o, rtol=1e-9 if exact else 1e-7)
     assert np.abs(pts - pt_o).max() <= atol
+
+
+@pytest.mark.parametrize("world,case,flags", [(2, "row_cfg2", 0), (3, "row_cfg2", 0), (4, "row_wide", 0), (3, "row_auto", 0), (2, "row_plain", 0),
+                                              (4, "row_cfg2", 0), (3, "row_wide", 0), (2, "row_chol", 0), (3, "row_cfg2", 1)])
+def test_row_sharded_hip_solve(sfm, oracle, world, case, flags):
+    """block rows of the reduced matrix per rank (options.shard_distributed_cg = 3, SFMBA_CREATE_ROW_SHARDED).  2, 3 and 4
+    ranks (processes) on the one MI355X, point counts no world size divides, native C loop with the collectives -- all-reduce AND the
+    all-gather of the per-point table -- through callbacks; against the ORACLE's solve of the whole problem.  Every rank ends up with the
+    WHOLE solution (the final points are all-gathered): replicas bit-identical in cameras AND points.  flags = 1: deterministic handles."""
+    kw, precision, linear, okw = CASES[case]
+    port = 29011 + (os.getpid() % 300) + 11 * world
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, True, 2, flags)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([out.get(timeout=420) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prob = sfm.make_problem(**kw)
+    assert prob.n_pt % world != 0
+    cam0, pts0, f0, s0 = results[0][2], results[0][3], results[0][4], results[0][1]
+    assert s0["distributed_cg"] and s0["row_sharded"] and not s0["implicit_schur_cg"]
+    assert pts0.shape == (prob.n_pt, 3)
+    for r in results[1:]:
+        assert np.array_equal(r[2], cam0) and r[4] == f0 and r[1]["final_cost"] == s0["final_cost"]     # replicas bit-identical
+        assert np.array_equal(r[3], pts0)                                                               # ... points included
+        for a, b in zip(results[0][6], r[6]):
+            assert np.array_equal(a, b)
+    if flags & 1:                                            # deterministic handles: the repeats are the first solve bit for bit
+        for a in results[0][6]:
+            assert np.array_equal(a, cam0)
+    cam_o, pt_o, f_o, s_o, _ = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    exact = precision == 0
+    assert s0["termination_name"] == s_o["termination_name"] == "CONVERGENCE" and s0["iterations"] == s_o["iterations"]
+    assert abs(s0["final_cost"] - s_o["final_cost"]) <= (1e-9 if exact else 1e-6) * s_o["final_cost"]
+    assert abs(np.sqrt(2 * s0["final_cost"] / prob.n_obs) - np.sqrt(2 * s_o["final_cost"] / prob.n_obs)) < 1e-4
+    atol = 1e-7 if exact else 5e-6
+    assert np.abs(cam0 - cam_o).max() <= atol and np.isclose(f0, f_o, rtol=1e-9 if exact else 1e-7)
+    assert np.abs(pts0 - pt_o).max() <= atol
+
+
+@pytest.mark.parametrize("case", ["row_cfg2", "row_wide", "row_auto"])
+def test_row_sharded_one_rank_with_and_without_rccl(sfm, oracle, case):
+    """One rank: the row-sharded loop through an RCCL communicator of one rank (ncclAllReduce AND ncclAllGather on the solver's stream)
+    and without any collective call; both = the oracle's solve."""
+    from sfm_toy_library_amd import capi
+    from sfm_toy_library_amd.sharded import HipRowShardBackend, RcclComm, solve_sharded_native
+    kw, precision, linear, okw = CASES[case]
+    prob = sfm.make_problem(**kw)
+    want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    be = HipRowShardBackend(prob, 0, 1, device=0, precision=precision)
+    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw)
+    comm = RcclComm(None, 0, 1, device=0)
+    exact = precision == 0
+    try:
+        for c in (comm, None):
+            be.reset()
+            s = solve_sharded_native(be, opt, comm=c)
+            cam, pt, f = be.get_params()
+            assert s["row_sharded"] and s["termination_name"] == "CONVERGENCE" and s["iterations"] == want[3]["iterations"]
+            assert abs(s["final_cost"] - want[3]["final_cost"]) <= (1e-9 if exact else 1e-6) * want[3]["final_cost"]
+            assert np.abs(cam - want[0]).max() < (1e-7 if exact else 5e-6) and np.abs(pt - want[1]).max() < (1e-7 if exact else 5e-6)
+    finally:
+        comm.close(); be.close()
+
+
+def test_rccl_bindings_execute_on_one_rank():
+    """sfmba_comm_reduce_scatter, sfmba_comm_allreduce_f32 and sfmba_comm_allgather had never been executed (the 2 - 4
+    rank tests go through gloo callbacks).  A communicator of ONE rank drives each binding through RCCL itself; with one rank every
+    collective is the identity on its input."""
+    import ctypes as C
+    import torch
+    from sfm_toy_library_amd import capi
+    from sfm_toy_library_amd.sharded import RcclComm
+    L = capi.lib()
+    comm = RcclComm(None, 0, 1, device=0)
+    try:
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        a64 = torch.rand(4099, dtype=torch.float64, device="cuda", generator=g); w64 = a64.clone()
+        assert L.sfmba_comm_allreduce(comm._h, C.c_void_p(a64.data_ptr()), C.c_int64(a64.numel()), st) == 0
+        a32 = torch.rand(4099, dtype=torch.float32, device="cuda", generator=g); w32 = a32.clone()
+        assert L.sfmba_comm_allreduce_f32(comm._h, C.c_void_p(a32.data_ptr()), C.c_int64(a32.numel()), st) == 0
+        r64 = torch.rand(3 * 36 * 7, dtype=torch.float64, device="cuda", generator=g); wr64 = r64.clone()
+        assert L.sfmba_comm_reduce_scatter(comm._h, C.c_void_p(r64.data_ptr()), C.c_void_p(r64.data_ptr()), C.c_int64(r64.numel()), C.c_int(0), st) == 0
+        r32 = torch.rand(3 * 36 * 7, dtype=torch.float32, device="cuda", generator=g); wr32 = r32.clone()
+        assert L.sfmba_comm_reduce_scatter(comm._h, C.c_void_p(r32.data_ptr()), C.c_void_p(r32.data_ptr()), C.c_int64(r32.numel()), C.c_int(1), st) == 0
+        gb = torch.randint(0, 255, (64 * 1001,), dtype=torch.uint8, device="cuda", generator=g); wgb = gb.clone()
+        assert L.sfmba_comm_allgather(comm._h, C.c_void_p(gb.data_ptr()), C.c_int64(gb.numel()), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(a64, w64) and torch.equal(a32, w32) and torch.equal(r64, wr64) and torch.equal(r32, wr32) and torch.equal(gb, wgb)
+    finally:
+        comm.close()
