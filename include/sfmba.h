@@ -117,16 +117,18 @@ typedef struct sfmba_options {
                                          |r| <= tol * max(|b_k|, |b_first|), never looser than 1e-4 |b_k| -- every LM step is then solved
                                          to the same ABSOLUTE accuracy (dense_solver.hip).  0: plain relative residual. */
     /* ---- ABI v4: behaviour switches that were environment variables only (a C caller could not set them per problem or
-       thread-safely).  0 = library default, 1 = on, -1 = off.  The environment variable named beside each switch, when set,
-       still OVERRIDES the field (process-wide debugging aid; "0" = off, anything else = on). ---- */
+       thread-safely).  0 = library default, 1 = on, -1 = off.  ABI v4 let the environment variable named beside each switch
+       override the field; since ABI v5 NOTHING below sfmba_problem_create* reads the environment: the fields are the only way
+       (what is still read from the environment, when a problem is BUILT: SFMBA_DETERMINISTIC, SFMBA_PAIR_LPB, SFMBA_PAIR_LIMIT,
+       SFMBA_BUILD_TIMING). ---- */
     int    pcg_coarse_space;          /* SFMBA_PCG_COARSE         default on : two-level CG preconditioner (8 gauge vectors).  Where the reduced
                                          matrix is sparsely filled (< 1/2 of its blocks) with >= 90 % of the blocks within a quarter of the cyclic camera
                                          order -- views registered along a path -- and >= 32 cameras, the seven similarity vectors are used restricted to
                                          overlapping SEGMENTS of the camera order (eight up to 213 cameras, cameras / 25 <= 20 up to 1007: 3 - 15x fewer CG
                                          iterations there; AUTO keeps that CG above 213 cameras instead of factorising).
-                                         1 = the eight global vectors only, 2 = the segments wherever they apply (SFMBA_PCG_SEGMENTS=0|1 likewise).
+                                         1 = the eight global vectors only, 2 = the segments wherever they apply.
                                          The sharded solve keeps the eight global vectors (the choice would have to be agreed between the ranks). */
-    int    pcg_persistent;            /* SFMBA_PCG_PERSISTENT     default off: whole CG solve in one cooperative launch (d <= 1280) */
+    int    pcg_persistent;            /* reserved (ABI v4: whole CG solve in one cooperative launch; never the default at any size, removed in ABI v5): ignored */
     int    pcg_f32_matrix;            /* SFMBA_PCG_F32_MATRIX     default on : F32J + streaming CG (d > 1280) store S~ in fp32 */
     int    early_linearise;           /* SFMBA_EARLY_LINEARISE    default on : next linearisation enqueued before the host reads the verdict */
     int    shard_two_phase;           /* SFMBA_SHARD_TWO_PHASE    default on : sharded CG path exchanges (A) diagonal data, (B) preconditioned blocks */
@@ -135,7 +137,7 @@ typedef struct sfmba_options {
                                          reduce-scatter of the upper-triangle blocks of S~ into ranges of block rows (half the bytes of the
                                          all-reduce), every rank multiplies the blocks it owns, one all-reduce of ld doubles per CG
                                          iteration's partial product (needs sfmba_problem_set_reduce_scatter when world > 1).
-                                         2 (SFMBA_SHARD_DIST_CG=2): the same CG with the product formed IMPLICITLY -- no pair pass, no
+                                         2: the same CG with the product formed IMPLICITLY -- no pair pass, no
                                          exchange (B) at all: per CG iteration every rank applies its own points' W V^-1 W^T to the
                                          all-reduced vector (two passes over its observations) and the ranks all-reduce ld doubles
                                          (needs no reduce-scatter; duplicate (camera, point) observations are part of the implicit
@@ -379,7 +381,7 @@ SFMBA_API int  sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options
 /* Optional single-precision all-reduce (same ctx as the fp64 one).  Where the CG stores the preconditioned matrix in fp32 anyway
  * (SFMBA_PRECISION_F32J and more than 1280 reduced unknowns: the streaming CG path) exchange (B) -- by far the largest: 18 Nc (Nc - 1)
  * values, 144 MB in fp64 at 1000 cameras -- is then summed and stored in fp32: half the bytes over xGMI, and the summed buffer is the
- * CG's matrix without a narrowing pass.  Without it (or with SFMBA_SHARD_F32_EXCHANGE=0) every exchange stays fp64. */
+ * CG's matrix without a narrowing pass.  Without it (or with options.shard_f32_exchange = -1) every exchange stays fp64. */
 typedef int (*sfmba_allreduce_f32_fn)(void* ctx, void* device_buf, int64_t n_floats, void* hip_stream);
 SFMBA_API int  sfmba_comm_allreduce_f32(void* comm /* sfmba_comm* */, void* device_buf, int64_t n_floats, void* hip_stream);   /* an sfmba_allreduce_f32_fn */
 SFMBA_API int  sfmba_problem_set_allreduce_f32(sfmba_problem* p, sfmba_allreduce_f32_fn allreduce_f32);                        /* NULL: fp64 only */

@@ -87,8 +87,14 @@ struct DeviceStructure {
     const int* obs_pt;        // [nobs] point slot, point-major order
     int nchunk;
     const int4* chunks;       // [nchunk] {camera slot, begin, end (camera-major entries), 0}: SFMBA_CAM_CHUNK entries each (k_cam_diag)
+    const int* chunk_order;   // [nchunk] launch order of the chunks: workgroup b takes chunk chunk_order[b].  Chunks are listed camera by camera (a camera's
+                              //       entries ascend in point slot); launched in that order, neighbouring workgroups walk ONE camera's list across the whole
+                              //       per-point table and every gather misses L2 once the table outgrows it (BASELINE config 5: 120 bytes of HBM-side traffic per
+                              //       observation).  Ordered by the chunk's relative position inside its camera's list instead, the workgroups in flight
+                              //       gather from the same window of the table whatever their camera.  Never null.
     int nchunk_coarse;
     const int4* chunks_coarse; // the same list cut every 1024 entries (column-norm pass: a block loops over its chunk); deterministic mode: one chunk per camera
+    const int* coarse_order;   // [nchunk_coarse] the same for the coarse chunks
     const int* cam_chunk_ptr;  // [ncam+1] first k_cam_diag chunk of every camera (deterministic mode)
     // camera-pair lists of the reduced-system pass: block b = (ja <= jb); pairs sorted by block
     int nblock;
@@ -176,7 +182,8 @@ void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffe
 void launch_cd_fold(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // deterministic + sharded: chunk sums into the partial system (before the exchange)
 void launch_gauge(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // gauge vectors from db.pcg_binv (see k_gauge)
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
+// fuse_control: the last workgroup to arrive runs the LM control logic (k_lm_control) -- no control launch behind this one
+template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, bool fuse_control = false);
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_eval_residuals(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(BLK) void k_colnorm_points(DeviceStructure ds, Devi
 template <typename T>
 __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[(BLK / 64) * 7];
-    const int4 ch = ds.chunks_coarse[blockIdx.x];
+    const int4 ch = ds.chunks_coarse[ds.coarse_order[blockIdx.x]];
     const int j = ch.x;
     const int cur = db.st->cur;
     const CamRow ct = { db.camtab[cur] + 4 * (size_t)(j), ds.ncam };
@@ -903,7 +903,7 @@ __device__ __forceinline__ void cam_diag_terms(const T (&rec)[YREC], const T (&z
 // sums of the 47 terms over the workgroup (fp64: halving butterfly inside the wave, LDS across the waves) and one atomic per value
 // per workgroup -- or, deterministic mode, the per-chunk slot that k_finalize / k_cd_fold add in chunk order
 template <typename T>
-__device__ __forceinline__ void cam_diag_finish(const DeviceStructure& ds, const DeviceBuffers& db, int j, T (&v)[CD_N], double (*red)[CD_N]) {
+__device__ __forceinline__ void cam_diag_finish(const DeviceStructure& ds, const DeviceBuffers& db, int j, int chunk_id, T (&v)[CD_N], double (*red)[CD_N]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // first halving step on the T values (one 32-bit shuffle each), the rest in fp64
     double acc[CD_N / 2];
@@ -926,7 +926,7 @@ __device__ __forceinline__ void cam_diag_finish(const DeviceStructure& ds, const
 #pragma unroll
         for (int ww = 0; ww < CD_BLK / 64; ++ww) s += red[ww][k];
         const int row0 = 6 * j, fo = ds.d - 1;
-        if (db.cd_part && k < 45) { db.cd_part[(size_t)blockIdx.x * 48 + k] = s; return; }      // deterministic mode: k_finalize adds the chunks in order
+        if (db.cd_part && k < 45) { db.cd_part[(size_t)chunk_id * 48 + k] = s; return; }      // deterministic mode: k_finalize adds the chunks in order
         if (k < 21) {
             int a = 0, rem = k;
             while (rem >= 6 - a) { rem -= 6 - a; ++a; }
@@ -955,7 +955,8 @@ __device__ __forceinline__ void cam_diag_finish(const DeviceStructure& ds, const
 template <typename T>
 __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double red[CD_BLK / 64][CD_N];
-    const int4 ch = ds.chunks[blockIdx.x];
+    const int chunk_id = ds.chunk_order[blockIdx.x];
+    const int4 ch = ds.chunks[chunk_id];
     const int j = ch.x;
     const LMState* st = db.st;
     const int cur = st->cur;
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(CD_BLK) void k_cam_diag_f(DeviceStructure ds, Devic
         z[4] = rr.x; z[5] = rr.y; z[6] = (T)0; z[7] = (T)0;
         cam_diag_terms<T, (CD_OBS > 1)>(rec, z, db.cscale + 6 * j, fscale, v);
     }
-    cam_diag_finish<T>(ds, db, j, v, red);
+    cam_diag_finish<T>(ds, db, j, chunk_id, v, red);
 }
 
 
@@ -1534,6 +1535,116 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), db.shared_weight * s2); atomicAdd(slot_ptr(db, ACC_XNEW2), db.shared_weight * x2); }
 }
 
+// ------------------------------------------------------------------------------------------
+// LM control: the accept/reject logic of ceres::internal::TrustRegionMinimizer::Minimize()
+// [Ceres-upstream], one thread.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lm_post(int* mb, int seq, int termination, int message, int iter, int cg_iters = 0) {
+    if (!mb) return;
+    __hip_atomic_store(mb + 4, cg_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mb + 1, termination, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mb + 2, message, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mb + 3, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mb, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// (all 64 lanes of ONE wave; every accumulator it reads must be complete and visible: a kernel of its own behind the passes, or the last
+// workgroup to arrive of k_point_update<T, true>)
+__device__ __forceinline__ void lm_control_body(const DeviceBuffers& db) {
+    LMState* st = db.st;
+    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) {
+        // the linear solve has not converged within the launches enqueued so far: tell the host (termination code -2),
+        // touch nothing -- it will enqueue more CG iterations followed by the same three kernels
+        if ((threadIdx.x & 63) == 0) { st->retry = 1; const int seq = ++st->mail_seq; lm_post(db.lm_mailbox, seq, -2, 0, st->iter); }
+        return;
+    }
+    double trial2, model, step2, xnew2, bad_trial;
+    if (db.shard_scal) {
+        // sharded solve: the sums over the ranks sit in the all-reduced scalar block (k_shard_pack emptied the slots)
+        trial2 = db.shard_scal[0]; model = db.shard_scal[1]; step2 = db.shard_scal[2]; xnew2 = db.shard_scal[3]; bad_trial = db.shard_scal[4];
+    } else {
+        const int ctl_acc[5] = { ACC_TRIAL_COST, ACC_MODEL, ACC_STEP2, ACC_XNEW2, ACC_BAD_TRIAL };
+        double ctl[5];
+        slots_take_n<5>(db, ctl_acc, ctl);
+        trial2 = ctl[0]; model = ctl[1]; step2 = ctl[2]; xnew2 = ctl[3]; bad_trial = ctl[4];
+    }
+    if ((threadIdx.x & 63) != 0) return;
+    st->retry = 0;
+    st->lin_info = *db.lin_info;
+    *db.lin_info = 0;
+    const int seq = ++st->mail_seq;
+    const int cg_iters = db.cg_gate ? db.cg_gate[1] : 0;          // CG iterations of this LM iteration (device-side count)
+    if (st->termination != -1) { if (db.st_mirror) *db.st_mirror = *st; lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters); return; }
+    const int it = ++st->iter;
+    TraceRow row = {};
+    row.iteration = it;
+    const bool lin_fail = st->lin_info != 0 || !finite_d(step2) || !finite_d(model);
+    const bool step_valid = !lin_fail && model > 0.0;
+    row.step_is_valid = step_valid;
+    row.gradient_max_norm = st->gmax;
+    double report_cost = st->cost;
+    st->last_step_successful = 0;
+    if (!step_valid) {
+        if (++st->consecutive_invalid >= st->max_consecutive_invalid) {
+            st->termination = SFMBA_FAILURE;
+            st->message = MSG_INVALID_STEPS;
+        } else {
+            st->radius *= 0.5;
+            st->unsuccessful++;
+        }
+    } else {
+        st->consecutive_invalid = 0;
+        double cand = 0.5 * trial2;
+        if (bad_trial != 0.0 || !finite_d(cand)) cand = DBL_MAX;
+        st->residual_evals++;
+        row.step_norm = sqrt(step2);
+        const double step_tol = st->parameter_tolerance * (st->x_norm + st->parameter_tolerance);
+        if (row.step_norm <= step_tol) {
+            st->termination = SFMBA_CONVERGENCE;
+            st->message = MSG_PARAMETER_TOL;
+        } else {
+            row.cost_change = st->cost - cand;
+            if (fabs(row.cost_change) <= st->function_tolerance * st->cost) {
+                st->termination = SFMBA_CONVERGENCE;
+                st->message = MSG_FUNCTION_TOL;
+            } else {
+                row.relative_decrease = row.cost_change / model;
+                if (row.relative_decrease > st->min_relative_decrease) {
+                    row.step_is_successful = 1;
+                    st->last_step_successful = 1;
+                    st->cur ^= 1;
+                    st->cost = cand;
+                    st->x_norm = sqrt(xnew2);
+                    const double t = 2.0 * row.relative_decrease - 1.0;
+                    st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+                    st->radius = fmin(st->max_radius, st->radius);
+                    st->decrease_factor = 2.0;
+                    st->successful++;
+                    st->x_is_new = 1;
+                    report_cost = cand;
+                } else {
+                    st->radius = st->radius / st->decrease_factor;
+                    st->decrease_factor *= 2.0;
+                    st->unsuccessful++;
+                    report_cost = cand;
+                }
+            }
+        }
+    }
+    if (st->termination == -1 && st->radius <= st->min_radius) {
+        st->termination = SFMBA_CONVERGENCE;
+        st->message = MSG_MIN_RADIUS;
+    }
+    row.cost = report_cost;
+    row.trust_region_radius = st->radius;
+    if (it < db.trace_cap) db.trace[it] = row;
+    st->lin_info = 0;
+    if (db.st_mirror) *db.st_mirror = *st;      // plain stores; the release store of the sequence number in lm_post orders them
+    lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters);
+}
+
+__global__ void k_lm_control(DeviceBuffers db) { lm_control_body(db); }
+
 // Back-substitution + trial point, four lanes per point like k_point_build:
 //   y_p = (V + D^2)^-1 (b_p - W^T y_c), trial point, model cost change, trial cost.
 // With V + D^2 = L L^T, t = L^-1 b_p and C = B~ L^-T (left behind per POINT by k_point_build: pt_t, M = diag(s_p) L^-T, the table entry):
@@ -1552,10 +1663,34 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
 // -- so the second sweep over the observations only evaluates the TRIAL residual (projection with the trial pose at the trial point): nothing
 // per observation has to survive the first sweep, no LDS, and the per-point arithmetic runs on all lanes (the lane-per-observation form
 // of the first half of round 4: 33.6 against 29.9 us at BASELINE config 3, 242 against 189 at config 5).
-template <typename T>
+// The last workgroup of the launch to arrive (agent-scope release / acquire around a ticket counter, as k_finalize) runs the LM control logic:
+// k_lm_control as a launch of its own was 5.9 us at the floor of a launch, three times per BASELINE-config-3 solve.
+__device__ __forceinline__ bool arrive_last(const DeviceBuffers& db, int* s_last) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(db.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = (ticket == (int)gridDim.x - 1);
+        if (*s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(db.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return *s_last != 0;
+}
+
+template <typename T, bool FUSE_CONTROL>
 __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[WPB * 5];
-    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // see k_cam_update
+    __shared__ int s_last;
+    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) {      // see k_cam_update
+        // (the CG's done flag was written by launches in front of this one: every workgroup sees the same value)
+        if (FUSE_CONTROL) { if (arrive_last(db, &s_last) && threadIdx.x < 64) lm_control_body(db); }
+        return;
+    }
     const LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
     const double* tab = db.camtab[cur];
@@ -1664,6 +1799,7 @@ __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, Dev
         const int which = threadIdx.x == 0 ? ACC_TRIAL_COST : threadIdx.x == 1 ? ACC_MODEL : threadIdx.x == 2 ? ACC_STEP2 : threadIdx.x == 3 ? ACC_XNEW2 : ACC_BAD_TRIAL;
         if (threadIdx.x < 4 || tot != 0.0) atomicAdd(slot_ptr(db, which), tot);
     }
+    if (FUSE_CONTROL) { if (arrive_last(db, &s_last) && threadIdx.x < 64) lm_control_body(db); }
 }
 
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
@@ -1671,118 +1807,14 @@ void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuf
 }
 
 template <typename T>
-void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
+void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, bool fuse_control) {
     const int per_wg = WPB * (64 / PB_LPP);
-    hipLaunchKernelGGL(k_point_update<T>, dim3(std::max(1, (ds.npt + per_wg - 1) / per_wg)), dim3(PBK), 0, s, ds, db);
+    const dim3 grid(std::max(1, (ds.npt + per_wg - 1) / per_wg));
+    if (fuse_control) hipLaunchKernelGGL((k_point_update<T, true>), grid, dim3(PBK), 0, s, ds, db);
+    else hipLaunchKernelGGL((k_point_update<T, false>), grid, dim3(PBK), 0, s, ds, db);
 }
-template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
-
-// ------------------------------------------------------------------------------------------
-// LM control: the accept/reject logic of ceres::internal::TrustRegionMinimizer::Minimize()
-// [Ceres-upstream], one thread.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lm_post(int* mb, int seq, int termination, int message, int iter, int cg_iters = 0) {
-    if (!mb) return;
-    __hip_atomic_store(mb + 4, cg_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mb + 1, termination, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mb + 2, message, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mb + 3, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mb, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ void k_lm_control(DeviceBuffers db) {
-    LMState* st = db.st;
-    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) {
-        // the linear solve has not converged within the launches enqueued so far: tell the host (termination code -2),
-        // touch nothing -- it will enqueue more CG iterations followed by the same three kernels
-        if (threadIdx.x == 0) { st->retry = 1; const int seq = ++st->mail_seq; lm_post(db.lm_mailbox, seq, -2, 0, st->iter); }
-        return;
-    }
-    double trial2, model, step2, xnew2, bad_trial;
-    if (db.shard_scal) {
-        // sharded solve: the sums over the ranks sit in the all-reduced scalar block (k_shard_pack emptied the slots)
-        trial2 = db.shard_scal[0]; model = db.shard_scal[1]; step2 = db.shard_scal[2]; xnew2 = db.shard_scal[3]; bad_trial = db.shard_scal[4];
-    } else {
-        const int ctl_acc[5] = { ACC_TRIAL_COST, ACC_MODEL, ACC_STEP2, ACC_XNEW2, ACC_BAD_TRIAL };
-        double ctl[5];
-        slots_take_n<5>(db, ctl_acc, ctl);
-        trial2 = ctl[0]; model = ctl[1]; step2 = ctl[2]; xnew2 = ctl[3]; bad_trial = ctl[4];
-    }
-    if (threadIdx.x != 0) return;
-    st->retry = 0;
-    st->lin_info = *db.lin_info;
-    *db.lin_info = 0;
-    const int seq = ++st->mail_seq;
-    const int cg_iters = db.cg_gate ? db.cg_gate[1] : 0;          // CG iterations of this LM iteration (device-side count)
-    if (st->termination != -1) { if (db.st_mirror) *db.st_mirror = *st; lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters); return; }
-    const int it = ++st->iter;
-    TraceRow row = {};
-    row.iteration = it;
-    const bool lin_fail = st->lin_info != 0 || !finite_d(step2) || !finite_d(model);
-    const bool step_valid = !lin_fail && model > 0.0;
-    row.step_is_valid = step_valid;
-    row.gradient_max_norm = st->gmax;
-    double report_cost = st->cost;
-    st->last_step_successful = 0;
-    if (!step_valid) {
-        if (++st->consecutive_invalid >= st->max_consecutive_invalid) {
-            st->termination = SFMBA_FAILURE;
-            st->message = MSG_INVALID_STEPS;
-        } else {
-            st->radius *= 0.5;
-            st->unsuccessful++;
-        }
-    } else {
-        st->consecutive_invalid = 0;
-        double cand = 0.5 * trial2;
-        if (bad_trial != 0.0 || !finite_d(cand)) cand = DBL_MAX;
-        st->residual_evals++;
-        row.step_norm = sqrt(step2);
-        const double step_tol = st->parameter_tolerance * (st->x_norm + st->parameter_tolerance);
-        if (row.step_norm <= step_tol) {
-            st->termination = SFMBA_CONVERGENCE;
-            st->message = MSG_PARAMETER_TOL;
-        } else {
-            row.cost_change = st->cost - cand;
-            if (fabs(row.cost_change) <= st->function_tolerance * st->cost) {
-                st->termination = SFMBA_CONVERGENCE;
-                st->message = MSG_FUNCTION_TOL;
-            } else {
-                row.relative_decrease = row.cost_change / model;
-                if (row.relative_decrease > st->min_relative_decrease) {
-                    row.step_is_successful = 1;
-                    st->last_step_successful = 1;
-                    st->cur ^= 1;
-                    st->cost = cand;
-                    st->x_norm = sqrt(xnew2);
-                    const double t = 2.0 * row.relative_decrease - 1.0;
-                    st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-                    st->radius = fmin(st->max_radius, st->radius);
-                    st->decrease_factor = 2.0;
-                    st->successful++;
-                    st->x_is_new = 1;
-                    report_cost = cand;
-                } else {
-                    st->radius = st->radius / st->decrease_factor;
-                    st->decrease_factor *= 2.0;
-                    st->unsuccessful++;
-                    report_cost = cand;
-                }
-            }
-        }
-    }
-    if (st->termination == -1 && st->radius <= st->min_radius) {
-        st->termination = SFMBA_CONVERGENCE;
-        st->message = MSG_MIN_RADIUS;
-    }
-    row.cost = report_cost;
-    row.trust_region_radius = st->radius;
-    if (it < db.trace_cap) db.trace[it] = row;
-    st->lin_info = 0;
-    if (db.st_mirror) *db.st_mirror = *st;      // plain stores; the release store of the sequence number in lm_post orders them
-    lm_post(db.lm_mailbox, seq, st->termination, st->message, st->iter, cg_iters);
-}
+template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, bool);
+template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, bool);
 
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     (void)ds;

@@ -48,12 +48,6 @@ struct DenseSolver {
     int* h_flags = nullptr;   // pinned host mirror
     volatile int* h_mailbox = nullptr;   // host-mapped {iterations, done}: polled instead of copy + synchronise
     int* d_mailbox = nullptr;
-    // persistent CG (one launch per solve): granule exchange buffers [2][2*ld], running epoch, timeout word
-    unsigned long long* gran = nullptr;
-    unsigned* tmo = nullptr;
-    unsigned epoch = 0;
-    bool coop_refused = false; // a cooperative launch of the persistent CG kernel was refused once: stay on per-iteration launches
-    int n_cu = 0;             // compute units of the device (persistent kernel needs one resident workgroup per row slab)
     DeviceArena* arena = nullptr;   // when set, the device arrays above live in (and are released with) this arena
     bool pinned_external = false;   // h_flags / h_mailbox are slices of the caller's pinned block
 };
@@ -96,10 +90,4 @@ void dense_pcg_note(DenseSolver* ws, int hist_key, int iters);
 int dense_pcg_ensure_workspace(DenseSolver* ws);
 // fp32 storage of the preconditioned matrix for the streaming (d > 1280) path; returns the buffer or null if not applicable
 float* dense_pcg_want_f32(DenseSolver* ws);
-// Whole CG solve in ONE cooperative launch (k_pcg_persistent: the runtime guarantees that all workgroups are co-resident),
-// asynchronous: nothing is waited for.  Requires the pretransformed system (see above) and d <= 1280 with one workgroup
-// per CU; returns false (nothing launched) when that does not hold or the cooperative launch is refused.  The iteration count is posted to ws->h_mailbox[0] (with h_mailbox[1] = 1) when the kernel ends; the solution
-// stays in transformed form for k_cam_update.
-bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof = nullptr, int anchor = 0);
-
 }  // namespace sfmba

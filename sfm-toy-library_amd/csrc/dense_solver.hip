@@ -576,20 +576,19 @@ __global__ __launch_bounds__(256, 1) void k_chol_small(double* __restrict__ A, i
 
 void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof) {
     const int ld = ws->ld, d = ws->d, nblk = ld / NB;
-    static const bool fused_env = [] { const char* e = std::getenv("SFMBA_CHOL_FUSED"); return !(e && e[0] == '0'); }();
-    if (fused_env && nblk == 1) {
+    if (nblk == 1) {
         static bool small_attr_set = false;
         if (!small_attr_set) { (void)hipFuncSetAttribute((const void*)k_chol_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * CS_LDS_DOUBLES)); small_attr_set = true; }
         ProfScope ps(prof, KID_CHOL_PANEL, s);
         hipLaunchKernelGGL(k_chol_small, dim3(1), dim3(256), sizeof(double) * CS_LDS_DOUBLES, s, S, ld, d, rhs, ws->minv, info_dev);
         return;
     }
-    static const bool backsolve_env = [] { const char* e = std::getenv("SFMBA_CHOL_BACKSOLVE"); return !(e && e[0] == '0'); }();
-    const bool one_launch_back = fused_env && backsolve_env && nblk <= CHOL_FUSED_MAX_BLOCKS && nblk <= 64;
+    // (the two-kernel factorisation and the step-by-step back substitution take over beyond CHOL_FUSED_MAX_BLOCKS block columns: chosen by size only)
+    const bool one_launch_back = nblk <= CHOL_FUSED_MAX_BLOCKS && nblk <= 64;
     { ProfScope ps(prof, KID_CHOL_AUGMENT, s);
       const int pending = one_launch_back ? nblk * NB : 0;
       hipLaunchKernelGGL(k_augment, dim3((std::max(d, pending) + 255) / 256), dim3(256), 0, s, S, ld, d, rhs, pending); }
-    if (fused_env && nblk <= CHOL_FUSED_MAX_BLOCKS) {
+    if (nblk <= CHOL_FUSED_MAX_BLOCKS) {
         // one launch per block column (k_chol_step); beyond ~2500 unknowns the redundant panel GEMMs of the fused step cost more than
         // the launch they save and the two-kernel form below takes over
         static bool attr_set = false;
@@ -613,7 +612,7 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
         hipLaunchKernelGGL(k_chol_backsolve, dim3(nblk), dim3(256), 0, s, S, ld, d, ws->minv, rhs, nblk);
         return;
     }
-    if (fused_env && nblk <= CHOL_FUSED_MAX_BLOCKS && nblk > 1)
+    if (nblk <= CHOL_FUSED_MAX_BLOCKS && nblk > 1)
         hipLaunchKernelGGL(k_chol_apply_minv, dim3(nblk * (nblk - 1) / 2), dim3(256), 0, s, S, ld, nblk, ws->minv);
     { ProfScope ps(prof, KID_CHOL_EXTRACT, s);
       hipLaunchKernelGGL(k_extract_y, dim3((ld + 255) / 256), dim3(256), 0, s, S, ld, d, ws->y); }
@@ -2535,174 +2534,6 @@ __global__ __launch_bounds__(SG_UT) void k_sg_p(int d, int ld, int G, const doub
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent CG (d <= 1280, one workgroup per CU): the WHOLE solve in one launch.
-//
-// The launch-per-iteration kernel above costs one dependent-launch boundary (~1.4 us) plus one full re-read of S~ from
-// MALL (L2 does not survive the boundary) per iteration.  Here every workgroup keeps its 5 rows of S~ in registers for
-// the whole solve and the only per-iteration exchange is the vector q = S~ p (d doubles): published as 8-byte
-// {tag, half} granules with write-through (sc1) stores and gathered by every workgroup with relaxed agent-scope loads
-// until all tags carry the iteration's epoch (MI355X_MICROARCH.md "allgather" row, cdna_hip_programming.md Guideline
-// 16 form R2: the data is the flag, no fences).  alpha, beta, r, p and x are rebuilt redundantly by every workgroup
-// from the same q in the same summation order, so all workgroups take bit-identical convergence decisions and leave
-// the loop together.  Two granule buffers (iteration parity) make reuse safe: a workgroup can only overwrite its
-// iteration-k granules after it has gathered iteration k+1, which every other workgroup publishes only after it has
-// finished reading iteration k.  Spins are bounded; a timeout is reported through *info like a failed factorisation.
-//
-// MEASURED (MI355X, cfg 3, d = 1201): 6.7 us per CG iteration inside this kernel vs 5.7 us kernel + 1.4 us boundary for
-// the launch-per-iteration path -- the gather costs two to three sc1 round trips of ~1.5 us each; end to end the solve
-// is 2.7 % SLOWER than with per-iteration launches (2405 vs 2475 LM iterations/s).  A single polling wave per
-// workgroup is 2.5x slower still.  For SMALL reduced systems the balance flips: the per-iteration launch floor dominates
-// and the exchange is a few hundred granules (20 cameras, d = 121: 0.67 -> 0.50 ms per solve; 7 cameras: 0.73 -> 0.56).
-// run_solve therefore uses this kernel for d <= 640 and per-iteration launches above (SFMBA_PCG_PERSISTENT=0|1 forces).
-constexpr int PCG_GPT = 10;                    // granules per thread per sweep (256 * 10 >= 2 d)
-constexpr unsigned PCG_SPIN_LIMIT = 1u << 22;
-
-__global__ __launch_bounds__(256) void k_pcg_persistent(int d, int ld, const double* __restrict__ F, const double* __restrict__ bt,
-                                                        double* __restrict__ vec, unsigned long long* gran, unsigned epoch0,
-                                                        int max_iters, double tol2, int rows_per_wg, int* flags, int* info,
-                                                        int* mailbox, unsigned* tmo, double* scal, int anchor, double cap) {
-    extern __shared__ __align__(16) double sm[];
-    double* pl = sm;                 // [ld] search direction
-    double* ql = sm + ld;            // [ld] q = S~ p of the current iteration
-    double* red = sm + 2 * ld;       // [8]
-    int* bail = reinterpret_cast<int*>(sm + 2 * ld + 8);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int row0 = blockIdx.x * rows_per_wg;
-    const int row1 = min(d, row0 + rows_per_wg);
-    if (tid == 0) *bail = 0;
-
-    // rows of S~ owned by this wave: registers for the whole solve
-    double2 fv[PCG_RPW][PCG_CPL / 2];
-#pragma unroll
-    for (int k = 0; k < PCG_RPW; ++k) {
-        const int row = row0 + w + 4 * k;
-        const double2* Fr = reinterpret_cast<const double2*>(F + (size_t)(row < row1 ? row : row0) * ld);
-#pragma unroll
-        for (int m = 0; m < PCG_CPL / 2; ++m) {
-            const int c2 = lane + 64 * m;
-            double2 v = make_double2(0.0, 0.0);
-            if (row < row1 && 2 * c2 < d) v = Fr[c2];
-            if (2 * c2 + 1 >= d) v.y = 0.0;
-            fv[k][m] = v;
-        }
-    }
-    // x0 = 0, r0 = p0 = b~
-    double rv[PCG_EPT], pv[PCG_EPT], xv[PCG_EPT];
-    double rr = 0.0, dummy = 0.0;
-#pragma unroll
-    for (int m = 0; m < PCG_EPT; ++m) {
-        const int e = tid + 256 * m;
-        rv[m] = (e < d) ? bt[e] : 0.0;
-        pv[m] = rv[m]; xv[m] = 0.0;
-        rr += rv[m] * rv[m];
-        if (e < ld) pl[e] = rv[m];
-    }
-    block_sum2(rr, dummy, red);
-    // every workgroup derives the same threshold base (scal[PS_RRF] was written by an earlier launch; with anchor == 1
-    // only workgroup 0 stores it and nobody reads it in this launch)
-    const double rr0 = (anchor == 2) ? fmin(fmax(rr, scal[PS_RRF]), cap * rr) : rr;
-    if (anchor == 1 && blockIdx.x == 0 && tid == 0) scal[PS_RRF] = rr;
-    double* x_out = pcg_vec(vec, 0, 0, ld);
-    int it = 0;
-    bool broke = false, timed_out = false;
-    if (rr > 0.0) {
-        for (it = 1;; ++it) {
-            __syncthreads();                                   // pl complete
-            const unsigned tag = epoch0 + (unsigned)it;
-            unsigned long long* gb = gran + (size_t)(it & 1) * 2 * ld;
-            // ---- q = S~ p for the rows of this workgroup; publish ----
-#pragma unroll
-            for (int k = 0; k < PCG_RPW; ++k) {
-                const int row = row0 + w + 4 * k;
-                double sacc = 0.0, sacc2 = 0.0;
-#pragma unroll
-                for (int m = 0; m < PCG_CPL / 2; ++m) {
-                    const int c2 = lane + 64 * m;
-                    double2 pv2 = (2 * c2 < d) ? reinterpret_cast<const double2*>(pl)[c2] : make_double2(0.0, 0.0);
-                    if (2 * c2 + 1 >= d) pv2.y = 0.0;
-                    sacc = fma(fv[k][m].x, pv2.x, sacc);
-                    sacc2 = fma(fv[k][m].y, pv2.y, sacc2);
-                }
-                sacc += sacc2;
-                sacc = wave_allsum(sacc);
-                if (lane < 2 && row < row1) {                  // lane 0: low half, lane 1: high half -- one aligned 8-byte store each
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
-                    const unsigned half = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
-                    __hip_atomic_store(gb + 2 * row + lane, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            // ---- gather all of q ----
-            unsigned gv[PCG_GPT];
-            unsigned spins = 0;
-            bool failed = false;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < PCG_GPT; ++k) {
-                    const int g = tid + 256 * k;
-                    if (g < 2 * d) {
-                        const unsigned long long x = __hip_atomic_load(gb + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        gv[k] = (unsigned)x;
-                        ok &= (unsigned)(x >> 32) == tag;
-                    } else gv[k] = 0u;
-                }
-                if (__all(ok)) break;
-                ++spins;
-                if (spins > PCG_SPIN_LIMIT || ((spins & 255u) == 0u && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch0)) { failed = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (failed) {
-                if (lane == 0) { __hip_atomic_store(tmo, epoch0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *bail = 1; }
-            } else {
-#pragma unroll
-                for (int k = 0; k < PCG_GPT; ++k) {
-                    const unsigned hi = __shfl_xor(gv[k], 1, 64);            // odd lane holds the high half of the even lane's element
-                    const int e = (tid + 256 * k) >> 1;
-                    if ((lane & 1) == 0 && e < d) ql[e] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | gv[k]));
-                }
-            }
-            __syncthreads();
-            if (*bail) { timed_out = true; break; }
-            // ---- alpha, x, r, beta, p (identical in every workgroup) ----
-            double qv[PCG_EPT];
-            double pq = 0.0;
-#pragma unroll
-            for (int m = 0; m < PCG_EPT; ++m) {
-                const int e = tid + 256 * m;
-                qv[m] = (e < d) ? ql[e] : 0.0;
-                pq += pv[m] * qv[m];
-            }
-            block_sum2(pq, dummy, red);
-            const double alpha = rr * fast_rcp(pq);          // rcp + 2 Newton steps: the generic fp64 division is a ~15-deep dependent chain on the critical path
-            double rrn = 0.0;
-#pragma unroll
-            for (int m = 0; m < PCG_EPT; ++m) { xv[m] += alpha * pv[m]; rv[m] -= alpha * qv[m]; rrn += rv[m] * rv[m]; }
-            block_sum2(rrn, dummy, red);
-            broke = !(pq > 0.0) || !(rrn == rrn);
-            if (rrn <= tol2 * rr0 || broke || it >= max_iters) break;
-            const double beta = rrn * fast_rcp(rr);
-            rr = rrn;
-#pragma unroll
-            for (int m = 0; m < PCG_EPT; ++m) {
-                const int e = tid + 256 * m;
-                pv[m] = rv[m] + beta * pv[m];
-                if (e < d) pl[e] = pv[m];
-            }
-        }
-    }
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int m = 0; m < PCG_EPT; ++m) { const int e = tid + 256 * m; if (e < d) x_out[e] = xv[m]; }
-        if (tid == 0) {
-            flags[PF_DONE] = 1; flags[PF_ITERS] = it; flags[PF_XBUF] = 0;
-            if (broke) atomicCAS(info, 0, d + 1);
-            if (timed_out) atomicCAS(info, 0, d + 2);
-            if (mailbox) pcg_post(mailbox, it, 1);
-        }
-    }
-}
-
 // solution of the original system: z = Lb^-T x~
 __global__ void k_pcg_finish(int d, int ld, const double* __restrict__ vec, const double* __restrict__ linv, const int* flags,
                              double* __restrict__ z) {
@@ -2793,76 +2624,6 @@ bool dense_pcg_segments_applicable(const DenseSolver* ws) {
 }
 
 
-// SFMBA_ML_DEBUG=1 (tools/segments_check.py): the set-up kernels' outputs against a host evaluation of the same definitions, printed per linear solve
-static void ml_debug_check(hipStream_t s, DenseSolver* ws, int nwg) {
-    (void)hipStreamSynchronize(s);
-    const int d = ws->d, ld = ws->ld, nc = (d - 1) / 6;
-    std::vector<double> F((size_t)d * ld), W((size_t)8 * ld), AW((size_t)d * 64), E(64 * 64), Ei(64 * 64), c0(64), bt(ld), V((size_t)nwg * 512);
-    (void)hipMemcpy(F.data(), ws->Sfull, sizeof(double) * F.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(W.data(), ws->W, sizeof(double) * W.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(AW.data(), ws->mlAW, sizeof(double) * AW.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(E.data(), ws->mlE, sizeof(double) * E.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(Ei.data(), ws->mlEinv, sizeof(double) * Ei.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(c0.data(), ws->mlC0, sizeof(double) * c0.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(bt.data(), ws->vec + (size_t)8 * ld, sizeof(double) * ld, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(V.data(), ws->mlV, sizeof(double) * V.size(), hipMemcpyDeviceToHost);
-    std::vector<double> Wt((size_t)57 * d, 0.0);
-    for (int j = 0; j < nc; ++j) {
-        const int gl = (j * 8) / nc, gh = (gl + 1) % 8;
-        const double fr = (double)(j * 8 - gl * nc) / (double)nc;
-        for (int k = 0; k < 7; ++k) for (int e = 0; e < 6; ++e) {
-            Wt[(size_t)(7 * gl + k) * d + 6 * j + e] += (1.0 - fr) * W[(size_t)k * ld + 6 * j + e];
-            Wt[(size_t)(7 * gh + k) * d + 6 * j + e] += fr * W[(size_t)k * ld + 6 * j + e];
-        }
-    }
-    for (int e = 0; e < d; ++e) Wt[(size_t)56 * d + e] = W[(size_t)7 * ld + e];
-    double eaw = 0, naw = 0, ee = 0, ne = 0, ec = 0, einv_err = 0;
-    std::vector<double> AWh((size_t)d * 57);
-    for (int r = 0; r < d; ++r) for (int i = 0; i < 57; ++i) {
-        double v = 0; for (int c = 0; c < d; ++c) v += F[(size_t)r * ld + c] * Wt[(size_t)i * d + c];
-        AWh[(size_t)r * 57 + i] = v; eaw = fmax(eaw, fabs(v - AW[(size_t)r * 64 + i])); naw = fmax(naw, fabs(v));
-    }
-    for (int i = 0; i < 57; ++i) {
-        for (int j = 0; j < 57; ++j) { double v = 0; for (int r = 0; r < d; ++r) v += Wt[(size_t)i * d + r] * AWh[(size_t)r * 57 + j]; ee = fmax(ee, fabs(v - E[i * 64 + j])); ne = fmax(ne, fabs(v)); }
-        double c = 0; for (int r = 0; r < d; ++r) c += Wt[(size_t)i * d + r] * bt[r]; ec = fmax(ec, fabs(c - c0[i]));
-    }
-    for (int i = 0; i < 57; ++i) for (int j = 0; j < 57; ++j) { double v = 0; for (int k = 0; k < 57; ++k) v += E[i * 64 + k] * Ei[k * 64 + j]; einv_err = fmax(einv_err, fabs(v - (i == j ? 1.0 : 0.0))); }
-    std::fprintf(stderr, "[ml debug] d %d: AW err %.3e (max %.3e)  E err %.3e (max %.3e)  c0 err %.3e  |E Einv - I| %.3e\n", d, eaw, naw, ee, ne, ec, einv_err);
-}
-
-
-// SFMBA_ML_DEBUG=1: E and E^-1 of the streaming-path segments against a host evaluation
-static void sg_debug_check(hipStream_t s, DenseSolver* ws, bool f32) {
-    (void)hipStreamSynchronize(s);
-    const int d = ws->d, ld = ws->ld, nc = (d - 1) / 6, G = sg_hats(nc), NC = 7 * G + 1;
-    std::vector<double> F((size_t)d * ld), W((size_t)8 * ld), E((size_t)SG_NCP * SG_NCP), Ei((size_t)SG_NCP * SG_NCP);
-    if (f32) { std::vector<float> F32((size_t)d * ld); (void)hipMemcpy(F32.data(), ws->Sfull32, sizeof(float) * F32.size(), hipMemcpyDeviceToHost); for (size_t e = 0; e < F.size(); ++e) F[e] = F32[e]; }
-    else (void)hipMemcpy(F.data(), ws->Sfull, sizeof(double) * F.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(W.data(), ws->W, sizeof(double) * W.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(E.data(), ws->sgE, sizeof(double) * E.size(), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(Ei.data(), ws->sgEinv, sizeof(double) * Ei.size(), hipMemcpyDeviceToHost);
-    std::vector<double> Wt((size_t)NC * d, 0.0);
-    for (int j = 0; j < nc; ++j) {
-        const int gl = (j * G) / nc, gh = (gl + 1) % G;
-        const double fr = (double)(j * G - gl * nc) / (double)nc;
-        for (int k = 0; k < 7; ++k) for (int e = 0; e < 6; ++e) {
-            Wt[(size_t)(7 * gl + k) * d + 6 * j + e] += (1.0 - fr) * (double)(float)W[(size_t)k * ld + 6 * j + e];
-            Wt[(size_t)(7 * gh + k) * d + 6 * j + e] += fr * (double)(float)W[(size_t)k * ld + 6 * j + e];
-        }
-    }
-    for (int e = 0; e < d; ++e) Wt[(size_t)(NC - 1) * d + e] = W[(size_t)7 * ld + e];
-    std::vector<double> AW((size_t)d * NC, 0.0);
-    for (int r = 0; r < d; ++r) for (int c = 0; c < d; ++c) { const double f = F[(size_t)r * ld + c]; if (f != 0.0) for (int i = 0; i < NC; ++i) AW[(size_t)r * NC + i] += f * Wt[(size_t)i * d + c]; }
-    double ee = 0, ne = 0, inv_err = 0;
-    for (int i = 0; i < NC; ++i) for (int j = 0; j < NC; ++j) {
-        double v = 0; for (int r = 0; r < d; ++r) v += Wt[(size_t)i * d + r] * AW[(size_t)r * NC + j];
-        ee = fmax(ee, fabs(v - E[(size_t)i * SG_NCP + j])); ne = fmax(ne, fabs(v));
-    }
-    for (int i = 0; i < NC; ++i) for (int j = 0; j < NC; ++j) { double v = 0; for (int k = 0; k < NC; ++k) v += E[(size_t)i * SG_NCP + k] * Ei[(size_t)k * SG_NCP + j]; inv_err = fmax(inv_err, fabs(v - (i == j ? 1.0 : 0.0))); }
-    std::fprintf(stderr, "[sg debug] d %d, %d hats, %d vectors: E err %.3e (max %.3e)  |E Einv - I| %.3e\n", d, G, NC, ee, ne, inv_err);
-}
-
-// ... and its streaming-path form: beyond the one-round-trip kernels, eight rows per workgroup of the product (d <= 8192)
 bool dense_pcg_segments_streaming_applicable(const DenseSolver* ws) {
     const int d = ws->d, nc = (d - 1) / 6;
     const bool fast = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL;
@@ -2920,16 +2681,14 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       hipLaunchKernelGGL(k_ml_aw, dim3(nwg), dim3(256), ML_AW_LDS, s, d, ld, ws->Sfull, ws->W, bt, ws->mlAW, ws->mlV, ws->mlU);
       hipLaunchKernelGGL(k_ml_e, dim3(ML_NC), dim3(256), 0, s, d, ws->mlV, ws->mlU, ws->mlE, ws->mlC0);
       hipLaunchKernelGGL(k_ml_invert, dim3(1), dim3(256), 0, s, ws->mlE, ws->mlEinv, ws->mlC0);
-      static const bool ml_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;      // (read once per process)
-      if (ml_debug) ml_debug_check(s, ws, nwg); }
+      }
     else if (sg) { ProfScope ps(prof, KID_PCG_SETUP, s, 3);
       const int nc = (d - 1) / 6, G = sg_hats(nc), NC = 7 * G + 1;
       if (f32) hipLaunchKernelGGL((k_sg_v<float>), dim3(nc + 1), dim3(256), 0, s, d, ld, G, ws->Sfull32, ws->W, ws->sgV);
       else hipLaunchKernelGGL((k_sg_v<double>), dim3(nc + 1), dim3(256), 0, s, d, ld, G, ws->Sfull, ws->W, ws->sgV);
       hipLaunchKernelGGL(k_sg_e, dim3(NC), dim3(3 * SG_NCP), 0, s, d, G, ws->sgV, ws->sgE);
       hipLaunchKernelGGL(k_sg_invert, dim3(1), dim3(SG_ITHREADS), 0, s, NC, ws->sgE, ws->sgEinv);
-      static const bool sg_debug = std::getenv("SFMBA_ML_DEBUG") != nullptr;
-      if (sg_debug) sg_debug_check(s, ws, f32); }
+      }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg, ws->vec + (size_t)(2 * 3 + 0) * ld);      // t -> the q buffer of parity 0 (pcg_vec)
       else if (f32) { if (rows_per_wg <= 8) hipLaunchKernelGGL((k_pcg_coarse<float, 2>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
@@ -2946,7 +2705,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       launch_cg_iteration<true>(s, ws, anchor, cap); }
     if (fast && coarse && !ml) ws->run.launched = 1;       // the merged first launch IS iteration 1 (max_iters counts it)
     int batch = 24;
-    static const int batch_extra = [] { const char* e = std::getenv("SFMBA_PCG_BATCH_EXTRA"); return e ? std::atoi(e) : 1; }();
+    constexpr int batch_extra = 1;
     // history + 1 (was + 2; +0.6 % on the headline): a solve that needs two more iterations than last time costs a host round trip, a surplus (early-exit) launch ~2 us
     // (run to 1e-12 -- AUTO -- a solve takes 13 +- 1 iterations from one call to the next, the atomics' summation order is enough: a batch one
     // launch short costs a host round trip of ~50 us, a surplus launch ~2: one more in reserve there)
@@ -2987,45 +2746,6 @@ template <typename T> static int ws_alloc(DenseSolver* ws, T** p, size_t bytes) 
     return hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess ? 0 : -1;
 }
 
-bool dense_pcg_solve_persistent(hipStream_t s, DenseSolver* ws, double tol, int max_iters, int* info_dev, Profiler* prof, int anchor) {
-    const int ld = ws->ld, d = ws->d;
-    if (dense_pcg_ensure_workspace(ws)) return false;
-    const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
-    const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
-    const bool fits = d <= 256 * PCG_EPT && d <= 64 * PCG_CPL && 2 * d <= 256 * PCG_GPT && rows_per_wg <= 4 * PCG_RPW;
-    if (!fits || !ws->gran || ws->coop_refused) return false;
-    if (ws->n_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); ws->n_cu = -1; }
-        else ws->n_cu = prop.multiProcessorCount;
-    }
-    if (nwg > ws->n_cu) return false;            // every workgroup must be resident for the in-kernel exchange
-    if (max_iters <= 0) max_iters = 4 * d;
-    if (ws->epoch > 0xE0000000u) {               // tag space nearly used up: start over with clean buffers
-        (void)hipMemsetAsync(ws->gran, 0, sizeof(unsigned long long) * 4 * (size_t)ld, s);
-        (void)hipMemsetAsync(ws->tmo, 0, sizeof(unsigned), s);
-        ws->epoch = 0;
-    }
-    const unsigned epoch0 = ws->epoch + 1;       // tags epoch0 + 1 .. epoch0 + max_iters; tmo marker = epoch0
-    ws->epoch = epoch0 + (unsigned)max_iters + 1;
-    if (ws->h_mailbox) { ws->h_mailbox[0] = -1; ws->h_mailbox[1] = 0; }
-    const size_t lds = sizeof(double) * (size_t)(2 * ld + 16);
-    double* bt = ws->vec + (size_t)8 * ld;
-    // The in-kernel exchange needs EVERY workgroup resident at the same time: a cooperative launch makes the runtime
-    // guarantee that (or refuse), whatever other streams / concurrent problems occupy the device.  A refusal falls back
-    // to the launch-per-iteration path (the caller sees `false`).
-    int d_ = d, ld_ = ld, max_iters_ = max_iters, rows_ = rows_per_wg, anchor_ = anchor;
-    unsigned epoch_ = epoch0;
-    double tol2_ = tol * tol, cap_ = pcg_cap(tol);
-    const double* F_ = ws->Sfull; const double* bt_ = bt;
-    void* args[] = { &d_, &ld_, &F_, &bt_, &ws->vec, &ws->gran, &epoch_, &max_iters_, &tol2_, &rows_, &ws->flags, &info_dev,
-                     &ws->d_mailbox, &ws->tmo, &ws->scal, &anchor_, &cap_ };
-    ProfScope ps(prof, KID_PCG_ITER, s);
-    const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_pcg_persistent), dim3(nwg), dim3(256), args, (unsigned)lds, s);
-    if (le != hipSuccess) { (void)hipGetLastError(); ws->coop_refused = true; return false; }
-    return true;
-}
-
 float* dense_pcg_want_f32(DenseSolver* ws) {
     const int d = ws->d;
     const int rows_per_wg = (d + PCG_MAXWG - 1) / PCG_MAXWG;
@@ -3036,14 +2756,6 @@ float* dense_pcg_want_f32(DenseSolver* ws) {
 }
 
 int dense_pcg_ensure_workspace(DenseSolver* ws) {
-    if (!ws->gran) {
-        if (ws_alloc(ws, &ws->gran, sizeof(unsigned long long) * 4 * (size_t)ws->ld)) return -1;
-        if (ws_alloc(ws, &ws->tmo, 256)) return -1;
-        // (arena memory is handed out zeroed)
-        if (!ws->arena && hipMemset(ws->gran, 0, sizeof(unsigned long long) * 4 * (size_t)ws->ld) != hipSuccess) return -1;
-        if (!ws->arena && hipMemset(ws->tmo, 0, 256) != hipSuccess) return -1;
-        ws->epoch = 0;
-    }
     if (!ws->Sfull) {
         if (ws_alloc(ws, &ws->Sfull, sizeof(double) * (size_t)ws->d * ws->ld)) return -1;
     }
@@ -3111,8 +2823,6 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->flags) (void)hipFree(ws->flags);
         if (ws->Sfull) (void)hipFree(ws->Sfull);
         if (ws->Sfull32) (void)hipFree(ws->Sfull32);
-        if (ws->gran) (void)hipFree(ws->gran);
-        if (ws->tmo) (void)hipFree(ws->tmo);
         if (ws->W) (void)hipFree(ws->W);
         if (ws->AW) (void)hipFree(ws->AW);
         if (ws->epart) (void)hipFree(ws->epart);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(CD_BLK) void k_imp_cams(DeviceStructure ds, DeviceB
                                                      double* __restrict__ acc, const int* __restrict__ flags) {
     __shared__ double red[CD_BLK / 64][6];
     if (flags && flags[0]) return;
-    const int4 ch = ds.chunks[blockIdx.x];
+    const int4 ch = ds.chunks[ds.chunk_order[blockIdx.x]];
     const int j = ch.x;
     const LMState* st = db.st;
     const int cur = st->cur;

@@ -125,17 +125,11 @@ int wait_mailbox(volatile int* word, int want, hipStream_t stream) {
     }
 }
 
-// A behaviour switch of sfmba_options (ABI v4): the environment variable, when set, overrides the field ("0" = off, else on);
-// otherwise the field (1 on, -1 off), otherwise the library default.
-// relative residual AUTO runs the CG to (see run_solve); SFMBA_AUTO_TOL overrides (experiments)
-static double auto_cg_tol() {
-    static const double v = [] { const char* e = std::getenv("SFMBA_AUTO_TOL"); const double t = e ? std::atof(e) : 0.0; return t > 0.0 ? t : 1e-12; }();
-    return v;
-}
-bool option_switch(int field, const char* env_name, bool dflt) {
-    if (const char* e = std::getenv(env_name)) return e[0] != '0';
-    return field > 0 ? true : field < 0 ? false : dflt;
-}
+// relative residual AUTO runs the CG to (see run_solve)
+constexpr double auto_cg_tol() { return 1e-12; }
+// A behaviour switch of sfmba_options: the field (1 on, -1 off), otherwise the library default.  (ABI v4 let an environment variable of the
+// name given here override the field; since ABI v5 nothing below sfmba_problem_create* reads the environment: the name documents the switch.)
+bool option_switch(int field, const char* /*name*/, bool dflt) { return field > 0 ? true : field < 0 ? false : dflt; }
 
 __global__ void k_fill(double* p, size_t n, double v) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,6 +210,7 @@ struct sfmba_problem {
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_pwg_desc = nullptr;
     int2* d_pwg_chunk = nullptr; int* d_multi_slots = nullptr; int* d_build_counters = nullptr; int* d_pt_order = nullptr;
+    int *d_chunk_order = nullptr, *d_coarse_order = nullptr;
     double block_fill = 1.0;              // non-empty off-diagonal blocks of the reduced matrix / all of them
     double block_band = 0.0;              // ... and the share of those that couple cameras within a quarter of the cyclic camera order
     int* d_blk_ptr = nullptr;
@@ -290,15 +285,14 @@ DeviceStructure ds_points(const sfmba_problem* p) {
 DeviceStructure ds_cams(const sfmba_problem* p) {
     DeviceStructure ds = p->ds;
     if (p->row_sharded) {
-        ds.chunks += p->own_chunk0; ds.nchunk = p->own_chunk1 - p->own_chunk0;
-        ds.chunks_coarse += p->own_coarse0; ds.nchunk_coarse = p->own_coarse1 - p->own_coarse0;
+        // (a contiguous share of the LAUNCH order: the rank's workgroups stay inside one window of the point table at a time)
+        ds.chunk_order += p->own_chunk0; ds.nchunk = p->own_chunk1 - p->own_chunk0;
+        ds.coarse_order += p->own_coarse0; ds.nchunk_coarse = p->own_coarse1 - p->own_coarse0;
     }
     return ds;
 }
 DeviceBuffers db_cams(const sfmba_problem* p) {
-    DeviceBuffers db = p->db;
-    if (p->row_sharded && db.cd_part) db.cd_part += (size_t)p->own_chunk0 * 48;      // (a chunk's slot is its GLOBAL index: k_cd_fold walks all of them, the others' stay zero)
-    return db;
+    return p->db;      // (deterministic mode: a chunk's slot in cd_part is its index in the chunk LIST, whatever the launch order; the slots of the others' chunks stay zero)
 }
 
 void init_state(sfmba_problem* p, LMState& st, const sfmba_options& o) {
@@ -400,10 +394,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     bool state_mirrored = false;
     bool first_linearisation = true;
     bool first_linear_solve = true;
-    const char* gate_env = std::getenv("SFMBA_PCG_GATED");
-    const bool gated_env = !(gate_env && gate_env[0] == '0');
     const bool f32_matrix = option_switch(o.pcg_f32_matrix, "SFMBA_PCG_F32_MATRIX", true);
-    const char* anchor_env = std::getenv("SFMBA_PCG_ANCHOR");
     // two-level preconditioner (8 gauge vectors as a coarse space, dense_solver.hip)
     const bool coarse_cg = option_switch(o.pcg_coarse_space, "SFMBA_PCG_COARSE", true);
     // ... and for a sparsely filled reduced matrix (a camera graph of large diameter) the same vectors restricted to eight segments of the
@@ -412,24 +403,19 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // (options.pcg_coarse_space: 0 = by structure, 1 = the eight global vectors only, 2 = the segments wherever they apply)
     const bool segments_cg = coarse_cg && (dense_pcg_segments_applicable(&p->solver) || dense_pcg_segments_streaming_applicable(&p->solver)) &&
                              option_switch(o.pcg_coarse_space == 2 ? 1 : o.pcg_coarse_space == 1 ? -1 : 0, "SFMBA_PCG_SEGMENTS", p->block_fill < 0.5 && p->block_band >= 0.9);
-    // One persistent (cooperative) launch per CG solve: opt-in only.  It used to win below d = 640 where the
-    // solve is launch-bound; with the gauge coarse space the launch-per-iteration path needs half the iterations and is as fast or
-    // faster at every size measured (cfg 4, d = 151: 4990 vs 4820 LM it/s; cfg 2: 6300 vs 6220; 7 views: 6170 vs 6380), and it has
-    // no device-wide spin barrier in it.
     const bool pcg_mode = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
     // AUTO above 256 unknowns = the DENSE_SCHUR result through the CG: plain relative residual <= 1e-12, bounded iteration count,
     // Cholesky on the same linearisation if the CG does not get there (include/sfmba.h)
     const bool exact_pcg = pcg_mode && o.linear_solver == SFMBA_LINEAR_AUTO;
     const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : auto_cg_tol(), auto_cg_tol()) : o.pcg_tolerance;
     const int cg_max_iters = exact_pcg ? (o.pcg_max_iters > 0 ? o.pcg_max_iters : std::min(4 * p->ds.d, 200)) : o.pcg_max_iters;
-    const bool anchored_cg = !exact_pcg && o.pcg_anchored != 0 && !(anchor_env && anchor_env[0] == '0');
-    const bool gated_cg = gated_env || exact_pcg;        // (the fallback is decided where the gated loop learns that the batch was too short)
+    const bool anchored_cg = !exact_pcg && o.pcg_anchored != 0;
+    const bool gated_cg = true;        // (the fallback is decided where the gated loop learns that the batch was too short)
     // AUTO picks per LM iteration: the CG while it is the cheaper way to the DENSE_SCHUR result, the factorisation once a linearisation
     // has needed more CG iterations than a factorisation costs (measured at d = 1201: 0.41 ms against 6.4 us per iteration = ~64
     // iterations; uniform co-visibility needs 14 per LM iteration, a banded reduced system ~160 -- profiles/r03_*_banded_*).
     const int nblk64 = p->ds.ld / 64;
     const int cg_break_even = std::max(30, (nblk64 <= 40 ? 33 : 20) * nblk64 / 10);
-    const bool persistent_cg = !exact_pcg && option_switch(o.pcg_persistent, "SFMBA_PCG_PERSISTENT", false);
     int launched_controls = 0;
     const bool speculate = option_switch(o.early_linearise, "SFMBA_EARLY_LINEARISE", true) && !p->prof.on;
     bool build_enqueued = false;
@@ -480,14 +466,11 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db, 0); }
         }
         DeviceBuffers dbu = p->db;
-        bool pcg_async = false, pcg_gated = false;
+        bool pcg_gated = false;
         if (pcg) {
-            // opt-in: one persistent launch for the whole CG solve when the reduced system fits (d <= 1280); its iteration
-            // count is read from the solver's mailbox after this LM iteration's control post
             const int anchor = anchored_cg ? (first_linear_solve ? 1 : 2) : 0;
             first_linear_solve = false;
-            pcg_async = persistent_cg && dense_pcg_solve_persistent(p->stream, &p->solver, cg_tol, cg_max_iters, p->d_info, prof, anchor);
-            if (!pcg_async) {
+            {
                 // Launch-per-iteration CG: a batch of the length the previous solve needed (+2) goes into the queue together
                 // with the three kernels that consume the solution; those are GATED on the CG's done flag, so the host does
                 // not wait for the linear solve.  If the batch was too short k_lm_control says so and more is enqueued.
@@ -506,9 +489,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         }
         bool lm_done = false;
         while (!lm_done) {
+            // (the LM control logic runs in the last workgroup of the point update to arrive: no launch of its own)
             { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
-            { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, dbu); }
-            { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, dbu); }
+            { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, dbu, /*fuse_control=*/true); }
             { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
             ++launched_controls;
             // every launch of this LM iteration is in the queue: a failed launch must not leave the host waiting for a post
@@ -554,11 +537,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             state_mirrored = true;
             host_iter = mb[3];
             if (mb[1] != -1) { term = mb[1]; msg = mb[2]; }
-            if (pcg_async) {      // posted before k_lm_control ran (same stream)
-                const int it = p->solver.h_mailbox[1] != 0 ? p->solver.h_mailbox[0] : 0;
-                sum.linear_iters += it;
-                lin_hist.push_back(it);
-            } else if (pcg_gated || (pcg && exact_pcg && dbu.cg_gate == nullptr)) {
+            if (pcg_gated || (pcg && exact_pcg && dbu.cg_gate == nullptr)) {
                 const int it = (pcg_gated || dbu.pcg_vec) ? mb[4] : p->solver.run.launched;      // after a fallback: the launches that were spent
                 if (exact_pcg && it > cg_break_even) auto_prefers_cholesky = true;                 // the next linearisations of THIS solve are factorised
                 dense_pcg_note(&p->solver, (int)lin_hist.size(), it);
@@ -789,7 +768,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     long long npair_total = 0;
     std::atomic<int> counts_state(0);            // 1 = pointers and pair total ready, -1 = counts inconsistent
     std::vector<int4> chunks, chunks_coarse;
-    std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0), pt_order;
+    std::vector<int> cam_chunk_ptr((size_t)ncam + 1, 0), pt_order, chunk_order, coarse_order;
     std::vector<int2> blk_cams, pwg_blocks;
     std::vector<double> cam0, pts0;
     std::vector<char> blob;
@@ -824,6 +803,23 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             }
         }
         cam_chunk_ptr[(size_t)ncam] = (int)chunks.size();
+        // launch order of the chunks (ba_kernels.h, chunk_order): by the chunk's relative position in its camera's list (a camera's entries ascend
+        // in point slot, so that is -- for any co-visibility that samples the points evenly -- the window of the per-point table it gathers from),
+        // cameras side by side inside a window.  The chunk list itself stays camera-major (deterministic mode adds a camera's chunks in list order).
+        auto order_of = [&](const std::vector<int4>& ch, std::vector<int>* order) {
+            order->resize(ch.size());
+            std::vector<unsigned long long> key(ch.size());
+            for (size_t c = 0; c < ch.size(); ++c) {
+                const int j = ch[c].x;
+                const long long cnt = std::max(1, cam_ptr[(size_t)j + 1] - cam_ptr[(size_t)j]);
+                const long long mid = (long long)(ch[c].y - cam_ptr[(size_t)j]) + (ch[c].z - ch[c].y) / 2;
+                key[c] = ((unsigned long long)(mid * 4096 / cnt) << 32) | (unsigned)c;      // 4096 windows; ties: list order
+            }
+            std::sort(key.begin(), key.end());
+            for (size_t c = 0; c < ch.size(); ++c) (*order)[c] = (int)(key[c] & 0xffffffffu);
+        };
+        order_of(chunks, &chunk_order);
+        order_of(chunks_coarse, &coarse_order);
         blk_cams.resize((size_t)nblock);
         for (int ja = 0; ja < ncam; ++ja)
             for (int jb = ja; jb < ncam; ++jb) { int2 c; c.x = ja; c.y = jb; blk_cams[(size_t)block_of(ja, jb)] = c; }
@@ -913,13 +909,15 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
             const size_t o_chunks = place(sizeof(int4) * chunks.size()), o_coarse = place(sizeof(int4) * chunks_coarse.size()),
                          o_ccp = place(sizeof(int) * cam_chunk_ptr.size()), o_bc = place(sizeof(int2) * blk_cams.size()),
-                         o_pwg = place(sizeof(int2) * pwg_blocks.size()), o_pto = place(sizeof(int) * pt_order.size());
+                         o_pwg = place(sizeof(int2) * pwg_blocks.size()), o_pto = place(sizeof(int) * pt_order.size()),
+                         o_co = place(sizeof(int) * chunk_order.size()), o_cco = place(sizeof(int) * coarse_order.size());
             blob.resize(off ? off : 1);
             auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(blob.data() + o, src, bytes); };
             put(o_chunks, chunks.data(), sizeof(int4) * chunks.size()); put(o_coarse, chunks_coarse.data(), sizeof(int4) * chunks_coarse.size());
             put(o_ccp, cam_chunk_ptr.data(), sizeof(int) * cam_chunk_ptr.size()); put(o_bc, blk_cams.data(), sizeof(int2) * blk_cams.size());
             put(o_pwg, pwg_blocks.data(), sizeof(int2) * pwg_blocks.size());
             put(o_pto, pt_order.data(), sizeof(int) * pt_order.size());
+            put(o_co, chunk_order.data(), sizeof(int) * chunk_order.size()); put(o_cco, coarse_order.data(), sizeof(int) * coarse_order.size());
             char* d_blob = nullptr;
             HIP_TRY(dev_alloc(&d_blob, blob.size()));
             HIP_TRY(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -927,6 +925,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             p->d_cam_chunk_ptr = reinterpret_cast<int*>(d_blob + o_ccp); p->d_blk_cams = reinterpret_cast<int2*>(d_blob + o_bc);
             p->d_pwg_blocks = reinterpret_cast<int2*>(d_blob + o_pwg);
             p->d_pt_order = pt_order.empty() ? nullptr : reinterpret_cast<int*>(d_blob + o_pto);
+            p->d_chunk_order = reinterpret_cast<int*>(d_blob + o_co); p->d_coarse_order = reinterpret_cast<int*>(d_blob + o_cco);
         }
         // (wave-per-block pass: one descriptor per chunk of SFMBA_PAIR_CHUNK pairs -- as many as the pair total allows at most)
         pair_slot_cap = p->no_pairs ? 1 : pair_lpb == 64 ? pwg_blocks.size() + (size_t)(npair_total / SFMBA_PAIR_CHUNK) + 1 : std::max<size_t>(pwg_blocks.size() * (size_t)blocks_per_wg, 1);
@@ -1081,7 +1080,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         p->own_chunk0 = (int)(nc_ * r_ / w_); p->own_chunk1 = (int)(nc_ * (r_ + 1) / w_);
         p->own_coarse0 = (int)(ncc * r_ / w_); p->own_coarse1 = (int)(ncc * (r_ + 1) / w_);
     }
-    ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks;
+    ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks; ds.chunk_order = p->d_chunk_order; ds.coarse_order = p->d_coarse_order;
     ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
     ds.obs_pt = p->d_obs_pt;
     ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pair_pt = p->d_pair_pt;
@@ -1820,7 +1819,6 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
         // formed implicitly from every rank's own points (implicit_schur.hip); duplicates live in diagonal blocks the
         // implicit form does not see: such a problem takes the explicit distributed form
         int dist_mode = o.shard_distributed_cg > 0 ? o.shard_distributed_cg : 0;
-        if (const char* e = std::getenv("SFMBA_SHARD_DIST_CG")) dist_mode = e[0] == '0' ? 0 : e[0] == '2' ? 2 : e[0] == '3' ? 3 : 1;
         // ... or with the block ROWS of S~ sharded (shard_distributed_cg = 3): a property of the problem handle -- every rank was given the whole problem
         if (p->no_pairs) dist_mode = 2;          // no pair list: the implicit product is the only one there is
         else if (p->row_sharded) dist_mode = 3;
@@ -1973,6 +1971,7 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
                     return fail(SFMBA_ERR_HIP, std::string("sharded LM iteration did not complete: ") + (se != hipSuccess ? hipGetErrorString(se) : "no control post"));
                 }
                 if (mb[1] != -2) break;
+                if (o.verbose) std::fprintf(stderr, "[sfmba shard %d/%d] CG batch too short after %d launches\n", p->shard_rank, p->shard_world, dist_cg ? dcg_launched : -1);
                 // the CG batch was too short (identically on every rank: same matrix, same arithmetic): more iterations, then the trio again
                 // (the early linearisation kernel behind that control kernel has returned without doing anything)
                 build_enqueued = false;
@@ -1988,6 +1987,7 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
             }
             dense_pcg_note(&p->solver, p->shard_host_iter, mb[4]);
             p->shard_sum.linear_iters += mb[4];
+            if (o.verbose) std::fprintf(stderr, "[sfmba shard %d/%d] LM iteration %d: %d CG iterations (%d launched), termination %d\n", p->shard_rank, p->shard_world, mb[3], mb[4], dist_cg ? dcg_launched : 0, mb[1]);
             p->shard_host_iter = mb[3];
             if (mb[1] != -1) {
                 p->shard_sum.termination = mb[1];

@@ -38,7 +38,7 @@ def test_over_the_pair_limit_is_solved_matrix_free(capi, sfm, oracle, allvis, mo
     assert np.abs(cam - cam_o).max() <= atol and np.abs(pt - pt_o).max() <= atol and np.isclose(f, f_o, rtol=1e-9 if exact else 1e-7)
     assert len(tr) == len(tr_o) and [r["step_is_successful"] for r in tr] == [r["step_is_successful"] for r in tr_o]
     for a, b in zip(tr, tr_o):
-        assert np.isclose(a["cost"], b["cost"], rtol=1e-9 if exact else 1e-6)
+        assert np.isclose(a["cost"], b["cost"], rtol=1e-9 if exact else 5e-5)        # (F32J: intermediate iterates to 5e-5, the final cost to 1e-6 above)
     # and a solve that did build its pair list (same library, limit back up): the same result
     monkeypatch.delenv("SFMBA_PAIR_LIMIT")
     cam_p, pt_p, f_p, s_p, _ = capi.solve(allvis, capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw))

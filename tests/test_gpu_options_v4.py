@@ -1,5 +1,5 @@
-"""ABI v4 (-m gpu): the behaviour switches that used to be environment variables only are fields of sfmba_options / create flags now
-(0 = library default, 1 = on, -1 = off; the environment variable, when set, still overrides).  Every switch is driven THROUGH THE
+"""ABI v4 / v5 (-m gpu): the behaviour switches that used to be environment variables only are fields of sfmba_options / create flags
+(0 = library default, 1 = on, -1 = off; since ABI v5 NOTHING below sfmba_problem_create* reads the environment any more).  Every switch is driven THROUGH THE
 C ABI here, with the environment clean, and must (a) act -- the observable the switch controls changes -- and (b) leave the result
 where the reference algorithm puts it (the oracle, or the default configuration)."""
 import os
@@ -90,19 +90,19 @@ def test_pcg_coarse_space_switch(capi, mid, mid_oracle):
         same(r, mid_oracle, atol=1e-6)
 
 
-def test_env_override_beats_the_field(capi, mid, monkeypatch):
+def test_the_environment_no_longer_overrides_a_solve(capi, mid, monkeypatch):
+    """ABI v5: no getenv below sfmba_problem_create*.  The ABI v4 override variables are ignored by a solve -- the
+    fields of sfmba_options are the only way to a solver family -- and the reserved pcg_persistent field (the cooperative one-launch CG,
+    never a default at any size, is gone) changes nothing."""
     base = dict(max_seconds=0.0, linear_solver=1, pcg_tolerance=1e-10, pcg_anchored=0)
-    on = capi.solve(mid, capi.default_options(**base))[3]["linear_iters"]
-    monkeypatch.setenv("SFMBA_PCG_COARSE", "0")
-    assert capi.solve(mid, capi.default_options(pcg_coarse_space=1, **base))[3]["linear_iters"] > 1.3 * on
-
-
-def test_pcg_persistent_switch(capi, sfm, mid):
-    base = dict(max_seconds=0.0, linear_solver=1, pcg_tolerance=1e-10, pcg_coarse_space=-1)
-    a = capi.solve(mid, capi.default_options(**base))
-    b = capi.solve(mid, capi.default_options(pcg_persistent=1, **base))
-    assert a[3]["iterations"] == b[3]["iterations"] and abs(a[3]["final_cost"] - b[3]["final_cost"]) <= 1e-10 * a[3]["final_cost"]
-    assert np.abs(a[0] - b[0]).max() < 1e-7
+    on = capi.solve(mid, capi.default_options(**base))
+    for var in ("SFMBA_PCG_COARSE", "SFMBA_PCG_SEGMENTS", "SFMBA_PCG_GATED", "SFMBA_PCG_ANCHOR", "SFMBA_EARLY_LINEARISE", "SFMBA_PCG_PERSISTENT"):
+        monkeypatch.setenv(var, "0")
+    env = capi.solve(mid, capi.default_options(pcg_persistent=1, **base))
+    assert env[3]["linear_iters"] == on[3]["linear_iters"] and env[3]["iterations"] == on[3]["iterations"]
+    assert abs(env[3]["final_cost"] - on[3]["final_cost"]) <= 1e-12 * on[3]["final_cost"]
+    off = capi.solve(mid, capi.default_options(pcg_coarse_space=-1, **base))
+    assert off[3]["linear_iters"] > 1.3 * on[3]["linear_iters"]                # the field, and only the field, acts
 
 
 def test_pcg_f32_matrix_switch(capi, sfm):

@@ -20,6 +20,7 @@ CASES = {
     # 230 cameras: reduced dimension 1381 > 1280 -> streaming CG (fp32-stored matrix in F32J mode); ~10 pairs per 6x6
     # block -> the sixteen-lane pair pass k_schur_pairs_sub_f; sharded ranks transform the all-reduced system (k_pcg_transform)
     "wide": (dict(name="cfg3", n_cam=230, n_pt=6000, seed=77), 1, 1, dict()),
+    "wide_x64": (dict(name="cfg3", n_cam=230, n_pt=6000, seed=77), 1, 1, dict(shard_f32_exchange=-1)),       # every exchange fp64
     # point counts that no world size of 2, 3 or 4 divides (5003 is prime, 6001 = 17 * 353): ranks hold shards of different sizes
     "cfg2_uneven": (dict(name="cfg2", n_pt=5003), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
     "wide_uneven": (dict(name="cfg3", n_cam=230, n_pt=6001, seed=78), 1, 1, dict()),
@@ -79,6 +80,27 @@ def _worker(rank, world, port, case, out, native=False, n_repeats=12, flags=0):
     dist.destroy_process_group()
 
 
+def _run_ranks(world, port, case, native, n_repeats, flags=0, timeout=420):
+    """Spawns the ranks, collects their results; whatever happens, no rank outlives the test (a rank stuck in a collective whose peer died
+    would keep the test session from exiting)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, native, n_repeats, flags)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = sorted([out.get(timeout=timeout) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return results
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
+
+
 @pytest.mark.parametrize("case,native,x32", [("small", False, True), ("cfg2", False, True), ("wide", False, True), ("cfg2", True, True),
                                              ("wide", True, True), ("wide", True, False)])
 def test_two_rank_sharded_hip_solve(sfm, oracle, monkeypatch, case, native, x32):
@@ -86,19 +108,9 @@ def test_two_rank_sharded_hip_solve(sfm, oracle, monkeypatch, case, native, x32)
     x32 (only the 'wide' native case has the fp32-stored matrix): the off-diagonal blocks of the preconditioned matrix are exchanged in
     single precision (sfmba_problem_set_allreduce_f32); False switches that off (every exchange fp64)."""
     from sfm_toy_library_amd import capi
-    if not x32:
-        monkeypatch.setenv("SFMBA_SHARD_F32_EXCHANGE", "0")         # (inherited by the spawned ranks)
-    kw, precision, linear, okw = CASES[case]
+    kw, precision, linear, okw = CASES["wide_x64" if not x32 else case]
     world, port = 2, 29711 + (os.getpid() % 500)
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, native)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = sorted([out.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run_ranks(world, port, "wide_x64" if not x32 else case, native, 12, timeout=300)
     prob = sfm.make_problem(**kw)
     (r0, s0, cam0, pt0, f0, rng0, rep0), (r1, s1, cam1, pt1, f1, rng1, rep1) = results
     for a, b in zip(rep0, rep1):
@@ -166,9 +178,8 @@ def test_sharded_exchange_variants_agree(sfm, monkeypatch, linear):
     try:
         got = {}
         for flag in ("1", "0"):
-            monkeypatch.setenv("SFMBA_SHARD_TWO_PHASE", flag)
             be.reset()
-            s = solve_sharded_native(be, opt, comm=None)
+            s = solve_sharded_native(be, capi.default_options(max_seconds=0.0, linear_solver=linear, precision=1, shard_two_phase=1 if flag == "1" else -1), comm=None)
             got[flag] = (s, be.get_params())
             assert s["termination_name"] == ref["termination_name"] and s["iterations"] == ref["iterations"]
             assert abs(s["final_cost"] - ref["final_cost"]) <= 1e-9 * ref["final_cost"]
@@ -190,15 +201,7 @@ def test_multi_rank_uneven_sharded_hip_solve(sfm, oracle, world, case):
     from sfm_toy_library_amd import capi
     kw, precision, linear, okw = CASES[case]
     port = 29311 + (os.getpid() % 300) + 7 * world
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, True, 2)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = sorted([out.get(timeout=420) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run_ranks(world, port, case, True, 2)
     prob = sfm.make_problem(**kw)
     assert prob.n_pt % world != 0
     ranges = [r[5] for r in results]
@@ -232,15 +235,7 @@ def test_row_sharded_hip_solve(sfm, oracle, world, case, flags):
     WHOLE solution (the final points are all-gathered): replicas bit-identical in cameras AND points.  flags = 1: deterministic handles."""
     kw, precision, linear, okw = CASES[case]
     port = 29011 + (os.getpid() % 300) + 11 * world
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, True, 2, flags)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = sorted([out.get(timeout=420) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    results = _run_ranks(world, port, case, True, 2, flags, timeout=240)
     prob = sfm.make_problem(**kw)
     assert prob.n_pt % world != 0
     cam0, pts0, f0, s0 = results[0][2], results[0][3], results[0][4], results[0][1]
