@@ -1663,14 +1663,17 @@ __global__ void k_lm_control(DeviceBuffers db) { lm_control_body(db); }
 // -- so the second sweep over the observations only evaluates the TRIAL residual (projection with the trial pose at the trial point): nothing
 // per observation has to survive the first sweep, no LDS, and the per-point arithmetic runs on all lanes (the lane-per-observation form
 // of the first half of round 4: 33.6 against 29.9 us at BASELINE config 3, 242 against 189 at config 5).
-// The last workgroup of the launch to arrive (agent-scope release / acquire around a ticket counter, as k_finalize) runs the LM control logic:
-// k_lm_control as a launch of its own was 5.9 us at the floor of a launch, three times per BASELINE-config-3 solve.
+// The last workgroup of the launch to arrive runs the LM control logic: k_lm_control as a launch of its own was 5.9 us at the floor of a
+// launch, three times per BASELINE-config-3 solve.  What the control logic reads from THIS launch are the slotted accumulators, and those
+// are only ever written by agent-scope atomics (performed at the memory side: MI355X_MICROARCH.md "{8-B agent atomics both sides}" is a
+// valid hand-off): a workgroup drains its own (s_waitcnt vmcnt(0): on gfx9 stores and atomics count until they are written) and takes a
+// ticket -- NO release fence.  A release (buffer_wbl2: the XCD's L2 written back) per workgroup is what the first version did: 3 125
+// workgroups of them took k_point_update from 27 to 83 us at BASELINE config 3 and from 190 to 747 at config 5.  The last arriver
+// invalidates its CU's L1 (one acquire) and reads the sums.
 __device__ __forceinline__ bool arrive_last(const DeviceBuffers& db, int* s_last) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int ticket = __hip_atomic_fetch_add(db.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last = (ticket == (int)gridDim.x - 1);
         if (*s_last) {

@@ -10,7 +10,7 @@ def worker(rank, world, port, case, out, secs):
     faulthandler.dump_traceback_later(secs, exit=True, file=sys.stderr)
     import test_gpu_sharded as t
     t.CASES[case][3]["verbose"] = 1
-    t._worker(rank, world, port, case, out, True, 0, 0)
+    t._worker(rank, world, port, case, out, True, int(os.environ.get('DBG_REPEATS', '2')), 0)
 
 
 if __name__ == "__main__":
