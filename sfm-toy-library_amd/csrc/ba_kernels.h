@@ -182,8 +182,7 @@ void launch_finalize(hipStream_t s, const DeviceStructure& ds, const DeviceBuffe
 void launch_cd_fold(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // deterministic + sharded: chunk sums into the partial system (before the exchange)
 void launch_gauge(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);   // gauge vectors from db.pcg_binv (see k_gauge)
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
-// fuse_control: the last workgroup to arrive runs the LM control logic (k_lm_control) -- no control launch behind this one
-template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, bool fuse_control = false);
+template <typename T> void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_eval_residuals(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,

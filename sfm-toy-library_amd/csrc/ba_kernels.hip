@@ -1548,8 +1548,7 @@ __device__ __forceinline__ void lm_post(int* mb, int seq, int termination, int m
     __hip_atomic_store(mb, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// (all 64 lanes of ONE wave; every accumulator it reads must be complete and visible: a kernel of its own behind the passes, or the last
-// workgroup to arrive of k_point_update<T, true>)
+// (all 64 lanes of ONE wave; every accumulator it reads must be complete and visible: a kernel of its own behind the passes)
 __device__ __forceinline__ void lm_control_body(const DeviceBuffers& db) {
     LMState* st = db.st;
     if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) {
@@ -1663,37 +1662,14 @@ __global__ void k_lm_control(DeviceBuffers db) { lm_control_body(db); }
 // -- so the second sweep over the observations only evaluates the TRIAL residual (projection with the trial pose at the trial point): nothing
 // per observation has to survive the first sweep, no LDS, and the per-point arithmetic runs on all lanes (the lane-per-observation form
 // of the first half of round 4: 33.6 against 29.9 us at BASELINE config 3, 242 against 189 at config 5).
-// The last workgroup of the launch to arrive runs the LM control logic: k_lm_control as a launch of its own was 5.9 us at the floor of a
-// launch, three times per BASELINE-config-3 solve.  What the control logic reads from THIS launch are the slotted accumulators, and those
-// are only ever written by agent-scope atomics (performed at the memory side: MI355X_MICROARCH.md "{8-B agent atomics both sides}" is a
-// valid hand-off): a workgroup drains its own (s_waitcnt vmcnt(0): on gfx9 stores and atomics count until they are written) and takes a
-// ticket -- NO release fence.  A release (buffer_wbl2: the XCD's L2 written back) per workgroup is what the first version did: 3 125
-// workgroups of them took k_point_update from 27 to 83 us at BASELINE config 3 and from 190 to 747 at config 5.  The last arriver
-// invalidates its CU's L1 (one acquire) and reads the sums.
-__device__ __forceinline__ bool arrive_last(const DeviceBuffers& db, int* s_last) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int ticket = __hip_atomic_fetch_add(db.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = (ticket == (int)gridDim.x - 1);
-        if (*s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(db.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    return *s_last != 0;
-}
-
-template <typename T, bool FUSE_CONTROL>
+// (Measured in round 5 and not kept: the LM control logic run by the LAST WORKGROUP TO ARRIVE of this launch instead of a launch of its own.
+// With a release fence per workgroup the launch went from 27 to 83 us at BASELINE config 3 (747 from 190 at config 5: buffer_wbl2 3 125 times);
+// with the slots read as agent atomics and no release, one ticket counter serialised the 3 125 arrivals (57 us); with two-level tickets on
+// separate cache lines 36.5 us against 29.9 + 5.6 for the two launches: 4 260 against 4 270 LM iterations/s -- a wash, so the simpler form stays.)
+template <typename T>
 __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[WPB * 5];
-    __shared__ int s_last;
-    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) {      // see k_cam_update
-        // (the CG's done flag was written by launches in front of this one: every workgroup sees the same value)
-        if (FUSE_CONTROL) { if (arrive_last(db, &s_last) && threadIdx.x < 64) lm_control_body(db); }
-        return;
-    }
+    if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // see k_cam_update
     const LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
     const double* tab = db.camtab[cur];
@@ -1802,7 +1778,6 @@ __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, Dev
         const int which = threadIdx.x == 0 ? ACC_TRIAL_COST : threadIdx.x == 1 ? ACC_MODEL : threadIdx.x == 2 ? ACC_STEP2 : threadIdx.x == 3 ? ACC_XNEW2 : ACC_BAD_TRIAL;
         if (threadIdx.x < 4 || tot != 0.0) atomicAdd(slot_ptr(db, which), tot);
     }
-    if (FUSE_CONTROL) { if (arrive_last(db, &s_last) && threadIdx.x < 64) lm_control_body(db); }
 }
 
 void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
@@ -1810,14 +1785,12 @@ void launch_cam_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuf
 }
 
 template <typename T>
-void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, bool fuse_control) {
+void launch_point_update(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     const int per_wg = WPB * (64 / PB_LPP);
-    const dim3 grid(std::max(1, (ds.npt + per_wg - 1) / per_wg));
-    if (fuse_control) hipLaunchKernelGGL((k_point_update<T, true>), grid, dim3(PBK), 0, s, ds, db);
-    else hipLaunchKernelGGL((k_point_update<T, false>), grid, dim3(PBK), 0, s, ds, db);
+    hipLaunchKernelGGL(k_point_update<T>, dim3(std::max(1, (ds.npt + per_wg - 1) / per_wg)), dim3(PBK), 0, s, ds, db);
 }
-template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, bool);
-template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, bool);
+template void launch_point_update<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
+template void launch_point_update<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&);
 
 void launch_control(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db) {
     (void)ds;

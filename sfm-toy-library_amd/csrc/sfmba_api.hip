@@ -489,9 +489,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         }
         bool lm_done = false;
         while (!lm_done) {
-            // (the LM control logic runs in the last workgroup of the point update to arrive: no launch of its own)
             { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
-            { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, dbu, /*fuse_control=*/true); }
+            { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, dbu); }
+            { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, dbu); }
             { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
             ++launched_controls;
             // every launch of this LM iteration is in the queue: a failed launch must not leave the host waiting for a post
