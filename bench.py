@@ -58,7 +58,8 @@ def parse():
                                                               "multi-workgroup distributed CG on the owned rows)")
     ap.add_argument("--extra-workloads", type=int, default=-1,
                     help="after the timed region also run the other BASELINE configurations (cfg 2 in fp64 with the reference's solver, cfg 3 in all-fp64, cfg3_banded, cfg 5) and hold "
-                         "each to the oracle's stored final cost: 1 = yes, 0 = no, -1 (default) = at N = 1 with the default workload")
+                         "each to the oracle's stored final cost: 1 = yes, 0 = no, -1 (default) = at N = 1 in the driver's plain invocation (default workload and solver, "
+                         "CPU baseline not switched off: the tool runs under rocprofv3 stay lean)")
     ap.add_argument("--extras-timeout", type=int, default=300, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -322,7 +323,7 @@ def main():
                                        "cg_iterations_per_step": li2 / args.steps, "cholesky_fallbacks": fb2,
                                        "final_cost": s2["final_cost"], "note": "same problem, sfmba_options_default (SFMBA_LINEAR_AUTO)"}
     if rank == 0 and world == 1 and not os.environ.get("SFMBA_BENCH_PMC_CHILD") and \
-            (args.extra_workloads == 1 or (args.extra_workloads == -1 and args.workload == "cfg3" and linear == 1 and precision == 1)):
+            (args.extra_workloads == 1 or (args.extra_workloads == -1 and args.workload == "cfg3" and linear == 1 and precision == 1 and not args.no_cpu_baseline)):
         try:
             line["extra_workloads"] = extra_workloads(args, torch, sfm, capi)
         except Exception as e:                                  # never lose the headline line to the extras

@@ -500,25 +500,58 @@ __global__ __launch_bounds__(256) void k_dcg_start(int d, int ld, int np, const 
     double rr = 0.0;
     if (W) {
         const double* lin = buf + (size_t)NW * ld;
-        if (tid < NW * NW) {
-            double e = 0.0;
-            for (int i = 0; i < np; ++i) e += lin[(size_t)i * LIN8_STRIDE + tid];       // fixed order: the same on every rank
-            tot[tid] = e;
+        {   // E = the partials of the product workgroups summed: entry tid % 64 over the rows tid / 64, tid / 64 + 4, ... (eight loads in flight per
+            // thread: one load per pass was np dependent L2 round trips, 74 us at 1000 cameras), the four quarters added in a fixed order
+            const int e = tid & 63, part = tid >> 6;
+            double acc = 0.0;
+            for (int i0 = part; i0 < np; i0 += 32) {
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + 4 * u; t[u] = lin[(size_t)(i < np ? i : part) * LIN8_STRIDE + e]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (i0 + 4 * u < np) ? t[u] : 0.0;
+            }
+            sa[tid & 63] = 0.0;      // (sa / sb are scratch of the inversion below; sa doubles as the staging of the quarters: 4 x 64 would not fit, so quarter by quarter)
+            __syncthreads();
+            for (int q = 0; q < 4; ++q) { if (part == q) sa[e] += acc; __syncthreads(); }
+            if (tid < NW * NW) tot[tid] = sa[tid];
         }
         __syncthreads();
         if (tid < 64) s_einv[tid] = coarse_invert_wave(tot, sa, sb);
         double v[NW + 1];
 #pragma unroll
         for (int k = 0; k <= NW; ++k) v[k] = 0.0;
-        for (int i = tid; i < d; i += 256) {
-            const double b = bt[i];
-            v[NW] = fma(b, b, v[NW]);
+        for (int i0 = tid; i0 < d; i0 += 1024) {          // four entries per pass: 36 loads in flight
+            double b4[4], w4[4][NW];
 #pragma unroll
-            for (int k = 0; k < NW; ++k) v[k] = fma(W[(size_t)k * ld + i], b, v[k]);
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u, ic = i < d ? i : 0;
+                b4[u] = bt[ic];
+#pragma unroll
+                for (int k = 0; k < NW; ++k) w4[u][k] = W[(size_t)k * ld + ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double b = (i0 + 256 * u < d) ? b4[u] : 0.0;
+                v[NW] = fma(b, b, v[NW]);
+#pragma unroll
+                for (int k = 0; k < NW; ++k) v[k] = fma(w4[u][k], b, v[k]);
+            }
         }
+        {   // nine block sums behind ONE pair of barriers
+            __shared__ double s9[4][NW + 1];
 #pragma unroll
-        for (int k = 0; k < NW; ++k) c0[k] = block_sum_all256(v[k], sh4);
-        rr = block_sum_all256(v[NW], sh4);
+            for (int k = 0; k <= NW; ++k) v[k] = wave_allsum(v[k]);
+            __syncthreads();
+            if ((tid & 63) == 0) {
+#pragma unroll
+                for (int k = 0; k <= NW; ++k) s9[tid >> 6][k] = v[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NW; ++k) c0[k] = s9[0][k] + s9[1][k] + s9[2][k] + s9[3][k];
+            rr = s9[0][NW] + s9[1][NW] + s9[2][NW] + s9[3][NW];
+        }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             double m = 0.0;
@@ -589,7 +622,13 @@ __global__ __launch_bounds__(256) void k_dcg_upd(int d, int ld, int np, const do
     const bool broke = !(pq > 0.0);
     const double alpha = broke ? 0.0 : rz / pq;
     double rr = 0.0;
-    for (int i = tid; i < d; i += 256) { const double rn = fma(-alpha, q[i], r_in[i]); rr = fma(rn, rn, rr); }
+    for (int i0 = tid; i0 < d; i0 += 2048) {              // eight entries per pass, sixteen loads in flight (one per pass: d / 256 dependent round trips)
+        double q8[8], r8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u, ic = i < d ? i : 0; q8[u] = q[ic]; r8[u] = r_in[ic]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double rn = fma(-alpha, q8[u], r8[u]); rr = (i0 + 256 * u < d) ? fma(rn, rn, rr) : rr; }
+    }
     rr = block_sum_all256(rr, sh4);
     double c[NW], mu[NW];
     double rzn = rr;

@@ -805,18 +805,21 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         cam_chunk_ptr[(size_t)ncam] = (int)chunks.size();
         // launch order of the chunks (ba_kernels.h, chunk_order): by the chunk's relative position in its camera's list (a camera's entries ascend
         // in point slot, so that is -- for any co-visibility that samples the points evenly -- the window of the per-point table it gathers from),
-        // cameras side by side inside a window.  The chunk list itself stays camera-major (deterministic mode adds a camera's chunks in list order).
+        // cameras side by side inside a window (1024 windows).  The chunk list itself stays camera-major (deterministic mode adds a camera's chunks in list order).
         auto order_of = [&](const std::vector<int4>& ch, std::vector<int>* order) {
+            // (a counting sort over 1024 windows, stable in list order: this runs on the append path of the incremental caller)
+            constexpr int NWIN = 1024;
             order->resize(ch.size());
-            std::vector<unsigned long long> key(ch.size());
+            std::vector<int> win(ch.size()), start(NWIN + 1, 0);
             for (size_t c = 0; c < ch.size(); ++c) {
                 const int j = ch[c].x;
                 const long long cnt = std::max(1, cam_ptr[(size_t)j + 1] - cam_ptr[(size_t)j]);
                 const long long mid = (long long)(ch[c].y - cam_ptr[(size_t)j]) + (ch[c].z - ch[c].y) / 2;
-                key[c] = ((unsigned long long)(mid * 4096 / cnt) << 32) | (unsigned)c;      // 4096 windows; ties: list order
+                win[c] = (int)std::min<long long>(NWIN - 1, mid * NWIN / cnt);
+                ++start[(size_t)win[c] + 1];
             }
-            std::sort(key.begin(), key.end());
-            for (size_t c = 0; c < ch.size(); ++c) (*order)[c] = (int)(key[c] & 0xffffffffu);
+            for (int w = 0; w < NWIN; ++w) start[(size_t)w + 1] += start[(size_t)w];
+            for (size_t c = 0; c < ch.size(); ++c) (*order)[(size_t)start[(size_t)win[c]]++] = (int)c;
         };
         order_of(chunks, &chunk_order);
         order_of(chunks_coarse, &coarse_order);
