@@ -433,7 +433,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // factorisation's 1 639 -- the factorisation stays AUTO's choice there; the PCG mode is where the segments pay: 1 224 -> 2 220.)
     // On the streaming path (d > 1280) it is the other way round: a 600-camera path costs 4.5 ms per factorisation against ~1.7 ms for the
     // segmented CG run to 1e-12 (tools/large_banded_check.py) -- AUTO keeps the CG there.
-    if (exact_pcg && p->block_fill < 0.5 && !(segments_cg && dense_pcg_segments_streaming_applicable(&p->solver))) auto_prefers_cholesky = true;
+    // (fill alone is not the signature of a path: an unordered but well-connected collection is sparsely filled too and its CG converges in a
+    // few iterations -- there the per-solve break-even below decides)
+    if (exact_pcg && p->block_fill < 0.5 && p->block_band >= 0.9 && !(segments_cg && dense_pcg_segments_streaming_applicable(&p->solver))) auto_prefers_cholesky = true;
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
@@ -856,7 +858,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
             std::sort(smp.begin(), smp.end());
             std::vector<int> keys;
             size_t npts_s = 0;
-            for (size_t a = 0; a < smp.size();) {
+            for (size_t a = 0; a < smp.size() && keys.size() < ((size_t)1 << 22);) {      // (bounded: long tracks make m (m - 1) / 2 keys per point)
                 size_t b = a;
                 while (b < smp.size() && smp[b].first == smp[a].first) ++b;
                 ++npts_s;
@@ -1926,7 +1928,9 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
                 p->dcg.x = p->solver.vec;
                 int drc = dcg_begin(p->stream, &p->dcg, da, ar_thunk, &arctx);
                 int batch = 24;
-                if (p->shard_host_iter < (int)p->solver.hist.size() && p->solver.hist[(size_t)p->shard_host_iter] > 0) batch = p->solver.hist[(size_t)p->shard_host_iter] + 2;
+                // (every launch of a batch issues its collective, converged or not: one launch in reserve, not two -- a surplus iteration is a whole
+                // all-reduce at N > 1; a batch one short costs one host round trip)
+                if (p->shard_host_iter < (int)p->solver.hist.size() && p->solver.hist[(size_t)p->shard_host_iter] > 0) batch = p->solver.hist[(size_t)p->shard_host_iter] + 1;
                 batch = std::min(batch, dcg_max);
                 if (!drc) drc = dcg_iterate(p->stream, &p->dcg, da, batch, ar_thunk, &arctx);
                 if (drc) return fail(SFMBA_ERR_HIP, "distributed CG: collective failed (rc " + std::to_string(drc) + ")");

@@ -141,3 +141,24 @@ def test_segments_streaming_path_long_camera_path(capi, sfm, oracle):
     assert [r["linear_iters"] for r in a[4][1:]] != [r["linear_iters"] for r in b[4][1:]] and a[3]["linear_iters"] < 0.5 * b[3]["linear_iters"]
     assert a[3]["termination_name"] == "CONVERGENCE" and abs(a[3]["final_cost"] - b[3]["final_cost"]) <= 1e-7 * b[3]["final_cost"]      # (F32J, CG at 1e-8)
     assert_same_solve(prob, a, want, param_atol=5e-5, trace_rtol=5e-5, point_atol=5e-3)
+
+
+@pytest.mark.parametrize("n_cam,n_pt,seed", [(330, 30000, 41), (520, 42000, 43)])
+def test_segments_streaming_path_other_hat_counts(capi, sfm, oracle, n_cam, n_pt, seed):
+    """the streaming segmented CG (k_sg_*) rested on ONE oracle test (240 cameras, G = 9 hats).  Here: 330 cameras (13 hats,
+    92 coarse vectors) and 520 cameras (20 hats, 141 vectors: the largest E the in-register inversion holds) -- against the oracle in fp64, in
+    F32J with the fp32 copy of the preconditioned matrix (the library's choice there) and in F32J with the matrix kept in fp64, and with
+    the library default (AUTO keeps the CG on this path).  The block-sparse product (fill < 1/4) is what runs at both sizes."""
+    prob = sfm.make_problem("cfg3_banded", n_cam=n_cam, n_pt=n_pt, seed=seed)
+    want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    a = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1))                       # fp64, segments by structure
+    assert_same_solve(prob, a, want, param_atol=1e-7, trace_rtol=1e-6, point_atol=1e-6)
+    g = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=1, pcg_coarse_space=1))   # the eight global vectors
+    assert a[3]["linear_iters"] < 0.5 * g[3]["linear_iters"]
+    for f32m in (0, -1):
+        b = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_f32_matrix=f32m))
+        assert b[3]["termination_name"] == "CONVERGENCE" and b[3]["iterations"] == want[3]["iterations"]
+        assert_same_solve(prob, b, want, param_atol=5e-5, trace_rtol=5e-5, point_atol=5e-3)
+    d = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0))                                         # AUTO: the CG at 1e-12, no factorisation
+    assert d[3]["cholesky_fallbacks"] == 0 and d[3]["linear_iters"] > 0
+    assert_same_solve(prob, d, want, param_atol=1e-8, trace_rtol=1e-9, point_atol=1e-7)
