@@ -75,8 +75,11 @@ enum { SFMBA_LINEAR_CHOLESKY = 0,   /* exact Schur + dense LLT == DENSE_SCHUR (B
 enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
        SFMBA_PRECISION_F32J = 1 };  /* fp32 Jacobian blocks AND fp32 observation coordinates (BASELINE config 3; the reference's
                                        observations are cv::Point2f anyway, BA.cpp:149-153 -- a caller holding genuinely double
-                                       observations loses ~1e-4 px at 2k-px coordinates); residuals, cost, sums and the reduced
-                                       system in fp64.  What to expect (tests/test_gpu_baseline_parity.py): final cost within 1e-6
+                                       observations loses ~1e-4 px at 2k-px coordinates).  What is summed in which precision: a lane's OWN
+                                       partial sum of block products is fp32 (at most 8 pair products of a 6x6 block of the reduced matrix,
+                                       ceil(track / 4) point-block products of a point); every sum ACROSS lanes, chunks, points and ranks is
+                                       fp64, and so are the residuals, the cost, the reduced system and its solve (ABI v4 summed a block's
+                                       up-to-512 pair products in fp32 before widening).  What to expect (tests/test_gpu_baseline_parity.py): final cost within 1e-6
                                        relative (measured 3e-13) and final RMS within 1e-4 px of the fp64 solve (measured < 1e-9 px),
                                        parameters within ~2e-5 -- EXCEPT points on weakly constrained tracks: a point seen by two
                                        nearly parallel views has almost no depth information, its 3x3 block is ill-conditioned and
