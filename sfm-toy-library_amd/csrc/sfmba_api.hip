@@ -1820,9 +1820,8 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
         const double cg_tol = exact_pcg ? std::min(o.pcg_tolerance > 0.0 ? o.pcg_tolerance : auto_cg_tol(), auto_cg_tol()) : o.pcg_tolerance;
         // the CG without the redundant solve (dist_cg.h): reduce-scatter of the blocks, products from the owned blocks, one small
         // all-reduce per CG iteration
-        // ... or WITHOUT any exchange of the reduced matrix (shard_distributed_cg = 2 / SFMBA_SHARD_DIST_CG=2): the product of a CG iteration is
-        // formed implicitly from every rank's own points (implicit_schur.hip); duplicates live in diagonal blocks the
-        // implicit form does not see: such a problem takes the explicit distributed form
+        // ... or WITHOUT any exchange of the reduced matrix (shard_distributed_cg = 2): the product of a CG iteration is formed implicitly from
+        // every rank's own points (implicit_schur.hip)
         int dist_mode = o.shard_distributed_cg > 0 ? o.shard_distributed_cg : 0;
         // ... or with the block ROWS of S~ sharded (shard_distributed_cg = 3): a property of the problem handle -- every rank was given the whole problem
         if (p->no_pairs) dist_mode = 2;          // no pair list: the implicit product is the only one there is
