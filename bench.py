@@ -60,7 +60,7 @@ def parse():
                     help="after the timed region also run the other BASELINE configurations (cfg 2 in fp64 with the reference's solver, cfg 3 in all-fp64, cfg3_banded, cfg 5) and hold "
                          "each to the oracle's stored final cost: 1 = yes, 0 = no, -1 (default) = at N = 1 in the driver's plain invocation (default workload and solver, "
                          "CPU baseline not switched off: the tool runs under rocprofv3 stay lean)")
-    ap.add_argument("--extras-timeout", type=int, default=300, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
+    ap.add_argument("--extras-timeout", type=int, default=420, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic live; the committed "
@@ -378,12 +378,15 @@ def main():
                 print(json.dumps(line), flush=True)
             os._exit(0)
         old_term = signal.signal(signal.SIGTERM, on_term)
-        for wl in (["cfg3", "cfg5"] if args.workload == "cfg3" else [args.workload]):
-            for variant in ("replicated_cg", "distributed_cg", "implicit_schur_cg", "row_sharded_cg"):          # the four forms of the reduced-system solve
+        # BASELINE config 5 first, and of its four forms the row-sharded one first: should the extras run out of their time,
+        # what is lost is the least interesting; one synthetic problem per workload, shared by its forms
+        for wl in (["cfg5", "cfg3"] if args.workload == "cfg3" else [args.workload]):
+            wl_prob = sfm.make_problem(wl)
+            for variant in ("row_sharded_cg", "replicated_cg", "distributed_cg", "implicit_schur_cg"):
                 key = wl if variant == "replicated_cg" else wl + "_" + variant
                 try:
                     sh[key] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)),
-                                          distributed={"replicated_cg": 0, "distributed_cg": 1, "implicit_schur_cg": 2, "row_sharded_cg": 3}[variant])
+                                          distributed={"replicated_cg": 0, "distributed_cg": 1, "implicit_schur_cg": 2, "row_sharded_cg": 3}[variant], prob=wl_prob)
                 except Exception as e:                       # never lose the headline line to the extras
                     sh[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         watchdog.cancel()
@@ -453,12 +456,13 @@ def extra_workloads(args, torch, sfm, capi):
     return out
 
 
-def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps, distributed=False):
+def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps, distributed=False, prob=None):
     """ONE problem, points sharded over the ranks; the LM loop runs inside the C library (sfmba_problem_solve_sharded) with
     ncclAllReduce on the solver's stream (sharded.RcclComm); every rank times the same K solves.  Returns the result dict."""
     from sfm_toy_library_amd import sharded
     import ctypes as C
-    prob = sfm.make_problem(workload)
+    if prob is None:
+        prob = sfm.make_problem(workload)
     be = (sharded.HipRowShardBackend if int(distributed) == 3 else sharded.HipShardBackend)(prob, rank, world, device=local_rank, precision=precision)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol,
                                shard_distributed_cg=int(distributed))
@@ -516,10 +520,29 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
             (L.sfmba_comm_allreduce_f32 if b_fp32 else L.sfmba_comm_allreduce)(comm._h, buf, C.c_int64(n_red), stream)
         barrier()
         t_ar = (time.perf_counter() - t1) / reps
-        tmax = torch.tensor([dt, t_ar], dtype=torch.float64, device="cuda")
+        # row-sharded: its two collectives on their own -- the all-gather of the per-point table (the one large message of a linearisation) and the
+        # small all-reduce of a CG iteration (latency-bound: what DESIGN.md section 6 prices at ~20 us)
+        t_ag = t_small = 0.0
+        if summ.get("row_sharded"):
+            stride = -(-prob.n_pt // world)
+            nbytes = stride * (88 if precision == 1 else 128)
+            scratch = torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda")
+            small = torch.zeros(ld + 16 * ((nc + 3) // 4 + 1), dtype=torch.float64, device="cuda")
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                L.sfmba_comm_allgather(comm._h, C.c_void_p(scratch.data_ptr()), C.c_int64(nbytes), stream)
+            barrier()
+            t_ag = (time.perf_counter() - t1) / reps
+            t1 = time.perf_counter()
+            for _ in range(50):
+                L.sfmba_comm_allreduce(comm._h, C.c_void_p(small.data_ptr()), C.c_int64(small.numel()), stream)
+            barrier()
+            t_small = (time.perf_counter() - t1) / 50
+        tmax = torch.tensor([dt, t_ar, t_ag, t_small], dtype=torch.float64, device="cuda")
         if dist is not None and world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        g_dt, g_ar = [float(v) for v in tmax.tolist()]
+        g_dt, g_ar, g_ag, g_small = [float(v) for v in tmax.tolist()]
         dist_note = None
         if summ.get("row_sharded"):
             dist_note = ("block ROWS of the preconditioned reduced matrix per rank: every rank holds the whole problem, eliminates its own range of points, the per-point table "
@@ -533,7 +556,7 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
             dist_note = ("reduce-scatter of the upper-triangle blocks of the preconditioned matrix into ranges of block rows (%d bytes in the buffer, a rank "
                          "receives 1 / %d of it), then per CG iteration ONE all-reduce of %d doubles (the partial product from the owned blocks); "
                          "vector updates replicated" % (ex_bytes[1], world, ld))
-        return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, points sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, world),
+        return {"workload": "%s: %d cams / %d pts / %d obs, ONE problem, %s sharded over %d rank(s)" % (workload, prob.n_cam, prob.n_pt, prob.n_obs, "points and block rows" if summ.get("row_sharded") else "points", world),
                 "reduced_system_solve": ("row-sharded: distributed CG on the rank's own block rows, formed from all their pairs" if summ.get("row_sharded") else
                                          "implicit Schur CG (no reduced matrix formed or exchanged)" if summ.get("implicit_schur_cg") else
                                          "distributed CG (no redundant solve)" if summ.get("distributed_cg") else "every rank runs the CG on the summed matrix (redundant)"),
@@ -545,9 +568,17 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
                 # one rank: the "all-reduce" is a no-op of the communicator, its time says nothing about xGMI
                 "allreduce_ms": 1e3 * g_ar if world > 1 else None,
                 "allreduce_GBps_algorithmic": ex_bytes[1] / g_ar / 1e9 if world > 1 else None, "exchange_b_dtype": "f32" if b_fp32 else "f64",
-                "collective": "three ncclAllReduce(SUM) per LM iteration on the solver stream: [6x6 diagonal blocks | camera-focal column | rhs | "
-                              "diagonals | scalars] (%d doubles), the off-diagonal blocks of the block-Jacobi-preconditioned reduced matrix (%d values, %s: the "
-                              "one timed here), 80 trial-step scalars; every rank runs the CG on the summed matrix redundantly" % (n_a, n_red, "fp32 like the CG's stored matrix" if b_fp32 else "fp64"),
+                # (row-sharded only; one rank: no-ops of the communicator)
+                "point_table_allgather_ms": (1e3 * g_ag if world > 1 else None) if summ.get("row_sharded") else None,
+                "cg_iteration_allreduce_us": (1e6 * g_small if world > 1 else None) if summ.get("row_sharded") else None,
+                "collective": ("per linearisation on the solver stream: two ncclAllGather (the halves of the per-point table: %d bytes per rank), one ncclAllReduce(SUM) of [6x6 diagonal "
+                               "blocks | camera-focal column | rhs | diagonals | scalars] (%d doubles), one of 8 ld + 64 (cameras / 4 + 1) doubles at the CG's set-up and one of "
+                               "ld + 16 (cameras / 4 + 1) = %d doubles per CG iteration, one of 80 trial-step scalars; one ncclAllGather of the final points per solve; `allreduce_ms` "
+                               "times an all-reduce of the size of exchange (B) of the point-sharded forms for comparison -- this form has no such exchange"
+                               % (-(-prob.n_pt // world) * (88 if precision == 1 else 128), n_a, ld + 16 * ((nc + 3) // 4 + 1))) if summ.get("row_sharded") else
+                              ("three ncclAllReduce(SUM) per LM iteration on the solver stream: [6x6 diagonal blocks | camera-focal column | rhs | "
+                               "diagonals | scalars] (%d doubles), the off-diagonal blocks of the block-Jacobi-preconditioned reduced matrix (%d values, %s: the "
+                               "one timed here), 80 trial-step scalars; every rank runs the CG on the summed matrix redundantly" % (n_a, n_red, "fp32 like the CG's stored matrix" if b_fp32 else "fp64")),
                 "final_rms_px": float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)), "final_cost": summ["final_cost"],
                 "termination": summ["termination_name"], "linear_iters_per_step": summ["linear_iters"]}
     finally:
