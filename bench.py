@@ -158,6 +158,16 @@ DTYPE_F32J = ("f32 Jacobian blocks and observation coordinates; a lane's own par
               "point) in f32, every sum across lanes, chunks, points and ranks in f64; residuals, cost, reduced system and solve in f64")
 
 
+def _flush_c_stdio():
+    """librccl prints a version banner into C stdio's buffer when the first communicator is created; left there it comes out at process exit,
+    BEHIND the JSON line.  Flushed here, the JSON line is the last line of stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -394,6 +404,7 @@ def main():
     if rank == 0:
         if sh is not None:
             line["sharded"] = sh
+        _flush_c_stdio()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -591,6 +602,7 @@ def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precisio
     r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps,
                     distributed=3 if args.row_sharded else 2 if args.implicit_cg else 1 if args.distributed_cg else 0)
     if rank == 0:
+        _flush_c_stdio()
         print(json.dumps({
             "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",

