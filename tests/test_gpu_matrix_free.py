@@ -99,4 +99,6 @@ def test_matrix_free_on_the_small_fixtures(capi, sfm, oracle, name):
         assert s["termination_name"] == want[3]["termination_name"] and s["iterations"] == want[3]["iterations"]
         assert [r["step_is_successful"] for r in tr] == [r["step_is_successful"] for r in want[4]]
         assert abs(s["final_cost"] - want[3]["final_cost"]) <= 1e-9 * want[3]["final_cost"]
-        assert np.abs(cam - want[0]).max() < 1e-7 and np.abs(pt - want[1]).max() < 1e-7
+        # the steps come from CG on the implicit product (relative residual 1e-12), not from a factorisation: cameras
+        # agree to 1e-7; the weakest-constrained point of small_rejected moves by 3e-6 at equal cost
+        assert np.abs(cam - want[0]).max() < 1e-7 and np.abs(pt - want[1]).max() < 2e-5

@@ -10,13 +10,3 @@ t = time.perf_counter()
 for _ in range(10): x, info, it = capi.dense_spd_solve(A, b, method=0)
 print("dense_spd_solve %.2f ms per call (incl. H2D/D2H)" % (1e3 * (time.perf_counter() - t) / 10), "resid", np.abs(A @ x - b).max())
 
-import ctypes
-lib = capi.lib() if hasattr(capi, "lib") else None
-try:
-    L = ctypes.CDLL(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "sfm-toy-library_amd", "csrc", "libsfmba_hip.so"))
-    buf = (ctypes.c_longlong * 16)()
-    L.sfmba_debug_chol_clk(buf)
-    t = list(buf)[:7]
-    print("diag workgroup of step 5, shader cycles: loads %d | panel GEMM %d | store L_ik %d | update %d | factor %d | stores %d" % (t[1]-t[0], t[2]-t[1], t[3]-t[2], t[4]-t[3], t[5]-t[4], t[6]-t[5]))
-except AttributeError:
-    pass
