@@ -108,7 +108,7 @@ struct DeviceStructure {
     int pwg_group;            // blocks per workgroup entry (SFMBA_PAIR_WAVES, or 64 / pair_lpb)
     const int4* pwg_desc;     // [npairwg * pwg_group] {block or -1, row camera ja, first pair, last pair + 1}: everything a wave (or lane
                               //       group) needs about its block in ONE load; jb follows from the block index
-    const int2* pwg_chunk;    // wave-per-block pass: [npairwg] {chunk index, chunks of the block}: heavy blocks are cut into chunks of
+    const int2* pwg_chunk;    // wave-per-block pass: [npairwg] {row of pair_partial, chunks of the block}: heavy blocks are cut into chunks of
                               //       SFMBA_PAIR_CHUNK pairs, one wave each (consecutive slots); null for the sixteen-lane pass
     int nmulti;               // blocks of more than one chunk ...
     const int* multi_slots;   // ... [nmulti] and the first slot of each (k_schur_combine adds their partial sums)
@@ -152,7 +152,7 @@ struct DeviceBuffers {
     float* pcg_F32;           // the same in fp32 instead (streaming CG path, d > 1280: the matvec is HBM-bound); else null
     double* pcg_bt;           // [ld]    Lb^-1 rhs
     double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
-    double* pair_partial;     // [npairwg][36] partial sums (factored coordinates) of the chunks of multi-chunk blocks
+    double* pair_partial;     // [chunks of multi-chunk blocks][36] their partial sums (factored coordinates); rows: pwg_chunk[].x
     double* pair_G;           // [ncam*36] per-camera factor the factored pair pass applies from both sides of a block (row-major 6 x 6):
                               // Linv D E^T (PCG: k_finalize) or D E^T (exact solver: k_pair_factors), E = diag(R K', I) -- sfmba_device.h
     double* pcg_W;            // [8][ld] gauge vectors in the transformed unknowns (coarse space of the two-level CG preconditioner,

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(De
     __shared__ double tile[36];
     const int lane = threadIdx.x & 63;
     const int4 dsc = ds.pwg_desc[blockIdx.x];       // one load: block, row camera, pair range of the chunk
-    const int2 chunk = ds.pwg_chunk[blockIdx.x];    // {chunk index, chunks of the block}
+    const int2 chunk = ds.pwg_chunk[blockIdx.x];    // {row of pair_partial (blocks of several chunks), chunks of the block}
     const int b = dsc.x, pbeg = dsc.z, p1 = dsc.w;
     int2 cj;
     cj.x = dsc.y;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 ? 4 : 2)) void k_schur_pairs(De
     int base = 0, len = 36;
     const double total = pair_block_reduce<PairAcc<T>, 36, 32>(acc, lane, base, len);
     if (chunk.y > 1) {                              // one of several chunks: the partial sums of this one
-        if (len >= 1) db.pair_partial[(size_t)blockIdx.x * 36 + base] = -total;
+        if (len >= 1) db.pair_partial[(size_t)chunk.x * 36 + base] = -total;
         return;
     }
     if (len >= 1) tile[base] = -total;
@@ -678,14 +678,15 @@ __global__ __launch_bounds__(64) void k_schur_combine(DeviceStructure ds, Device
     const int lane = threadIdx.x & 63;
     const int slot0 = ds.multi_slots[blockIdx.x];
     const int4 dsc = ds.pwg_desc[slot0];
-    const int nch = ds.pwg_chunk[slot0].y;
+    const int2 rows = ds.pwg_chunk[slot0];          // {first row of pair_partial, chunks}
+    const int nch = rows.y;
     const int b = dsc.x;
     int2 cj;
     cj.x = dsc.y;
     cj.y = dsc.y + (b - (int)((long long)dsc.y * ds.ncam - (long long)dsc.y * (dsc.y - 1) / 2));
     if (lane < 36) {
         double v = 0.0;
-        for (int c = 0; c < nch; ++c) v += db.pair_partial[(size_t)(slot0 + c) * 36 + lane];
+        for (int c = 0; c < nch; ++c) v += db.pair_partial[(size_t)(rows.x + c) * 36 + lane];
         tile[lane] = v;
     }
     wave_lds_fence();

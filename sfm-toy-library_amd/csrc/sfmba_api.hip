@@ -1046,10 +1046,10 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     volatile int* build_report = reinterpret_cast<volatile int*>(p->kit.pinned + 1536);      // [1536, 1568) of the mailbox slice
     build_report[0] = -1;
     int* d_report = reinterpret_cast<int*>(p->d_pinned + 1536);
-    build_report[1] = -1; build_report[4] = -1; build_report[5] = -1; build_report[6] = -1;
+    build_report[1] = -1; build_report[4] = -1; build_report[5] = -1; build_report[6] = -1; build_report[7] = -1;
     HIP_TRY(hipMemsetAsync(p->d_build_counters, 0, 4 * sizeof(int), p->stream));
     if (pwg_blocks.empty()) {
-        build_report[4] = 0; build_report[5] = 0;      // (a row-sharded rank without a block row, or no pair list: no pair pass)
+        build_report[4] = 0; build_report[5] = 0; build_report[7] = 0;      // (a row-sharded rank without a block row, or no pair list: no pair pass)
     } else if (pair_lpb == 64) {
         const int crc = build_pair_chunks(p->stream, &staging, (int)pwg_blocks.size(), SFMBA_PAIR_CHUNK, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr,
                                           p->d_pwg_desc, p->d_pwg_chunk, p->d_multi_slots, p->d_build_counters, d_report);
@@ -1171,7 +1171,6 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
     db.pcg_binv = p->solver.binv;
     HIP_TRY(dev_alloc(&db.pair_G, (size_t)36 * std::max(ncam, 1)));
-    if (pair_lpb == 64 && !no_pairs) HIP_TRY(dev_alloc(&db.pair_partial, (size_t)36 * pair_slot_cap));
     bt_mark("alloc buffers");
     // the one wait of the build: sorts, lists and descriptors are in place; the staging arena and the host vectors may go
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1179,8 +1178,11 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         return fail(SFMBA_ERR_HIP, "structure build: the device's pair count differs from the host's");
     ds.ndupwg = no_pairs ? 0 : build_report[0];
     if (pair_lpb == 64) {
-        if (build_report[4] < 0 || (size_t)build_report[4] > pair_slot_cap || build_report[5] < 0) return fail(SFMBA_ERR_HIP, "structure build: pair-chunk descriptors out of range");
+        if (build_report[4] < 0 || (size_t)build_report[4] > pair_slot_cap || build_report[5] < 0 || build_report[7] < 0 || build_report[7] > build_report[4])
+            return fail(SFMBA_ERR_HIP, "structure build: pair-chunk descriptors out of range");
         ds.npairwg = build_report[4]; ds.nmulti = build_report[5];
+        // partial sums: one row per chunk of the blocks that HAVE several chunks (the build counted them), not one per descriptor slot
+        if (!no_pairs) HIP_TRY(dev_alloc(&db.pair_partial, (size_t)36 * std::max((int)build_report[7], 1)));
     }
     // fill of the reduced matrix: non-empty off-diagonal blocks / all of them (what SFMBA_LINEAR_AUTO reads the co-visibility from)
     p->block_fill = ncam > 1 ? (double)std::max((int)build_report[1], 0) / ((double)ncam * (ncam - 1) / 2.0) : 1.0;

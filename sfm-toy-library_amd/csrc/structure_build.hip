@@ -360,12 +360,15 @@ __global__ __launch_bounds__(256) void k_chunk_fill(int nwg, int chunk, const in
     const int2 cj = blk_cams[b];
     const int pb = blk_ptr[b], pe = blk_ptr[b + 1];
     const int o = off[s], nch = off[s + 1] - o;
+    // a block of several chunks gets nch consecutive rows of the partial-sum buffer (pair_partial): which ones is a storage detail (the
+    // combine adds them in chunk order), so the rows are handed out by a counter and the buffer is as large as the chunks that need it
+    const int prow = nch > 1 ? atomicAdd(&counters[3], nch) : 0;
     for (int c = 0; c < nch; ++c) {
         int4 d; d.x = b; d.y = cj.x;
         d.z = nch == 1 ? pb : pb + c * chunk;
         d.w = nch == 1 ? pe : min(pe, pb + (c + 1) * chunk);
         desc[o + c] = d;
-        int2 ci; ci.x = c; ci.y = nch;
+        int2 ci; ci.x = prow + c; ci.y = nch;
         info[o + c] = ci;
     }
     if (nch > 1) multi[atomicAdd(&counters[0], 1)] = o;
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(256) void k_chunk_fill(int nwg, int chunk, const in
 __global__ void k_chunk_report(int nwg, const int* __restrict__ off, const int* __restrict__ counters, int* __restrict__ report) {
     report[4] = off[nwg];
     report[5] = counters[0];
+    report[7] = counters[3];
     __threadfence_system();
 }
 // number of off-diagonal blocks of the upper triangle that hold at least one pair -> report[1], those close to the diagonal -> report[6] (the fill of the reduced matrix: what
