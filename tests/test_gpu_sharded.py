@@ -84,25 +84,33 @@ def _worker(rank, world, port, case, out, native=False, n_repeats=12, flags=0):
     dist.destroy_process_group()
 
 
-def _run_ranks(world, port, case, native, n_repeats, flags=0, timeout=420):
+def _run_ranks(world, port, case, native, n_repeats, flags=0, timeout=180):
     """Spawns the ranks, collects their results; whatever happens, no rank outlives the test (a rank stuck in a collective whose peer died
-    would keep the test session from exiting)."""
+    would keep the test session from exiting).  Several processes on ONE GPU with a gloo rendezvous is a test-only arrangement (the product
+    is one process per GPU): a run in which no rank reports within the timeout is repeated ONCE on another port, with a warning in the
+    session summary -- a wrong result is never retried."""
+    import queue, warnings
     ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out, native, n_repeats, flags)) for r in range(world)]
-    for p in procs:
-        p.start()
-    try:
-        results = sorted([out.get(timeout=timeout) for _ in range(world)], key=lambda t: t[0])
+    for attempt in range(2):
+        out = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, world, port + 1000 * attempt, case, out, native, n_repeats, flags)) for r in range(world)]
         for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
-        return results
-    finally:
-        for p in procs:
-            if p.is_alive():
-                p.kill()
-                p.join(timeout=10)
+            p.start()
+        try:
+            results = sorted([out.get(timeout=timeout) for _ in range(world)], key=lambda t: t[0])
+            for p in procs:
+                p.join(timeout=60)
+                assert p.exitcode == 0
+            return results
+        except queue.Empty:
+            if attempt == 1:
+                raise
+            warnings.warn("sharded test %s (world %d): no result within %d s, ranks killed and the run repeated once" % (case, world, timeout))
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+                    p.join(timeout=10)
 
 
 @pytest.mark.parametrize("case,native,x32", [("small", False, True), ("cfg2", False, True), ("wide", False, True), ("cfg2", True, True),
@@ -114,7 +122,7 @@ def test_two_rank_sharded_hip_solve(sfm, oracle, monkeypatch, case, native, x32)
     from sfm_toy_library_amd import capi
     kw, precision, linear, okw = CASES["wide_x64" if not x32 else case]
     world, port = 2, 29711 + (os.getpid() % 500)
-    results = _run_ranks(world, port, "wide_x64" if not x32 else case, native, 12, timeout=300)
+    results = _run_ranks(world, port, "wide_x64" if not x32 else case, native, 12)
     prob = sfm.make_problem(**kw)
     (r0, s0, cam0, pt0, f0, rng0, rep0), (r1, s1, cam1, pt1, f1, rng1, rep1) = results
     for a, b in zip(rep0, rep1):
@@ -240,7 +248,7 @@ def test_row_sharded_hip_solve(sfm, oracle, world, case, flags):
     WHOLE solution (the final points are all-gathered): replicas bit-identical in cameras AND points.  flags = 1: deterministic handles."""
     kw, precision, linear, okw = CASES[case]
     port = 29011 + (os.getpid() % 300) + 11 * world
-    results = _run_ranks(world, port, case, True, 2, flags, timeout=240)
+    results = _run_ranks(world, port, case, True, 2, flags)
     prob = sfm.make_problem(**kw)
     assert prob.n_pt % world != 0 or case == "row_tiny"
     cam0, pts0, f0, s0 = results[0][2], results[0][3], results[0][4], results[0][1]
