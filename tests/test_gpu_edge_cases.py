@@ -1,0 +1,77 @@
+"""Edge cases of the adjustBundle() path that the reference hands to Ceres without looking (SfMBundleAdjustmentUtils.cpp:111-179): non-finite
+inputs, a single view, tracks of length one (no camera pair shares a point: the reduced system is block diagonal), points nobody observes.
+Each case: the HIP path through the C ABI against the oracle on the same input, for every linear solver and the sharded entry points where the
+case has a meaning there."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from sfm_toy_library_amd import capi as c
+    assert c.device_count() >= 1, "no HIP device: the GPU tests must run on the MI355X box"
+    return c
+
+
+@pytest.mark.parametrize("what", ["obs_nan", "obs_inf", "pt_nan", "cam_nan", "cam_inf", "focal_nan"])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_non_finite_input_is_failure_and_leaves_the_parameters_alone(capi, sfm, oracle, what, precision):
+    """Ceres: 'Residual and Jacobian evaluation failed' at the initial point -> FAILURE, parameter blocks untouched
+    (the reference then prints 'Bundle adjustment failed.' and returns, BA.cpp:182-185)."""
+    prob = sfm.make_problem("tiny").copy()
+    if what == "obs_nan": prob.obs_xy[7, 1] = np.nan
+    if what == "obs_inf": prob.obs_xy[7, 0] = np.inf
+    if what == "pt_nan": prob.pt3[3, 2] = np.nan
+    if what == "cam_nan": prob.cam6[1, 4] = np.nan
+    if what == "cam_inf": prob.cam6[2, 0] = np.inf
+    if what == "focal_nan": prob.focal = float("nan")
+    want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))[3]
+    assert want["termination_name"] == "FAILURE" and want["iterations"] == 0
+    for linear in (0, 1, 2):
+        cam, pt, f, s, tr = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear))
+        assert s["termination_name"] == "FAILURE" and s["iterations"] == 0
+        assert np.array_equal(cam, prob.cam6, equal_nan=True) and np.array_equal(pt, prob.pt3, equal_nan=True)
+        assert f == prob.focal or (np.isnan(f) and np.isnan(prob.focal))
+    # the matrix-free handle (no pair list) takes the same exit
+    with capi.Problem(prob, precision=precision, flags=sfm.CREATE_NO_PAIR_LIST) as P:
+        s, _ = P.solve(capi.default_options(max_seconds=0.0, precision=precision))
+        cam, pt, f = P.get_params()
+    assert s["termination_name"] == "FAILURE" and np.array_equal(cam, prob.cam6, equal_nan=True) and np.array_equal(pt, prob.pt3, equal_nan=True)
+
+
+@pytest.mark.parametrize("n_cam,n_pt,views", [(1, 200, 1), (5, 300, 1), (2, 150, 2), (3, 1, 3)])
+@pytest.mark.parametrize("linear", [0, 1, 2])
+def test_degenerate_shapes_follow_the_oracle(capi, sfm, oracle, n_cam, n_pt, views, linear):
+    """One view; tracks of length one (no off-diagonal block of the reduced matrix holds a pair: S is block diagonal plus the focal border);
+    two views (the reference's baseline pair, SfM.cpp:215-321); a single point.  Under-determined where views == 1 -- the damping makes every
+    step unique and the cost goes to ~0: same termination, iteration count and accept / reject sequence as the oracle."""
+    prob = sfm.make_problem("cfg2", n_cam=n_cam, n_pt=n_pt, views=views, seed=100 + n_cam)
+    cam_o, pt_o, f_o, s_o, tr_o = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    cam, pt, f, s, tr = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=linear))
+    assert s["termination_name"] == s_o["termination_name"] and s["iterations"] == s_o["iterations"]
+    assert [r["step_is_successful"] for r in tr] == [r["step_is_successful"] for r in tr_o]
+    assert np.isclose(s["initial_cost"], s_o["initial_cost"], rtol=1e-12)
+    # costs that ran into the rounding floor of an exactly satisfiable problem compare against the initial cost
+    assert abs(s["final_cost"] - s_o["final_cost"]) <= 1e-9 * s_o["final_cost"] + 1e-14 * s_o["initial_cost"]
+    assert np.abs(cam - cam_o).max() < 1e-6 and np.abs(pt - pt_o).max() < 1e-6 and abs(f - f_o) < 1e-6 * abs(f_o)
+
+
+def test_points_nobody_observes_and_cameras_without_observations(capi, sfm, oracle):
+    """Parameter blocks without a residual block are not part of the Ceres problem (BA.cpp:142-166 adds blocks per observation only):
+    they come back bit for bit, the rest as if they were not there -- through every entry point."""
+    base = sfm.make_problem("small")
+    cam6 = np.vstack([base.cam6, [[0.1, -0.2, 0.3, 1.0, 2.0, 3.0]]])                 # a view without features
+    pt3 = np.vstack([base.pt3, [[9.0, 9.0, 9.0], [-7.0, 0.5, 2.0]]])                 # two points without views
+    prob = sfm.BAProblem(cam6, pt3, base.focal, base.obs_cam, base.obs_pt, base.obs_xy)
+    cam_o, pt_o, f_o, s_o, _ = oracle.solve(base, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    for flags in (0, sfm.CREATE_NO_PAIR_LIST):
+        with capi.Problem(prob, precision=0, flags=flags) as P:
+            s, _ = P.solve(capi.default_options(max_seconds=0.0))
+            cam, pt, f = P.get_params()
+        assert s["termination_name"] == "CONVERGENCE" and s["iterations"] == s_o["iterations"]
+        assert np.array_equal(cam[-1], cam6[-1]) and np.array_equal(pt[-2:], pt3[-2:])
+        assert abs(s["final_cost"] - s_o["final_cost"]) <= 1e-9 * s_o["final_cost"]
+        tol = 1e-7 if flags == 0 else 2e-5
+        assert np.abs(cam[:-1] - cam_o).max() < tol and np.abs(pt[:-2] - pt_o).max() < tol
