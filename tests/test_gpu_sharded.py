@@ -52,7 +52,24 @@ CASES = {
     # a handful of cameras (d = 43: the one-launch Cholesky size, served by the CG here), fewer points than a rank's stride would suggest
     "row_two_cams": (dict(name="cfg2", n_cam=2, n_pt=301, views=2, seed=5), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
     "row_tiny": (dict(name="tiny"), 0, 2, dict()),
+    # degenerate shapes through every sharded form (test_sharded_edge_shapes): one view (d = 7, no off-diagonal block at all), tracks of length one
+    # (no pair anywhere: S is block diagonal + the focal border), a non-finite observation (FAILURE on every rank, nothing moves)
+    "row_one_cam": (dict(name="cfg2", n_cam=1, n_pt=201, views=1, seed=101), 0, 2, dict()),
+    "row_views1": (dict(name="cfg2", n_cam=5, n_pt=301, views=1, seed=105), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0)),
+    "row_nan": (dict(name="tiny"), 0, 2, dict()),
+    "rep_views1": (dict(name="cfg2", n_cam=5, n_pt=301, views=1, seed=105), 0, 2, dict()),
+    "dist_views1": (dict(name="cfg2", n_cam=5, n_pt=301, views=1, seed=105), 0, 1, dict(pcg_tolerance=1e-12, pcg_anchored=0, shard_distributed_cg=1)),
+    "dist_imp_one_cam": (dict(name="cfg2", n_cam=1, n_pt=201, views=1, seed=101), 0, 2, dict(shard_distributed_cg=2)),
+    "dist_nan": (dict(name="tiny"), 0, 2, dict(shard_distributed_cg=1)),
 }
+
+
+def _edge_problem(sfm, case):
+    kw = CASES[case][0]
+    prob = sfm.make_problem(**kw)
+    if case.endswith("_nan"):
+        prob.obs_xy[7, 1] = np.nan
+    return prob
 
 
 def _worker(rank, world, port, case, out, native=False, n_repeats=12, flags=0):
@@ -66,7 +83,7 @@ def _worker(rank, world, port, case, out, native=False, n_repeats=12, flags=0):
     from sfm_toy_library_amd import capi
     from sfm_toy_library_amd.sharded import HipShardBackend, HipRowShardBackend, solve_sharded, solve_sharded_native
     kw, precision, linear, okw = CASES[case]
-    prob = sfm.make_problem(**kw)
+    prob = _edge_problem(sfm, case)
     backend = (HipRowShardBackend if case.startswith("row_") else HipShardBackend)(prob, rank, world, device=0, precision=precision, flags=flags)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw)
     summ = solve_sharded_native(backend, opt, dist=dist) if native else solve_sharded(backend, dist, opt)
@@ -270,6 +287,28 @@ def test_row_sharded_hip_solve(sfm, oracle, world, case, flags):
     atol = 1e-7 if exact else 5e-6
     assert np.abs(cam0 - cam_o).max() <= atol and np.isclose(f0, f_o, rtol=1e-9 if exact else 1e-7)
     assert np.abs(pts0 - pt_o).max() <= atol
+
+
+@pytest.mark.parametrize("world,case", [(2, "row_one_cam"), (3, "row_views1"), (2, "row_nan"), (2, "rep_views1"), (3, "dist_views1"),
+                                        (2, "dist_imp_one_cam"), (3, "dist_nan")])
+def test_sharded_edge_shapes(sfm, oracle, world, case):
+    """The degenerate inputs of test_gpu_edge_cases.py through the sharded entry points (native loop, gloo callbacks, several ranks on the one GPU):
+    ranks that own no block row / no pair / no point of a camera, and the FAILURE exit taken by every rank from the same all-reduced cost."""
+    kw, precision, linear, okw = CASES[case]
+    results = _run_ranks(world, 29411 + (os.getpid() % 300) + 13 * world, case, True, 1)
+    prob = _edge_problem(sfm, case)
+    cam_o, pt_o, f_o, s_o, tr_o = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
+    s0, cam0, f0 = results[0][1], results[0][2], results[0][4]
+    pts = results[0][3] if case.startswith("row_") else np.vstack([r[3] for r in results])
+    for r in results[1:]:
+        assert r[1]["termination_name"] == s0["termination_name"] and r[1]["iterations"] == s0["iterations"]
+        assert np.array_equal(r[2], cam0, equal_nan=True) and r[4] == f0
+    assert s0["termination_name"] == s_o["termination_name"] and s0["iterations"] == s_o["iterations"]
+    if case.endswith("_nan"):
+        assert s0["termination_name"] == "FAILURE" and np.array_equal(cam0, prob.cam6) and np.array_equal(pts, prob.pt3) and f0 == prob.focal
+        return
+    assert abs(s0["final_cost"] - s_o["final_cost"]) <= 1e-9 * s_o["final_cost"] + 1e-14 * s_o["initial_cost"]
+    assert np.abs(cam0 - cam_o).max() < 1e-6 and np.abs(pts - pt_o).max() < 1e-6 and abs(f0 - f_o) < 1e-6 * abs(f_o)
 
 
 @pytest.mark.parametrize("case", ["row_cfg2", "row_wide", "row_auto"])
