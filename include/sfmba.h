@@ -174,9 +174,9 @@ enum { SFMBA_CREATE_DETERMINISTIC = 1,
                                              a solve every rank holds ALL parameters (the final points are all-gathered): sfmba_problem_get_params returns the
                                              whole solution on every rank. */  /* SFMBA_DETERMINISTIC=1 forces it on: every workgroup owns its accumulator slot and multi-chunk
                                              sums are added in a fixed order, so results do not depend on the order fp64 atomics arrive in
-                                             (bitwise reproducible run to run; ~30 % slower).  Sharded problems included (ABI v4) -- EXCEPT the forms that
-                                             apply the reduced matrix implicitly (shard_distributed_cg = 2, SFMBA_CREATE_NO_PAIR_LIST): their per-camera sums of a
-                                             CG product are fp64 atomics across chunks (implicit_schur.hip), repeatable to rounding only. */
+                                             (bitwise reproducible run to run; ~30 % slower).  Sharded problems included (ABI v4), and the forms that apply the
+                                             reduced matrix implicitly (shard_distributed_cg = 2, SFMBA_CREATE_NO_PAIR_LIST): the per-camera sums of a CG product
+                                             are then written per chunk and added in chunk order (implicit_schur.hip). */
 
 typedef struct sfmba_summary {
     int    termination;               /* SFMBA_CONVERGENCE / NO_CONVERGENCE / FAILURE */

@@ -197,6 +197,7 @@ struct ImplicitProduct {
     double* dtab = nullptr;            // [ncam][8] direction table (two component quads per camera)
     double* spt = nullptr;             // [npt][3] per-point sums
     double* acc = nullptr;             // [ncam][6] per-camera sums
+    double* part = nullptr;            // deterministic handles: [nchunk][6] per-chunk sums, added in chunk order by k_imp_out; else null (atomics into acc)
     const double* focal_row = nullptr; const float* focal_row32 = nullptr;     // row d-1 of the CG's matrix (left by the glue)
     int rank = 0;
     bool f32 = false;                  // precision of the Jacobian blocks

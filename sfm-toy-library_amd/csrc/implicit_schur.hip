@@ -95,11 +95,12 @@ __global__ PB_BOUNDS void k_imp_points(DeviceStructure ds, DeviceBuffers db, con
 }
 
 template <typename T>
-__global__ __launch_bounds__(CD_BLK) void k_imp_cams(DeviceStructure ds, DeviceBuffers db, const double* __restrict__ dtab, const double* __restrict__ spt,
+__global__ __launch_bounds__(CD_BLK) void k_imp_cams(DeviceStructure ds, DeviceBuffers db, const double* __restrict__ dtab, const double* __restrict__ spt, double* __restrict__ part,
                                                      double* __restrict__ acc, const int* __restrict__ flags) {
     __shared__ double red[CD_BLK / 64][6];
     if (flags && flags[0]) return;
-    const int4 ch = ds.chunks[ds.chunk_order[blockIdx.x]];
+    const int chunk_id = ds.chunk_order[blockIdx.x];
+    const int4 ch = ds.chunks[chunk_id];
     const int j = ch.x;
     const LMState* st = db.st;
     const int cur = st->cur;
@@ -142,13 +143,15 @@ __global__ __launch_bounds__(CD_BLK) void k_imp_cams(DeviceStructure ds, DeviceB
         double t = 0.0;
 #pragma unroll
         for (int ww = 0; ww < CD_BLK / 64; ++ww) t += red[ww][threadIdx.x];
-        atomicAdd(&acc[6 * j + threadIdx.x], t);
+        // deterministic handles: the chunk's own slot, added in chunk order by k_imp_out (the order fp64 atomics arrive in would show in the CG's iterates)
+        if (part) part[(size_t)chunk_id * 6 + threadIdx.x] = t;
+        else atomicAdd(&acc[6 * j + threadIdx.x], t);
     }
 }
 
 // FF: the type the focal row of S~ is stored in (the CG's matrix: fp64, or fp32 on the streaming path)
 template <typename FF>
-__global__ __launch_bounds__(1024) void k_imp_out(DeviceStructure ds, DeviceBuffers db, int rank, const double* __restrict__ pt, const double* __restrict__ acc,
+__global__ __launch_bounds__(1024) void k_imp_out(DeviceStructure ds, DeviceBuffers db, int rank, const double* __restrict__ pt, const double* __restrict__ acc, const double* __restrict__ part,
                                                   const FF* __restrict__ focal_row, double* __restrict__ out, const int* __restrict__ flags) {
     if (flags && flags[0]) return;
     __shared__ double sh[16];
@@ -164,6 +167,12 @@ __global__ __launch_bounds__(1024) void k_imp_out(DeviceStructure ds, DeviceBuff
         double a[6], g[6], Q9[9];
 #pragma unroll
         for (int e = 0; e < 6; ++e) a[e] = acc[6 * j + e];
+        if (part) {
+            for (int c = ds.cam_chunk_ptr[j]; c < ds.cam_chunk_ptr[j + 1]; ++c) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) a[e] += part[(size_t)c * 6 + e];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 9; ++e) Q9[e] = db.camtab[cur][cam_tab_index(CT_QD + e, j, ds.ncam)];
         // A^T e summed over the camera's observations in the factored coordinates: [Q^T (sum X_g x h); sum h], Jacobi scales, sign of S_off
@@ -195,13 +204,13 @@ void launch_implicit_product(hipStream_t s, const ImplicitProduct& ip, const dou
     hipLaunchKernelGGL(k_imp_dir, dim3((ds.ncam + 255) / 256), dim3(256), 0, s, ds, ip.db, p_tilde, ip.dtab, ip.acc, flags);
     if (ip.f32) {
         hipLaunchKernelGGL(k_imp_points<float>, dim3((ds.npt + WPB * (64 / PB_LPP) - 1) / (WPB * (64 / PB_LPP))), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
-        hipLaunchKernelGGL(k_imp_cams<float>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.acc, flags);
+        hipLaunchKernelGGL(k_imp_cams<float>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.part, ip.acc, flags);
     } else {
         hipLaunchKernelGGL(k_imp_points<double>, dim3((ds.npt + WPB * (64 / PB_LPP) - 1) / (WPB * (64 / PB_LPP))), dim3(PBK), 0, s, ds, ip.db, ip.dtab, ip.spt, flags);
-        hipLaunchKernelGGL(k_imp_cams<double>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.acc, flags);
+        hipLaunchKernelGGL(k_imp_cams<double>, dim3(ds.nchunk), dim3(CD_BLK), 0, s, ds, ip.db, ip.dtab, ip.spt, ip.part, ip.acc, flags);
     }
-    if (ip.focal_row32) hipLaunchKernelGGL(k_imp_out<float>, dim3(1), dim3(1024), 0, s, ds, ip.db, ip.rank, p_tilde, ip.acc, ip.focal_row32, out, flags);
-    else hipLaunchKernelGGL(k_imp_out<double>, dim3(1), dim3(1024), 0, s, ds, ip.db, ip.rank, p_tilde, ip.acc, ip.focal_row, out, flags);
+    if (ip.focal_row32) hipLaunchKernelGGL(k_imp_out<float>, dim3(1), dim3(1024), 0, s, ds, ip.db, ip.rank, p_tilde, ip.acc, ip.part, ip.focal_row32, out, flags);
+    else hipLaunchKernelGGL(k_imp_out<double>, dim3(1), dim3(1024), 0, s, ds, ip.db, ip.rank, p_tilde, ip.acc, ip.part, ip.focal_row, out, flags);
 }
 
 // The glue of the block-Jacobi transform on its own (the pair pass does it on the way when it runs, k_schur_pairs MODE 1): focal row /

@@ -258,7 +258,7 @@ struct sfmba_problem {
     int own_coarse0 = 0, own_coarse1 = 0;             // ... and of the coarse ones (column norms)
     sfmba_allgather_fn allgather = nullptr;
     DistCg dcg;                                       // distributed CG workspace (created by the first solve that asks for it)
-    double *imp_dtab = nullptr, *imp_spt = nullptr, *imp_acc = nullptr;   // implicit Schur product workspace (shard_distributed_cg = 2; allocated by the first solve that asks)
+    double *imp_dtab = nullptr, *imp_spt = nullptr, *imp_acc = nullptr, *imp_part = nullptr;   // implicit Schur product workspace (shard_distributed_cg = 2; allocated by the first solve that asks)
     long long shard_blocks_off = 0;                   // doubles: where the block region of d_red starts (behind the region of exchange (A))
     int dcg_last_f32 = -1;
     sfmba_summary shard_sum;
@@ -1120,7 +1120,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         p->shard_blocks_off = (shard_diag_len(ds) + 63) / 64 * 64;
         HIP_TRY(dev_alloc(&p->d_red, (size_t)p->shard_blocks_off));
         p->dcg = DistCg(); p->dcg_last_f32 = -1;
-        p->imp_dtab = p->imp_spt = p->imp_acc = nullptr;
+        p->imp_dtab = p->imp_spt = p->imp_acc = p->imp_part = nullptr;
     }
     if (sharded) {
         // the all-reduce buffer: packed triangle of S + tail (exact solver), or the two blocks of the CG path (ba_kernels.hip, k_shard_diag)
@@ -1132,7 +1132,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         const size_t dist = (size_t)p->shard_blocks_off + (size_t)p->shard_world * (size_t)chunk * 36;
         HIP_TRY(dev_alloc(&p->d_red, std::max(std::max(tri, dist), (size_t)std::max(shard_diag_len(ds), shard_offdiag_len(ds)))));
         p->dcg = DistCg(); p->dcg_last_f32 = -1;
-        p->imp_dtab = p->imp_spt = p->imp_acc = nullptr;
+        p->imp_dtab = p->imp_spt = p->imp_acc = p->imp_part = nullptr;
     }
     db.S = p->d_sys;
     db.rhs = db.S + (size_t)ds.ld * ds.ld;
@@ -1854,7 +1854,8 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
             p->imp_dtab = p->arena.alloc_n<double>((size_t)8 * std::max(p->ds.ncam, 1));
             p->imp_spt = p->arena.alloc_n<double>((size_t)3 * std::max(p->ds.npt, 1));
             p->imp_acc = p->arena.alloc_n<double>((size_t)6 * std::max(p->ds.ncam, 1));
-            if (!p->imp_dtab || !p->imp_spt || !p->imp_acc) { p->imp_dtab = nullptr; return fail(SFMBA_ERR_ALLOC, "implicit Schur workspace allocation failed"); }
+            if (p->deterministic) p->imp_part = p->arena.alloc_n<double>((size_t)6 * std::max(p->ds.nchunk, 1));
+            if (!p->imp_dtab || !p->imp_spt || !p->imp_acc || (p->deterministic && !p->imp_part)) { p->imp_dtab = nullptr; return fail(SFMBA_ERR_ALLOC, "implicit Schur workspace allocation failed"); }
         }
         ImplicitProduct ip;
         int first_build = o.jacobi_scaling ? 1 : 2;          // the first point pass also forms the point scales
@@ -1895,7 +1896,7 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
               if (implicit_cg) {
                 // no pair pass, no exchange (B): the glue the pair pass does on the way (focal row of S~, b~, post-linearisation) on its own
                 launch_pcg_glue(p->stream, p->ds, p->db);
-                ip.ds = p->ds; ip.db = p->db; ip.dtab = p->imp_dtab; ip.spt = p->imp_spt; ip.acc = p->imp_acc;
+                ip.ds = p->ds; ip.db = p->db; ip.dtab = p->imp_dtab; ip.spt = p->imp_spt; ip.acc = p->imp_acc; ip.part = p->imp_part;
                 ip.focal_row = p->solver.Sfull + (size_t)fo * p->ds.ld; ip.focal_row32 = nullptr; ip.rank = p->shard_rank; ip.f32 = f32;
                 da.implicit = &ip;
                 p->shard_exchange[1] = 0; p->shard_exchange[3] = 2 | 4;

@@ -86,19 +86,47 @@ def test_two_to_the_31_pairs_for_real(capi, sfm):
 @pytest.mark.parametrize("name", ["tiny", "small", "small_rejected"])
 def test_matrix_free_on_the_small_fixtures(capi, sfm, oracle, name):
     """The flag on the fixtures of the parity suite (7 - 20 cameras: d <= 256, where the pair-list path runs the one-launch Cholesky; a fixture whose
-    trajectory contains a REJECTED step): same LM trajectory as the oracle's, step by step; a deterministic handle as well (the implicit products are
-    its documented exception: repeatable to rounding, not bit for bit)."""
+    trajectory contains a REJECTED step): same LM trajectory as the oracle's, step by step; a deterministic handle as well -- and that one bit for
+    bit from solve to solve (the per-camera sums of the implicit product are written per chunk and added in chunk order)."""
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".sfmba")
     prob = sfm.load_problem(path) if os.path.exists(path) else sfm.make_problem(name)
     want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))
     for flags in (sfm.CREATE_NO_PAIR_LIST, sfm.CREATE_NO_PAIR_LIST | sfm.CREATE_DETERMINISTIC):
+        runs = []
         with capi.Problem(prob, precision=0, flags=flags) as P:
-            s, tr = P.solve(capi.default_options(max_seconds=0.0))
-            cam, pt, f = P.get_params()
+            for _ in range(3 if flags & sfm.CREATE_DETERMINISTIC else 1):
+                P.reset()
+                s, tr = P.solve(capi.default_options(max_seconds=0.0))
+                cam, pt, f = P.get_params()
+                runs.append((cam.copy(), pt.copy(), f, s["final_cost"], s["linear_iters"]))
+        for cam_r, pt_r, f_r, cost_r, li_r in runs[1:]:
+            assert np.array_equal(cam_r, runs[0][0]) and np.array_equal(pt_r, runs[0][1]) and f_r == runs[0][2] and cost_r == runs[0][3] and li_r == runs[0][4]
         assert s["termination_name"] == want[3]["termination_name"] and s["iterations"] == want[3]["iterations"]
         assert [r["step_is_successful"] for r in tr] == [r["step_is_successful"] for r in want[4]]
         assert abs(s["final_cost"] - want[3]["final_cost"]) <= 1e-9 * want[3]["final_cost"]
         # the steps come from CG on the implicit product (relative residual 1e-12), not from a factorisation: cameras
         # agree to 1e-7; the weakest-constrained point of small_rejected moves by 3e-6 at equal cost
         assert np.abs(cam - want[0]).max() < 1e-7 and np.abs(pt - want[1]).max() < 2e-5
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_implicit_form_of_a_deterministic_handle_is_bitwise_repeatable(capi, sfm, precision):
+    """Several chunks per camera (60 cameras x 8000 points: ~1300 observations per camera, chunks of 256): a deterministic matrix-free handle gives the
+    same bits on every solve, in both precisions; a plain handle agrees with it to rounding."""
+    prob = sfm.make_problem("cfg3", n_cam=60, n_pt=8003, seed=5)
+    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=1)
+    outs = []
+    with capi.Problem(prob, precision=precision, flags=sfm.CREATE_NO_PAIR_LIST | sfm.CREATE_DETERMINISTIC) as P:
+        for _ in range(3):
+            P.reset()
+            s, tr = P.solve(opt)
+            cam, pt, f = P.get_params()
+            outs.append((cam.copy(), pt.copy(), f, [r["cost"] for r in tr], s["linear_iters"]))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and o[2] == outs[0][2] and o[3] == outs[0][3] and o[4] == outs[0][4]
+    with capi.Problem(prob, precision=precision, flags=sfm.CREATE_NO_PAIR_LIST) as P:
+        s2, _ = P.solve(opt)
+        cam2, pt2, f2 = P.get_params()
+    assert s2["iterations"] == s["iterations"] and abs(s2["final_cost"] - s["final_cost"]) <= 1e-9 * s["final_cost"]
+    assert np.abs(cam2 - outs[0][0]).max() < 1e-6 and np.abs(pt2 - outs[0][1]).max() < 1e-5
