@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 1: the new paths first (row-sharded, matrix-free, RCCL bindings), then the A/B of the pair-pass accumulation, then the bench line with its extras
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_1
 mkdir -p $OUT
 cd $REPO

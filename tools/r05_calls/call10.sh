@@ -1,7 +1,7 @@
 #!/bin/bash
 # counter traffic of the row-sharded solve's kernels (cfg 5, one rank), a 200-step headline run, the whole GPU suite
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_10
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # ordered kernel traces of the sharded loops on one rank (which memsets / copies sit between the kernels of an LM iteration)
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_11
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

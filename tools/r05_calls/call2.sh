@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 2: the multi-rank tests of the new paths, then one-rank kernel statistics of the row-sharded and the distributed solve at cfg 5
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_2
 mkdir -p $OUT
 cd $REPO

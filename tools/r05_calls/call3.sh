@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 3: the 4-rank row_wide hang under a watchdog, the tests of what changed since call 2, quick benches, the AUTO float sweep, the shim
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_3
 mkdir -p $OUT
 cd $REPO

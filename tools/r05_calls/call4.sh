@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 4: the 4-rank row_wide case with repeats under a watchdog, the whole GPU suite, quick benches, the shim
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_4
 mkdir -p $OUT
 cd $REPO

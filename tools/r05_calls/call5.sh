@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 5: fused control (two-level tickets) against the control launch of its own, cfg 3 and cfg 5
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_5
 mkdir -p $OUT
 cd $REPO

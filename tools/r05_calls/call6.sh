@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 6: sharded tests after the dcg kernel changes, then the evidence sets r05_a (cfg 3) and r05_a (cfg 5)
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 cd $REPO
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r05_6

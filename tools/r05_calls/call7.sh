@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 7: the driver's commands as the driver runs them (smoke, default bench with its wall time, the sharded extras at one rank), then the whole GPU suite
 set -u
-REPO=$(cd "$(dirname "$0")/.." && pwd)
+REPO=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$REPO/gpurun_out/r05_7
 mkdir -p $OUT
 cd $REPO
