@@ -1460,13 +1460,13 @@ void launch_iter0(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers&
 // back-substitution + trial point
 // ------------------------------------------------------------------------------------------
 // One thread per camera: delta = scale * y ; trial camera = camera - delta ; step table; table of the trial camera
-__global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
+__global__ __launch_bounds__(BLK) void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[BLK / 64];
     if (db.cg_gate && !db.cg_force && db.cg_gate[0] == 0) return;      // the CG batch in front of this launch was too short
     LMState* st = db.st;
     const int cur = st->cur, nxt = cur ^ 1;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double step2 = 0.0, xn2 = 0.0;
+    double step2 = 0.0, xn2 = 0.0, gdot = 0.0;
     if (j < ds.ncam) {
         double dlt[6], cn[6], z[6];
         // every load of this camera before the first store (the stores below may alias as far as the compiler can tell: a load behind
@@ -1479,6 +1479,13 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) Q9[e] = db.camtab[cur][cam_tab_index(CT_QD + e, j, ds.ncam)];
         const double small_cur = db.camtab[cur][cam_tab_index(CT_SMALL, j, ds.ncam)];
+        double Rt_cur[12], bcj[6];
+        if (db.pu32) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) Rt_cur[e] = db.camtab[cur][cam_tab_index(CT_R + e, j, ds.ncam)];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) bcj[e] = db.bc[6 * j + e];
+        }
         if (db.pcg_vec) {          // z_j = Linv_j^T x~_j  (block-Jacobi transformed unknowns)
             const double* x = db.pcg_vec + (size_t)db.pcg_flags[2] * ds.ld + 6 * j;
             const double* Li = db.pcg_linv + (size_t)j * 36;
@@ -1520,6 +1527,17 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
         }
         stb[ST_SMALL] = small_cur;
         for (int e = 0; e < ST_STRIDE; ++e) db.steptab[cam_tab_index(e, j, ds.ncam)] = stb[e];
+        if (db.pu32) {
+            // the first sweep of k_point_update in F32J mode: what it needs of this camera as ONE 80-byte fp32 record; and the part of the model
+            // cost change that sweep no longer forms per observation: sum_obs u . r = (step) . (gradient) = sum z_i bc_i in the scaled unknowns
+            float* rec = db.pu32 + 20 * (size_t)j;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) rec[e] = (float)Rt_cur[e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rec[12 + e] = (float)stb[e];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) gdot += z[e] * bcj[e];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double f0 = st->focal[cur];
@@ -1530,10 +1548,15 @@ __global__ void k_cam_update(DeviceStructure ds, DeviceBuffers db) {
         const double df = f0 - fn;
         step2 += df * df;
         xn2 += fn * fn;
+        if (db.pu32) gdot += zf * db.bc[ds.d - 1];
     }
     const double s2 = block_sum(step2, scratch);
     const double x2 = block_sum(xn2, scratch);
     if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), db.shared_weight * s2); atomicAdd(slot_ptr(db, ACC_XNEW2), db.shared_weight * x2); }
+    if (db.pu32) {
+        const double gd = block_sum(gdot, scratch);
+        if (threadIdx.x == 0) atomicAdd(slot_ptr(db, ACC_MODEL), gd);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1689,7 +1712,31 @@ __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, Dev
     const PtRecA<T> pa = load_ptrec(reinterpret_cast<const PtRecA<T>*>(db.PA) + i);
     double zacc[3] = { 0, 0, 0 }, ur = 0.0, uu = 0.0;
     T G[6] = { (T)0, (T)0, (T)0, (T)0, (T)0, (T)0 };       // (sum C^T C: a second-order term of the model cost change; summed in the precision of C)
-    {
+    if (sizeof(T) == 4 && db.pu32) {
+        // F32J, unsharded: the camera's R, t and step as ONE fp32 record (k_cam_update), five 16-byte gathers instead of ten -- the pass is bound by the
+        // number of gather instructions (every lane another camera: 64 lines each; TA_TA_BUSY 92 % at BASELINE config 5).  sum u . r is not formed here.
+        const float4* recs = reinterpret_cast<const float4*>(db.pu32);
+        int q = q0 + sub;
+        int j_next = q < q1 ? ds.obs_cam[q] : 0;
+        while (__any(q < q1)) {
+            const bool act = q < q1;
+            const float4* rec = recs + 5 * (size_t)j_next;
+            const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
+            const double Rt[12] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w };
+            const double dr[8] = { a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w };
+            q += PB_LPP;
+            if (q < q1) j_next = ds.obs_cam[q];
+            if (act) {
+                ImpObs o; T C[6];
+                imp_eval<T>(Rt, dr, focal, pa, o, C);
+                const double u0 = o.u[0] + o.xp * dfoc, u1 = o.u[1] + o.yp * dfoc;
+                uu += u0 * u0 + u1 * u1;
+                zacc[0] += (double)C[0] * u0 + (double)C[3] * u1; zacc[1] += (double)C[1] * u0 + (double)C[4] * u1; zacc[2] += (double)C[2] * u0 + (double)C[5] * u1;
+                G[0] += C[0] * C[0] + C[3] * C[3]; G[1] += C[0] * C[1] + C[3] * C[4]; G[2] += C[0] * C[2] + C[3] * C[5];
+                G[3] += C[1] * C[1] + C[4] * C[4]; G[4] += C[1] * C[2] + C[4] * C[5]; G[5] += C[2] * C[2] + C[5] * C[5];
+            }
+        }
+    } else {
         int q = q0 + sub;
         int j_next = q < q1 ? ds.obs_cam[q] : 0;
         double ox_next = 0.0, oy_next = 0.0;

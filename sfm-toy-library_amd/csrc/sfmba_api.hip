@@ -209,6 +209,7 @@ struct sfmba_problem {
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_pwg_desc = nullptr;
+    float* d_pu32 = nullptr;                // fp32 camera records of the back-substitution's first sweep (F32J, unsharded solves)
     int2* d_pwg_chunk = nullptr; int* d_multi_slots = nullptr; int* d_build_counters = nullptr; int* d_pt_order = nullptr;
     int *d_chunk_order = nullptr, *d_coarse_order = nullptr;
     double block_fill = 1.0;              // non-empty off-diagonal blocks of the reduced matrix / all of them
@@ -468,6 +469,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db, 0); }
         }
         DeviceBuffers dbu = p->db;
+        if (sizeof(T) == 4) dbu.pu32 = p->d_pu32;       // F32J: the back-substitution's first sweep gathers fp32 camera records (ba_kernels.hip, k_cam_update / k_point_update)
         bool pcg_gated = false;
         if (pcg) {
             const int anchor = anchored_cg ? (first_linear_solve ? 1 : 2) : 0;
@@ -1102,6 +1104,7 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         HIP_TRY(dev_alloc(&db.camtab[b], (size_t)CT_STRIDE * ncam));
     }
     HIP_TRY(dev_alloc(&db.steptab, (size_t)ST_STRIDE * ncam));
+    HIP_TRY(dev_alloc(&p->d_pu32, (size_t)20 * std::max(ncam, 1)));
     HIP_TRY(dev_alloc(&db.cscale, (size_t)6 * ncam));
     HIP_TRY(dev_alloc(&db.pscale, (size_t)3 * npt));
     // Nothing is stored per observation: the reduced-system passes and the back-substitution re-evaluate every observation from the

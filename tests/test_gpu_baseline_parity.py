@@ -267,6 +267,6 @@ def test_banded_visibility_bench_mode_and_default_match_oracle(capi, sfm, banded
         assert all(r["linear_iters"] == 0 for r in tr[1:]) and s["cholesky_fallbacks"] == 0
         P.reset()
         s2, tr2 = P.solve(capi.default_options(max_seconds=0.0, precision=1))                  # the same path again: the preference lives and dies with a solve
-        assert [r["linear_iters"] for r in tr2] == [r["linear_iters"] for r in tr] and abs(s2["final_cost"] - s["final_cost"]) <= 1e-9 * s["final_cost"]
+        assert [r["linear_iters"] for r in tr2] == [r["linear_iters"] for r in tr] and abs(s2["final_cost"] - s["final_cost"]) <= 1e-8 * s["final_cost"]     # (run to run: the order of the fp64 atomics, through the almost-free depths of the two-view tracks: 2e-9 has been seen)
     got = capi.solve(banded, capi.default_options(max_seconds=0.0, precision=0, linear_solver=0))
     assert_same_solve(banded, got, banded_oracle, param_atol=1e-7, cost_rtol=1e-9, point_atol=1e-6)
