@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(BLK) void k_cam_update(DeviceStructure ds, DeviceBu
     if (threadIdx.x == 0) { atomicAdd(slot_ptr(db, ACC_STEP2), db.shared_weight * s2); atomicAdd(slot_ptr(db, ACC_XNEW2), db.shared_weight * x2); }
     if (db.pu32) {
         const double gd = block_sum(gdot, scratch);
-        if (threadIdx.x == 0) atomicAdd(slot_ptr(db, ACC_MODEL), gd);
+        if (threadIdx.x == 0) atomicAdd(slot_ptr(db, ACC_MODEL), db.shared_weight * gd);      // (sharded: the cameras are replicated, rank 0 counts them)
     }
 }
 

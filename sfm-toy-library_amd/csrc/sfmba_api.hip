@@ -1680,6 +1680,7 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     launch_shard_unpack(p->stream, p->db, p->d_scal, 1, p->shard_world);
     { DeviceBuffers dbf = p->db; dbf.cd_part = nullptr; launch_finalize(p->stream, p->ds, dbf, 0); }     // (chunk sums: folded before the exchange)
     DeviceBuffers dbu = p->db;
+    if (p->precision == SFMBA_PRECISION_F32J) dbu.pu32 = p->d_pu32;      // (the gradient . step term is added by rank 0 only: shared_weight)
     if (o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) {
         // fp32 Jacobian mode: the streaming CG path keeps the preconditioned matrix in fp32 (k_pcg_transform writes it)
         p->solver.use_f32 = p->precision == SFMBA_PRECISION_F32J && dense_pcg_want_f32(&p->solver) != nullptr;
@@ -1699,8 +1700,8 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
         dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, nullptr);
     }
     launch_cam_update(p->stream, p->ds, dbu);
-    if (p->precision == SFMBA_PRECISION_F32J) launch_point_update<float>(p->stream, p->ds, p->db);
-    else launch_point_update<double>(p->stream, p->ds, p->db);
+    if (p->precision == SFMBA_PRECISION_F32J) launch_point_update<float>(p->stream, p->ds, dbu);      // (dbu: the same pu32 as k_cam_update saw -- sum u . r is formed in ONE of the two)
+    else launch_point_update<double>(p->stream, p->ds, dbu);
     launch_shard_pack(p->stream, p->db, p->d_scal, 2, p->shard_rank);
     return SFMBA_OK;
 }
@@ -1960,6 +1961,7 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
             if (it0 < 0) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
             }
             DeviceBuffers dbu = p->db;
+            if (f32) dbu.pu32 = p->d_pu32;
             dbu.pcg_vec = p->solver.vec; dbu.pcg_linv = p->solver.binv; dbu.pcg_flags = p->solver.flags;
             dbu.cg_gate = p->solver.flags; dbu.cg_force = 0;
             volatile int* mb = p->h_lm_mail;
