@@ -79,7 +79,9 @@ enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
                                        partial sum of block products is fp32 (at most 8 pair products of a 6x6 block of the reduced matrix,
                                        ceil(track / 4) point-block products of a point); every sum ACROSS lanes, chunks, points and ranks is
                                        fp64, and so are the residuals, the cost, the reduced system and its solve (ABI v4 summed a block's
-                                       up-to-512 pair products in fp32 before widening).  What to expect (tests/test_gpu_baseline_parity.py): final cost within 1e-6
+                                       up-to-512 pair products in fp32 before widening).  The back-substitution evaluates the Jacobian-type terms of an observation (J x step,
+                                       C = B~ L^-T) from an fp32 copy of the camera's R, t and step; the TRIAL residuals, which decide accept / reject, from the fp64 pose.
+                                       What to expect (tests/test_gpu_baseline_parity.py): final cost within 1e-6
                                        relative (measured 3e-13) and final RMS within 1e-4 px of the fp64 solve (measured < 1e-9 px),
                                        parameters within ~2e-5 -- EXCEPT points on weakly constrained tracks: a point seen by two
                                        nearly parallel views has almost no depth information, its 3x3 block is ill-conditioned and
