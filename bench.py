@@ -710,8 +710,9 @@ LIMITERS = {
                 "a third of them the fp64 reduction tree of the 47 sums; index -> point-table gather in front of them",
     "point_build": "VALU issue at ~60 % + wave lifetime: two dependent memory levels and a 7-lanes-of-64 per-point phase per wave; since round 4 it "
                    "writes nothing per observation and gathers three component quads of the camera table instead of six (48 -> 35 us)",
-    "point_update": "VALU issue + wave lifetime: re-evaluates every observation from the camera rows and the point table instead of streaming a 64-byte "
-                    "record (92.8 -> ~35 MB per launch, +5 us of arithmetic: the pass was not bandwidth-bound)",
+    "point_update": "texture addresser (TA_TA_BUSY ~90 % of the launch, VALU 26 %): every lane gathers another camera's rows, each 16-byte load is an instruction over 64 "
+                    "distinct lines; F32J gathers one 80-byte fp32 record per camera in the first sweep (5 loads instead of 10: 27.7 -> 21 us at cfg 3, 181 -> 135 at cfg 5), "
+                    "the trial sweep its 6 loads of the fp64 trial pose",
     "chol_panel": "the serial chain of 64 pivots in the diagonal tile (one workgroup: ~250 cycles per pivot) + one launch boundary per block column",
     "chol_update": "fp64 MFMA, short launches",
 }
