@@ -86,7 +86,8 @@ enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
                                        parameters within ~2e-5 -- EXCEPT points on weakly constrained tracks: a point seen by two
                                        nearly parallel views has almost no depth information, its 3x3 block is ill-conditioned and
                                        the fp32 rounding of its Jacobian moves it by up to ~1e-3..5e-3 scene units along the ray at
-                                       (numerically) the same cost (cfg3_banded: 8e-4 and 2.1e-3 seen).  Use F64 if such points'
+                                       (numerically) the same cost (cfg3_banded: 8e-4 and 2.1e-3 seen; the worst of 42 000 points of a 520-camera
+                                       path: 0.03 .. 0.07, with 99.9 % of the points within 2e-3).  Use F64 if such points'
                                        coordinates matter beyond that. */
 
 /* Return codes of every entry point. */

@@ -76,6 +76,29 @@ __device__ void make_cam_table(const double cam[6], const double* scale6, double
     ct[CT_CQ] = cq;
 }
 
+// [R | t] of a camera from its six parameters: the rotation part of make_cam_table (same expressions, same branches), for a pass that would
+// rather rebuild R per observation than gather nine more doubles of it (k_point_update's trial sweep: the pass is bound by its gather instructions)
+__device__ __forceinline__ void pose_from_params(const double (&cam)[6], double (&RT)[12]) {
+    const double w0 = cam[0], w1 = cam[1], w2 = cam[2];
+    const double theta2 = w0 * w0 + w1 * w1 + w2 * w2;
+    if (theta2 > DBL_EPSILON) {
+        const double theta = sqrt(theta2);
+        double s, c;
+        sincos(theta, &s, &c);
+        const double ti = 1.0 / theta;
+        const double k0 = w0 * ti, k1 = w1 * ti, k2 = w2 * ti;
+        const double oc = 1.0 - c;
+        RT[0] = c + k0 * k0 * oc;       RT[1] = k0 * k1 * oc - k2 * s;  RT[2] = k0 * k2 * oc + k1 * s;
+        RT[3] = k0 * k1 * oc + k2 * s;  RT[4] = c + k1 * k1 * oc;       RT[5] = k1 * k2 * oc - k0 * s;
+        RT[6] = k0 * k2 * oc - k1 * s;  RT[7] = k1 * k2 * oc + k0 * s;  RT[8] = c + k2 * k2 * oc;
+    } else {
+        RT[0] = 1.0;  RT[1] = -w2;  RT[2] = w1;
+        RT[3] = w2;   RT[4] = 1.0;  RT[5] = -w0;
+        RT[6] = -w1;  RT[7] = w0;   RT[8] = 1.0;
+    }
+    RT[9] = cam[3]; RT[10] = cam[4]; RT[11] = cam[5];
+}
+
 __global__ void k_cam_setup(int ncam, const double* __restrict__ cam, const double* __restrict__ cscale, double* __restrict__ camtab) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ncam) return;
@@ -1690,6 +1713,12 @@ __global__ void k_lm_control(DeviceBuffers db) { lm_control_body(db); }
 // With a release fence per workgroup the launch went from 27 to 83 us at BASELINE config 3 (747 from 190 at config 5: buffer_wbl2 3 125 times);
 // with the slots read as agent atomics and no release, one ticket counter serialised the 3 125 arrivals (57 us); with two-level tickets on
 // separate cache lines 36.5 us against 29.9 + 5.6 for the two launches: 4 260 against 4 270 LM iterations/s -- a wash, so the simpler form stays.)
+#ifndef SFMBA_TRIAL_POSE_FROM_PARAMS
+#define SFMBA_TRIAL_POSE_FROM_PARAMS 1
+#endif
+#ifndef SFMBA_TRIAL_POSE_MIN_CAMS
+#define SFMBA_TRIAL_POSE_MIN_CAMS 400     // 96 bytes of [R | t] per camera against a 32 KB L1: between the two measured sizes (200: table, 1 000: parameters)
+#endif
 template <typename T>
 __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, DeviceBuffers db) {
     __shared__ double scratch[WPB * 5];
@@ -1797,6 +1826,10 @@ __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, Dev
         const double zGz = Gd[0] * z0 * z0 + Gd[3] * z1 * z1 + Gd[5] * z2 * z2 + 2.0 * (Gd[1] * z0 * z1 + Gd[2] * z0 * z2 + Gd[4] * z1 * z2);
         model += ur + (z0 * tp[0] + z1 * tp[1] + z2 * tp[2]) - 0.5 * uu - (z0 * zacc[0] + z1 * zacc[1] + z2 * zacc[2]) - 0.5 * zGz;
     }
+    // Trial sweep.  F32J with more cameras than an L1 holds rows of (SFMBA_TRIAL_POSE_MIN_CAMS): three gathers of the trial camera's PARAMETERS and R rebuilt per
+    // observation (fp64 sincos on a VALU that is a third busy) instead of six gathers of the stored [R | t] -- measured 142 -> 116 us at BASELINE config 5
+    // (1 000 cameras: the pass is bound by its gather instructions), but 23.4 -> 25.4 us at config 3 (200 cameras: it is not), hence the threshold.
+    const bool pose_from_cam = SFMBA_TRIAL_POSE_FROM_PARAMS && sizeof(T) == 4 && ds.ncam >= SFMBA_TRIAL_POSE_MIN_CAMS;
     {
         int q = q0 + sub;
         int j_next = q < q1 ? ds.obs_cam[q] : 0;
@@ -1806,10 +1839,18 @@ __global__ __launch_bounds__(PBK, 4) void k_point_update(DeviceStructure ds, Dev
             const bool act = q < q1;
             const int j = j_next;
             const double ox = ox_next, oy = oy_next;
-            const CamRow stb = { stab + 4 * (size_t)(j), ds.ncam };
             double RTn[12];
+            if (pose_from_cam) {
+                // the trial camera's six parameters (three 16-byte gathers) and R rebuilt here, instead of six gathers of the stored [R | t]
+                const double2* cp = reinterpret_cast<const double2*>(db.cam[nxt] + 6 * (size_t)j);
+                const double2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
+                const double cn6[6] = { c0.x, c0.y, c1.x, c1.y, c2.x, c2.y };
+                pose_from_params(cn6, RTn);
+            } else {
+                const CamRow stb = { stab + 4 * (size_t)(j), ds.ncam };
 #pragma unroll
-            for (int e = 0; e < 12; ++e) RTn[e] = stb[ST_RN + e];
+                for (int e = 0; e < 12; ++e) RTn[e] = stb[ST_RN + e];
+            }
             q += PB_LPP;
             if (q < q1) { j_next = ds.obs_cam[q]; load_obs<T>(ds.obs_xy, q, ox_next, oy_next); }
             if (act) {
