@@ -1,6 +1,8 @@
 """Regenerates tests/golden/oracle_final_costs.json: iterations and final cost of oracle/sfmba_oracle.c (the CPU restatement of the reference's
 ceres::Solve, reference options BA.cpp:171-177 without the 10 s limit) on the BASELINE configurations -- what bench.py's `extra_workloads` and the
-full-size GPU tests hold the HIP path to.  cfg5 takes ~3 minutes on 16 threads.     python tests/golden/make_oracle_final_costs.py [names...]"""
+full-size GPU tests hold the HIP path to.  cfg5 takes ~3 minutes on 16 threads.     python tests/golden/make_oracle_final_costs.py [names...]
+A name "cfg4.3" is sub-problem 3 of cfg4 (make_problem("cfg4", sub=3)): BASELINE config 4's eight independent sub-problems are cfg4.0 ... cfg4.7, and
+cfg3.0 ... cfg3.7 are the independent cfg-3 problems the ranks of `bench.py --gpus N` solve (rank g: sub = g)."""
 import json
 import os
 import sys
@@ -14,7 +16,8 @@ from oracle import oracle_py as oracle
 path = os.path.join(ROOT, "tests", "golden", "oracle_final_costs.json")
 out = json.load(open(path)) if os.path.exists(path) else {}
 for name in (sys.argv[1:] or ["cfg2", "cfg3", "cfg3_banded", "cfg5"]):
-    prob = sfm.make_problem(name)
+    base, _, sub = name.partition(".")
+    prob = sfm.make_problem(base, sub=int(sub) if sub else None)
     s = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))[3]
     out[name] = {"n_cam": prob.n_cam, "n_pt": prob.n_pt, "n_obs": prob.n_obs, "iterations": s["iterations"], "termination": s["termination_name"],
                  "initial_cost": s["initial_cost"], "final_cost": s["final_cost"], "final_rms_px": float(np.sqrt(2 * s["final_cost"] / prob.n_obs))}
