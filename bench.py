@@ -4,6 +4,11 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Both forms run N ranks, one device each: started plain with N > 1 the script re-executes itself under torch.distributed.run (ensure_ranks), it refuses when
+fewer than N devices are visible or when --gpus contradicts the launcher's WORLD_SIZE, and the line's `n_gpus` is the rank count RCCL itself reports for the
+library's own communicator (rccl_rank_count).  Every number of the line -- headline, extra_workloads, cfg4, sharded.* -- carries `parity_ok` against the
+oracle's stored result for its problem (tests/golden/oracle_final_costs.json).
+
 A "step" is one full pass of the hot path over one batch of synthetic input: one complete
 adjustBundle()-equivalent solve (ceres::Solve semantics, reference options BA.cpp:171-177 except the
 10 s wall limit, which is disabled as BASELINE.md prescribes) of the device-resident problem, restarted
@@ -18,6 +23,8 @@ The same invocation then ALSO runs the path that does have an exchange step -- O
 1000-camera cfg 5) with its points sharded over the N ranks and the reduced camera system all-reduced over
 RCCL / xGMI once per LM iteration (sfmba_problem_solve_sharded, strong scaling) -- and reports it in the
 "sharded" object of the same JSON line (--sharded-extras 0 turns that off; at N = 1 it is off unless asked for).
+BASELINE config 4 as written (the 200-camera problem as 8 independent sub-problems of 25 cams / 12.5k pts / 125k obs) is timed too: at N > 1 as
+`cfg4_replicas` (rank g solves sub-problem g), at N = 1 as `extra_workloads.cfg4_8_concurrent` (the eight on eight streams of the one GPU).
 
 value = LM iterations (successful + unsuccessful) of all ranks / max-over-ranks wall time.
 """
@@ -35,7 +42,13 @@ sys.path.insert(0, ROOT)
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE when started by torch.distributed.run, else 1).  Started as a plain "
+                         "`python bench.py --gpus N` with N > 1 the script starts its own N ranks (torch.distributed.run, one device each) and "
+                         "refuses when fewer than N devices are visible")
+    ap.add_argument("--launch-only", action="store_true",
+                    help="dry run of the launcher: every rank prints its RANK / LOCAL_RANK / WORLD_SIZE as one JSON line and exits without touching a GPU "
+                         "(tests/test_bench_launcher_cpu.py)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", help="name in synthetic.CONFIGS (default: the BASELINE metric config)")
@@ -69,6 +82,59 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU sample (0 = swept upwards from 16 while it still gets faster; "
                                                                "nproc itself is 650x SLOWER than 16 threads on the 256-thread box, see cpu_baseline())")
     return ap.parse_args()
+
+
+def ensure_ranks(args):
+    """The contract is `python bench.py --gpus N`; the N > 1 form normally arrives wrapped in torch.distributed.run, but a plain invocation
+    must not silently run ONE rank and print n_gpus = 1.  Returns (rank, local_rank, world) of THIS process; when N > 1 ranks
+    are asked for and none were started, this process is REPLACED by `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`."""
+    started = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if started:
+        world = int(os.environ["WORLD_SIZE"])
+        if args.gpus is not None and args.gpus != world:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to report a line for either" % (args.gpus, world))
+        args.gpus = world
+        return int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"])), world
+    if args.gpus is None:
+        args.gpus = 1
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus == 1:
+        return 0, 0, 1
+    if not args.launch_only:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing (a run on fewer devices would not be an N-GPU number)"
+                             % (args.gpus, have))
+    import socket
+    with socket.socket() as sk:                       # a free port on the loop-back interface for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)                     # does not return
+
+
+def parity_vs_oracle(summ, n_obs, key, tol_rel_cost=1e-6):
+    """A solve's summary against the ORACLE's stored result (tests/golden/oracle_final_costs.json): termination, LM iteration count, final cost
+    (north_star's 1e-6 relative unless a tighter bar is passed) and RMS within 1e-4 px.  Returns a dict with `parity_ok` (None: nothing stored)."""
+    global _ORACLE_WANT
+    if _ORACLE_WANT is None:
+        with open(os.path.join(ROOT, "tests", "golden", "oracle_final_costs.json")) as f:
+            _ORACLE_WANT = json.load(f)
+    w = _ORACLE_WANT.get(key)
+    if w is None:
+        return {"parity_ok": None, "oracle_key": key, "note": "no stored oracle result for this problem"}
+    rms = float(np.sqrt(2.0 * summ["final_cost"] / n_obs))
+    rel = abs(summ["final_cost"] - w["final_cost"]) / w["final_cost"]
+    ok = (summ["termination_name"] == w["termination"] and summ["iterations"] == w["iterations"] and rel <= tol_rel_cost and abs(rms - w["final_rms_px"]) < 1e-4)
+    return {"parity_ok": bool(ok), "oracle_key": key, "oracle_final_cost": w["final_cost"], "oracle_iterations": w["iterations"],
+            "rel_cost_diff_vs_oracle": rel, "rms_diff_vs_oracle_px": rms - w["final_rms_px"], "parity_tolerance_rel_cost": tol_rel_cost}
+
+
+_ORACLE_WANT = None
 
 
 def algorithmic_bytes_per_iteration(n_obs, n_pt, n_cam, s_o, n_lin):
@@ -181,18 +247,24 @@ def _cpu_model():
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = ensure_ranks(args)
+    if args.launch_only:
+        print(json.dumps({"launch_only": True, "rank": rank, "local_rank": local_rank, "world_size": world, "gpus_arg": args.gpus,
+                          "master_addr": os.environ.get("MASTER_ADDR"), "pid": os.getpid()}), flush=True)
+        return
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP back end has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
+    n_gpus, rccl_check = 1, None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        n_gpus, rccl_check = rccl_rank_count(torch, dist, rank, local_rank, world)
 
     import sfm_toy_library_amd as sfm
     from sfm_toy_library_amd import capi
@@ -200,7 +272,7 @@ def main():
     precision = 1 if args.precision == "f32j" else 0
     linear = {"cholesky": 0, "pcg": 1, "auto": 2}[args.linear]
     if args.mode == "sharded":
-        return main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear)
+        return main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, n_gpus)
     sub = rank if world > 1 else None
     globals()["PMC_WORKLOAD"] = args.workload
     prob = sfm.make_problem(args.workload, sub=sub)
@@ -244,13 +316,16 @@ def main():
     profile = P.get_profile()
     P.set_profiling(False)
 
-    tot = torch.tensor([float(iters), float(res_evals + jac_evals), dt], dtype=torch.float64, device="cuda")
+    # every rank's own result against the oracle's stored one for ITS problem (rank g of N > 1 solves make_problem(workload, sub=g))
+    par = parity_vs_oracle(summ, prob.n_obs, args.workload if sub is None else "%s.%d" % (args.workload, sub))
+    tot = torch.tensor([float(iters), float(res_evals + jac_evals), dt, 0.0 if par["parity_ok"] is False else 1.0], dtype=torch.float64, device="cuda")
     if dist is not None:
-        tmax = tot[2:3].clone()
+        tmax, tmin = tot[2:3].clone(), tot[3:4].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)
-        tot[2] = tmax[0]
-    g_iters, g_evals, g_dt = [float(v) for v in tot.tolist()]
+        tot[2], tot[3] = tmax[0], tmin[0]
+    g_iters, g_evals, g_dt, g_par = [float(v) for v in tot.tolist()]
 
     if rank == 0:
         n_obs, n_pt, n_cam = prob.n_obs, prob.n_pt, prob.n_cam
@@ -260,7 +335,7 @@ def main():
             "metric": "BA LM iterations/sec (200 cams, 100k pts, 1M obs)" if args.workload == "cfg3" else "BA LM iterations/sec",
             "value": g_iters / g_dt,
             "unit": "LM iterations/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,               # N > 1: ncclCommCount of the library's own communicator (rccl_rank_count), never the argument
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * g_dt / args.steps,
@@ -281,7 +356,11 @@ def main():
             "final_rms_px": rms,
             "final_cost": summ["final_cost"],
             "termination": summ["termination_name"],
+            # every rank's result against the oracle's stored one for its own problem (None: nothing stored for this workload)
+            "parity_ok": None if par["parity_ok"] is None else bool(g_par == 1.0), "parity_rank0": par,
         }
+        if rccl_check is not None:
+            line["rccl_check"] = rccl_check
         # fraction of the HBM roofline of the whole LM iteration (algorithmic bytes of SURVEY 8d)
         n_lin = 1 if linear == 0 else max(1.0, lin_iters / max(iters, 1))
         b_iter = algorithmic_bytes_per_iteration(n_obs, n_pt, n_cam, s_o, n_lin)
@@ -362,6 +441,14 @@ def main():
                                                "termination": s3["termination_name"],
                                                "note": "same resident problem and solver, CG tolerance 1e-3 instead of 1e-8; not the headline"}
     P.close()
+    if world > 1 and args.workload == "cfg3":
+        # BASELINE config 4 as written: one 25-camera sub-problem per GPU (all ranks take part; rank 0 reports)
+        try:
+            c4 = cfg4_replicas(args, rank, local_rank, world, torch, dist, sfm, capi)
+        except Exception as e:
+            c4 = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            line["cfg4_replicas"] = c4
     # ---- the path with a real exchange step: one problem, points sharded over the ranks (all ranks take part) ----
     want_sharded = args.sharded_extras == 1 or (args.sharded_extras == -1 and world > 1)
     sh = None
@@ -409,6 +496,119 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rccl_rank_count(torch, dist, rank, local_rank, world):
+    """`n_gpus` of the JSON line is what RCCL itself reports (ncclCommCount of the library's own communicator, sfmba_comm_size), not an argument;
+    beside it: every rank sits on its own device, and one all-reduce through that communicator sums to the rank count."""
+    import ctypes as C
+    from sfm_toy_library_amd import sharded
+    comm = sharded.RcclComm(dist, rank, world, device=local_rank)
+    try:
+        n, r = comm.size()
+        ones = torch.ones(8, dtype=torch.float64, device="cuda")
+        rc = comm.L.sfmba_comm_allreduce(comm._h, C.c_void_p(ones.data_ptr()), C.c_int64(8), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        summed = float(ones[0].item())
+    finally:
+        comm.close()
+    try:
+        ident = str(torch.cuda.get_device_properties(local_rank).uuid)
+    except Exception:
+        ident = "device %d" % local_rank
+    ids = [None] * world
+    dist.all_gather_object(ids, (os.uname().nodename, local_rank, ident))
+    check = {"nccl_comm_count": n, "nccl_user_rank_matches": r == rank, "allreduce_of_ones": summed, "allreduce_rc": int(rc),
+             "distinct_devices": len(set(ids)) == world, "devices": [list(i) for i in ids]}
+    if n != world or r != rank or rc != 0 or summed != float(world) or len(set(ids)) != world:
+        raise SystemExit("bench.py: RCCL reports %d ranks (rank %d) for WORLD_SIZE=%d rank %d, all-reduce of ones = %r, devices %r: refusing" % (n, r, world, rank, summed, ids))
+    return n, check
+
+
+def cfg4_replicas(args, rank, local_rank, world, torch, dist, sfm, capi):
+    """BASELINE config 4 AS WRITTEN at N > 1: the 200-camera problem as independent sub-problems of 25 cams / 12.5k pts / 125k obs, rank g solves
+    sub-problem g (mod 8) -- no data-path collective; every rank's result held to the oracle's stored one."""
+    sub = rank % 8
+    prob = sfm.make_problem("cfg4", sub=sub)
+    opt = capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_tolerance=args.pcg_tol)
+    steps = max(args.steps, 10)
+    with capi.Problem(prob, precision=1, device=local_rank) as P:
+        for _ in range(3):
+            P.reset(); P.solve(opt)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        iters = 0
+        for _ in range(steps):
+            P.reset()
+            s, _ = P.solve(opt)
+            iters += s["iterations"]
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    par = parity_vs_oracle(s, prob.n_obs, "cfg4.%d" % sub)
+    t = torch.tensor([float(iters), dt, 1.0 if par["parity_ok"] else 0.0], dtype=torch.float64, device="cuda")
+    tmax, tmin = t[1:2].clone(), t[2:3].clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(tmin, op=dist.ReduceOp.MIN); dist.all_reduce(t[:1], op=dist.ReduceOp.SUM)
+    return {"workload": "cfg4: %d independent sub-problems of %d cams / %d pts / %d obs, one per GPU (rank g: sub-problem g mod 8)" % (world, prob.n_cam, prob.n_pt, prob.n_obs),
+            "scaling": "weak", "ranks": world, "steps": steps, "value": float(t[0].item()) / float(tmax[0].item()), "unit": "LM iterations/s",
+            "ms_per_step": 1e3 * float(tmax[0].item()) / steps, "dtype": DTYPE_F32J, "linear_solver": SOLVER_NAMES[1],
+            "parity_ok": bool(tmin[0].item() == 1.0), "rank0": par}
+
+
+def cfg4_concurrent(args, torch, sfm, capi, nprob=8):
+    """BASELINE config 4 on ONE GPU: its eight sub-problems resident side by side, each on its own stream with its own host thread (the C ABI call
+    releases the GIL), solved concurrently -- and one after the other for comparison; each held to the oracle's stored result."""
+    import threading
+    probs = [sfm.make_problem("cfg4", sub=g) for g in range(nprob)]
+    opt = capi.default_options(max_seconds=0.0, precision=1, linear_solver=1, pcg_tolerance=args.pcg_tol)
+    steps = 20
+    P = [capi.Problem(p, precision=1, device=torch.cuda.current_device()) for p in probs]
+    try:
+        for h in P:
+            for _ in range(2):
+                h.reset(); h.solve(opt)
+        last = [None] * nprob
+
+        def work(k, out, gate=None):
+            if gate is not None:
+                gate.wait()
+            its = 0
+            for _ in range(steps):
+                P[k].reset()
+                s, _ = P[k].solve(opt)
+                its += s["iterations"]
+            out[k] = its
+            last[k] = s
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); seq = [0] * nprob
+        for k in range(nprob):
+            work(k, seq)
+        torch.cuda.synchronize()
+        dt_seq = time.perf_counter() - t0
+        con = [0] * nprob
+        gate = threading.Barrier(nprob + 1)
+        th = [threading.Thread(target=work, args=(k, con, gate)) for k in range(nprob)]
+        for t in th:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt_con = time.perf_counter() - t0
+    finally:
+        for h in P:
+            h.close()
+    pars = [parity_vs_oracle(last[k], probs[k].n_obs, "cfg4.%d" % k) for k in range(nprob)]
+    out = {"workload": "cfg4: the %d independent sub-problems of %d cams / %d pts / %d obs, all resident on ONE GPU, one stream + one host thread each"
+                       % (nprob, probs[0].n_cam, probs[0].n_pt, probs[0].n_obs),
+           "dtype": DTYPE_F32J, "linear_solver": SOLVER_NAMES[1], "steps": steps, "value": sum(con) / dt_con, "unit": "LM iterations/s",
+           "ms_per_round_of_%d_solves" % nprob: 1e3 * dt_con / steps,
+           "one_after_the_other": {"value": sum(seq) / dt_seq, "unit": "LM iterations/s", "ms_per_solve": 1e3 * dt_seq / (steps * nprob)},
+           "lm_iterations_per_step": sum(con) / (steps * nprob), "parity_ok": all(p["parity_ok"] for p in pars),
+           "max_rel_cost_diff_vs_oracle": max(p["rel_cost_diff_vs_oracle"] for p in pars),
+           "max_abs_rms_diff_vs_oracle_px": max(abs(p["rms_diff_vs_oracle_px"]) for p in pars)}
+    assert out["parity_ok"], "cfg4_8_concurrent: a sub-problem's result differs from the oracle's stored one: %r" % pars
+    return out
 
 
 def extra_workloads(args, torch, sfm, capi):
@@ -464,6 +664,11 @@ def extra_workloads(args, torch, sfm, capi):
             out.setdefault(key, {})["error"] = str(e)
         except Exception as e:
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    cache.clear()
+    try:                                       # BASELINE config 4 as written, on the one GPU there is
+        out["cfg4_8_concurrent"] = cfg4_concurrent(args, torch, sfm, capi)
+    except Exception as e:
+        out["cfg4_8_concurrent"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -550,10 +755,14 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
                 L.sfmba_comm_allreduce(comm._h, C.c_void_p(small.data_ptr()), C.c_int64(small.numel()), stream)
             barrier()
             t_small = (time.perf_counter() - t1) / 50
-        tmax = torch.tensor([dt, t_ar, t_ag, t_small], dtype=torch.float64, device="cuda")
+        # the result of EVERY rank against the oracle's stored solve of the whole problem (the replicas of a sharded solve must all agree with it)
+        g_par = parity_vs_oracle(summ, prob.n_obs, workload)
+        tmax = torch.tensor([dt, t_ar, t_ag, t_small, 1.0 if g_par["parity_ok"] is False else 0.0], dtype=torch.float64, device="cuda")
         if dist is not None and world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        g_dt, g_ar, g_ag, g_small = [float(v) for v in tmax.tolist()]
+        g_dt, g_ar, g_ag, g_small, bad = [float(v) for v in tmax.tolist()]
+        if g_par["parity_ok"] is not None:
+            g_par["parity_ok"] = bool(bad == 0.0)
         dist_note = None
         if summ.get("row_sharded"):
             dist_note = ("block ROWS of the preconditioned reduced matrix per rank: every rank holds the whole problem, eliminates its own range of points, the per-point table "
@@ -572,7 +781,7 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
                                          "implicit Schur CG (no reduced matrix formed or exchanged)" if summ.get("implicit_schur_cg") else
                                          "distributed CG (no redundant solve)" if summ.get("distributed_cg") else "every rank runs the CG on the summed matrix (redundant)"),
                 "distributed_cg_exchange": dist_note,
-                "scaling": "strong", "n_gpus": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
+                "scaling": "strong", "ranks": world, "steps": steps, "value": iters / g_dt, "unit": "LM iterations/s",
                 "ms_per_step": 1e3 * g_dt / steps, "lm_iterations_per_step": iters / steps,
                 "one_rank_without_collective": no_comm,
                 "allreduce_bytes_per_lm_iteration": int(sum(ex_bytes)),
@@ -591,25 +800,27 @@ def sharded_run(workload, args, rank, local_rank, world, torch, dist, sfm, capi,
                                "diagonals | scalars] (%d doubles), the off-diagonal blocks of the block-Jacobi-preconditioned reduced matrix (%d values, %s: the "
                                "one timed here), 80 trial-step scalars; every rank runs the CG on the summed matrix redundantly" % (n_a, n_red, "fp32 like the CG's stored matrix" if b_fp32 else "fp64")),
                 "final_rms_px": float(np.sqrt(2 * summ["final_cost"] / prob.n_obs)), "final_cost": summ["final_cost"],
-                "termination": summ["termination_name"], "linear_iters_per_step": summ["linear_iters"]}
+                "termination": summ["termination_name"], "linear_iters_per_step": summ["linear_iters"],
+                "lm_iterations_last_step": summ["iterations"], **g_par}
     finally:
         comm.close()
         be.close()
 
 
-def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear):
+def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, n_gpus):
     """--mode sharded: the sharded run IS the headline line (strong scaling)."""
     r = sharded_run(args.workload, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=args.steps,
                     distributed=3 if args.row_sharded else 2 if args.implicit_cg else 1 if args.distributed_cg else 0)
     if rank == 0:
         _flush_c_stdio()
         print(json.dumps({
-            "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
+            "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if precision == 0 else DTYPE_F32J,
             "data": "synthetic", "config": {"workload": r["workload"], "step": "one full LM solve to ceres CONVERGENCE",
                                             "lm_iterations_per_step": r["lm_iterations_per_step"], "collective": r["collective"]},
-            "sharded": r, "final_rms_px": r["final_rms_px"], "final_cost": r["final_cost"], "termination": r["termination"]}), flush=True)
+            "sharded": r, "final_rms_px": r["final_rms_px"], "final_cost": r["final_cost"], "termination": r["termination"],
+            "parity_ok": r.get("parity_ok")}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

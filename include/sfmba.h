@@ -382,6 +382,7 @@ typedef int (*sfmba_allreduce_fn)(void* ctx, void* device_buf, int64_t n_doubles
 SFMBA_API int  sfmba_comm_unique_id(unsigned char id[SFMBA_COMM_ID_BYTES]);
 SFMBA_API int  sfmba_comm_create(const unsigned char id[SFMBA_COMM_ID_BYTES], int rank, int world, int device, sfmba_comm** out);
 SFMBA_API void sfmba_comm_destroy(sfmba_comm* comm);
+SFMBA_API int  sfmba_comm_size(const sfmba_comm* comm, int* world, int* rank);   /* ncclCommCount / ncclCommUserRank: what RCCL itself says the communicator is (bench.py's n_gpus) */
 SFMBA_API int  sfmba_comm_abort(sfmba_comm* comm);      /* ncclCommAbort: call on the ranks that failed; the communicator is unusable afterwards */
 SFMBA_API int  sfmba_comm_allreduce(void* comm /* sfmba_comm* */, void* device_buf, int64_t n_doubles, void* hip_stream);   /* an sfmba_allreduce_fn */
 SFMBA_API int  sfmba_problem_solve_sharded(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx,

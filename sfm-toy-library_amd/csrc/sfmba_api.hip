@@ -2064,6 +2064,8 @@ struct RcclApi {
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 RcclApi* rccl() {
     static RcclApi api;
@@ -2080,6 +2082,8 @@ RcclApi* rccl() {
             api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
             api.ReduceScatter = reinterpret_cast<decltype(api.ReduceScatter)>(dlsym(api.handle, "ncclReduceScatter"));
             api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
+            api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
+            api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.handle, "ncclCommUserRank"));
             if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.handle = nullptr;
         }
     }
@@ -2121,6 +2125,18 @@ void sfmba_comm_destroy(sfmba_comm* c) {
     RcclApi* a = rccl();
     if (a && c->comm) (void)a->CommDestroy(c->comm);
     delete c;
+}
+
+int sfmba_comm_size(const sfmba_comm* c, int* world, int* rank) {
+    RcclApi* a = rccl();
+    if (!c || !c->comm || !a || !a->CommCount || !a->CommUserRank) return fail(SFMBA_ERR_HIP, "ncclCommCount is not available");
+    int n = 0, r = -1;
+    ncclResult_t e = a->CommCount(c->comm, &n);
+    if (e == ncclSuccess) e = a->CommUserRank(c->comm, &r);
+    if (e != ncclSuccess) return fail(SFMBA_ERR_HIP, std::string("ncclCommCount: ") + (a->GetErrorString ? a->GetErrorString(e) : "error"));
+    if (world) *world = n;
+    if (rank) *rank = r;
+    return SFMBA_OK;
 }
 
 int sfmba_comm_abort(sfmba_comm* c) {

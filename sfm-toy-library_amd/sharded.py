@@ -167,6 +167,12 @@ class RcclComm:
         capi._check(L.sfmba_comm_create(ident, C.c_int(rank), C.c_int(world), C.c_int(device), C.byref(self._h)))
         self.L = L
 
+    def size(self):
+        """(world, rank) as RCCL itself reports them (ncclCommCount / ncclCommUserRank)."""
+        w, r = C.c_int(0), C.c_int(-1)
+        capi._check(self.L.sfmba_comm_size(self._h, C.byref(w), C.byref(r)))
+        return int(w.value), int(r.value)
+
     def close(self):
         if self._h:
             self.L.sfmba_comm_destroy(self._h)

@@ -46,3 +46,49 @@ def test_bench_line_has_the_contract_keys():
 def test_bench_cholesky_and_f64_modes_run():
     d = _run("--linear", "cholesky", "--precision", "f64", "--no-cpu-baseline", "--no-live-traffic")
     assert d["termination"] == "CONVERGENCE" and "cpu_baseline" not in d
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_headline_and_modes_carry_parity_against_the_stored_oracle_result():
+    d = _run("--no-cpu-baseline", "--no-live-traffic")
+    assert d["parity_ok"] is True and d["parity_rank0"]["oracle_key"] == "cfg2" and d["parity_rank0"]["rel_cost_diff_vs_oracle"] < 1e-6
+    s = _run("--no-cpu-baseline", "--no-live-traffic", "--mode", "sharded", "--row-sharded")
+    assert s["n_gpus"] == 1 and s["parity_ok"] is True and s["sharded"]["parity_ok"] is True and s["sharded"]["oracle_key"] == "cfg2"
+
+
+def test_cfg4_eight_concurrent_subproblems_on_one_gpu_match_the_oracle():
+    """BASELINE config 4 as written, on the one GPU of this box: eight resident sub-problems, eight streams, eight host threads."""
+    import argparse
+    import torch
+    import sfm_toy_library_amd as sfm
+    from sfm_toy_library_amd import capi
+    b = _bench_module()
+    r = b.cfg4_concurrent(argparse.Namespace(pcg_tol=1e-8), torch, sfm, capi)
+    assert r["parity_ok"] is True and r["value"] > 0 and r["one_after_the_other"]["value"] > 0
+    assert r["lm_iterations_per_step"] == 3.0 and r["max_abs_rms_diff_vs_oracle_px"] < 1e-4
+
+
+def test_rank_count_comes_from_rccl_itself():
+    """n_gpus of the bench line = ncclCommCount of the library's own communicator (sfmba_comm_size), checked with an all-reduce of ones: here with the one
+    rank this box has (the process group only carries the unique id and the device list)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    b = _bench_module()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        torch.cuda.set_device(0)
+        n, chk = b.rccl_rank_count(torch, dist, 0, 0, 1)
+    finally:
+        dist.destroy_process_group()
+    assert n == 1 and chk["nccl_comm_count"] == 1 and chk["nccl_user_rank_matches"] and chk["allreduce_of_ones"] == 1.0 and chk["distinct_devices"]
