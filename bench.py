@@ -74,6 +74,8 @@ def parse():
                          "each to the oracle's stored final cost: 1 = yes, 0 = no, -1 (default) = at N = 1 in the driver's plain invocation (default workload and solver, "
                          "CPU baseline not switched off: the tool runs under rocprofv3 stay lean)")
     ap.add_argument("--extras-timeout", type=int, default=420, help="seconds after which the sharded extras are abandoned (the headline line is printed regardless)")
+    ap.add_argument("--opt", action="append", default=[], metavar="FIELD=VALUE",
+                    help="set a field of sfmba_options for the headline solve (A/B runs: --opt pcg_symmetric=-1); may be repeated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic live; the committed "
@@ -278,6 +280,9 @@ def main():
     prob = sfm.make_problem(args.workload, sub=sub)
     P = capi.Problem(prob, precision=precision, device=local_rank)
     opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, pcg_tolerance=args.pcg_tol)
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        setattr(opt, k, type(getattr(opt, k))(float(v)))
 
     def barrier():
         torch.cuda.synchronize()

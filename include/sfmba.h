@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SFMBA_ABI_VERSION 5
+#define SFMBA_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define SFMBA_API __attribute__((visibility("default")))
@@ -134,7 +134,9 @@ typedef struct sfmba_options {
                                          iterations there; AUTO keeps that CG above 213 cameras instead of factorising).
                                          1 = the eight global vectors only, 2 = the segments wherever they apply.
                                          The sharded solve keeps the eight global vectors (the choice would have to be agreed between the ranks). */
-    int    pcg_persistent;            /* reserved (ABI v4: whole CG solve in one cooperative launch; never the default at any size, removed in ABI v5): ignored */
+    int    pcg_symmetric;             /* ABI v6 (the slot ABI v4 called pcg_persistent; reserved in v5)  default on : the streaming CG (d > 1280, no
+                                         segmented coarse space, not a deterministic handle) reads ONE triangle of S~ per iteration and uses every entry
+                                         twice (k_pcg_iter_sym); the pair pass then writes that triangle only.  -1 = both triangles, the round-5 kernels */
     int    pcg_f32_matrix;            /* SFMBA_PCG_F32_MATRIX     default on : F32J + streaming CG (d > 1280) store S~ in fp32 */
     int    early_linearise;           /* SFMBA_EARLY_LINEARISE    default on : next linearisation enqueued before the host reads the verdict */
     int    shard_two_phase;           /* SFMBA_SHARD_TWO_PHASE    default on : sharded CG path exchanges (A) diagonal data, (B) preconditioned blocks */

@@ -152,6 +152,7 @@ struct DeviceBuffers {
     int cg_force;             //           (the host enqueues them behind a CG batch of guessed length without waiting for it)
     double* pcg_F;            // [d][ld] preconditioned reduced matrix S~ written directly by k_schur_pairs (PCG mode)
     float* pcg_F32;           // the same in fp32 instead (streaming CG path, d > 1280: the matvec is HBM-bound); else null
+    int pcg_upper_only;       // 1: the CG reads ONE triangle of S~ (dense_solver.hip, symmetric streaming path): store_block_entry writes the upper block only
     double* pcg_bt;           // [ld]    Lb^-1 rhs
     double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
     double* pair_partial;     // [chunks of multi-chunk blocks][36] their partial sums (factored coordinates); rows: pwg_chunk[].x

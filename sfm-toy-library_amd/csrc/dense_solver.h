@@ -19,8 +19,13 @@ struct DenseSolver {
     double* Sfull = nullptr;  // [ld*ld] full symmetric copy (PCG only, allocated lazily)
     float* Sfull32 = nullptr; // fp32 copy for the streaming path (allocated by dense_pcg_want_f32)
     // launch parameters of the running CG solve (dense_pcg_solve ... dense_pcg_more)
-    struct CgRun { int nwg = 0, rows_per_wg = 0; size_t lds = 0; bool fast = false, f32 = false, coarse = false, ml = false, sg = false; double tol2 = 0.0; int in = 1, launched = 0, max_iters = 0; int* info = nullptr; } run;
+    struct CgRun { int nwg = 0, rows_per_wg = 0; size_t lds = 0; bool fast = false, f32 = false, coarse = false, ml = false, sg = false, sym = false; double tol2 = 0.0; int in = 1, launched = 0, max_iters = 0; int* info = nullptr; } run;
     bool use_f32 = false;     // set by the caller per solve: the preconditioned matrix of THIS solve lives in Sfull32
+    bool symmetric = false;   // set by the caller per solve: take the symmetric streaming path (k_sy_vec + k_sy_prod: the UPPER triangle of S~ read once per
+                              // iteration) where it applies -- d > 1280, no segmented coarse space
+    double* q3 = nullptr;     // [2][ld] the products of the symmetric path by iteration parity (added into with atomics; zeroed by the vector kernel in front)
+    double* sym_part = nullptr;   // [2][9][64 slots] its partial sums (p_r . q, (S~ W~)^T p_r), one 128-byte line per accumulator
+    int4* sym_tiles = nullptr; int sym_ntiles = 0;   // its tiles of the upper triangle
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][9][1024] per-workgroup partial sums of one iteration (p_r.q, W~^T q), by iteration parity
     // coarse space of the two-level preconditioner (dense_solver.hip): 8 gauge vectors in the transformed unknowns
@@ -88,6 +93,8 @@ int dense_pcg_transform(hipStream_t s, DenseSolver* ws, double* S, double* rhs, 
 int dense_pcg_more(hipStream_t s, DenseSolver* ws, int n, Profiler* prof = nullptr);
 void dense_pcg_note(DenseSolver* ws, int hist_key, int iters);
 int dense_pcg_ensure_workspace(DenseSolver* ws);
+// true where ws->symmetric selects the symmetric streaming path (d > 1280): the caller's pair pass may then write the upper triangle of S~ only
+bool dense_pcg_symmetric_applicable(const DenseSolver* ws);
 // fp32 storage of the preconditioned matrix for the streaming (d > 1280) path; returns the buffer or null if not applicable
 float* dense_pcg_want_f32(DenseSolver* ws);
 }  // namespace sfmba

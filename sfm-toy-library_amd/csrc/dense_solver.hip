@@ -333,7 +333,7 @@ __device__ __forceinline__ void coarse_sum_partials(int nwg, const double* __res
     }
 }
 
-// stand-alone version (streaming CG path: up to 1024 workgroups of partials): out = [Einv 64 | c_0 8]
+// stand-alone version (streaming CG path: up to 1024 workgroups of partials): out = [Einv 64 | c_0 8 | E 64]
 __global__ __launch_bounds__(256) void k_pcg_coarse_invert(int nwg, const double* __restrict__ epart, double* __restrict__ out) {
     constexpr int N = PCG_NW, NV = N * N + N;
     __shared__ double tot[NV];
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256) void k_pcg_coarse_invert(int nwg, const double
     __syncthreads();
     if (threadIdx.x >= 64) return;
     if (threadIdx.x < N) out[N * N + threadIdx.x] = tot[N * N + threadIdx.x];
+    out[N * N + N + threadIdx.x] = tot[threadIdx.x];          // E itself (symmetric streaming path: W~^T q = AW^T p_r + E p_mu)
     out[threadIdx.x] = coarse_invert_wave(tot, sa, sb);
 }
 
@@ -628,6 +629,275 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
     if (COARSE && lane >= 8 && lane < 8 + PCG_NW) red[40 + 9 * w + 1 + (lane - 8)] = gacc;
     __syncthreads();
     if (tid < NV) pcg_part(part, out, tid)[blockIdx.x] = red[40 + tid] + red[49 + tid] + red[58 + tid] + red[67 + tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Symmetric streaming path (round 6).  S~ is symmetric: the CG reads ONE triangle of it per iteration -- 72 MB instead of
+// 144 MB at d = 6001 -- and uses every entry twice from the one 16-byte load that brought it in:
+//     q_i += U_ij p_j      (row use: summed across the wave by a halving butterfly)
+//     q_j += U_ij p_i      (column use, j > i: kept per lane, summed across the four waves of the tile in LDS)
+// over TILES of SY_R rows x SY_C columns of the scalar upper triangle (diagonal included; the lower triangle and the padding are never multiplied),
+// ONE TILE PER WORKGROUP: every load of the product is in flight as soon as the launch starts (2 396 workgroups at d = 6001).  A row of q collects
+// sums from every tile of its row strip and of its column chunk: fp64 device-scope atomics on a zeroed q buffer, every atomic instruction on
+// CONSECUTIVE addresses (tools/micro/symv_bench.hip: the memory side retires ~6 G line-sized atomic transactions per second whatever they carry;
+// 48 k of them per product cost nothing next to the stream -- 12 - 14 us, 5.2 - 5.9 TB/s of the 72 MB, against 27.8 us for both triangles --, the
+// 2 M of a form with one flush per wave and strided lanes cost 100 us).
+// What does NOT survive a grid of 2 396 workgroups is the vector phase of k_pcg_iter (every workgroup forms alpha, |r - alpha q|^2, beta from the
+// whole vectors: 96 KB from L2 per workgroup -- measured +5 ... +10 us at 512 ... 1 024 workgroups in the same micro-benchmark, fused forms of the
+// iteration land at 20 - 26 us).  So an iteration is TWO launches here:
+//   k_sy_vec   (SY_VEC_WG workgroups) the scalars of the iteration, x, r, the new search direction p = p_r (its own slice of each), the stopping test;
+//              zeroes its slice of the q buffer and of the partial sums the product is about to add into
+//   k_sy_prod  (one workgroup per tile) the product; the slotted partial sums p_r . q; its first workgroups also add (S~ W~) p_mu to their slice of q
+//              and form the partials of W~^T q = (S~ W~)^T p_r (+ E p_mu in k_sy_vec): S~ is symmetric, so W~^T S~ p_r needs no pass over W~ per tile
+// q and the partial sums are double-buffered by iteration parity like the other vectors.  Not for deterministic handles (the order the atomics
+// arrive in is not fixed): those keep k_pcg_iter.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SY_R = 32;              // rows of a tile: eight per wave, one batch of eight 16-byte loads in flight per lane
+constexpr int SY_C = 256;             // columns of a tile: 64 lanes x four entries
+constexpr int SY_VEC_WG = 64;         // workgroups of the vector kernel (each forms the scalars for itself and updates its slice)
+constexpr int SY_SLOTS = 64;          // slots of the partial sums (one 128-byte line per value and slot: atomics on one line serialise)
+constexpr int SY_SLOT_STRIDE = 16;    // doubles between two accumulators
+
+// sums of eight per-lane values over the wave: afterwards every lane of the group lane / 8 holds the total of value lane / 8
+__device__ __forceinline__ double rows8_reduce(const double (&v)[8], int lane) {
+    double a[4], b[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = xlane_pairsum<32>(v[k], v[4 + k]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) b[k] = xlane_pairsum<16>(a[k], a[2 + k]);
+    const bool up = (lane & 8) != 0;
+    const double send = up ? b[0] : b[1], keep = up ? b[1] : b[0];
+    double c = keep + xlane_get<8>(send);
+    c = xlane_add<4>(c); c = xlane_add<2>(c); c = xlane_add<1>(c);
+    return c;
+}
+__device__ __forceinline__ double* sy_slot(double* part, int parity, int v, int slot) { return part + ((size_t)(parity * PCG_NPART + v) * SY_SLOTS + slot) * SY_SLOT_STRIDE; }
+
+// the vector half of an iteration (see above).  q2: [2][ld] the products by parity; part: [2][9][SY_SLOTS] accumulators, one line each
+// EPT > 0: the whole of r and q in registers (EPT entries per thread, 256 EPT >= d), requested together with everything else the launch reads BEFORE
+// the first reduction -- one memory round trip per launch instead of one per phase; EPT = 0: looped (any d)
+template <bool INIT, bool COARSE, int EPT>
+__global__ __launch_bounds__(256) void k_sy_vec(int d, int ld, double* __restrict__ vec, double* __restrict__ q2, const double* __restrict__ bt,
+                                                double* __restrict__ part, double* scal, int* flags, double tol2, int in, int* info, int* mailbox,
+                                                int anchor, double cap, const double* __restrict__ W, const double* __restrict__ coarse) {
+    __shared__ double red[PCG_RED];
+    const int seq = in >> 1;
+    in &= 1;
+    if (!INIT) { const int dn = flags[PF_DONE]; if (dn != 0 && seq >= dn) return; }
+    constexpr int NV = COARSE ? PCG_NPART : 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
+    const int nwg = (int)gridDim.x;
+    const int per = (d + nwg - 1) / nwg;
+    const int row0 = min(d, (int)blockIdx.x * per), row1 = min(d, row0 + per);
+    double* x_out = pcg_vec(vec, 0, out, ld); double* r_out = pcg_vec(vec, 1, out, ld); double* p_out = pcg_vec(vec, 2, out, ld);
+    const double* x_in = pcg_vec(vec, 0, in, ld); const double* r_in = INIT ? bt : pcg_vec(vec, 1, in, ld);
+    const double* p_in = pcg_vec(vec, 2, in, ld);
+    const double* q_in = q2 + (size_t)in * ld;
+    double* q_next = q2 + (size_t)out * ld;         // the product of THIS iteration is added into it
+    const double* st_in = scal + PS_STATE + PS_STATE_LEN * in;
+    double* st_out = scal + PS_STATE + PS_STATE_LEN * out;
+    if (COARSE && tid < PCG_NW * PCG_NW) { red[80 + tid] = coarse[tid]; red[144 + tid] = coarse[PCG_NW * PCG_NW + PCG_NW + tid]; }      // E^-1, E
+    // the buffers the product adds into: zero (this workgroup's slice of q, its share of the accumulators)
+    for (int e = row0 + tid; e < row1; e += 256) q_next[e] = 0.0;
+    for (int i = blockIdx.x * 256 + tid; i < NV * SY_SLOTS; i += nwg * 256) sy_slot(part, out, 0, 0)[(size_t)i * SY_SLOT_STRIDE] = 0.0;
+    double c_new[PCG_NW], mu_new[PCG_NW], pmu_new[PCG_NW], pmu_in[PCG_NW];
+    double rz_new = 0.0;
+    if (INIT) {
+        double rr = 0.0;
+        for (int e0 = tid; e0 < d; e0 += 256 * 8) {
+            double bv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; bv8[u] = bt[e < d ? e : d - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < d) rr += bv8[u] * bv8[u]; }
+        }
+        rr = wave_allsum(rr);
+        if (lane == 0) red[16 + w] = rr;
+        __syncthreads();
+        rr = red[16] + red[17] + red[18] + red[19];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = COARSE ? coarse[PCG_NW * PCG_NW + k] : 0.0; mu_new[k] = 0.0; pmu_in[k] = 0.0; }
+        if (COARSE) einv_apply(red + 80, c_new, mu_new);
+        rz_new = rr + (COARSE ? dot8(c_new, mu_new) : 0.0);
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = mu_new[k];
+        for (int e = row0 + tid; e < row1; e += 256) { const double b = bt[e]; x_out[e] = 0.0; r_out[e] = b; p_out[e] = b; }
+        if (blockIdx.x == 0 && tid == 0) {
+            scal[PS_RR0] = pcg_threshold_base(rr, scal, anchor, cap); flags[PF_DONE] = (rr == 0.0); flags[PF_ITERS] = 0; flags[PF_XBUF] = out;
+            if (mailbox && rr == 0.0) pcg_post(mailbox, 0, 1);
+        }
+    } else {
+        // the slotted sums of the previous product: wave w owns values w, w + 4, w + 8; one slot per lane
+        double mine[3] = { 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int v = w + 4 * j; mine[j] = (4 * j < NV && v < NV) ? *sy_slot(part, in, v, lane) : 0.0; }
+        reduce_partials<NV>(mine, red);
+        __syncthreads();
+        double g[PCG_NW], Eg[PCG_NW], c_in[PCG_NW], mu_in[PCG_NW];
+        const double rz_in = st_in[PS_RZ];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) {
+            pmu_in[k] = COARSE ? st_in[PS_PMU + k] : 0.0;
+            c_in[k] = COARSE ? st_in[PS_C + k] : 0.0;
+            mu_in[k] = COARSE ? st_in[PS_MU + k] : 0.0;
+            Eg[k] = 0.0;
+        }
+        // W~^T q = (S~ W~)^T p_r (the partials) + E p_mu
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) {
+            double erow[PCG_NW];
+#pragma unroll
+            for (int j = 0; j < PCG_NW; ++j) erow[j] = COARSE ? red[144 + PCG_NW * k + j] : 0.0;
+            g[k] = COARSE ? red[1 + k] + dot8(erow, pmu_in) : 0.0;
+        }
+        if (COARSE) einv_apply(red + 80, g, Eg);
+        const double pq = red[0] + (COARSE ? dot8(pmu_in, g) : 0.0);
+        const double alpha = rz_in / pq;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { c_new[k] = fma(-alpha, g[k], c_in[k]); mu_new[k] = fma(-alpha, Eg[k], mu_in[k]); }
+        const double cmu = COARSE ? dot8(c_new, mu_new) : 0.0;
+        double rrn = 0.0;
+        for (int e0 = tid; e0 < d; e0 += 256 * 8) {
+            double rv8[8], qv8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u, ec = e < d ? e : d - 1; rv8[u] = r_in[ec]; qv8[u] = q_in[ec]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < d) { const double v = fma(-alpha, qv8[u], rv8[u]); rrn = fma(v, v, rrn); } }
+        }
+        rrn = wave_allsum(rrn);
+        if (lane == 0) red[16 + w] = rrn;
+        for (int e = row0 + tid; e < row1; e += 256) {            // x += alpha p  with p = p_r + W~ p_mu, own slice
+            double pe = p_in[e];
+            if (COARSE) {
+#pragma unroll
+                for (int k = 0; k < PCG_NW; ++k) pe = fma(W[(size_t)k * ld + e], pmu_in[k], pe);
+            }
+            x_out[e] = x_in[e] + alpha * pe;
+        }
+        __syncthreads();
+        rrn = red[16] + red[17] + red[18] + red[19];
+        rz_new = rrn + cmu;
+        const bool broke = !(pq > 0.0) || !(rrn == rrn);
+        if (rrn <= tol2 * scal[PS_RR0] || broke) {
+            if (blockIdx.x == 0 && tid == 0) {
+                flags[PF_DONE] = seq + 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
+                if (broke) atomicCAS(info, 0, d + 1);
+                if (mailbox) pcg_post(mailbox, it, 1);
+            }
+            return;
+        }
+        const double beta = rz_new / rz_in;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = fma(beta, pmu_in[k], mu_new[k]);
+        for (int e = row0 + tid; e < row1; e += 256) {
+            const double rn = fma(-alpha, q_in[e], r_in[e]);
+            r_out[e] = rn;
+            p_out[e] = fma(beta, p_in[e], rn);
+        }
+        if (blockIdx.x == 0 && tid == 0) { const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, it, 0); }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        st_out[PS_RZ] = rz_new;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { st_out[PS_C + k] = c_new[k]; st_out[PS_MU + k] = mu_new[k]; st_out[PS_PMU + k] = pmu_new[k]; }
+    }
+}
+
+// the product half: tiles[blockIdx.x] = {first row, first column (a multiple of SY_C), rows, 1 if the tile overlaps the diagonal}.  `in` as k_sy_vec's
+// (the launch pair of one iteration shares it): p_r and the state of parity out = in ^ 1 are what k_sy_vec just wrote.
+template <typename FT, bool COARSE>
+__global__ __launch_bounds__(256) void k_sy_prod(int d, int ld, const FT* __restrict__ F, const double* __restrict__ vec, double* __restrict__ q2,
+                                                 double* __restrict__ part, const double* __restrict__ scal, const int* __restrict__ flags,
+                                                 const int4* __restrict__ tiles, int in, int nslice, const double* __restrict__ AW) {
+    __shared__ __align__(16) double colsh[4 * SY_C];
+    __shared__ double red[4 * PCG_NPART];
+    const int seq = in >> 1;
+    in &= 1;
+    { const int dn = flags[PF_DONE]; if (dn != 0 && seq + 1 >= dn) return; }       // (k_sy_vec of this iteration has raised it: nothing left to multiply)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
+    const double* p = vec + (size_t)(2 * 2 + out) * ld;        // pcg_vec(vec, 2, out, ld)
+    double* q = q2 + (size_t)out * ld;
+    const int4 tl = tiles[blockIdx.x];
+    const int r0 = tl.x, c0 = tl.y, rend = tl.x + tl.z;
+    const bool diag = tl.w != 0;
+    const int j0 = c0 + 4 * lane, rw0 = r0 + 8 * w;
+    Quad<FT> f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int row = rw0 + u; f[u].load(F + (size_t)(row < rend ? row : r0) * ld + j0); }
+    double pj[4];
+    {
+        const double2 a = reinterpret_cast<const double2*>(p + j0)[0], b = reinterpret_cast<const double2*>(p + j0)[1];      // (j0 + 3 < ld: the padding is selected away)
+        pj[0] = j0 + 0 < d ? a.x : 0.0; pj[1] = j0 + 1 < d ? a.y : 0.0; pj[2] = j0 + 2 < d ? b.x : 0.0; pj[3] = j0 + 3 < d ? b.y : 0.0;
+    }
+    const int myrow = rw0 + (lane >> 3);              // the row whose total this lane group publishes
+    const double prow = myrow < rend ? p[myrow] : 0.0;
+    double pq_acc = 0.0;
+    double racc[8], colacc[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = rw0 + u;                      // wave-uniform
+        const double pi = lane_bcast(prow, 8 * u);    // (0 for a row beyond the tile)
+        const bool live = row < rend;
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            double x = f[u].get(e);
+            if (!live || j >= d || (diag && j < row)) x = 0.0;
+            s = fma(x, pj[e], s);
+            colacc[e] = fma((diag && j == row) ? 0.0 : x, pi, colacc[e]);       // the diagonal entry is used once
+        }
+        racc[u] = s;
+    }
+    const double tot = rows8_reduce(racc, lane);
+    if ((lane & 7) == 0 && myrow < rend) { atomicAdd(q + myrow, tot); pq_acc = prow * tot; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) colsh[w * SY_C + 4 * lane + e] = colacc[e];
+    __syncthreads();
+    if (c0 + tid < d) {
+        const double cs = (colsh[tid] + colsh[SY_C + tid]) + (colsh[2 * SY_C + tid] + colsh[3 * SY_C + tid]);
+        atomicAdd(q + c0 + tid, cs);
+        pq_acc = fma(p[c0 + tid], cs, pq_acc);
+    }
+    // ---- the first nslice workgroups: q += (S~ W~) p_mu on their slice, and the partials of (S~ W~)^T p_r ----
+    double gpart[PCG_NW];
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) gpart[k] = 0.0;
+    const bool slice = COARSE && (int)blockIdx.x < nslice;
+    if (slice) {
+        const int per = (d + nslice - 1) / nslice;
+        const int e0 = min(d, (int)blockIdx.x * per), e1 = min(d, e0 + per);
+        const double* st = scal + PS_STATE + PS_STATE_LEN * out;
+        double pmu[PCG_NW];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) pmu[k] = st[PS_PMU + k];
+        for (int e = e0 + tid; e < e1; e += 256) {
+            const double pe = p[e];
+            double aw[PCG_NW];
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) aw[k] = AW[(size_t)e * PCG_NW + k];
+            const double a = dot8(aw, pmu);
+            atomicAdd(q + e, a);
+            pq_acc = fma(pe, a, pq_acc);
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) gpart[k] = fma(aw[k], pe, gpart[k]);
+        }
+    }
+    pq_acc = wave_allsum(pq_acc);
+    if (slice) {
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) gpart[k] = wave_allsum(gpart[k]);
+    }
+    if (lane == 0) {
+        red[PCG_NPART * w] = pq_acc;
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) red[PCG_NPART * w + 1 + k] = gpart[k];
+    }
+    __syncthreads();
+    if (tid == 0 || (slice && tid < PCG_NPART)) {
+        const double v = (red[tid] + red[PCG_NPART + tid]) + (red[2 * PCG_NPART + tid] + red[3 * PCG_NPART + tid]);
+        atomicAdd(sy_slot(part, out, tid, (int)(blockIdx.x % SY_SLOTS)), v);
+    }
 }
 
 // Fast path of one CG iteration for d <= 1280 (all BASELINE single-GPU configs): every global load of
@@ -1985,6 +2255,22 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
         // (with the coarse space the first launch is also the first iteration: MODE 2, see k_pcg_iter_fast)
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT ? 2 : 0, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
         else hipLaunchKernelGGL((k_pcg_iter_fast<INIT ? 1 : 0, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
+    } else if (r.sym) {
+        // two launches per iteration: the vector half, then one workgroup per tile of the upper triangle
+        const int nvec = std::max(1, std::min(SY_VEC_WG, (d + 63) / 64)), nslice = std::min(ws->sym_ntiles, 256);
+#define SYV_ARGS d, ld, ws->vec, ws->q3, bt, ws->sym_part, ws->scal, ws->flags, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->coarse
+#define SYV(C, E) hipLaunchKernelGGL((k_sy_vec<INIT, C, E>), dim3(nvec), dim3(256), 0, s, SYV_ARGS)
+        const int ept = INIT ? 0 : (d <= 256 * 8 ? 8 : d <= 256 * 16 ? 16 : d <= 256 * 24 ? 24 : d <= 256 * 32 ? 32 : 0);
+        if (r.coarse) { if (ept == 8) SYV(true, 8); else if (ept == 16) SYV(true, 16); else if (ept == 24) SYV(true, 24); else if (ept == 32) SYV(true, 32); else SYV(true, 0); }
+        else { if (ept == 8) SYV(false, 8); else if (ept == 16) SYV(false, 16); else if (ept == 24) SYV(false, 24); else if (ept == 32) SYV(false, 32); else SYV(false, 0); }
+#undef SYV
+#undef SYV_ARGS
+#define SY_ARGS(Fptr) d, ld, Fptr, ws->vec, ws->q3, ws->sym_part, ws->scal, ws->flags, ws->sym_tiles, in, nslice, ws->AW
+        if (r.f32) { if (r.coarse) hipLaunchKernelGGL((k_sy_prod<float, true>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull32));
+                     else hipLaunchKernelGGL((k_sy_prod<float, false>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull32)); }
+        else { if (r.coarse) hipLaunchKernelGGL((k_sy_prod<double, true>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull));
+               else hipLaunchKernelGGL((k_sy_prod<double, false>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull)); }
+#undef SY_ARGS
     } else if (r.f32) {
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter<INIT, float, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
         else hipLaunchKernelGGL((k_pcg_iter<INIT, float, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
@@ -2040,6 +2326,12 @@ static void pcg_geometry(const DenseSolver* ws, bool* fast, bool* f32) {
     *f32 = !*fast && ws->use_f32 && ws->Sfull32 != nullptr;
 }
 
+bool dense_pcg_symmetric_applicable(const DenseSolver* ws) {
+    bool fast, f32;
+    pcg_geometry(ws, &fast, &f32);
+    return !fast;
+}
+
 int dense_pcg_transform(hipStream_t s, DenseSolver* ws, double* S, double* rhs, int* info_dev, Profiler* prof) {
     if (dense_pcg_ensure_workspace(ws)) return -1;
     const int ld = ws->ld, d = ws->d;
@@ -2069,6 +2361,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     // ... its streaming-path form (d > 1280): classical PCG, three launches per iteration
     const bool sg = segments && coarse && !fast && dense_pcg_segments_streaming_applicable(ws) && ws->W && ws->sgV;
     if (sg) rows_per_wg = 8;
+    // symmetric streaming path: the caller's pair pass wrote (at least) the upper triangle; one read of it per iteration (k_pcg_iter_sym)
+    const bool sym = !fast && !sg && ws->symmetric && ws->sym_tiles != nullptr;
     const int nwg = (d + rows_per_wg - 1) / rows_per_wg;
     const size_t lds = sizeof(double) * (size_t)(ld + (ml ? ML_LDS_TAIL : sg ? 0 : PCG_RED));
     double* bt = ws->vec + (size_t)8 * ld;
@@ -2092,6 +2386,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       hipLaunchKernelGGL(k_sg_invert, dim3(1), dim3(SG_ITHREADS), 0, s, NC, ws->sgE, ws->sgEinv);
       }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
+      const int nwg = (d + rows_per_wg - 1) / rows_per_wg;       // (the set-up keeps the row geometry whatever the iteration kernel's grid)
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg, ws->vec + (size_t)(2 * 3 + 0) * ld);      // t -> the q buffer of parity 0 (pcg_vec)
       else if (f32) { if (rows_per_wg <= 8) hipLaunchKernelGGL((k_pcg_coarse<float, 2>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg);
                       else hipLaunchKernelGGL((k_pcg_coarse<float, CO_MAXROWS>), dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, bt, ws->AW, ws->epart, rows_per_wg); }
@@ -2102,6 +2397,8 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     volatile int* mb = ws->h_mailbox;
     if (mb) { mb[0] = -1; mb[1] = 0; }
     ws->run.nwg = nwg; ws->run.rows_per_wg = rows_per_wg; ws->run.lds = lds; ws->run.fast = fast; ws->run.f32 = f32; ws->run.coarse = coarse; ws->run.ml = ml; ws->run.sg = sg;
+    ws->run.sym = sym;
+
     ws->run.tol2 = tol * tol; ws->run.in = 1; ws->run.launched = 0; ws->run.max_iters = max_iters; ws->run.info = info_dev;
     { ProfScope ps(prof, KID_PCG_ITER, s);
       launch_cg_iteration<true>(s, ws, anchor, cap); }
@@ -2165,7 +2462,24 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
         if (ws_alloc(ws, &ws->W, sizeof(double) * (size_t)PCG_NW * ws->ld)) return -1;
         if (ws_alloc(ws, &ws->AW, sizeof(double) * (size_t)PCG_NW * ws->ld)) return -1;
         if (ws_alloc(ws, &ws->epart, sizeof(double) * (size_t)(PCG_NW * PCG_NW + 2 * PCG_NW) * PCG_PART)) return -1;
-        if (ws_alloc(ws, &ws->coarse, sizeof(double) * (size_t)(PCG_NW * PCG_NW + PCG_NW))) return -1;
+        if (ws_alloc(ws, &ws->coarse, sizeof(double) * (size_t)(2 * PCG_NW * PCG_NW + PCG_NW))) return -1;
+    }
+    {
+        bool fast, f32;
+        pcg_geometry(ws, &fast, &f32);
+        if (!fast && !ws->sym_tiles) {
+            // tiles of the scalar upper triangle for k_pcg_iter_sym: SY_R rows x SY_C columns, columns aligned to SY_C
+            std::vector<int4> tiles;
+            for (int r0 = 0; r0 < ws->d; r0 += SY_R) {
+                const int nrows = std::min(SY_R, ws->d - r0);
+                for (int c0 = (r0 / SY_C) * SY_C; c0 < ws->d; c0 += SY_C) tiles.push_back(make_int4(r0, c0, nrows, c0 < r0 + nrows ? 1 : 0));
+            }
+            if (ws_alloc(ws, &ws->q3, sizeof(double) * 2 * (size_t)ws->ld)) return -1;
+            if (ws_alloc(ws, &ws->sym_part, sizeof(double) * 2 * PCG_NPART * SY_SLOTS * SY_SLOT_STRIDE)) return -1;
+            if (ws_alloc(ws, &ws->sym_tiles, sizeof(int4) * tiles.size())) return -1;
+            if (hipMemcpy(ws->sym_tiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+            ws->sym_ntiles = (int)tiles.size();
+        }
     }
     if (!ws->mlAW && dense_pcg_segments_applicable(ws)) {
         const size_t nwg = (size_t)(ws->d - 1) / 6 + 1;
@@ -2229,6 +2543,9 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->AW) (void)hipFree(ws->AW);
         if (ws->epart) (void)hipFree(ws->epart);
         if (ws->coarse) (void)hipFree(ws->coarse);
+        if (ws->q3) (void)hipFree(ws->q3);
+        if (ws->sym_tiles) (void)hipFree(ws->sym_tiles);
+        if (ws->sym_part) (void)hipFree(ws->sym_part);
         for (double* q : { ws->mlAW, ws->mlV, ws->mlU, ws->mlE, ws->mlEinv, ws->mlC0, ws->mlState, ws->sgV, ws->sgE, ws->sgEinv, ws->sgT, ws->sgRR, ws->sgState }) if (q) (void)hipFree(q);
     }
     if (!ws->pinned_external) {

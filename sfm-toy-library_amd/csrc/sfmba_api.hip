@@ -404,6 +404,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     // (options.pcg_coarse_space: 0 = by structure, 1 = the eight global vectors only, 2 = the segments wherever they apply)
     const bool segments_cg = coarse_cg && (dense_pcg_segments_applicable(&p->solver) || dense_pcg_segments_streaming_applicable(&p->solver)) &&
                              option_switch(o.pcg_coarse_space == 2 ? 1 : o.pcg_coarse_space == 1 ? -1 : 0, "SFMBA_PCG_SEGMENTS", p->block_fill < 0.5 && p->block_band >= 0.9);
+    const bool symmetric_cg = option_switch(o.pcg_symmetric, "SFMBA_PCG_SYMMETRIC", true) && !p->deterministic &&
+                              !(segments_cg && dense_pcg_segments_streaming_applicable(&p->solver));
     const bool pcg_mode = o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256);
     // AUTO above 256 unknowns = the DENSE_SCHUR result through the CG: plain relative residual <= 1e-12, bounded iteration count,
     // Cholesky on the same linearisation if the CG does not get there (include/sfmba.h)
@@ -450,6 +452,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             // fp32 Jacobian mode + streaming CG path: the preconditioned matrix is stored in fp32 (halves the HBM-bound matvec)
             p->db.pcg_F32 = (p->precision == SFMBA_PRECISION_F32J && f32_matrix) ? dense_pcg_want_f32(&p->solver) : nullptr;
             p->solver.use_f32 = p->db.pcg_F32 != nullptr;
+            // the streaming CG on ONE triangle of S~ (dense_solver.hip "Symmetric streaming path"); its sums arrive through atomics: not for deterministic handles
+            p->solver.symmetric = symmetric_cg && dense_pcg_symmetric_applicable(&p->solver);
+            p->db.pcg_upper_only = 0;
         }
         if (!build_enqueued) {
             ProfScope ps(prof, KID_POINT_BUILD, p->stream);

@@ -33,7 +33,7 @@ class SfmbaOptions(C.Structure):
         ("pcg_anchored", C.c_int),
         # ABI v4: behaviour switches (0 = library default, 1 = on, -1 = off; the SFMBA_* environment variable overrides)
         ("pcg_coarse_space", C.c_int),
-        ("pcg_persistent", C.c_int),
+        ("pcg_symmetric", C.c_int),
         ("pcg_f32_matrix", C.c_int),
         ("early_linearise", C.c_int),
         ("shard_two_phase", C.c_int),

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sfmba_abi_version() == 5
+    assert L.sfmba_abi_version() == 6
 
 
 def test_default_options_match_reference_values(capi, sfm, oracle):

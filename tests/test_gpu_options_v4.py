@@ -92,13 +92,13 @@ def test_pcg_coarse_space_switch(capi, mid, mid_oracle):
 
 def test_the_environment_no_longer_overrides_a_solve(capi, mid, monkeypatch):
     """ABI v5: no getenv below sfmba_problem_create*.  The ABI v4 override variables are ignored by a solve -- the
-    fields of sfmba_options are the only way to a solver family -- and the reserved pcg_persistent field (the cooperative one-launch CG,
-    never a default at any size, is gone) changes nothing."""
+    fields of sfmba_options are the only way to a solver family -- and the slot that was pcg_persistent (the cooperative one-launch CG, never a
+    default at any size, is gone; ABI v6: pcg_symmetric, a switch of the streaming CG) changes nothing at this size."""
     base = dict(max_seconds=0.0, linear_solver=1, pcg_tolerance=1e-10, pcg_anchored=0)
     on = capi.solve(mid, capi.default_options(**base))
     for var in ("SFMBA_PCG_COARSE", "SFMBA_PCG_SEGMENTS", "SFMBA_PCG_GATED", "SFMBA_PCG_ANCHOR", "SFMBA_EARLY_LINEARISE", "SFMBA_PCG_PERSISTENT"):
         monkeypatch.setenv(var, "0")
-    env = capi.solve(mid, capi.default_options(pcg_persistent=1, **base))
+    env = capi.solve(mid, capi.default_options(pcg_symmetric=1, **base))
     assert env[3]["linear_iters"] == on[3]["linear_iters"] and env[3]["iterations"] == on[3]["iterations"]
     assert abs(env[3]["final_cost"] - on[3]["final_cost"]) <= 1e-12 * on[3]["final_cost"]
     off = capi.solve(mid, capi.default_options(pcg_coarse_space=-1, **base))
