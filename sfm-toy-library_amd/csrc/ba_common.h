@@ -159,7 +159,9 @@ __device__ __forceinline__ void store_block_entry(const DeviceStructure& ds, con
         return;
     }
     store_F(db, (size_t)(6 * cj.x + r) * ds.ld + 6 * cj.y + c, v);
+#ifndef SFMBA_WHATIF_UPPER_ONLY       // (timing what-if: the lower triangle never written -- wrong results where a kernel reads it)
     if (!db.pcg_upper_only) store_F(db, (size_t)(6 * cj.y + c) * ds.ld + 6 * cj.x + r, v);
+#endif
 }
 
 // after a linearisation: initial cost (iteration 0), gradient tolerance, evaluation failure.  One wave.

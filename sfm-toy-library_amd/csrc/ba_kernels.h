@@ -153,6 +153,8 @@ struct DeviceBuffers {
     double* pcg_F;            // [d][ld] preconditioned reduced matrix S~ written directly by k_schur_pairs (PCG mode)
     float* pcg_F32;           // the same in fp32 instead (streaming CG path, d > 1280: the matvec is HBM-bound); else null
     int pcg_upper_only;       // 1: the CG reads ONE triangle of S~ (dense_solver.hip, symmetric streaming path): store_block_entry writes the upper block only
+    double* pcg_zero;         // ... and its coarse set-up ADDS S~ W~ into this buffer (atomics): k_finalize(pcg = 1) zeroes pcg_zero_n doubles of it; else null
+    int pcg_zero_n;
     double* pcg_bt;           // [ld]    Lb^-1 rhs
     double* pcg_binv;         // [ncam*36 + 1] Linv of the diagonal blocks, written by k_finalize (PCG mode)
     double* pair_partial;     // [chunks of multi-chunk blocks][36] their partial sums (factored coordinates); rows: pwg_chunk[].x

@@ -1256,6 +1256,7 @@ __global__ __launch_bounds__(256) void k_finalize(DeviceStructure ds, DeviceBuff
     __shared__ int is_last;
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const LMState* st = db.st;
+    if (pcg && db.pcg_zero) { for (int i = gt; i < db.pcg_zero_n; i += gridDim.x * blockDim.x) db.pcg_zero[i] = 0.0; }      // (the symmetric CG's S~ W~ is accumulated with atomics)
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x >= 192) {
         // focal-focal entries were accumulated in the slotted buffer: the last wave of the last block owns them
         const int foc_acc[4] = { ACC_SFF, ACC_RHSF, ACC_UDF, ACC_BCF };

@@ -26,6 +26,8 @@ struct DenseSolver {
     double* q3 = nullptr;     // [2][ld] the products of the symmetric path by iteration parity (added into with atomics; zeroed by the vector kernel in front)
     double* sym_part = nullptr;   // [2][9][64 slots] its partial sums (p_r . q, (S~ W~)^T p_r), one 128-byte line per accumulator
     int4* sym_tiles = nullptr; int sym_ntiles = 0;   // its tiles of the upper triangle
+    int4* sym_ctiles = nullptr; int sym_nctiles = 0; // ... and the taller ones of its coarse set-up (k_sy_coarse)
+    double* AWt = nullptr;    // [8][ld] S~ W~ of the symmetric path, vector-major; added into with atomics: the caller's linearisation zeroes it
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][9][1024] per-workgroup partial sums of one iteration (p_r.q, W~^T q), by iteration parity
     // coarse space of the two-level preconditioner (dense_solver.hip): 8 gauge vectors in the transformed unknowns

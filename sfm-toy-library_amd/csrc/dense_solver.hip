@@ -731,10 +731,21 @@ __global__ __launch_bounds__(256) void k_sy_vec(int d, int ld, double* __restric
         double mine[3] = { 0.0, 0.0, 0.0 };
 #pragma unroll
         for (int j = 0; j < 3; ++j) { const int v = w + 4 * j; mine[j] = (4 * j < NV && v < NV) ? *sy_slot(part, in, v, lane) : 0.0; }
-        reduce_partials<NV>(mine, red);
-        __syncthreads();
+        // ... and every other load of the launch, before anything waits: r and q (whole), this thread's entry of the slice
+        double rv[EPT > 0 ? EPT : 1], qv[EPT > 0 ? EPT : 1];
+        if (EPT > 0) {
+#pragma unroll
+            for (int m = 0; m < EPT; ++m) { const int e = tid + 256 * m, ec = e < d ? e : d - 1; rv[m] = r_in[ec]; qv[m] = q_in[ec]; }
+        }
+        const int eo = row0 + tid;
+        const bool own = eo < row1;                      // (per <= 256: one entry per thread; longer slices loop below)
+        const int eoc = own ? eo : 0;
+        const double xo = x_in[eoc], po = p_in[eoc], ro = r_in[eoc], qo = q_in[eoc];
+        double wo[PCG_NW];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) wo[k] = COARSE ? W[(size_t)k * ld + eoc] : 0.0;
+        const double rz_in = st_in[PS_RZ], rr0 = scal[PS_RR0];
         double g[PCG_NW], Eg[PCG_NW], c_in[PCG_NW], mu_in[PCG_NW];
-        const double rz_in = st_in[PS_RZ];
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) {
             pmu_in[k] = COARSE ? st_in[PS_PMU + k] : 0.0;
@@ -742,6 +753,8 @@ __global__ __launch_bounds__(256) void k_sy_vec(int d, int ld, double* __restric
             mu_in[k] = COARSE ? st_in[PS_MU + k] : 0.0;
             Eg[k] = 0.0;
         }
+        reduce_partials<NV>(mine, red);
+        __syncthreads();
         // W~^T q = (S~ W~)^T p_r (the partials) + E p_mu
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) {
@@ -750,23 +763,30 @@ __global__ __launch_bounds__(256) void k_sy_vec(int d, int ld, double* __restric
             for (int j = 0; j < PCG_NW; ++j) erow[j] = COARSE ? red[144 + PCG_NW * k + j] : 0.0;
             g[k] = COARSE ? red[1 + k] + dot8(erow, pmu_in) : 0.0;
         }
-        if (COARSE) einv_apply(red + 80, g, Eg);
         const double pq = red[0] + (COARSE ? dot8(pmu_in, g) : 0.0);
-        const double alpha = rz_in / pq;
+        const double alpha = rz_in * fast_rcp(pq);
+        if (COARSE) einv_apply(red + 80, g, Eg);         // independent of alpha: overlaps the reciprocal
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) { c_new[k] = fma(-alpha, g[k], c_in[k]); mu_new[k] = fma(-alpha, Eg[k], mu_in[k]); }
         const double cmu = COARSE ? dot8(c_new, mu_new) : 0.0;
         double rrn = 0.0;
-        for (int e0 = tid; e0 < d; e0 += 256 * 8) {
-            double rv8[8], qv8[8];
+        if (EPT > 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u, ec = e < d ? e : d - 1; rv8[u] = r_in[ec]; qv8[u] = q_in[ec]; }
+            for (int m = 0; m < EPT; ++m) { const double v = fma(-alpha, qv[m], rv[m]); rrn = (tid + 256 * m < d) ? fma(v, v, rrn) : rrn; }
+        } else {
+            for (int e0 = tid; e0 < d; e0 += 256 * 8) {
+                double rv8[8], qv8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < d) { const double v = fma(-alpha, qv8[u], rv8[u]); rrn = fma(v, v, rrn); } }
+                for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u, ec = e < d ? e : d - 1; rv8[u] = r_in[ec]; qv8[u] = q_in[ec]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int e = e0 + 256 * u; if (e < d) { const double v = fma(-alpha, qv8[u], rv8[u]); rrn = fma(v, v, rrn); } }
+            }
         }
         rrn = wave_allsum(rrn);
         if (lane == 0) red[16 + w] = rrn;
-        for (int e = row0 + tid; e < row1; e += 256) {            // x += alpha p  with p = p_r + W~ p_mu, own slice
+        // x += alpha p  with p = p_r + W~ p_mu, own slice
+        if (own) x_out[eo] = xo + alpha * (po + (COARSE ? dot8(wo, pmu_in) : 0.0));
+        for (int e = eo + 256; e < row1; e += 256) {
             double pe = p_in[e];
             if (COARSE) {
 #pragma unroll
@@ -778,7 +798,7 @@ __global__ __launch_bounds__(256) void k_sy_vec(int d, int ld, double* __restric
         rrn = red[16] + red[17] + red[18] + red[19];
         rz_new = rrn + cmu;
         const bool broke = !(pq > 0.0) || !(rrn == rrn);
-        if (rrn <= tol2 * scal[PS_RR0] || broke) {
+        if (rrn <= tol2 * rr0 || broke) {
             if (blockIdx.x == 0 && tid == 0) {
                 flags[PF_DONE] = seq + 1; flags[PF_XBUF] = out; const int it = flags[PF_ITERS] + 1; flags[PF_ITERS] = it;
                 if (broke) atomicCAS(info, 0, d + 1);
@@ -786,10 +806,11 @@ __global__ __launch_bounds__(256) void k_sy_vec(int d, int ld, double* __restric
             }
             return;
         }
-        const double beta = rz_new / rz_in;
+        const double beta = rz_new * fast_rcp(rz_in);
 #pragma unroll
         for (int k = 0; k < PCG_NW; ++k) pmu_new[k] = fma(beta, pmu_in[k], mu_new[k]);
-        for (int e = row0 + tid; e < row1; e += 256) {
+        if (own) { const double rn = fma(-alpha, qo, ro); r_out[eo] = rn; p_out[eo] = fma(beta, po, rn); }
+        for (int e = eo + 256; e < row1; e += 256) {
             const double rn = fma(-alpha, q_in[e], r_in[e]);
             r_out[e] = rn;
             p_out[e] = fma(beta, p_in[e], rn);
@@ -875,7 +896,7 @@ __global__ __launch_bounds__(256) void k_sy_prod(int d, int ld, const FT* __rest
             const double pe = p[e];
             double aw[PCG_NW];
 #pragma unroll
-            for (int k = 0; k < PCG_NW; ++k) aw[k] = AW[(size_t)e * PCG_NW + k];
+            for (int k = 0; k < PCG_NW; ++k) aw[k] = AW[(size_t)k * ld + e];        // (AWt: vector-major)
             const double a = dot8(aw, pmu);
             atomicAdd(q + e, a);
             pq_acc = fma(pe, a, pq_acc);
@@ -898,6 +919,127 @@ __global__ __launch_bounds__(256) void k_sy_prod(int d, int ld, const FT* __rest
         const double v = (red[tid] + red[PCG_NPART + tid]) + (red[2 * PCG_NPART + tid] + red[3 * PCG_NPART + tid]);
         atomicAdd(sy_slot(part, out, tid, (int)(blockIdx.x % SY_SLOTS)), v);
     }
+}
+
+// The coarse set-up on the same triangle: AW = S~ W~ for the eight gauge vectors at once, every entry of the triangle used sixteen times from its
+// one load.  With eight vectors the atomics are what has to be budgeted (the memory side retires ~6 G line-sized atomic transactions per second,
+// see above): TALL tiles, SY_CR rows x SY_C columns -- the eight column sums of a lane's four columns stay in registers over the wave's 32 rows
+// and leave through LDS (ds_add_f64 across the four waves), the row sums of a wave's rows are parked in LDS until the tile is done -- so a tile
+// issues 8 x (256 + 128) atomics as 192 instructions on consecutive addresses (~115 k lines per pass at d = 6001).  The result is vector-major,
+// AWt[k][i] (consecutive lanes = consecutive entries), zeroed by the linearisation (k_finalize: DeviceBuffers::pcg_zero).
+#ifndef SFMBA_SY_CR
+#define SFMBA_SY_CR 128
+#endif
+constexpr int SY_CR = SFMBA_SY_CR;
+// (Measured and not kept, profiles/r06_ab_sy_coarse.txt: the batch specialised on the diagonal flag with the prefetch peeled -- four copies of the loop,
+// 86 spilled registers, 86 us --; W~ of the lane's columns held as floats with the widening kept opaque -- 18 spills, 58 us; this form, one spill: 51 us.
+// The pass is bound by its instruction count, ~1 800 per eight rows of 256 columns -- 512 fp64 FMAs, 330 v_readlane for W~ of the rows, ~300 for the
+// eight halving reductions, the masks -- at two waves per SIMD: the 72 MB stream at 1.4 TB/s.)
+template <typename FT>
+__global__ __launch_bounds__(256, 2) void k_sy_coarse(int d, int ld, const FT* __restrict__ F, const double* __restrict__ W, double* __restrict__ AWt,
+                                                      const int4* __restrict__ tiles) {
+    __shared__ double colsh[PCG_NW * SY_C];      // [k][column]
+    __shared__ double rowsh[PCG_NW * SY_CR];     // [k][row]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int4 tl = tiles[blockIdx.x];
+    const int r0 = tl.x, c0 = tl.y, rend = tl.x + tl.z;
+    const bool diag = tl.w != 0;
+    const int j0 = c0 + 4 * lane;
+    for (int i = tid; i < PCG_NW * SY_C; i += 256) colsh[i] = 0.0;
+    double wj[4][PCG_NW], colacc[4][PCG_NW];
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) {
+        const double2 a = reinterpret_cast<const double2*>(W + (size_t)k * ld + j0)[0], b = reinterpret_cast<const double2*>(W + (size_t)k * ld + j0)[1];
+        wj[0][k] = j0 + 0 < d ? a.x : 0.0; wj[1][k] = j0 + 1 < d ? a.y : 0.0; wj[2][k] = j0 + 2 < d ? b.x : 0.0; wj[3][k] = j0 + 3 < d ? b.y : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) colacc[e][k] = 0.0;
+    }
+    constexpr int RPWV = SY_CR / 4, NBATCH = RPWV / 8;
+    const int rw = r0 + RPWV * w;                     // this wave's rows, eight at a time
+    Quad<FT> f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int row = rw + u; f[u].load(F + (size_t)(row < rend ? row : r0) * ld + j0); }
+#pragma unroll 1
+    for (int b = 0; b < NBATCH; ++b) {
+        const int rb = rw + 8 * b;
+        // W~ of the batch's rows: lane l holds vector l % 8 of row l / 8; a row's eight values reach the FMAs as scalar operands (v_readlane)
+        const int wr = rb + (lane >> 3);
+        const double wrow = wr < rend ? W[(size_t)(lane & 7) * ld + wr] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = rb + u;
+            const bool live = row < rend;
+            double x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int j = j0 + e; x[e] = (!live || j >= d || (diag && j < row)) ? 0.0 : f[u].get(e); }
+            if (b < NBATCH - 1) { const int nrow = rb + 8 + u; f[u].load(F + (size_t)(nrow < rend ? nrow : r0) * ld + j0); }      // the next batch's load of this slot goes out at once
+            double sacc[PCG_NW];
+#pragma unroll
+            for (int k = 0; k < PCG_NW; ++k) {
+                const double wi = lane_bcast(wrow, 8 * u + k);
+                double sk = 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sk = fma(x[e], wj[e][k], sk);
+                    colacc[e][k] = fma((diag && j0 + e == row) ? 0.0 : x[e], wi, colacc[e][k]);       // the diagonal entry is used once
+                }
+                sacc[k] = sk;
+            }
+            const double tot = rows8_reduce(sacc, lane);          // lanes of group g: vector g of this row
+            if ((lane & 7) == 0) rowsh[(lane >> 3) * SY_CR + RPWV * w + 8 * b + u] = tot;
+        }
+    }
+    __syncthreads();                                  // colsh zeroed, rowsh complete
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&colsh[k * SY_C + 4 * lane + e], colacc[e][k]);
+    // the row sums: consecutive threads = consecutive rows of one vector
+#pragma unroll
+    for (int m = 0; m < PCG_NW * SY_CR / 256; ++m) {
+        const int v = tid + 256 * m, k = v / SY_CR, row = r0 + (v % SY_CR);
+        if (row < rend) atomicAdd(AWt + (size_t)k * ld + row, rowsh[v]);
+    }
+    __syncthreads();
+    if (c0 + tid < d) {
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) atomicAdd(AWt + (size_t)k * ld + c0 + tid, colsh[k * SY_C + tid]);
+    }
+}
+
+// E = W~^T (S~ W~) and c_0 = W~^T b~ from the finished AWt: partials per workgroup into epart (the layout k_pcg_coarse_invert sums)
+__global__ __launch_bounds__(256) void k_sy_e(int d, int ld, const double* __restrict__ W, const double* __restrict__ AWt, const double* __restrict__ bt,
+                                              double* __restrict__ epart) {
+    __shared__ double sh[4][PCG_NW * PCG_NW + PCG_NW];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = (d + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(d, i0 + per);
+    double e[PCG_NW][PCG_NW], c[PCG_NW];
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) { c[k] = 0.0;
+#pragma unroll
+        for (int l = 0; l < PCG_NW; ++l) e[k][l] = 0.0; }
+    for (int i = i0 + tid; i < i1; i += 256) {
+        double wv[PCG_NW], av[PCG_NW];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { wv[k] = W[(size_t)k * ld + i]; av[k] = AWt[(size_t)k * ld + i]; }
+        const double b = bt[i];
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { c[k] = fma(wv[k], b, c[k]);
+#pragma unroll
+            for (int l = 0; l < PCG_NW; ++l) e[k][l] = fma(wv[k], av[l], e[k][l]); }
+    }
+#pragma unroll
+    for (int k = 0; k < PCG_NW; ++k) { c[k] = wave_allsum(c[k]);
+#pragma unroll
+        for (int l = 0; l < PCG_NW; ++l) e[k][l] = wave_allsum(e[k][l]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < PCG_NW; ++k) { sh[w][PCG_NW * PCG_NW + k] = c[k];
+#pragma unroll
+            for (int l = 0; l < PCG_NW; ++l) sh[w][k * PCG_NW + l] = e[k][l]; }
+    }
+    __syncthreads();
+    if (tid < PCG_NW * PCG_NW + PCG_NW) epart[(size_t)tid * PCG_PART + blockIdx.x] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
 }
 
 // Fast path of one CG iteration for d <= 1280 (all BASELINE single-GPU configs): every global load of
@@ -2265,7 +2407,7 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
         else { if (ept == 8) SYV(false, 8); else if (ept == 16) SYV(false, 16); else if (ept == 24) SYV(false, 24); else if (ept == 32) SYV(false, 32); else SYV(false, 0); }
 #undef SYV
 #undef SYV_ARGS
-#define SY_ARGS(Fptr) d, ld, Fptr, ws->vec, ws->q3, ws->sym_part, ws->scal, ws->flags, ws->sym_tiles, in, nslice, ws->AW
+#define SY_ARGS(Fptr) d, ld, Fptr, ws->vec, ws->q3, ws->sym_part, ws->scal, ws->flags, ws->sym_tiles, in, nslice, ws->AWt
         if (r.f32) { if (r.coarse) hipLaunchKernelGGL((k_sy_prod<float, true>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull32));
                      else hipLaunchKernelGGL((k_sy_prod<float, false>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull32)); }
         else { if (r.coarse) hipLaunchKernelGGL((k_sy_prod<double, true>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull));
@@ -2385,6 +2527,12 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
       hipLaunchKernelGGL(k_sg_e, dim3(NC), dim3(3 * SG_NCP), 0, s, d, G, ws->sgV, ws->sgE);
       hipLaunchKernelGGL(k_sg_invert, dim3(1), dim3(SG_ITHREADS), 0, s, NC, ws->sgE, ws->sgEinv);
       }
+    else if (coarse && sym) { ProfScope ps(prof, KID_PCG_SETUP, s, 3);
+      // the set-up on the one triangle as well: AWt = S~ W~ (zeroed by the linearisation), then E and c_0 from it
+      if (f32) hipLaunchKernelGGL((k_sy_coarse<float>), dim3(ws->sym_nctiles), dim3(256), 0, s, d, ld, ws->Sfull32, ws->W, ws->AWt, ws->sym_ctiles);
+      else hipLaunchKernelGGL((k_sy_coarse<double>), dim3(ws->sym_nctiles), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, ws->AWt, ws->sym_ctiles);
+      hipLaunchKernelGGL(k_sy_e, dim3(SY_VEC_WG), dim3(256), 0, s, d, ld, ws->W, ws->AWt, bt, ws->epart);
+      hipLaunchKernelGGL(k_pcg_coarse_invert, dim3(1), dim3(256), 0, s, SY_VEC_WG, ws->epart, ws->coarse); }
     else if (coarse) { ProfScope ps(prof, KID_PCG_SETUP, s, fast ? 1 : 2);
       const int nwg = (d + rows_per_wg - 1) / rows_per_wg;       // (the set-up keeps the row geometry whatever the iteration kernel's grid)
       if (fast) hipLaunchKernelGGL(k_pcg_coarse_fast, dim3(nwg), dim3(256), 0, s, d, ld, ws->Sfull, ws->W, bt, ws->AW, ws->epart, rows_per_wg, ws->vec + (size_t)(2 * 3 + 0) * ld);      // t -> the q buffer of parity 0 (pcg_vec)
@@ -2476,6 +2624,16 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
             }
             if (ws_alloc(ws, &ws->q3, sizeof(double) * 2 * (size_t)ws->ld)) return -1;
             if (ws_alloc(ws, &ws->sym_part, sizeof(double) * 2 * PCG_NPART * SY_SLOTS * SY_SLOT_STRIDE)) return -1;
+            std::vector<int4> ctiles;
+            for (int r0 = 0; r0 < ws->d; r0 += SY_CR) {
+                const int nrows = std::min(SY_CR, ws->d - r0);
+                for (int c0 = (r0 / SY_C) * SY_C; c0 < ws->d; c0 += SY_C) ctiles.push_back(make_int4(r0, c0, nrows, c0 < r0 + nrows ? 1 : 0));
+            }
+            if (ws_alloc(ws, &ws->sym_ctiles, sizeof(int4) * ctiles.size())) return -1;
+            if (hipMemcpy(ws->sym_ctiles, ctiles.data(), sizeof(int4) * ctiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+            ws->sym_nctiles = (int)ctiles.size();
+            if (ws_alloc(ws, &ws->AWt, sizeof(double) * PCG_NW * (size_t)ws->ld)) return -1;
+            if (hipMemset(ws->AWt, 0, sizeof(double) * PCG_NW * (size_t)ws->ld) != hipSuccess) return -1;
             if (ws_alloc(ws, &ws->sym_tiles, sizeof(int4) * tiles.size())) return -1;
             if (hipMemcpy(ws->sym_tiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
             ws->sym_ntiles = (int)tiles.size();
@@ -2546,6 +2704,8 @@ void dense_solver_destroy(DenseSolver* ws) {
         if (ws->q3) (void)hipFree(ws->q3);
         if (ws->sym_tiles) (void)hipFree(ws->sym_tiles);
         if (ws->sym_part) (void)hipFree(ws->sym_part);
+        if (ws->sym_ctiles) (void)hipFree(ws->sym_ctiles);
+        if (ws->AWt) (void)hipFree(ws->AWt);
         for (double* q : { ws->mlAW, ws->mlV, ws->mlU, ws->mlE, ws->mlEinv, ws->mlC0, ws->mlState, ws->sgV, ws->sgE, ws->sgEinv, ws->sgT, ws->sgRR, ws->sgState }) if (q) (void)hipFree(q);
     }
     if (!ws->pinned_external) {

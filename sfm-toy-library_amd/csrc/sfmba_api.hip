@@ -454,7 +454,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             p->solver.use_f32 = p->db.pcg_F32 != nullptr;
             // the streaming CG on ONE triangle of S~ (dense_solver.hip "Symmetric streaming path"); its sums arrive through atomics: not for deterministic handles
             p->solver.symmetric = symmetric_cg && dense_pcg_symmetric_applicable(&p->solver);
-            p->db.pcg_upper_only = 0;
+            p->db.pcg_upper_only = p->solver.symmetric ? 1 : 0;      // ... and the pair pass then writes that triangle only
+            p->db.pcg_zero = p->solver.symmetric ? p->solver.AWt : nullptr;
+            p->db.pcg_zero_n = p->solver.symmetric ? 8 * p->ds.ld : 0;
         }
         if (!build_enqueued) {
             ProfScope ps(prof, KID_POINT_BUILD, p->stream);
@@ -1689,6 +1691,7 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     if (o.linear_solver == SFMBA_LINEAR_PCG || (o.linear_solver == SFMBA_LINEAR_AUTO && p->ds.d > 256)) {
         // fp32 Jacobian mode: the streaming CG path keeps the preconditioned matrix in fp32 (k_pcg_transform writes it)
         p->solver.use_f32 = p->precision == SFMBA_PRECISION_F32J && dense_pcg_want_f32(&p->solver) != nullptr;
+        p->solver.symmetric = false; p->db.pcg_upper_only = 0; p->db.pcg_zero = nullptr; p->db.pcg_zero_n = 0;      // (the step-wise sharded protocol keeps both triangles)
         // block factors and S~ from the all-reduced system, then the gauge vectors from those factors (two-level preconditioner)
         if (dense_pcg_transform(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, nullptr)) return fail(SFMBA_ERR_ALLOC, "PCG workspace allocation failed");
         const bool coarse_cg = option_switch(o.pcg_coarse_space, "SFMBA_PCG_COARSE", true);
@@ -1874,6 +1877,7 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
             p->db.pcg_W = coarse_cg ? p->solver.W : nullptr;
             float* F32 = (f32 && !implicit_cg) ? dense_pcg_want_f32(&p->solver) : nullptr;      // (implicit product: there is no matrix to store)
             p->solver.use_f32 = F32 != nullptr;
+            p->solver.symmetric = false; p->db.pcg_upper_only = 0; p->db.pcg_zero = nullptr; p->db.pcg_zero_n = 0;      // (sharded solves keep both triangles of the replicated matrix)
             // the streaming CG path stores S~ in fp32: with a single-precision all-reduce the partial blocks are exchanged in fp32 and
             // the sum is the CG's matrix (what the camera pass and the pair epilogue write directly -- diagonal blocks, focal column --
             // goes to the fp32 matrix as on one GPU); otherwise everything is summed in fp64 and narrowed after the sum

@@ -3,7 +3,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-Wno-unused-function",
+out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-Wno-unused-function", *__import__("os").environ.get("EXTRA","").split(),
                       "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src], capture_output=True, text=True).stderr
 cur = None
 rows = {}
