@@ -172,6 +172,21 @@ def solve(prob, opt=None, trace_cap=1024):
     return cam6, pt3, focal.value, summ.as_dict(), rows
 
 
+def solve_dense(problem, x0, opt=None, trace_cap=256):
+    """The oracle's trust-region loop on a small DENSE problem (sfmba_oracle_solve_dense; problem 0 = Powell's function of the Ceres tutorial,
+    solved through a dense QR step like the tutorial's DENSE_QR).  Returns (x, summary, trace rows)."""
+    x = _d(x0).copy()
+    opt = opt or SfmbaOptions.defaults()
+    summ = SfmbaSummary()
+    trace = (SfmbaIteration * trace_cap)()
+    tl = C.c_int(0)
+    rc = lib().sfmba_oracle_solve_dense(C.c_int(problem), C.c_int(len(x)), _p(x, C.POINTER(C.c_double)), C.byref(opt), C.byref(summ), trace,
+                                        C.c_int(trace_cap), C.byref(tl))
+    if rc != 0:
+        raise RuntimeError("sfmba_oracle_solve_dense rc=%d" % rc)
+    return x, summ.as_dict(), [trace[i].as_dict() for i in range(min(tl.value, trace_cap))]
+
+
 def adjust_bundle(poses, K, points, views, feats, opt=None):
     """Flat-array restatement of adjustBundle() (BA.cpp:99-222).
     poses [n_views,3,4] f32, K [3,3] f32, points [n_pts,3] f32, views: list of dict{view: featIdx}

@@ -22,10 +22,15 @@
  * [1e-6,1e32], radius update, tolerance tests) and SchurEliminator + dense LLT.
  *
  * PARITY STATUS: the projection model is pinned by the reference's own known-answer
- * fixture (SfMUnitTests.cpp:153-189, tests/test_oracle_kat.py).  The SOLVER result is
- * "parity unpinned": the reference stores no expected cost / pose for adjustBundle and
- * cannot be built here; the LM loop is cross-checked against scipy.optimize.least_squares
- * and KKT conditions instead (tests/test_oracle_solver.py).
+ * fixture (SfMUnitTests.cpp:153-189, tests/test_oracle_kat.py).  The SOLVER result on a bundle
+ * adjustment is "parity unpinned": the reference stores no expected cost / pose for adjustBundle
+ * and cannot be built here.  What IS pinned since round 6 is the LM / trust-region CONTROL FLOW:
+ * lm_trust_region() below is one function that runs both the bundle adjustment and Powell's
+ * function, and on the latter it reproduces the minimizer output Ceres itself published in its
+ * tutorial to every printed digit (14 rows x 6 numbers, the final cost and x, the gradient of the
+ * termination message: tests/golden/ceres_powell_trace.json, tests/test_oracle_kat.py).  The
+ * Schur elimination underneath is cross-checked against scipy.optimize.least_squares, the KKT
+ * conditions and the full normal equations (tests/test_oracle_solver.py).
  */
 #include <math.h>
 #include <float.h>
@@ -799,54 +804,34 @@ static void trace_push(sfmba_iteration* trace, int cap, int* len, const sfmba_it
     if (len) (*len)++;
 }
 
-ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3,
-                                  int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
-                                  double* focal, const sfmba_options* opt_in, sfmba_summary* summary,
-                                  sfmba_iteration* trace, int trace_cap, int* trace_len) {
-    sfmba_options opt;
-    if (opt_in) opt = *opt_in; else sfmba_oracle_options_default(&opt);
-    sfmba_summary sum;
-    memset(&sum, 0, sizeof(sum));
-    int tl = 0;
-    const double t_start = wall_seconds();
+/* ------------------------------------------------------------------------------------------
+ * The trust-region loop itself, on a generic (evaluate, solve) pair -- round 6: the SAME loop runs the bundle adjustment below and
+ * the dense test problems of sfmba_oracle_solve_dense (Powell's function from the Ceres tutorial, whose per-iteration output Ceres
+ * itself published: tests/golden/ceres_powell_trace.json).  Everything that is LM / trust-region CONTROL FLOW lives here --
+ * IterationZero, Jacobi scaling computed once at x_0, the clamped diagonal re-used after an unsuccessful step, invalid-step handling,
+ * parameter tolerance -> function tolerance -> IsStepSuccessful, the radius update of LevenbergMarquardtStrategy::StepAccepted /
+ * StepRejected / StepIsInvalid, gradient tolerance, minimum radius, the iteration and time limits [Ceres-upstream
+ * TrustRegionMinimizer::Minimize, LevenbergMarquardtStrategy]; a model supplies the arithmetic on its own storage.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    void* ctx;
+    double (*x_norm)(void* ctx);                             /* |x| at the current point */
+    int    (*linearise)(void* ctx, double* cost);            /* residuals + UNSCALED Jacobian at the current point; 1 = evaluation failed */
+    double (*gradient_max)(void* ctx, int with_col_norms);   /* max |J^T r| of the unscaled Jacobian just evaluated; with_col_norms: also keep its squared column norms */
+    void   (*jacobi_scale_init)(void* ctx, int enabled);     /* s = 1 / (1 + sqrt(column norm^2)) from the norms kept above (or 1) */
+    void   (*apply_scale)(void* ctx);                        /* J <- J diag(s) */
+    void   (*lm_diagonal)(void* ctx, double lo, double hi);  /* diag <- clamp(diag(J~^T J~), lo, hi) */
+    int    (*solve)(void* ctx, double radius);               /* (J~^T J~ + diag / radius) y = J~^T r; 1 = failed or non-finite */
+    double (*model_cost_change)(void* ctx);                  /* -(J~ step)^T (r + J~ step / 2), step = -y */
+    double (*candidate)(void* ctx, double* cand_cost);       /* x_n = x + step * s; returns |x - x_n|; cost at x_n (DBL_MAX if the evaluation fails) */
+    void   (*accept)(void* ctx);                             /* x <- x_n */
+} lm_model;
 
-    ba_structure s;
-    if (ba_structure_init(&s, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy)) {
-        ba_structure_free(&s);
-        sum.termination = SFMBA_FAILURE;
-        snprintf(sum.message, sizeof(sum.message), "invalid observation indices");
-        if (summary) *summary = sum;
-        if (trace_len) *trace_len = 0;
-        return SFMBA_ERR_INVALID_ARG;
-    }
-    if (n_obs == 0) {
-        /* Ceres: nothing to optimise -> CONVERGENCE without touching parameters. */
-        sum.termination = SFMBA_CONVERGENCE;
-        snprintf(sum.message, sizeof(sum.message), "Function tolerance reached. No non-constant parameter blocks found.");
-        if (summary) *summary = sum;
-        if (trace_len) *trace_len = 0;
-        ba_structure_free(&s);
-        return SFMBA_OK;
-    }
-    const int nc = 6 * s.n_acam, np = 3 * s.n_apt;
-    ba_params x = { (double*)malloc(sizeof(double) * (size_t)nc), (double*)malloc(sizeof(double) * (size_t)np), *focal };
-    ba_params xn = { (double*)malloc(sizeof(double) * (size_t)nc), (double*)malloc(sizeof(double) * (size_t)np), 0.0 };
-    for (int j = 0; j < s.n_acam; ++j) memcpy(x.cam + 6 * j, cam6 + 6 * (size_t)s.acam_id[j], 6 * sizeof(double));
-    for (int i = 0; i < s.n_apt; ++i) memcpy(x.pt + 3 * i, pt3 + 3 * (size_t)s.apt_id[i], 3 * sizeof(double));
-    ba_lin lin = { (double*)malloc(sizeof(double) * 2 * (size_t)n_obs), (double*)malloc(sizeof(double) * 12 * (size_t)n_obs),
-                   (double*)malloc(sizeof(double) * 6 * (size_t)n_obs), (double*)malloc(sizeof(double) * 2 * (size_t)n_obs) };
-    double* scam = (double*)malloc(sizeof(double) * (size_t)nc);
-    double* spt = (double*)malloc(sizeof(double) * (size_t)np);
-    double* gcam = (double*)malloc(sizeof(double) * (size_t)nc);
-    double* gpt = (double*)malloc(sizeof(double) * (size_t)np);
-    double* diagc = (double*)malloc(sizeof(double) * (size_t)nc);
-    double* diagp = (double*)malloc(sizeof(double) * (size_t)np);
-    double* dcam = (double*)malloc(sizeof(double) * (size_t)nc);
-    double* dpt = (double*)malloc(sizeof(double) * (size_t)np);
-    double* ycam = (double*)malloc(sizeof(double) * (size_t)nc);
-    double* ypt = (double*)malloc(sizeof(double) * (size_t)np);
-    double sfocal = 1.0, gfocal = 0.0, diagf = 0.0, yfocal = 0.0;
-
+static void lm_trust_region(const lm_model* m, const sfmba_options* optp, sfmba_summary* sump, double* cost_out,
+                            sfmba_iteration* trace, int trace_cap, int* tlp, double t_start) {
+    const sfmba_options opt = *optp;
+    sfmba_summary sum = *sump;
+    int tl = *tlp;
     double cost = 0.0;
     double radius = opt.initial_radius;
     double decrease_factor = 2.0;
@@ -856,27 +841,18 @@ ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3
     memset(&it, 0, sizeof(it));
 
     /* ---- iteration 0: IterationZero() ---- */
-    double x_norm = params_norm(&s, &x);
-    if (eval_lin(&s, &x, &lin, &cost)) {
+    double x_norm = m->x_norm(m->ctx);
+    if (m->linearise(m->ctx, &cost)) {
         sum.termination = SFMBA_FAILURE;
         snprintf(sum.message, sizeof(sum.message), "Initial residual and Jacobian evaluation failed.");
         goto done;
     }
     sum.jacobian_evals = 1;
     sum.initial_cost = cost;
-    accumulate_columns(&s, &lin, gcam, &gfocal, gpt, scam, &sfocal, spt);
-    if (opt.jacobi_scaling) {
-        for (int e = 0; e < nc; ++e) scam[e] = 1.0 / (1.0 + sqrt(scam[e]));
-        for (int e = 0; e < np; ++e) spt[e] = 1.0 / (1.0 + sqrt(spt[e]));
-        sfocal = 1.0 / (1.0 + sqrt(sfocal));
-    } else {
-        for (int e = 0; e < nc; ++e) scam[e] = 1.0;
-        for (int e = 0; e < np; ++e) spt[e] = 1.0;
-        sfocal = 1.0;
-    }
-    scale_columns(&s, &lin, scam, sfocal, spt);
+    it.gradient_max_norm = m->gradient_max(m->ctx, 1);
+    m->jacobi_scale_init(m->ctx, opt.jacobi_scaling);
+    m->apply_scale(m->ctx);
     it.iteration = 0; it.cost = cost; it.trust_region_radius = radius;
-    it.gradient_max_norm = fmax(fmax(max_abs(gcam, nc), max_abs(gpt, np)), fabs(gfocal));
     trace_push(trace, trace_cap, &tl, &it);
     if (opt.verbose) fprintf(stderr, "[oracle] it %3d cost %.12e |g|inf %.3e radius %.3e\n", 0, cost, it.gradient_max_norm, radius);
     if (it.gradient_max_norm <= opt.gradient_tolerance) {
@@ -903,42 +879,14 @@ ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3
         sum.iterations = it.iteration;
 
         /* LevenbergMarquardtStrategy::ComputeStep */
-        if (!reuse_diagonal) {
-            accumulate_columns(&s, &lin, NULL, NULL, NULL, diagc, &diagf, diagp);
-            for (int e = 0; e < nc; ++e) diagc[e] = fmin(fmax(diagc[e], opt.min_lm_diagonal), opt.max_lm_diagonal);
-            for (int e = 0; e < np; ++e) diagp[e] = fmin(fmax(diagp[e], opt.min_lm_diagonal), opt.max_lm_diagonal);
-            diagf = fmin(fmax(diagf, opt.min_lm_diagonal), opt.max_lm_diagonal);
-        }
-        for (int e = 0; e < nc; ++e) dcam[e] = diagc[e] / radius;
-        for (int e = 0; e < np; ++e) dpt[e] = diagp[e] / radius;
-        const double dfocal = diagf / radius;
-        int lin_fail = schur_solve(&s, &lin, dcam, dfocal, dpt, ycam, &yfocal, ypt, NULL, NULL, 1);
-        if (!lin_fail) {
-            int ok = isfinite(yfocal);
-            for (int e = 0; e < nc && ok; ++e) ok = isfinite(ycam[e]);
-            for (int e = 0; e < np && ok; ++e) ok = isfinite(ypt[e]);
-            lin_fail = !ok;
-        }
+        if (!reuse_diagonal) m->lm_diagonal(m->ctx, opt.min_lm_diagonal, opt.max_lm_diagonal);
+        const int lin_fail = m->solve(m->ctx, radius);
         reuse_diagonal = 1;
 
         double model_cost_change = 0.0;
         int step_valid = 0;
         if (!lin_fail) {
-            /* step = -y ; model_cost_change = -(J step)^T (r + J step / 2) */
-            double m = 0.0;
-#pragma omp parallel for reduction(+ : m) schedule(static)
-            for (int64_t k = 0; k < n_obs; ++k) {
-                const int j = s.cam_slot[obs_cam[k]];
-                const int i = s.pt_slot[obs_pt[k]];
-                const double* A = lin.jc + 12 * k;
-                const double* B = lin.jp + 6 * k;
-                const double* G = lin.jf + 2 * k;
-                double u0 = -G[0] * yfocal, u1 = -G[1] * yfocal;
-                for (int a = 0; a < 6; ++a) { u0 -= A[a] * ycam[6 * j + a]; u1 -= A[6 + a] * ycam[6 * j + a]; }
-                for (int a = 0; a < 3; ++a) { u0 -= B[a] * ypt[3 * i + a]; u1 -= B[3 + a] * ypt[3 * i + a]; }
-                m -= u0 * (lin.r[2 * k] + 0.5 * u0) + u1 * (lin.r[2 * k + 1] + 0.5 * u1);
-            }
-            model_cost_change = m;
+            model_cost_change = m->model_cost_change(m->ctx);
             step_valid = model_cost_change > 0.0;
         }
         it.step_is_valid = step_valid;
@@ -963,16 +911,11 @@ ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3
         consecutive_invalid = 0;
 
         /* candidate x + delta, delta = step * scale (undo Jacobi scaling) */
-        double step_norm2 = 0.0;
-        for (int e = 0; e < nc; ++e) { const double dlt = -ycam[e] * scam[e]; xn.cam[e] = x.cam[e] + dlt; const double df = x.cam[e] - xn.cam[e]; step_norm2 += df * df; }
-        for (int e = 0; e < np; ++e) { const double dlt = -ypt[e] * spt[e]; xn.pt[e] = x.pt[e] + dlt; const double df = x.pt[e] - xn.pt[e]; step_norm2 += df * df; }
-        { const double dlt = -yfocal * sfocal; xn.focal = x.focal + dlt; const double df = x.focal - xn.focal; step_norm2 += df * df; }
         double cand_cost;
-        if (eval_cost(&s, &xn, &cand_cost)) cand_cost = DBL_MAX;
+        it.step_norm = m->candidate(m->ctx, &cand_cost);
         sum.residual_evals++;
 
         /* ParameterToleranceReached() */
-        it.step_norm = sqrt(step_norm2);
         const double step_size_tolerance = opt.parameter_tolerance * (x_norm + opt.parameter_tolerance);
         if (it.step_norm <= step_size_tolerance) {
             sum.termination = SFMBA_CONVERGENCE;
@@ -998,9 +941,7 @@ ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3
         if (ftol_hit) {
             /* variant 1 ("step first"): the terminating iteration's candidate is taken if it is a successful step, then the exit */
             if (it.step_is_successful) {
-                memcpy(x.cam, xn.cam, sizeof(double) * (size_t)nc);
-                memcpy(x.pt, xn.pt, sizeof(double) * (size_t)np);
-                x.focal = xn.focal;
+                m->accept(m->ctx);
                 cost = cand_cost;
                 sum.successful_steps++;
             }
@@ -1013,19 +954,16 @@ ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3
 
         if (it.step_is_successful) {
             /* HandleSuccessfulStep() */
-            memcpy(x.cam, xn.cam, sizeof(double) * (size_t)nc);
-            memcpy(x.pt, xn.pt, sizeof(double) * (size_t)np);
-            x.focal = xn.focal;
-            x_norm = params_norm(&s, &x);
-            if (eval_lin(&s, &x, &lin, &cost)) {
+            m->accept(m->ctx);
+            x_norm = m->x_norm(m->ctx);
+            if (m->linearise(m->ctx, &cost)) {
                 sum.termination = SFMBA_FAILURE;
                 snprintf(sum.message, sizeof(sum.message), "Residual and Jacobian evaluation failed.");
                 break;
             }
             sum.jacobian_evals++;
-            accumulate_columns(&s, &lin, gcam, &gfocal, gpt, NULL, NULL, NULL);
-            scale_columns(&s, &lin, scam, sfocal, spt);
-            it.gradient_max_norm = fmax(fmax(max_abs(gcam, nc), max_abs(gpt, np)), fabs(gfocal));
+            it.gradient_max_norm = m->gradient_max(m->ctx, 0);
+            m->apply_scale(m->ctx);
             /* StepAccepted */
             radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * it.relative_decrease - 1.0, 3));
             radius = fmin(opt.max_radius, radius);
@@ -1059,20 +997,305 @@ ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3
             break;
         }
     }
-
 done:
+    *cost_out = cost;
+    *sump = sum;
+    *tlp = tl;
+}
+
+/* ---- the bundle-adjustment model of that loop: SchurEliminator + dense LLT on the storage of ba_structure / ba_lin ---- */
+typedef struct {
+    const ba_structure* s;
+    ba_params x, xn;
+    ba_lin lin;
+    double *scam, *spt, *gcam, *gpt, *diagc, *diagp, *dcam, *dpt, *ycam, *ypt;
+    double sfocal, gfocal, diagf, yfocal;
+} ba_model;
+
+static double bam_x_norm(void* c) { ba_model* b = (ba_model*)c; return params_norm(b->s, &b->x); }
+static int bam_linearise(void* c, double* cost) { ba_model* b = (ba_model*)c; return eval_lin(b->s, &b->x, &b->lin, cost); }
+static double bam_gradient_max(void* c, int with_col_norms) {
+    ba_model* b = (ba_model*)c;
+    const int nc = 6 * b->s->n_acam, np = 3 * b->s->n_apt;
+    if (with_col_norms) accumulate_columns(b->s, &b->lin, b->gcam, &b->gfocal, b->gpt, b->scam, &b->sfocal, b->spt);
+    else accumulate_columns(b->s, &b->lin, b->gcam, &b->gfocal, b->gpt, NULL, NULL, NULL);
+    return fmax(fmax(max_abs(b->gcam, nc), max_abs(b->gpt, np)), fabs(b->gfocal));
+}
+static void bam_jacobi_scale_init(void* c, int enabled) {
+    ba_model* b = (ba_model*)c;
+    const int nc = 6 * b->s->n_acam, np = 3 * b->s->n_apt;
+    if (enabled) {
+        for (int e = 0; e < nc; ++e) b->scam[e] = 1.0 / (1.0 + sqrt(b->scam[e]));
+        for (int e = 0; e < np; ++e) b->spt[e] = 1.0 / (1.0 + sqrt(b->spt[e]));
+        b->sfocal = 1.0 / (1.0 + sqrt(b->sfocal));
+    } else {
+        for (int e = 0; e < nc; ++e) b->scam[e] = 1.0;
+        for (int e = 0; e < np; ++e) b->spt[e] = 1.0;
+        b->sfocal = 1.0;
+    }
+}
+static void bam_apply_scale(void* c) { ba_model* b = (ba_model*)c; scale_columns(b->s, &b->lin, b->scam, b->sfocal, b->spt); }
+static void bam_lm_diagonal(void* c, double lo, double hi) {
+    ba_model* b = (ba_model*)c;
+    const int nc = 6 * b->s->n_acam, np = 3 * b->s->n_apt;
+    accumulate_columns(b->s, &b->lin, NULL, NULL, NULL, b->diagc, &b->diagf, b->diagp);
+    for (int e = 0; e < nc; ++e) b->diagc[e] = fmin(fmax(b->diagc[e], lo), hi);
+    for (int e = 0; e < np; ++e) b->diagp[e] = fmin(fmax(b->diagp[e], lo), hi);
+    b->diagf = fmin(fmax(b->diagf, lo), hi);
+}
+static int bam_solve(void* c, double radius) {
+    ba_model* b = (ba_model*)c;
+    const int nc = 6 * b->s->n_acam, np = 3 * b->s->n_apt;
+    for (int e = 0; e < nc; ++e) b->dcam[e] = b->diagc[e] / radius;
+    for (int e = 0; e < np; ++e) b->dpt[e] = b->diagp[e] / radius;
+    const double dfocal = b->diagf / radius;
+    int lin_fail = schur_solve(b->s, &b->lin, b->dcam, dfocal, b->dpt, b->ycam, &b->yfocal, b->ypt, NULL, NULL, 1);
+    if (!lin_fail) {
+        int ok = isfinite(b->yfocal);
+        for (int e = 0; e < nc && ok; ++e) ok = isfinite(b->ycam[e]);
+        for (int e = 0; e < np && ok; ++e) ok = isfinite(b->ypt[e]);
+        lin_fail = !ok;
+    }
+    return lin_fail;
+}
+static double bam_model_cost_change(void* c) {
+    ba_model* b = (ba_model*)c;
+    const ba_structure* s = b->s;
+    const ba_lin lin = b->lin;
+    const double* ycam = b->ycam; const double* ypt = b->ypt; const double yfocal = b->yfocal;
+    /* step = -y ; model_cost_change = -(J step)^T (r + J step / 2) */
+    double m = 0.0;
+#pragma omp parallel for reduction(+ : m) schedule(static)
+    for (int64_t k = 0; k < s->n_obs; ++k) {
+        const int j = s->cam_slot[s->obs_cam[k]];
+        const int i = s->pt_slot[s->obs_pt[k]];
+        const double* A = lin.jc + 12 * k;
+        const double* B = lin.jp + 6 * k;
+        const double* G = lin.jf + 2 * k;
+        double u0 = -G[0] * yfocal, u1 = -G[1] * yfocal;
+        for (int a = 0; a < 6; ++a) { u0 -= A[a] * ycam[6 * j + a]; u1 -= A[6 + a] * ycam[6 * j + a]; }
+        for (int a = 0; a < 3; ++a) { u0 -= B[a] * ypt[3 * i + a]; u1 -= B[3 + a] * ypt[3 * i + a]; }
+        m -= u0 * (lin.r[2 * k] + 0.5 * u0) + u1 * (lin.r[2 * k + 1] + 0.5 * u1);
+    }
+    return m;
+}
+static double bam_candidate(void* c, double* cand_cost) {
+    ba_model* b = (ba_model*)c;
+    const int nc = 6 * b->s->n_acam, np = 3 * b->s->n_apt;
+    ba_params x = b->x, xn = b->xn;
+    double step_norm2 = 0.0;
+    for (int e = 0; e < nc; ++e) { const double dlt = -b->ycam[e] * b->scam[e]; xn.cam[e] = x.cam[e] + dlt; const double df = x.cam[e] - xn.cam[e]; step_norm2 += df * df; }
+    for (int e = 0; e < np; ++e) { const double dlt = -b->ypt[e] * b->spt[e]; xn.pt[e] = x.pt[e] + dlt; const double df = x.pt[e] - xn.pt[e]; step_norm2 += df * df; }
+    { const double dlt = -b->yfocal * b->sfocal; xn.focal = x.focal + dlt; const double df = x.focal - xn.focal; step_norm2 += df * df; }
+    b->xn.focal = xn.focal;
+    if (eval_cost(b->s, &b->xn, cand_cost)) *cand_cost = DBL_MAX;
+    return sqrt(step_norm2);
+}
+static void bam_accept(void* c) {
+    ba_model* b = (ba_model*)c;
+    const int nc = 6 * b->s->n_acam, np = 3 * b->s->n_apt;
+    memcpy(b->x.cam, b->xn.cam, sizeof(double) * (size_t)nc);
+    memcpy(b->x.pt, b->xn.pt, sizeof(double) * (size_t)np);
+    b->x.focal = b->xn.focal;
+}
+
+ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3,
+                                  int64_t n_obs, const int32_t* obs_cam, const int32_t* obs_pt, const double* obs_xy,
+                                  double* focal, const sfmba_options* opt_in, sfmba_summary* summary,
+                                  sfmba_iteration* trace, int trace_cap, int* trace_len) {
+    sfmba_options opt;
+    if (opt_in) opt = *opt_in; else sfmba_oracle_options_default(&opt);
+    sfmba_summary sum;
+    memset(&sum, 0, sizeof(sum));
+    int tl = 0;
+    const double t_start = wall_seconds();
+
+    ba_structure s;
+    if (ba_structure_init(&s, n_cam, n_pt, n_obs, obs_cam, obs_pt, obs_xy)) {
+        ba_structure_free(&s);
+        sum.termination = SFMBA_FAILURE;
+        snprintf(sum.message, sizeof(sum.message), "invalid observation indices");
+        if (summary) *summary = sum;
+        if (trace_len) *trace_len = 0;
+        return SFMBA_ERR_INVALID_ARG;
+    }
+    if (n_obs == 0) {
+        /* Ceres: nothing to optimise -> CONVERGENCE without touching parameters. */
+        sum.termination = SFMBA_CONVERGENCE;
+        snprintf(sum.message, sizeof(sum.message), "Function tolerance reached. No non-constant parameter blocks found.");
+        if (summary) *summary = sum;
+        if (trace_len) *trace_len = 0;
+        ba_structure_free(&s);
+        return SFMBA_OK;
+    }
+    const int nc = 6 * s.n_acam, np = 3 * s.n_apt;
+    ba_model b;
+    memset(&b, 0, sizeof(b));
+    b.s = &s;
+    b.x.cam = (double*)malloc(sizeof(double) * (size_t)nc); b.x.pt = (double*)malloc(sizeof(double) * (size_t)np); b.x.focal = *focal;
+    b.xn.cam = (double*)malloc(sizeof(double) * (size_t)nc); b.xn.pt = (double*)malloc(sizeof(double) * (size_t)np); b.xn.focal = 0.0;
+    for (int j = 0; j < s.n_acam; ++j) memcpy(b.x.cam + 6 * j, cam6 + 6 * (size_t)s.acam_id[j], 6 * sizeof(double));
+    for (int i = 0; i < s.n_apt; ++i) memcpy(b.x.pt + 3 * i, pt3 + 3 * (size_t)s.apt_id[i], 3 * sizeof(double));
+    b.lin.r = (double*)malloc(sizeof(double) * 2 * (size_t)n_obs); b.lin.jc = (double*)malloc(sizeof(double) * 12 * (size_t)n_obs);
+    b.lin.jp = (double*)malloc(sizeof(double) * 6 * (size_t)n_obs); b.lin.jf = (double*)malloc(sizeof(double) * 2 * (size_t)n_obs);
+    b.scam = (double*)malloc(sizeof(double) * (size_t)nc); b.spt = (double*)malloc(sizeof(double) * (size_t)np);
+    b.gcam = (double*)malloc(sizeof(double) * (size_t)nc); b.gpt = (double*)malloc(sizeof(double) * (size_t)np);
+    b.diagc = (double*)malloc(sizeof(double) * (size_t)nc); b.diagp = (double*)malloc(sizeof(double) * (size_t)np);
+    b.dcam = (double*)malloc(sizeof(double) * (size_t)nc); b.dpt = (double*)malloc(sizeof(double) * (size_t)np);
+    b.ycam = (double*)malloc(sizeof(double) * (size_t)nc); b.ypt = (double*)malloc(sizeof(double) * (size_t)np);
+    b.sfocal = 1.0;
+
+    const lm_model model = { &b, bam_x_norm, bam_linearise, bam_gradient_max, bam_jacobi_scale_init, bam_apply_scale, bam_lm_diagonal, bam_solve,
+                             bam_model_cost_change, bam_candidate, bam_accept };
+    double cost = 0.0;
+    lm_trust_region(&model, &opt, &sum, &cost, trace, trace_cap, &tl, t_start);
+
     sum.final_cost = cost;
     sum.seconds = wall_seconds() - t_start;
     /* parameters are updated whatever the termination type, as ceres::Solve does */
-    for (int j = 0; j < s.n_acam; ++j) memcpy(cam6 + 6 * (size_t)s.acam_id[j], x.cam + 6 * j, 6 * sizeof(double));
-    for (int i = 0; i < s.n_apt; ++i) memcpy(pt3 + 3 * (size_t)s.apt_id[i], x.pt + 3 * i, 3 * sizeof(double));
-    *focal = x.focal;
+    for (int j = 0; j < s.n_acam; ++j) memcpy(cam6 + 6 * (size_t)s.acam_id[j], b.x.cam + 6 * j, 6 * sizeof(double));
+    for (int i = 0; i < s.n_apt; ++i) memcpy(pt3 + 3 * (size_t)s.apt_id[i], b.x.pt + 3 * i, 3 * sizeof(double));
+    *focal = b.x.focal;
     if (summary) *summary = sum;
     if (trace_len) *trace_len = tl;
-    free(x.cam); free(x.pt); free(xn.cam); free(xn.pt);
-    free(lin.r); free(lin.jc); free(lin.jp); free(lin.jf);
-    free(scam); free(spt); free(gcam); free(gpt); free(diagc); free(diagp); free(dcam); free(dpt); free(ycam); free(ypt);
+    free(b.x.cam); free(b.x.pt); free(b.xn.cam); free(b.xn.pt);
+    free(b.lin.r); free(b.lin.jc); free(b.lin.jp); free(b.lin.jf);
+    free(b.scam); free(b.spt); free(b.gcam); free(b.gpt); free(b.diagc); free(b.diagp); free(b.dcam); free(b.dpt); free(b.ycam); free(b.ypt);
     ba_structure_free(&s);
+    return SFMBA_OK;
+}
+
+/* ---- a DENSE model of the same loop: m residuals of n parameters with a caller-supplied evaluator; the LM step by Householder QR of the
+ * stacked [J~; sqrt(D)] (DENSE_QR [Ceres-upstream]: the solver the Ceres tutorial runs Powell's function with).  This is how the loop above is
+ * anchored to output Ceres itself published.  problem: 0 = Powell's function (examples/powell.cc [Ceres-upstream], four residuals of four
+ * parameters: f1 = x1 + 10 x2, f2 = sqrt(5) (x3 - x4), f3 = (x2 - 2 x3)^2, f4 = sqrt(10) (x1 - x4)^2). ---- */
+enum { DENSE_MAX_N = 8, DENSE_MAX_M = 8 };
+typedef struct {
+    int problem, n, m;
+    double x[DENSE_MAX_N], xn[DENSE_MAX_N], y[DENSE_MAX_N], s[DENSE_MAX_N], g[DENSE_MAX_N], diag[DENSE_MAX_N], colsq[DENSE_MAX_N];
+    double r[DENSE_MAX_M], J[DENSE_MAX_M][DENSE_MAX_N];
+} dense_model;
+
+static int dense_eval(int problem, const double* x, double* r, double (*J)[DENSE_MAX_N]) {
+    if (problem == 0) {
+        const double s5 = sqrt(5.0), s10 = sqrt(10.0);
+        r[0] = x[0] + 10.0 * x[1];
+        r[1] = s5 * (x[2] - x[3]);
+        r[2] = (x[1] - 2.0 * x[2]) * (x[1] - 2.0 * x[2]);
+        r[3] = s10 * (x[0] - x[3]) * (x[0] - x[3]);
+        if (J) {
+            memset(J, 0, sizeof(double) * DENSE_MAX_M * DENSE_MAX_N);
+            J[0][0] = 1.0; J[0][1] = 10.0;
+            J[1][2] = s5; J[1][3] = -s5;
+            J[2][1] = 2.0 * (x[1] - 2.0 * x[2]); J[2][2] = -4.0 * (x[1] - 2.0 * x[2]);
+            J[3][0] = 2.0 * s10 * (x[0] - x[3]); J[3][3] = -2.0 * s10 * (x[0] - x[3]);
+        }
+        return 0;
+    }
+    return 1;
+}
+static double dm_x_norm(void* c) { dense_model* d = (dense_model*)c; double n = 0.0; for (int e = 0; e < d->n; ++e) n += d->x[e] * d->x[e]; return sqrt(n); }
+static int dm_linearise(void* c, double* cost) {
+    dense_model* d = (dense_model*)c;
+    if (dense_eval(d->problem, d->x, d->r, d->J)) return 1;
+    double cc = 0.0; int bad = 0;
+    for (int k = 0; k < d->m; ++k) { cc += d->r[k] * d->r[k]; bad |= !isfinite(d->r[k]); for (int e = 0; e < d->n; ++e) bad |= !isfinite(d->J[k][e]); }
+    *cost = 0.5 * cc;
+    return bad;
+}
+static double dm_gradient_max(void* c, int with_col_norms) {
+    dense_model* d = (dense_model*)c;
+    for (int e = 0; e < d->n; ++e) {
+        double g = 0.0, q = 0.0;
+        for (int k = 0; k < d->m; ++k) { g += d->J[k][e] * d->r[k]; q += d->J[k][e] * d->J[k][e]; }
+        d->g[e] = g;
+        if (with_col_norms) d->colsq[e] = q;
+    }
+    return max_abs(d->g, d->n);
+}
+static void dm_jacobi_scale_init(void* c, int enabled) { dense_model* d = (dense_model*)c; for (int e = 0; e < d->n; ++e) d->s[e] = enabled ? 1.0 / (1.0 + sqrt(d->colsq[e])) : 1.0; }
+static void dm_apply_scale(void* c) { dense_model* d = (dense_model*)c; for (int k = 0; k < d->m; ++k) for (int e = 0; e < d->n; ++e) d->J[k][e] *= d->s[e]; }
+static void dm_lm_diagonal(void* c, double lo, double hi) {
+    dense_model* d = (dense_model*)c;
+    for (int e = 0; e < d->n; ++e) { double q = 0.0; for (int k = 0; k < d->m; ++k) q += d->J[k][e] * d->J[k][e]; d->diag[e] = fmin(fmax(q, lo), hi); }
+}
+/* min |J~ y - r|^2 + |sqrt(diag / radius) y|^2 by Householder QR of the (m + n) x n stacked matrix */
+static int dm_solve(void* c, double radius) {
+    dense_model* d = (dense_model*)c;
+    const int n = d->n, rows = d->m + d->n;
+    double A[DENSE_MAX_M + DENSE_MAX_N][DENSE_MAX_N], b[DENSE_MAX_M + DENSE_MAX_N];
+    for (int k = 0; k < d->m; ++k) { for (int e = 0; e < n; ++e) A[k][e] = d->J[k][e]; b[k] = d->r[k]; }
+    for (int e = 0; e < n; ++e) { for (int f = 0; f < n; ++f) A[d->m + e][f] = 0.0; A[d->m + e][e] = sqrt(d->diag[e] / radius); b[d->m + e] = 0.0; }
+    for (int col = 0; col < n; ++col) {
+        double nrm = 0.0;
+        for (int k = col; k < rows; ++k) nrm += A[k][col] * A[k][col];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0)) return 1;
+        const double alpha = A[col][col] > 0.0 ? -nrm : nrm;
+        double v[DENSE_MAX_M + DENSE_MAX_N], vtv = 0.0;
+        for (int k = col; k < rows; ++k) { v[k] = A[k][col]; }
+        v[col] -= alpha;
+        for (int k = col; k < rows; ++k) vtv += v[k] * v[k];
+        if (!(vtv > 0.0)) continue;
+        for (int f = col; f < n; ++f) {
+            double dot = 0.0;
+            for (int k = col; k < rows; ++k) dot += v[k] * A[k][f];
+            const double t = 2.0 * dot / vtv;
+            for (int k = col; k < rows; ++k) A[k][f] -= t * v[k];
+        }
+        double dot = 0.0;
+        for (int k = col; k < rows; ++k) dot += v[k] * b[k];
+        const double t = 2.0 * dot / vtv;
+        for (int k = col; k < rows; ++k) b[k] -= t * v[k];
+    }
+    for (int e = n - 1; e >= 0; --e) {
+        double v = b[e];
+        for (int f = e + 1; f < n; ++f) v -= A[e][f] * d->y[f];
+        d->y[e] = v / A[e][e];
+        if (!isfinite(d->y[e])) return 1;
+    }
+    return 0;
+}
+static double dm_model_cost_change(void* c) {
+    dense_model* d = (dense_model*)c;
+    double mc = 0.0;
+    for (int k = 0; k < d->m; ++k) { double u = 0.0; for (int e = 0; e < d->n; ++e) u -= d->J[k][e] * d->y[e]; mc -= u * (d->r[k] + 0.5 * u); }
+    return mc;
+}
+static double dm_candidate(void* c, double* cand_cost) {
+    dense_model* d = (dense_model*)c;
+    double sn = 0.0, r[DENSE_MAX_M] = { 0.0 }, cc = 0.0;
+    for (int e = 0; e < d->n; ++e) { const double dlt = -d->y[e] * d->s[e]; d->xn[e] = d->x[e] + dlt; const double df = d->x[e] - d->xn[e]; sn += df * df; }
+    int bad = dense_eval(d->problem, d->xn, r, NULL);
+    for (int k = 0; k < d->m; ++k) { cc += r[k] * r[k]; bad |= !isfinite(r[k]); }
+    *cand_cost = bad ? DBL_MAX : 0.5 * cc;
+    return sqrt(sn);
+}
+static void dm_accept(void* c) { dense_model* d = (dense_model*)c; memcpy(d->x, d->xn, sizeof(double) * (size_t)d->n); }
+
+/* x [n] in-out.  The options are the solver's (the reference's: BA.cpp:171-177 + Ceres defaults); the linear solver field is ignored (dense QR). */
+ORACLE_API int sfmba_oracle_solve_dense(int problem, int n, double* x, const sfmba_options* opt_in, sfmba_summary* summary,
+                                        sfmba_iteration* trace, int trace_cap, int* trace_len) {
+    if (problem != 0 || n != 4 || !x) return SFMBA_ERR_INVALID_ARG;
+    sfmba_options opt;
+    if (opt_in) opt = *opt_in; else sfmba_oracle_options_default(&opt);
+    sfmba_summary sum;
+    memset(&sum, 0, sizeof(sum));
+    int tl = 0;
+    const double t_start = wall_seconds();
+    dense_model d;
+    memset(&d, 0, sizeof(d));
+    d.problem = problem; d.n = 4; d.m = 4;
+    memcpy(d.x, x, sizeof(double) * 4);
+    const lm_model model = { &d, dm_x_norm, dm_linearise, dm_gradient_max, dm_jacobi_scale_init, dm_apply_scale, dm_lm_diagonal, dm_solve,
+                             dm_model_cost_change, dm_candidate, dm_accept };
+    double cost = 0.0;
+    lm_trust_region(&model, &opt, &sum, &cost, trace, trace_cap, &tl, t_start);
+    sum.final_cost = cost;
+    sum.seconds = wall_seconds() - t_start;
+    memcpy(x, d.x, sizeof(double) * 4);
+    if (summary) *summary = sum;
+    if (trace_len) *trace_len = tl;
     return SFMBA_OK;
 }
 
