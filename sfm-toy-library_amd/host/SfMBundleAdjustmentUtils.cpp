@@ -153,7 +153,14 @@ public:
         for (unsigned spin = 0; pending_.load(std::memory_order_acquire) != 0; ++spin) {
             if (spin < 20000) { __builtin_ia32_pause(); continue; }
             std::unique_lock<std::mutex> lk(mu_);
+#if defined(__SANITIZE_THREAD__)
+            // (make tsan: gcc 11's libtsan does not intercept pthread_cond_clockwait -- what wait_for compiles to -- and then believes mu_ is still held:
+            // every later lock is reported as a double lock / lock-order inversion.  The untimed wait is equivalent here: the task that takes pending_ to
+            // zero notifies done_ under mu_, and the predicate is tested under mu_.)
+            done_.wait(lk, [&] { return pending_.load() == 0; });
+#else
             done_.wait_for(lk, std::chrono::microseconds(200), [&] { return pending_.load() == 0; });
+#endif
         }
         run_mu_.unlock();
     }
