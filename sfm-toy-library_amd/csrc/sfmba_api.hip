@@ -131,6 +131,34 @@ constexpr double auto_cg_tol() { return 1e-12; }
 // name given here override the field; since ABI v5 nothing below sfmba_problem_create* reads the environment: the name documents the switch.)
 bool option_switch(int field, const char* /*name*/, bool dflt) { return field > 0 ? true : field < 0 ? false : dflt; }
 
+// ---- roctx ranges around the phases of an LM iteration: `rocprofv3 --marker-trace` then shows linearise / reduce / solve / update
+// per iteration on the host timeline next to the kernels they enqueue.  Bound at run time like RCCL (no link-time dependency); switched on when a
+// problem is BUILT with SFMBA_ROCTX=1 in the environment (nothing below sfmba_problem_create* reads the environment). ----
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const RoctxApi* roctx_api() {
+    static RoctxApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" }) {
+            if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                api.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                api.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (api.push && api.pop) break;
+                api.push = nullptr; api.pop = nullptr;
+            }
+        }
+    });
+    return api.push ? &api : nullptr;
+}
+struct RoctxRange {
+    const RoctxApi* a;
+    RoctxRange(bool on, const char* name) : a(on ? roctx_api() : nullptr) { if (a) a->push(name); }
+    void end() { if (a) { a->pop(); a = nullptr; } }
+    ~RoctxRange() { end(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 __global__ void k_fill(double* p, size_t n, double v) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) p[e] = v;
@@ -218,6 +246,7 @@ struct sfmba_problem {
     unsigned* d_blk_mask = nullptr;       // per camera: cameras with a non-empty block in common (block-sparse CG product)
     int* d_cam_chunk_ptr = nullptr;
     bool deterministic = false;             // SFMBA_DETERMINISTIC=1 at build time
+    bool roctx = false;                     // SFMBA_ROCTX=1 at build time: roctx ranges around the phases of an LM iteration
     bool cam_identity = false, pt_identity = false;   // slot == caller index for every camera / point (arrays copied as they are)
     bool reset_pending = false;             // sfmba_problem_reset() was called: the initial parameters are restored by the next solve's first kernel
                                             // (or by flush_reset() if anything else looks at the problem first)
@@ -458,6 +487,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             p->db.pcg_zero = p->solver.symmetric ? p->solver.AWt : nullptr;
             p->db.pcg_zero_n = p->solver.symmetric ? 8 * p->ds.ld : 0;
         }
+        RoctxRange rx_iter(p->roctx, "sfmba LM iteration");
+        {
+        RoctxRange rx(p->roctx, "linearise: point_build + cam_diag");
         if (!build_enqueued) {
             ProfScope ps(prof, KID_POINT_BUILD, p->stream);
             launch_point_build<T>(p->stream, p->ds, p->db, first_linearisation ? (o.jacobi_scaling ? 1 : 2) : 0);
@@ -466,6 +498,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         first_linearisation = false;
         { ProfScope ps(prof, KID_CAM_DIAG, p->stream); launch_cam_diag<T>(p->stream, p->ds, p->db); }
         launch_schur_pairs<T>(p->stream, p->ds, p->db, 2);      // duplicate pairs inside diagonal blocks (usually none)
+        }
+        RoctxRange rx_reduce(p->roctx, "reduce: finalize + schur_pairs (reduced camera system)");
         if (pcg) {
             // the preconditioner (Linv of the damped diagonal blocks) is known before the pair pass, which then writes the
             // preconditioned matrix directly
@@ -475,9 +509,11 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             { ProfScope ps(prof, KID_SCHUR_PAIRS, p->stream); launch_schur_pairs<T>(p->stream, p->ds, p->db, 0); }
             { ProfScope ps(prof, KID_FINALIZE, p->stream); launch_finalize(p->stream, p->ds, p->db, 0); }
         }
+        rx_reduce.end();
         DeviceBuffers dbu = p->db;
         if (sizeof(T) == 4) dbu.pu32 = p->d_pu32;       // F32J: the back-substitution's first sweep gathers fp32 camera records (ba_kernels.hip, k_cam_update / k_point_update)
         bool pcg_gated = false;
+        RoctxRange rx_solve(p->roctx, pcg ? "solve: two-level CG on the reduced system" : "solve: Cholesky of the reduced system");
         if (pcg) {
             const int anchor = anchored_cg ? (first_linear_solve ? 1 : 2) : 0;
             first_linear_solve = false;
@@ -498,6 +534,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, prof);
             lin_hist.push_back(0);
         }
+        rx_solve.end();
+        RoctxRange rx_update(p->roctx, "update: cam_update + point_update + lm_control (and the wait for its verdict)");
         bool lm_done = false;
         while (!lm_done) {
             { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
@@ -1228,6 +1266,7 @@ static int create_impl(int device, int precision, int flags, int n_cam, const do
     p->sharded = cam_active != nullptr || p->row_sharded;
     // create flag, or the environment override (kept across appends: the structure is rebuilt in the same mode)
     { const char* e = std::getenv("SFMBA_DETERMINISTIC"); p->deterministic = e ? e[0] == '1' : (flags & SFMBA_CREATE_DETERMINISTIC) != 0; }
+    { const char* e = std::getenv("SFMBA_ROCTX"); p->roctx = e && e[0] == '1'; }
     struct Guard { sfmba_problem* p; ~Guard() { if (p) sfmba_problem_destroy(p); } } guard{ p };
 
     // active (observed) cameras / points -> slots, ascending caller index
