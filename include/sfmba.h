@@ -90,6 +90,18 @@ enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
                                        path: 0.03 .. 0.07, with 99.9 % of the points within 2e-3).  Use F64 if such points'
                                        coordinates matter beyond that. */
 
+/* The F32J ERROR BUDGET (round 6): what SFMBA_PRECISION_F32J may cost against the library's fp64 mode under the same solver, in the units of the caller.
+ * tests/test_gpu_f32j_budget.py measures every line on nine problem shapes, two solvers and two other scene scales (|t| ~ 1e3 and ~ 5e-2) and FAILS beyond
+ * it: a faster fp32 kernel that moves a result past one of these numbers is a regression, not a tolerance to widen (rounds 4 - 5 loosened three tests to
+ * make room for speed; this is where that stops).  scale = max(1, max |t|) of the solution: the budget does not depend on the units of the scene. */
+/*                                             budget     measured, round 6 (profiles/r06_c_f32j_budget.txt: the worst of 22 runs)                          */
+#define SFMBA_F32J_BUDGET_COST_REL     1e-8    /* 4.8e-10  final cost, relative (north_star asks 1e-6 at BASELINE config 2) */
+#define SFMBA_F32J_BUDGET_RMS_PX       1e-6    /* 1.0e-10  final RMS reprojection error, px (north_star asks 1e-4) */
+#define SFMBA_F32J_BUDGET_ROTATION     2e-5    /* 5.5e-6   angle-axis components of a camera, rad; LM iterations and termination type: identical */
+#define SFMBA_F32J_BUDGET_TRANSLATION  1e-5    /* 1.6e-6   camera translation / scale */
+#define SFMBA_F32J_BUDGET_FOCAL_REL    1e-6    /* 3.0e-9   the shared focal, relative */
+#define SFMBA_F32J_BUDGET_POINT_P999   2e-5    /* 1.5e-6   99.9th percentile of the point displacement / scale (the weakly constrained tracks above are the rest) */
+
 /* Return codes of every entry point. */
 enum {
     SFMBA_OK              = 0,
@@ -224,6 +236,11 @@ SFMBA_API int         sfmba_device_count(void);
  * reference's call pattern -- adjustBundle() re-creating the problem after every added view, SfM.cpp:464-466 -- performs
  * no hipMalloc/hipFree in steady state.  This returns the cached memory to HIP; the number of bytes released. */
 SFMBA_API long long   sfmba_release_cache(void);
+/* ABI v6.  What the FIRST call of a process pays once -- the HIP context, the first pinned allocation, the first device chunks: 138 ms at BASELINE
+ * config 3 against 2.6 - 3 ms for every later adjustBundle() -- can be paid at start-up instead: creates the context on `device`, one stream + pinned
+ * block and device chunks for a problem of about `expected_obs` observations (0: the fixed-size pieces only) and leaves them in the cache the first
+ * sfmba_problem_create* draws from.  Optional and idempotent; rc as everywhere (SFMBA_ERR_NO_DEVICE without a GPU). */
+SFMBA_API int         sfmba_device_warmup(int device, int64_t expected_obs);
 
 /*
  * One-shot solve == the ceres::Problem build + ceres::Solve of BA.cpp:109-179.

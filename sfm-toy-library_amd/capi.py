@@ -33,7 +33,7 @@ SYMBOLS = [
     "sfmba_comm_unique_id", "sfmba_comm_create", "sfmba_comm_destroy", "sfmba_comm_allreduce", "sfmba_problem_solve_sharded",
     "sfmba_comm_allreduce_f32", "sfmba_problem_set_allreduce_f32", "sfmba_shard_last_exchange",
     "sfmba_problem_create_ex", "sfmba_comm_abort", "sfmba_comm_reduce_scatter", "sfmba_problem_set_reduce_scatter",
-    "sfmba_comm_allgather", "sfmba_problem_set_allgather", "sfmba_comm_size",
+    "sfmba_comm_allgather", "sfmba_problem_set_allgather", "sfmba_comm_size", "sfmba_device_warmup",
 ]
 
 
@@ -198,6 +198,11 @@ def _p(a, t):
 
 def device_count():
     return int(lib().sfmba_device_count())
+
+
+def device_warmup(device=0, expected_obs=0):
+    """sfmba_device_warmup: pay the process-wide first-call costs (HIP context, pinned pool, device chunks) now."""
+    _check(lib().sfmba_device_warmup(C.c_int(device), C.c_int64(expected_obs)))
 
 
 def default_options(**overrides):

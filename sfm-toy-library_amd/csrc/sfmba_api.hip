@@ -679,6 +679,36 @@ int sfmba_device_count(void) {
     return n;
 }
 
+namespace { __global__ void k_warm(int* p) { if (p && threadIdx.x == 0) *p = 1; } }
+
+// What the first call of a process pays once (measured at BASELINE config 3, profiles/r05_b_shim_incremental.txt: 138 ms of which 113 in
+// sfmba_problem_create -- the HIP context, the first pinned allocation, the first device chunks -- against 2.6 - 3 ms for every later adjustBundle()):
+// a host can pay it at start-up instead.  Creates the context, one stream + pinned block (cached for the first problem), a pinned upload buffer and
+// device chunks for a problem of `expected_obs` observations (0: contexts and the fixed-size pieces only), launches one kernel.  Idempotent.
+int sfmba_device_warmup(int device, int64_t expected_obs) {
+    if (expected_obs < 0) return fail(SFMBA_ERR_INVALID_ARG, "negative size");
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));
+    HostKit kit;
+    if (!hostkit_acquire(device, &kit)) return fail(SFMBA_ERR_HIP, "stream / pinned memory creation failed");
+    struct KitGuard { HostKit* k; ~KitGuard() { if (k->stream) (void)hipStreamSynchronize(k->stream); hostkit_release(*k); } } kg{ &kit };
+    if (expected_obs > 0) (void)hostkit_upload(&kit, std::min((size_t)HOSTKIT_UPLOAD_MAX, (size_t)expected_obs * 24));      // (camera, point, xy as doubles: the packed upload of a build)
+    {
+        DeviceArena arena(device);
+        // a resident problem holds ~150 bytes per observation in structure, tables and sort temporaries (18 + 20 + 12 + 18 MB ... at one million: DESIGN.md section 3)
+        const size_t want = (size_t)(4 << 20) + (size_t)expected_obs * 160;
+        int* flag = static_cast<int*>(arena.alloc(want));
+        if (!flag) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+        hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, kit.stream, flag);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(kit.stream));
+        arena.release();          // -> the chunk cache the first problem draws from
+    }
+    return SFMBA_OK;
+}
+
 void sfmba_problem_destroy(sfmba_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);

@@ -64,6 +64,8 @@ def test_no_cpu_fallback_without_device(capi, sfm):
         capi.solve(prob)
     with pytest.raises(capi.SfmbaError, match="no HIP device"):
         capi.dense_spd_solve(np.eye(3), np.ones(3))
+    with pytest.raises(capi.SfmbaError, match="no HIP device"):
+        capi.device_warmup(0, 1000)
 
 
 def test_product_never_imports_the_oracle():

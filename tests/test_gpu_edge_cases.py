@@ -75,3 +75,19 @@ def test_points_nobody_observes_and_cameras_without_observations(capi, sfm, orac
         assert abs(s["final_cost"] - s_o["final_cost"]) <= 1e-9 * s_o["final_cost"]
         tol = 1e-7 if flags == 0 else 2e-5
         assert np.abs(cam[:-1] - cam_o).max() < tol and np.abs(pt[:-2] - pt_o).max() < tol
+
+
+def test_device_warmup_is_idempotent_and_changes_no_result(sfm):
+    """sfmba_device_warmup (ABI v6): the first-call costs of a process (HIP context, pinned pool, device chunks) paid up front; a solve afterwards gives
+    what it gives without it; bad arguments are refused."""
+    from sfm_toy_library_amd import capi
+    prob = sfm.make_problem("small")
+    ref = capi.solve(prob, capi.default_options(max_seconds=0.0))
+    for n in (0, 100000, 100000):
+        capi.device_warmup(0, n)
+    got = capi.solve(prob, capi.default_options(max_seconds=0.0))
+    assert got[3]["iterations"] == ref[3]["iterations"] and got[3]["final_cost"] == ref[3]["final_cost"]
+    with pytest.raises(capi.SfmbaError):
+        capi.device_warmup(0, -1)
+    with pytest.raises(capi.SfmbaError):
+        capi.device_warmup(capi.device_count() + 3, 0)

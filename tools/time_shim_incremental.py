@@ -5,7 +5,15 @@ import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sfm_toy_library_amd as sfm
-prob = sfm.make_problem(sys.argv[1] if len(sys.argv) > 1 else "cfg3")
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+prob = sfm.make_problem(args[0] if args else "cfg3")
+if "--warmup" in sys.argv:
+    # sfmba_device_warmup (include/sfmba.h): the process-wide first-call costs paid before the first adjustBundle()
+    # (through the C ABI directly, as a C++ host would: capi.lib() would import torch first)
+    hip = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sfm-toy-library_amd", "csrc", "libsfmba_hip.so"), mode=C.RTLD_GLOBAL)
+    t0 = time.perf_counter()
+    rc = hip.sfmba_device_warmup(C.c_int(0), C.c_int64(prob.n_obs))
+    print("sfmba_device_warmup(0, %d): rc %d, %.1f ms" % (prob.n_obs, rc, 1e3 * (time.perf_counter() - t0)), flush=True)
 os.environ["SFMBA_SHIM_TIMING"] = "1"
 os.environ.setdefault("SFMBA_MAX_SECONDS", "0")
 os.environ.setdefault("SFMBA_PRECISION", "f32j")
