@@ -173,27 +173,31 @@ typedef struct sfmba_options {
 } sfmba_options;
 
 /* Flags of sfmba_problem_create_ex (ABI v4; were environment variables read at create time). */
-enum { SFMBA_CREATE_DETERMINISTIC = 1,
-       SFMBA_CREATE_NO_PAIR_LIST = 4,     /* ABI v5: do not build the list of observation pairs (4 bytes per pair of observations of one point: O(sum of squared
+enum { SFMBA_CREATE_DETERMINISTIC = 1,    /* (SFMBA_DETERMINISTIC=1 in the environment forces it on) every workgroup owns its accumulator slot and multi-chunk
+                                             sums are added in a fixed order, so results do not depend on the order fp64 atomics arrive in (bitwise reproducible
+                                             run to run; ~30 % slower).  Sharded problems included (ABI v4), and the forms that apply the reduced matrix
+                                             implicitly (shard_distributed_cg = 2, SFMBA_CREATE_NO_PAIR_LIST): the per-camera sums of a CG product are then
+                                             written per chunk and added in chunk order (implicit_schur.hip).  The symmetric streaming CG (pcg_symmetric, ABI v6:
+                                             its products arrive through atomics) is not used on such a handle. */
+       SFMBA_CREATE_ROW_SHARDED = 2,      /* ABI v5, sfmba_problem_create_ex only: EVERY rank passes the WHOLE problem (all observations) with its rank / world;
+                                             cam_active may be NULL.  The rank owns the points of a contiguous range of point slots (ceil(n / world) each), a
+                                             contiguous share of the camera-major list and a balanced range of block rows of the reduced matrix
+                                             (sfmba_options.shard_distributed_cg = 3).  Solved with sfmba_problem_solve_sharded (needs sfmba_problem_set_allgather
+                                             when world > 1); always through the CG (SFMBA_LINEAR_CHOLESKY is treated as SFMBA_LINEAR_AUTO: CG to 1e-12).  After
+                                             a solve every rank holds ALL parameters (the final points are all-gathered): sfmba_problem_get_params returns the
+                                             whole solution on every rank. */
+       SFMBA_CREATE_NO_PAIR_LIST = 4 };   /* ABI v5: do not build the list of observation pairs (4 bytes per pair of observations of one point: O(sum of squared
                                              track lengths) memory, and 2^31 pairs at most) and never form the reduced camera matrix: sfmba_problem_solve then runs the
                                              two-level CG with the matrix applied IMPLICITLY from the observations -- per CG iteration two passes over them, memory
                                              O(observations) whatever the track lengths.  A problem with 2^31 or more pairs (100 cameras that all see 440 000 points:
                                              the reference adds a residual block per (view, point) with no bound on the track length, BA.cpp:142-166) takes this path
                                              by itself -- no problem the reference's solver accepts is refused for its size.  Every linear_solver setting is served by
                                              that CG: SFMBA_LINEAR_PCG at pcg_tolerance, SFMBA_LINEAR_AUTO / _CHOLESKY at a relative residual of 1e-12 (the DENSE_SCHUR
-                                             result to ~1e-10, not bit for bit); max_seconds is not applied; sfmba_problem_build_reduced and sfmba_problem_append are
-                                             refused.  Slower than the formed matrix wherever that fits (~8x per CG iteration at BASELINE config 5). */
-       SFMBA_CREATE_ROW_SHARDED = 2 };    /* ABI v5, sfmba_problem_create_ex only: EVERY rank passes the WHOLE problem (all observations) with its rank / world;
-                                             cam_active may be NULL.  The rank owns the points of a contiguous range of point slots (ceil(n / world) each), a
-                                             contiguous share of the camera-major list and a balanced range of block rows of the reduced matrix
-                                             (sfmba_options.shard_distributed_cg = 3).  Solved with sfmba_problem_solve_sharded (needs sfmba_problem_set_allgather
-                                             when world > 1); always through the CG (SFMBA_LINEAR_CHOLESKY is treated as SFMBA_LINEAR_AUTO: CG to 1e-12).  After
-                                             a solve every rank holds ALL parameters (the final points are all-gathered): sfmba_problem_get_params returns the
-                                             whole solution on every rank. */  /* SFMBA_DETERMINISTIC=1 forces it on: every workgroup owns its accumulator slot and multi-chunk
-                                             sums are added in a fixed order, so results do not depend on the order fp64 atomics arrive in
-                                             (bitwise reproducible run to run; ~30 % slower).  Sharded problems included (ABI v4), and the forms that apply the
-                                             reduced matrix implicitly (shard_distributed_cg = 2, SFMBA_CREATE_NO_PAIR_LIST): the per-camera sums of a CG product
-                                             are then written per chunk and added in chunk order (implicit_schur.hip). */
+                                             result to ~1e-10, not bit for bit); max_seconds is checked once per LM iteration; sfmba_problem_build_reduced and
+                                             sfmba_problem_append are refused.  A resident handle that GROWS past 2^31 pairs in sfmba_problem_append takes this path
+                                             from that append on (the append itself succeeds; the NEXT one is refused with SFMBA_ERR_INVALID_ARG "cannot grow in
+                                             place" -- the drop-in shim then rebuilds).  Slower than the formed matrix wherever that fits (~8x per CG iteration at
+                                             BASELINE config 5). */
 
 typedef struct sfmba_summary {
     int    termination;               /* SFMBA_CONVERGENCE / NO_CONVERGENCE / FAILURE */

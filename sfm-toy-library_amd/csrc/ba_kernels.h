@@ -121,7 +121,7 @@ struct DeviceBuffers {
     double* pts[2];           // [npt][3]
     double* camtab[2];        // [ncam][CT_STRIDE]
     double* steptab;          // [ncam][ST_STRIDE]
-    float* pu32;              // F32J, unsharded solves: [ncam][20] fp32 record {R, t of the linearisation point (12), Q dw, dt, first-order flag (8)} written by
+    float* pu32;              // F32J, every LM loop (rank 0 of a sharded solve adds gradient . step): [ncam][20] fp32 record {R, t of the linearisation point (12), Q dw, dt, first-order flag (8)} written by
                               //         k_cam_update for the FIRST sweep of k_point_update (five 16-byte gathers per observation instead of ten); else null
     double* cscale;           // [6*ncam] Jacobi scale of the camera columns
     double* pscale;           // [npt][3]

@@ -150,6 +150,19 @@ const RoctxApi* roctx_api() {
     });
     return api.push ? &api : nullptr;
 }
+// The back-substitution is ONE step in two launches that share a convention: in F32J k_cam_update writes the fp32 camera records (pu32) AND adds
+// the gradient . step term of the model cost change, and k_point_update<float> then forms no residual term -- pairing a cam_update that saw pu32 with a
+// point_update that did not (or the other way round) would count that term twice or not at all and skew the step quality rho.  Every LM loop goes through
+// this helper: both kernels see the SAME DeviceBuffers, and an fp64 point pass can never meet a pu32 camera pass.  ds_points: the point pass's structure
+// (a row-sharded rank passes the view with its own point range).
+template <typename T>
+void launch_back_substitution(hipStream_t s, const DeviceStructure& ds, const DeviceStructure& ds_points, const DeviceBuffers& dbu, Profiler* prof) {
+    DeviceBuffers b = dbu;
+    if (sizeof(T) == 8) b.pu32 = nullptr;
+    { ProfScope ps(prof, KID_CAM_UPDATE, s); launch_cam_update(s, ds, b); }
+    { ProfScope ps(prof, KID_POINT_UPDATE, s); launch_point_update<T>(s, ds_points, b); }
+}
+
 struct RoctxRange {
     const RoctxApi* a;
     RoctxRange(bool on, const char* name) : a(on ? roctx_api() : nullptr) { if (a) a->push(name); }
@@ -237,7 +250,7 @@ struct sfmba_problem {
     int *d_obs_pt = nullptr, *d_perm = nullptr;   // contiguous [2*nobs]: point slot, perm
     void* d_obs_xy = nullptr;
     int4* d_chunks = nullptr, *d_chunks_coarse = nullptr, *d_pwg_desc = nullptr;
-    float* d_pu32 = nullptr;                // fp32 camera records of the back-substitution's first sweep (F32J, unsharded solves)
+    float* d_pu32 = nullptr;                // fp32 camera records of the back-substitution's first sweep (F32J, every LM loop; launch_back_substitution)
     int2* d_pwg_chunk = nullptr; int* d_multi_slots = nullptr; int* d_build_counters = nullptr; int* d_pt_order = nullptr;
     int *d_chunk_order = nullptr, *d_coarse_order = nullptr;
     double block_fill = 1.0;              // non-empty off-diagonal blocks of the reduced matrix / all of them
@@ -538,8 +551,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         RoctxRange rx_update(p->roctx, "update: cam_update + point_update + lm_control (and the wait for its verdict)");
         bool lm_done = false;
         while (!lm_done) {
-            { ProfScope ps(prof, KID_CAM_UPDATE, p->stream); launch_cam_update(p->stream, p->ds, dbu); }
-            { ProfScope ps(prof, KID_POINT_UPDATE, p->stream); launch_point_update<T>(p->stream, p->ds, dbu); }
+            launch_back_substitution<T>(p->stream, p->ds, p->ds, dbu, prof);
             { ProfScope ps(prof, KID_CONTROL, p->stream); launch_control(p->stream, p->ds, dbu); }
             { ProfScope ps(prof, KID_EMPTY, p->stream); }   // two back-to-back event records: the bracketing overhead itself
             ++launched_controls;
@@ -1776,9 +1788,8 @@ int sfmba_shard_solve_update(sfmba_problem* p) {
     } else {
         dense_cholesky_solve(p->stream, &p->solver, p->db.S, p->db.rhs, p->d_info, nullptr);
     }
-    launch_cam_update(p->stream, p->ds, dbu);
-    if (p->precision == SFMBA_PRECISION_F32J) launch_point_update<float>(p->stream, p->ds, dbu);      // (dbu: the same pu32 as k_cam_update saw -- sum u . r is formed in ONE of the two)
-    else launch_point_update<double>(p->stream, p->ds, dbu);
+    if (p->precision == SFMBA_PRECISION_F32J) launch_back_substitution<float>(p->stream, p->ds, p->ds, dbu, nullptr);      // (one DeviceBuffers for both: sum u . r is formed in ONE of the two)
+    else launch_back_substitution<double>(p->stream, p->ds, p->ds, dbu, nullptr);
     launch_shard_pack(p->stream, p->db, p->d_scal, 2, p->shard_rank);
     return SFMBA_OK;
 }
@@ -1864,6 +1875,7 @@ static int solve_matrix_free(sfmba_problem* p, const sfmba_options& o, sfmba_sum
 
 static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_allreduce_fn allreduce, void* ctx, sfmba_summary* summary) {
     if (p->shard_world > 1 && !allreduce) return fail(SFMBA_ERR_INVALID_ARG, "world > 1 needs an all-reduce");
+    const double t_shard0 = now_seconds();
     auto reduce = [&](void* buf, int64_t n) -> int {
         if (!allreduce) return SFMBA_OK;          // (a communicator of one rank is still called: the RCCL path is exercised on a one-GPU box)
         const int arc = allreduce(ctx, buf, n, (void*)p->stream);
@@ -2044,8 +2056,7 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
             dbu.cg_gate = p->solver.flags; dbu.cg_force = 0;
             volatile int* mb = p->h_lm_mail;
             for (;;) {
-                launch_cam_update(p->stream, p->ds, dbu);
-                if (f32) launch_point_update<float>(p->stream, dsp, dbu); else launch_point_update<double>(p->stream, dsp, dbu);
+                if (f32) launch_back_substitution<float>(p->stream, p->ds, dsp, dbu, nullptr); else launch_back_substitution<double>(p->stream, p->ds, dsp, dbu, nullptr);
                 launch_shard_pack(p->stream, p->db, p->d_scal, 2, p->shard_rank);
                 if ((rc = reduce(sfmba_shard_scalars_buf(p), SFMBA_SHARD_SCALARS))) return rc;
                 dbu.shard_scal = p->d_scal;        // k_lm_control reads the sums from the all-reduced block
@@ -2089,6 +2100,13 @@ static int solve_sharded_impl(sfmba_problem* p, const sfmba_options* opt, sfmba_
             if (p->shard_host_iter >= o.max_iters) {
                 p->shard_sum.termination = SFMBA_NO_CONVERGENCE;
                 std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(MSG_MAX_ITERS));
+                break;
+            }
+            // one rank (the matrix-free solve of an unsharded handle): the wall-clock limit of the reference (BA.cpp:176) applies; between
+            // ranks it cannot (they would disagree on it)
+            if (p->shard_world == 1 && o.max_seconds > 0.0 && now_seconds() - t_shard0 >= o.max_seconds) {
+                p->shard_sum.termination = SFMBA_NO_CONVERGENCE;
+                std::snprintf(p->shard_sum.message, sizeof(p->shard_sum.message), "%s", message_text(MSG_MAX_TIME));
                 break;
             }
         }

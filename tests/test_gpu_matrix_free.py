@@ -68,6 +68,10 @@ def test_no_pair_list_flag_on_a_resident_problem(capi, sfm, oracle):
             P.append(prob.cam6, prob.pt3, prob.focal, prob.obs_cam[:1], prob.obs_pt[:1], prob.obs_xy[:1])
         res, cost = P.eval_residuals()
         assert np.isclose(cost, s["final_cost"], rtol=1e-12)
+        # the reference's wall-clock limit (BA.cpp:176) is honoured on this path too (checked once per LM iteration)
+        P.reset()
+        st, _ = P.solve(capi.default_options(max_seconds=1e-7, linear_solver=1))
+        assert st["termination_name"] == "NO_CONVERGENCE" and "time" in st["message"].lower() and st["iterations"] <= 1
 
 
 def test_two_to_the_31_pairs_for_real(capi, sfm):
