@@ -304,11 +304,19 @@ template <typename FT, typename FF>
 __global__ __launch_bounds__(256) void k_dcg_prod(int d, int ld, int ncam, int row0, int row1, int rank, const FT* __restrict__ owned,
                                                   const FF* __restrict__ focal_row, const double* __restrict__ p, const double* __restrict__ W,
                                                   double* __restrict__ out, const int* __restrict__ flags, int launch_no) {
-    if (dcg_done(flags, launch_no)) return;
     __shared__ double sh[4][9];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fo = d - 1;
     double* lin = out + ld + (size_t)blockIdx.x * LIN_STRIDE;
+    if (dcg_done(flags, launch_no)) {
+        // a surplus launch of the batch: the collective behind it is issued regardless (the host cannot know), and an in-place all-reduce of the stale,
+        // already summed buffer would multiply it by the world size once per surplus launch (inf / NaN after a long forced batch at large world).
+        // Hand it zeros: this workgroup's part of the buffer.
+        if (blockIdx.x == gridDim.x - 1) { if (tid == 0) out[fo] = 0.0; }
+        else { const int c = blockIdx.x * CPW + w; if (c < ncam && lane < 6) out[6 * c + lane] = 0.0; }
+        if (tid < 9) lin[tid] = 0.0;
+        return;
+    }
     if (blockIdx.x == gridDim.x - 1) {
         // the focal entry: known on every rank from exchange (A) -- rank 0 contributes it
         double fd = 0.0;
