@@ -173,7 +173,7 @@ struct DeviceBuffers {
 template <typename T> void launch_cam_setup(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int which);
 void launch_xnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db);
 template <typename T> void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi_scaling, bool clear_udiag = true,
-                                         bool points = true, bool finish_xnorm = false);
+                                         bool points = true, bool finish_xnorm = false, bool with_xnorm = false);
 void launch_begin(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, const LMState& st, const double* cam_src = nullptr,
                   const double* pts_src = nullptr);
 template <typename T> void launch_point_build(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db,

@@ -196,9 +196,11 @@ __global__ __launch_bounds__(BLK) void k_colnorm_points(DeviceStructure ds, Devi
 }
 
 // squared column norms of the camera / focal columns -> udiag (atomics), one block per chunk
+// with_xnorm: the launch also sums ||x||^2 of the current parameters (k_xnorm's job: a launch of its own, 4.6 us per solve, for one strided pass
+// over 2.4 MB) -- every workgroup takes a stride of the parameter arrays beside its chunk
 template <typename T>
-__global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, DeviceBuffers db) {
-    __shared__ double scratch[(BLK / 64) * 7];
+__global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, DeviceBuffers db, int with_xnorm) {
+    __shared__ double scratch[(BLK / 64) * 8];
     const int4 ch = ds.chunks_coarse[ds.coarse_order[blockIdx.x]];
     const int j = ch.x;
     const int cur = db.st->cur;
@@ -206,7 +208,19 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
     const double focal = db.st->focal[cur];
     const typename ObsXY<T>::type* oxy = reinterpret_cast<const typename ObsXY<T>::type*>(ds.obs_xy);
     (void)oxy;
-    double n[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    double n[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (with_xnorm) {
+        const double* cam = db.cam[cur];
+        const double* pts = db.pts[cur];
+        const int nc = 6 * ds.ncam, np = 3 * ds.npt;
+        double s = 0.0;
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nc + np; e += gridDim.x * blockDim.x) {
+            const double v = e < nc ? cam[e] : pts[(size_t)3 * ds.pt_base + (e - nc)];
+            s += (e < nc ? db.shared_weight : 1.0) * v * v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) s += db.shared_weight * focal * focal;
+        n[7] = s;
+    }
     for (int e = ch.y + threadIdx.x; e < ch.z; e += blockDim.x) {
         const int i = ds.cam_obs_pt[e];
         const double X[3] = { db.pts[cur][3 * i], db.pts[cur][3 * i + 1], db.pts[cur][3 * i + 2] };
@@ -218,8 +232,9 @@ __global__ __launch_bounds__(BLK) void k_colnorm_cams(DeviceStructure ds, Device
         for (int c = 0; c < 6; ++c) n[c] += (double)A[c] * (double)A[c] + (double)A[6 + c] * (double)A[6 + c];
         n[6] += pr.xp * pr.xp + pr.yp * pr.yp;
     }
-    const double tot = block_sums<7>(n, scratch);            // (one barrier instead of seven pairs of them)
+    const double tot = block_sums<8>(n, scratch);            // (one barrier instead of eight pairs of them)
     if (threadIdx.x < 7) atomicAdd(threadIdx.x < 6 ? &db.udiag[6 * j + threadIdx.x] : slot_ptr(db, ACC_UDF), tot);
+    if (with_xnorm && threadIdx.x == 7) atomicAdd(slot_ptr(db, ACC_XNEW2), tot);
 }
 
 __global__ void k_colnorm_finish(DeviceStructure ds, DeviceBuffers db, int jacobi, int finish_xnorm) {
@@ -243,22 +258,23 @@ void launch_colnorm_points_only(hipStream_t s, const DeviceStructure& ds, const 
 void launch_colnorm_cams_only(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, int f32, bool clear_udiag) {
     if (clear_udiag) (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
     if (!jacobi || ds.nchunk_coarse <= 0) return;
-    if (f32) hipLaunchKernelGGL(k_colnorm_cams<float>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
-    else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
+    if (f32) hipLaunchKernelGGL(k_colnorm_cams<float>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db, 0);
+    else hipLaunchKernelGGL(k_colnorm_cams<double>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db, 0);
 }
 void launch_colnorm_finish(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi) {
     hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi, 0);
 }
 
+// with_xnorm: ||x||^2 is summed by the camera pass itself (launch_colnorm_sums_xnorm says whether that pass runs: else launch_xnorm first)
 template <typename T>
-void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, bool clear_udiag, bool points, bool finish_xnorm) {
+void launch_colnorm(hipStream_t s, const DeviceStructure& ds, const DeviceBuffers& db, int jacobi, bool clear_udiag, bool points, bool finish_xnorm, bool with_xnorm) {
     if (clear_udiag) (void)hipMemsetAsync(db.udiag, 0, sizeof(double) * ds.ld, s);
     if (points) hipLaunchKernelGGL(k_colnorm_points<T>, dim3((ds.npt + BLK - 1) / BLK), dim3(BLK), 0, s, ds, db, jacobi);
-    if (jacobi) hipLaunchKernelGGL(k_colnorm_cams<T>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db);
+    if (jacobi && ds.nchunk_coarse > 0) hipLaunchKernelGGL(k_colnorm_cams<T>, dim3(ds.nchunk_coarse), dim3(BLK), 0, s, ds, db, with_xnorm ? 1 : 0);
     hipLaunchKernelGGL(k_colnorm_finish, dim3((ds.d + 255) / 256), dim3(256), 0, s, ds, db, jacobi, finish_xnorm ? 1 : 0);
 }
-template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool, bool);
-template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool, bool);
+template void launch_colnorm<float>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool, bool, bool);
+template void launch_colnorm<double>(hipStream_t, const DeviceStructure&, const DeviceBuffers&, int, bool, bool, bool, bool);
 
 // ------------------------------------------------------------------------------------------
 // 3x3 SPD: L^-1 (lower, 6 values l00 l10 l11 l20 l21 l22 of the INVERSE factor). Returns false if not PD.
