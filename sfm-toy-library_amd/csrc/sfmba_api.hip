@@ -499,8 +499,8 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
             // the streaming CG on ONE triangle of S~ (dense_solver.hip "Symmetric streaming path"); its sums arrive through atomics: not for deterministic handles
             p->solver.symmetric = symmetric_cg && dense_pcg_symmetric_applicable(&p->solver);
             p->db.pcg_upper_only = p->solver.symmetric ? 1 : 0;      // ... and the pair pass then writes that triangle only
-            p->db.pcg_zero = p->solver.symmetric ? p->solver.AWt : nullptr;
-            p->db.pcg_zero_n = p->solver.symmetric ? 8 * p->ds.ld : 0;
+            p->db.pcg_zero = p->solver.symmetric ? p->solver.sym_zero : nullptr;        // S~ W~, the CG's products and partial sums: added into with atomics
+            p->db.pcg_zero_n = p->solver.symmetric ? (int)p->solver.sym_zero_n : 0;
         }
         RoctxRange rx_iter(p->roctx, "sfmba LM iteration");
         {

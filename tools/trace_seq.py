@@ -3,8 +3,8 @@ import csv, sys, glob, os
 f = glob.glob(os.path.join(sys.argv[1], "**", "*_kernel_trace.csv"), recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 nm = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sfmba::", "")[:40]
-idx = [i for i, r in enumerate(rows) if "k_xnorm" in r["Kernel_Name"]]
-a = idx[-1] - 4; b = len(rows)
+idx = [i for i, r in enumerate(rows) if "k_begin" in r["Kernel_Name"]]
+a = idx[-1]; b = len(rows)
 t0 = int(rows[a]["Start_Timestamp"])
 prev = t0
 for r in rows[a:b]:
