@@ -28,9 +28,7 @@ struct DenseSolver {
     int4* sym_tiles = nullptr; int sym_ntiles = 0;   // its tiles of the upper triangle
     int4* sym_ctiles = nullptr; int sym_nctiles = 0; // ... and the taller ones of its coarse set-up (k_sy_coarse)
     double* AWt = nullptr;    // [8][ld] S~ W~ of the symmetric path, vector-major; added into with atomics: the caller's linearisation zeroes it
-    double* w3 = nullptr;     // [3][ld] the products of k_sy_cg by launch number mod 3
-    double* cg_part = nullptr;// [3][16 slots][16] its slotted partial sums: one 128-byte line per slot holds the ten values
-    double* sym_zero = nullptr; size_t sym_zero_n = 0;   // the block [AWt | w3 | cg_part]: everything the symmetric path adds into (zeroed by the caller's linearisation)
+    double* sym_zero = nullptr; size_t sym_zero_n = 0;   // (= AWt) what the caller's linearisation has to zero
     double* vec = nullptr;    // [9*ld] x[2] r[2] p[2] q[2] btilde
     double* part = nullptr;   // [2][9][1024] per-workgroup partial sums of one iteration (p_r.q, W~^T q), by iteration parity
     // coarse space of the two-level preconditioner (dense_solver.hip): 8 gauge vectors in the transformed unknowns

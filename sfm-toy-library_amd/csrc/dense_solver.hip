@@ -921,259 +921,6 @@ __global__ __launch_bounds__(256) void k_sy_prod(int d, int ld, const FT* __rest
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// ONE launch per iteration on the triangle: the Chronopoulos - Gear form of the same preconditioned CG (SIAM J. Sci. Comput. 1989: "s-step
-// iterative methods"; the one-step member).  The product is taken of the RESIDUAL, w_n = S~ u_n with u_n = M^-1 r_n = r_n + W~ mu_n, and the search
-// direction and its image follow by recurrences,
-//     p_n = u_n + beta_n p_{n-1},   s_n = w_n + beta_n s_{n-1}  (= S~ p_n),   x_{n+1} = x_n + alpha_n p_n,   r_{n+1} = r_n - alpha_n s_n,
-//     gamma_n = r_n . u_n,   delta_n = w_n . u_n,   beta_n = gamma_n / gamma_{n-1},   alpha_n = gamma_n / (delta_n - beta_n gamma_n / alpha_{n-1}):
-// the same iterates as CG in exact arithmetic, and EVERY inner product of iteration n is a sum of per-workgroup partials of launch n -- |r_n|^2 and
-// (S~ W~)^T r_n over the slices (r_n is the launch's INPUT, known entry by entry), r_n^T S~ r_n over the tiles (linear in the tile sums, like p . q before) --
-// so launch n + 1 starts from a few hundred slotted sums instead of a pass over the vectors: no k_sy_vec, no 96 KB per workgroup.  With the two-level
-// preconditioner:  gamma = |r|^2 + c . mu,  W~^T w = (S~W~)^T r + E mu =: t,  delta = r^T S~ r + 2 mu . (S~W~)^T r + mu^T E mu,  h_n = t_n + beta_n h_{n-1}
-// (= W~^T s_n),  c_{n+1} = c_n - alpha_n h_n,  mu_{n+1} = E^-1 c_{n+1}  -- eight-vectors carried in the scalar state.
-// A tile forms its 32 + 256 entries of r_n on the fly: r_n[j] = r_{n-1}[j] - alpha_{n-1} (w_{n-1}[j] + beta_{n-1} s_{n-2}[j]) -- three loads per entry from
-// vectors that are complete when the launch starts; the slice owners (the first workgroups) store s_{n-1}, p_{n-1}, x_n, r_n for the next launch, add
-// (S~W~) mu_n to their slice of w_n and zero the next w.  The stopping test of r_{n-1} is taken at the start of launch n (one launch later than the
-// two-launch form: batches are one longer).  Vectors: x, r, p by parity in ws->vec, s in its q slots, w in ws->q3.
-// ---------------------------------------------------------------------------------------------------------------------
-enum { SYP_ARR = 0, SYP_R2 = 1, SYP_T = 2, SYP_NV = 10 };          // partial sums of a launch: r^T S~ r, |r|^2, (S~W~)^T r (8)
-// ... slotted: SYC_SLOTS lines of 16 doubles, ONE line per slot with all ten values (a workgroup's atomics hit one line, and a reader -- EVERY workgroup
-// of the next launch -- fetches 16 lines: with one line per value and slot, 640 lines per workgroup, the 2 396 workgroups pulled 190 MB of lines the atomics
-// had left on the memory side and the launch took 31 us)
-constexpr int SYC_SLOTS = 16, SYC_LINE = 16;
-enum { SYS_GAMMA = 0, SYS_C = 1, SYS_MU = 9, SYS_H = 17, SYS_ALPHA = 25, SYS_BASE = 26 };      // scalar state by parity (PS_STATE_LEN doubles)
-__device__ __forceinline__ double* syc_line(double* part, int slot3, int slot) { return part + ((size_t)slot3 * SYC_SLOTS + slot) * SYC_LINE; }
-// sum over the 8 lanes of a group lane / 8 (every lane of the group gets it)
-__device__ __forceinline__ double sum8(double v) { v = xlane_add<4>(v); v = xlane_add<2>(v); v = xlane_add<1>(v); return v; }
-
-template <bool INIT, typename FT, bool COARSE>
-__global__ __launch_bounds__(256, 4) void k_sy_cg(int d, int ld, const FT* __restrict__ F, double* __restrict__ vec, double* __restrict__ w2, const double* __restrict__ bt,
-                                                  double* __restrict__ part, double* scal, int* flags, const int4* __restrict__ tiles, int nslice, double tol2, int in,
-                                                  int* info, int* mailbox, int anchor, double cap, const double* __restrict__ W, const double* __restrict__ AW,
-                                                  const double* __restrict__ coarse) {
-    __shared__ __align__(16) double colsh[4 * SY_C];
-    __shared__ double red[4 * 16 + 2 * PCG_NW * PCG_NW + 4 * SYP_NV + 2 * PCG_NW];       // per-wave totals [4][16] | E^-1 | E | end-of-kernel partials | mu_{n-1}, mu_n
-    double* einv_s = red + 64; double* e_s = red + 64 + PCG_NW * PCG_NW; double* endp = red + 64 + 2 * PCG_NW * PCG_NW; double* mu_s = endp + 4 * SYP_NV;
-    const int n = in >> 1;                      // launch number: 0 = the first product (of b~), n >= 1: iteration n - 1 is completed here
-    in &= 1;
-    if (!INIT) { const int dn = flags[PF_DONE]; if (dn != 0 && n >= dn) return; }
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, out = in ^ 1;
-    // vectors: [in] = what launch n - 1 stored, [out] = what this launch stores
-    const double* x_in = pcg_vec(vec, 0, in, ld); double* x_out = pcg_vec(vec, 0, out, ld);
-    const double* r_in = (n == 1) ? bt : pcg_vec(vec, 1, in, ld); double* r_out = pcg_vec(vec, 1, out, ld);        // r_{n-1}; r_0 = b~ is read where it lies
-    const double* p_in = pcg_vec(vec, 2, in, ld); double* p_out = pcg_vec(vec, 2, out, ld);                        // p_{n-2} -> p_{n-1}
-    const double* s_in = pcg_vec(vec, 3, in, ld); double* s_out = pcg_vec(vec, 3, out, ld);                        // s_{n-2} -> s_{n-1}
-    // w and the slotted partials are ADDED into: three slots by launch number -- launch n reads slot (n - 1) % 3, adds into n % 3 and zeroes (n + 1) % 3
-    // (the one launch n + 1 adds into: it cannot be the slot this launch's workgroups are still reading); the linearisation zeroes all three
-    const int sl_in = (n + 2) % 3, sl_acc = n % 3, sl_zero = (n + 1) % 3;
-    const double* w_in = w2 + (size_t)sl_in * ld;                // w_{n-1}, complete
-    double* w_acc = w2 + (size_t)sl_acc * ld;                    // w_n
-    double* w_zero = w2 + (size_t)sl_zero * ld;
-    const double* st_in = scal + PS_STATE + PS_STATE_LEN * in;
-    double* st_out = scal + PS_STATE + PS_STATE_LEN * out;
-    // the tile's eight 16-byte loads first: the scalars below run under them
-    const int4 tl = tiles[blockIdx.x];
-    const int r0 = tl.x, c0 = tl.y, rend = tl.x + tl.z;
-    const bool diag = tl.w != 0;
-    const int j0 = c0 + 4 * lane, rw0 = r0 + 8 * w;
-    Quad<FT> f[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { const int row = rw0 + u; f[u].load(F + (size_t)(row < rend ? row : r0) * ld + j0); }
-    // ---- the scalars of iteration n - 1, every wave for itself.  Eight-vectors live ONE COMPONENT PER LANE (component lane % 8, eight copies per wave):
-    // as arrays per lane they were 128 registers and took the launch from four waves per SIMD to three ----
-    const int k8 = lane & 7;
-    if (COARSE && tid < PCG_NW * PCG_NW) { einv_s[tid] = coarse[tid]; e_s[tid] = coarse[PCG_NW * PCG_NW + PCG_NW + tid]; }
-    double alpha = 0.0, beta = 0.0, gamma_prev = 0.0, base = 0.0;      // alpha_{n-1}, beta_{n-1}, gamma_{n-1}
-    double mu_prev_k = 0.0, mu_n_k = 0.0, c_n_k = 0.0, h_prev_k = 0.0;
-    if (INIT) {
-        c_n_k = COARSE ? coarse[PCG_NW * PCG_NW + k8] : 0.0;          // c_0 = W~^T b~
-        __syncthreads();
-        if (COARSE) {
-            double m = 0.0;
-#pragma unroll
-            for (int j = 0; j < PCG_NW; ++j) m = fma(einv_s[k8 * PCG_NW + j], lane_bcast(c_n_k, j), m);
-            mu_n_k = m;
-        }
-    } else {
-        // the slotted sums of launch n - 1: lane l reads values 4 (l / 16) .. + 3 of slot l % 16; summed over the sixteen slots = over a row of sixteen lanes
-        // (xlane_add<4> pairs lane ^ 7, not lane ^ 4: only a FULL row sum may use it)
-        double v4[4];
-        {
-            const double2* ln = reinterpret_cast<const double2*>(syc_line(part, sl_in, lane & 15) + 4 * (lane >> 4));
-            const double2 a = ln[0], b2 = ln[1];
-            v4[0] = a.x; v4[1] = a.y; v4[2] = b2.x; v4[3] = b2.y;
-        }
-        const double gamma_pp = st_in[SYS_GAMMA], alpha_pp = st_in[SYS_ALPHA];       // gamma_{n-2}, alpha_{n-2}
-        const double c_prev_k = COARSE ? st_in[SYS_C + k8] : 0.0, h_pp_k = COARSE ? st_in[SYS_H + k8] : 0.0;
-        mu_prev_k = COARSE ? st_in[SYS_MU + k8] : 0.0;
-        base = n == 1 ? 0.0 : st_in[SYS_BASE];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { double t = v4[j]; t = xlane_add<8>(t); t = xlane_add<4>(t); t = xlane_add<2>(t); t = xlane_add<1>(t); v4[j] = t; }
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) red[16 * w + 4 * (lane >> 4) + j] = v4[j];
-        }
-        __syncthreads();                         // (also: E^-1, E in LDS)
-        const double arr = red[16 * w + SYP_ARR], r2 = red[16 * w + SYP_R2];
-        const double T_k = COARSE ? red[16 * w + SYP_T + k8] : 0.0;
-        if (n == 1) base = pcg_threshold_base(r2, scal, blockIdx.x == 0 && tid == 0 ? anchor : (anchor == 1 ? 0 : anchor), cap);     // (only one thread stores |b~|^2 of an anchored run)
-        double em_k = 0.0;                       // (E mu_{n-1})[k]
-        if (COARSE) {
-#pragma unroll
-            for (int j = 0; j < PCG_NW; ++j) em_k = fma(e_s[k8 * PCG_NW + j], lane_bcast(mu_prev_k, j), em_k);
-        }
-        const double t_k = T_k + em_k;
-        const double cmu = COARSE ? sum8(c_prev_k * mu_prev_k) : 0.0, muT = COARSE ? sum8(mu_prev_k * T_k) : 0.0, mEm = COARSE ? sum8(mu_prev_k * em_k) : 0.0;
-        gamma_prev = r2 + cmu;                                                      // gamma_{n-1}
-        const double delta = arr + 2.0 * muT + mEm;
-        beta = n == 1 ? 0.0 : gamma_prev / gamma_pp;
-        const double den = n == 1 ? delta : delta - beta * gamma_prev / alpha_pp;
-        const bool broke = !(den > 0.0) || !(r2 == r2);
-        // the stopping test of r_{n-1}: x_{n-1} is what launch n - 1 stored
-        if (r2 <= tol2 * base || broke) {
-            if (blockIdx.x == 0 && tid == 0) {
-                flags[PF_DONE] = n; flags[PF_XBUF] = in; flags[PF_ITERS] = n - 1;
-                if (broke && !(r2 <= tol2 * base)) atomicCAS(info, 0, d + 1);
-                if (mailbox) pcg_post(mailbox, n - 1, 1);
-            }
-            return;
-        }
-        alpha = gamma_prev / den;
-        h_prev_k = fma(beta, h_pp_k, t_k);
-        c_n_k = fma(-alpha, h_prev_k, c_prev_k);
-        if (COARSE) {
-            double m = 0.0;
-#pragma unroll
-            for (int j = 0; j < PCG_NW; ++j) m = fma(einv_s[k8 * PCG_NW + j], lane_bcast(c_n_k, j), m);
-            mu_n_k = m;
-        }
-        if (blockIdx.x == 0 && tid == 0) { flags[PF_ITERS] = n; flags[PF_XBUF] = out; if (mailbox) pcg_post(mailbox, n, 0); }
-    }
-    if (blockIdx.x == 0 && tid < PCG_NW) {
-        if (tid == 0) { st_out[SYS_GAMMA] = gamma_prev; st_out[SYS_ALPHA] = alpha; st_out[SYS_BASE] = base; if (INIT) { flags[PF_DONE] = 0; flags[PF_ITERS] = 0; flags[PF_XBUF] = out; } }
-        st_out[SYS_C + tid] = c_n_k; st_out[SYS_MU + tid] = mu_n_k; st_out[SYS_H + tid] = h_prev_k;
-    }
-    if (COARSE && tid < PCG_NW) { mu_s[tid] = mu_prev_k; mu_s[PCG_NW + tid] = mu_n_k; }       // for the slice owners (read after the barrier below)
-    // r_n, entry by entry (the SAME expression in the tiles and in the slice that stores it)
-    auto r_now = [&](int e) -> double {
-        if (INIT) return bt[e];
-        return fma(-alpha, fma(beta, s_in[e], w_in[e]), r_in[e]);
-    };
-    // ---- the tile: w_n += S~ r_n on the triangle ----
-    double rj[4];
-    {
-        const int jc = j0 + 3 < d ? j0 : 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const double v = r_now(jc + e); rj[e] = (j0 + 3 < d) ? v : 0.0; }
-        if (j0 + 3 >= d) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (j0 + e < d) rj[e] = r_now(j0 + e);
-        }
-    }
-    const int myrow = rw0 + (lane >> 3);
-    const double rrow = myrow < rend ? r_now(myrow) : 0.0;
-    const double rcol = c0 + tid < d ? r_now(c0 + tid) : 0.0;      // (for r^T S~ r: requested now, used behind the barrier)
-    double arr_acc = 0.0;
-    double racc[8], colacc[4] = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int row = rw0 + u;
-        const double ri = lane_bcast(rrow, 8 * u);
-        const bool live = row < rend;
-        double sacc = 0.0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = j0 + e;
-            double x = f[u].get(e);
-            if (!live || j >= d || (diag && j < row)) x = 0.0;
-            sacc = fma(x, rj[e], sacc);
-            colacc[e] = fma((diag && j == row) ? 0.0 : x, ri, colacc[e]);
-        }
-        racc[u] = sacc;
-    }
-    const double tot = rows8_reduce(racc, lane);
-#ifndef SFMBA_WHATIF_SYCG_NO_WATOMIC
-    if ((lane & 7) == 0 && myrow < rend) { atomicAdd(w_acc + myrow, tot); arr_acc = rrow * tot; }
-#else
-    if ((lane & 7) == 0 && myrow < rend) { if (tot == 1.2345) w_acc[myrow] = tot; arr_acc = rrow * tot; }
-#endif
-#pragma unroll
-    for (int e = 0; e < 4; ++e) colsh[w * SY_C + 4 * lane + e] = colacc[e];
-    __syncthreads();
-    if (c0 + tid < d) {
-        const double cs = (colsh[tid] + colsh[SY_C + tid]) + (colsh[2 * SY_C + tid] + colsh[3 * SY_C + tid]);
-#ifndef SFMBA_WHATIF_SYCG_NO_WATOMIC
-        atomicAdd(w_acc + c0 + tid, cs);
-#else
-        if (cs == 1.2345) w_acc[c0 + tid] = cs;
-#endif
-        arr_acc = fma(rcol, cs, arr_acc);
-    }
-    // ---- the slice (first nslice workgroups): the recurrences of iteration n - 1, the sums over r_n, w_n += (S~W~) mu_n, the next w zeroed ----
-    double r2_acc = 0.0, tpart[PCG_NW];
-#pragma unroll
-    for (int k = 0; k < PCG_NW; ++k) tpart[k] = 0.0;
-#ifdef SFMBA_WHATIF_SYCG_NO_SLICE
-    const bool slice = false;
-#else
-    const bool slice = (int)blockIdx.x < nslice;
-#endif
-    if (slice) {
-        const int per = (d + nslice - 1) / nslice;
-        const int e0 = min(d, (int)blockIdx.x * per), e1 = min(d, e0 + per);
-        for (int e = e0 + tid; e < e1; e += 256) {
-            w_zero[e] = 0.0;
-            double rn;
-            if (INIT) {
-                rn = bt[e];
-                x_out[e] = 0.0; p_out[e] = 0.0; s_out[e] = 0.0;
-            } else {
-                const double sp = fma(beta, s_in[e], w_in[e]);                      // s_{n-1}
-                double up = r_in[e];                                                // u_{n-1} = r_{n-1} + W~ mu_{n-1}
-                if (COARSE) {
-#pragma unroll
-                    for (int k = 0; k < PCG_NW; ++k) up = fma(W[(size_t)k * ld + e], mu_s[k], up);
-                }
-                const double pp = fma(beta, p_in[e], up);                           // p_{n-1}
-                rn = fma(-alpha, sp, r_in[e]);                                      // r_n  (== r_now(e))
-                s_out[e] = sp; p_out[e] = pp; x_out[e] = fma(alpha, pp, x_in[e]);
-            }
-            r_out[e] = rn;
-            r2_acc = fma(rn, rn, r2_acc);
-            if (COARSE) {
-                double a = 0.0;
-#pragma unroll
-                for (int k = 0; k < PCG_NW; ++k) { const double aw = AW[(size_t)k * ld + e]; a = fma(aw, mu_s[PCG_NW + k], a); tpart[k] = fma(aw, rn, tpart[k]); }      // (AWt: vector-major)
-                atomicAdd(w_acc + e, a);
-            }
-        }
-    }
-    if (blockIdx.x == 0) { for (int i = tid; i < SYC_SLOTS * SYC_LINE; i += 256) syc_line(part, sl_zero, 0)[i] = 0.0; }
-    arr_acc = wave_allsum(arr_acc);
-    if (slice) {
-        r2_acc = wave_allsum(r2_acc);
-        if (COARSE) {
-#pragma unroll
-            for (int k = 0; k < PCG_NW; ++k) tpart[k] = wave_allsum(tpart[k]);
-        }
-    }
-    if (lane == 0) {
-        endp[SYP_NV * w + SYP_ARR] = arr_acc; endp[SYP_NV * w + SYP_R2] = r2_acc;
-#pragma unroll
-        for (int k = 0; k < PCG_NW; ++k) endp[SYP_NV * w + SYP_T + k] = tpart[k];
-    }
-    __syncthreads();
-    if (tid == 0 || (slice && tid < (COARSE ? SYP_NV : 2))) {
-        const double v = (endp[tid] + endp[SYP_NV + tid]) + (endp[2 * SYP_NV + tid] + endp[3 * SYP_NV + tid]);
-#ifndef SFMBA_WHATIF_SYCG_NO_PARTATOMIC
-        atomicAdd(syc_line(part, sl_acc, (int)(blockIdx.x % SYC_SLOTS)) + tid, v);
-#else
-        if (v == 1.2345) part[0] = v;
-#endif
-    }
-}
-
 // The coarse set-up on the same triangle: AW = S~ W~ for the eight gauge vectors at once, every entry of the triangle used sixteen times from its
 // one load.  With eight vectors the atomics are what has to be budgeted (the memory side retires ~6 G line-sized atomic transactions per second,
 // see above): TALL tiles, SY_CR rows x SY_C columns -- the eight column sums of a lane's four columns stay in registers over the wave's 32 rows
@@ -2651,8 +2398,9 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter_fast<INIT ? 2 : 0, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
         else hipLaunchKernelGGL((k_pcg_iter_fast<INIT ? 1 : 0, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull), ws->epart);
     } else if (r.sym) {
-#ifdef SFMBA_SY_TWO_LAUNCH
-        // (round-6 first form, kept for the A/B: the vector half, then one workgroup per tile of the upper triangle)
+        // two launches per iteration: the vector half, then one workgroup per tile of the upper triangle.  (ONE launch per iteration was built and measured --
+        // the Chronopoulos - Gear form of the CG, whose inner products are all sums of per-workgroup partials, so that no launch needs a pass over the vectors:
+        // correct, and 27 us per iteration against 17.9 + 7.5 here: profiles/r06_ab_sy_one_launch.txt, commit "k_sy_cg".)
         const int nvec = std::max(1, std::min(SY_VEC_WG, (d + 63) / 64)), nslice = std::min(ws->sym_ntiles, 256);
 #define SYV_ARGS d, ld, ws->vec, ws->q3, bt, ws->sym_part, ws->scal, ws->flags, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->coarse
 #define SYV(C, E) hipLaunchKernelGGL((k_sy_vec<INIT, C, E>), dim3(nvec), dim3(256), 0, s, SYV_ARGS)
@@ -2667,16 +2415,6 @@ static void launch_cg_iteration(hipStream_t s, DenseSolver* ws, int anchor, doub
         else { if (r.coarse) hipLaunchKernelGGL((k_sy_prod<double, true>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull));
                else hipLaunchKernelGGL((k_sy_prod<double, false>), dim3(ws->sym_ntiles), dim3(256), 0, s, SY_ARGS(ws->Sfull)); }
 #undef SY_ARGS
-#else
-        // ONE launch per iteration, one workgroup per tile of the upper triangle (k_sy_cg: the Chronopoulos - Gear form)
-        const int nslice = std::min(ws->sym_ntiles, 256);
-#define SYC_ARGS(Fptr) d, ld, Fptr, ws->vec, ws->w3, bt, ws->cg_part, ws->scal, ws->flags, ws->sym_tiles, nslice, r.tol2, in, r.info, ws->d_mailbox, anchor, cap, ws->W, ws->AWt, ws->coarse
-        if (r.f32) { if (r.coarse) hipLaunchKernelGGL((k_sy_cg<INIT, float, true>), dim3(ws->sym_ntiles), dim3(256), 0, s, SYC_ARGS(ws->Sfull32));
-                     else hipLaunchKernelGGL((k_sy_cg<INIT, float, false>), dim3(ws->sym_ntiles), dim3(256), 0, s, SYC_ARGS(ws->Sfull32)); }
-        else { if (r.coarse) hipLaunchKernelGGL((k_sy_cg<INIT, double, true>), dim3(ws->sym_ntiles), dim3(256), 0, s, SYC_ARGS(ws->Sfull));
-               else hipLaunchKernelGGL((k_sy_cg<INIT, double, false>), dim3(ws->sym_ntiles), dim3(256), 0, s, SYC_ARGS(ws->Sfull)); }
-#undef SYC_ARGS
-#endif
     } else if (r.f32) {
         if (r.coarse) hipLaunchKernelGGL((k_pcg_iter<INIT, float, true>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
         else hipLaunchKernelGGL((k_pcg_iter<INIT, float, false>), dim3(r.nwg), dim3(256), r.lds, s, CG_ARGS(ws->Sfull32));
@@ -2820,8 +2558,7 @@ int dense_pcg_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs, doub
     // history + 1 (was + 2; +0.6 % on the headline): a solve that needs two more iterations than last time costs a host round trip, a surplus (early-exit) launch ~2 us
     // (run to 1e-12 -- AUTO -- a solve takes 13 +- 1 iterations from one call to the next, the atomics' summation order is enough: a batch one
     // launch short costs a host round trip of ~50 us, a surplus launch ~2: one more in reserve there)
-    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra + (tol < 1e-10 ? 1 : 0) - ((fast && coarse && !ml && !sg) ? 1 : 0)     // (the merged first launch is iteration 1)
-                                                                                               + (sym ? 1 : 0);                          // (k_sy_cg tests r_{n-1} at the start of launch n)
+    if (hist_key >= 0 && hist_key < (int)ws->hist.size() && ws->hist[hist_key] > 0) batch = ws->hist[hist_key] + batch_extra + (tol < 1e-10 ? 1 : 0) - ((fast && coarse && !ml && !sg) ? 1 : 0);     // (the merged first launch is iteration 1)
     if (no_wait) return dense_pcg_more(s, ws, batch, prof);
     bool done = false;
     while (!done) {
@@ -2897,12 +2634,11 @@ int dense_pcg_ensure_workspace(DenseSolver* ws) {
             if (ws_alloc(ws, &ws->sym_ctiles, sizeof(int4) * ctiles.size())) return -1;
             if (hipMemcpy(ws->sym_ctiles, ctiles.data(), sizeof(int4) * ctiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
             ws->sym_nctiles = (int)ctiles.size();
-            // ONE block of everything the symmetric path ADDS into with atomics: [AWt 8 ld | w 3 ld | slotted partials 3 x 16 lines]; the caller's
-            // linearisation zeroes it (DeviceBuffers::pcg_zero: sym_zero / sym_zero_n)
-            ws->sym_zero_n = (size_t)(PCG_NW + 3) * ws->ld + (size_t)3 * SYC_SLOTS * SYC_LINE;
+            // what the coarse set-up ADDS into with atomics (the caller's linearisation zeroes it: DeviceBuffers::pcg_zero = sym_zero / sym_zero_n)
+            ws->sym_zero_n = (size_t)PCG_NW * ws->ld;
             if (ws_alloc(ws, &ws->sym_zero, sizeof(double) * ws->sym_zero_n)) return -1;
             if (hipMemset(ws->sym_zero, 0, sizeof(double) * ws->sym_zero_n) != hipSuccess) return -1;
-            ws->AWt = ws->sym_zero; ws->w3 = ws->sym_zero + (size_t)PCG_NW * ws->ld; ws->cg_part = ws->w3 + (size_t)3 * ws->ld;
+            ws->AWt = ws->sym_zero;
             if (ws_alloc(ws, &ws->sym_tiles, sizeof(int4) * tiles.size())) return -1;
             if (hipMemcpy(ws->sym_tiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
             ws->sym_ntiles = (int)tiles.size();
