@@ -266,7 +266,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        n_gpus, rccl_check = rccl_rank_count(torch, dist, rank, local_rank, world)
+        if args.mode == "sharded":
+            n_gpus, rccl_check = rccl_rank_count(torch, dist, rank, local_rank, world)
+        # (headline mode: the library's own communicator is counted AFTER the timed region, under the watchdog below -- a collective of
+        # the N > 1 RCCL path that never returns must not cost the headline line; until then n_gpus is torch.distributed's world size)
 
     import sfm_toy_library_amd as sfm
     from sfm_toy_library_amd import capi
@@ -331,7 +334,10 @@ def main():
         dist.all_reduce(tot[:2], op=dist.ReduceOp.SUM)
         tot[2], tot[3] = tmax[0], tmin[0]
     g_iters, g_evals, g_dt, g_par = [float(v) for v in tot.tolist()]
+    if world > 1:
+        n_gpus = dist.get_world_size()
 
+    line = None
     if rank == 0:
         n_obs, n_pt, n_cam = prob.n_obs, prob.n_pt, prob.n_cam
         s_o = 4 if precision == 1 else 8
@@ -364,8 +370,6 @@ def main():
             # every rank's result against the oracle's stored one for its own problem (None: nothing stored for this workload)
             "parity_ok": None if par["parity_ok"] is None else bool(g_par == 1.0), "parity_rank0": par,
         }
-        if rccl_check is not None:
-            line["rccl_check"] = rccl_check
         # fraction of the HBM roofline of the whole LM iteration (algorithmic bytes of SURVEY 8d)
         n_lin = 1 if linear == 0 else max(1.0, lin_iters / max(iters, 1))
         b_iter = algorithmic_bytes_per_iteration(n_obs, n_pt, n_cam, s_o, n_lin)
@@ -446,6 +450,38 @@ def main():
                                                "termination": s3["termination_name"],
                                                "note": "same resident problem and solver, CG tolerance 1e-3 instead of 1e-8; not the headline"}
     P.close()
+    # Everything from here on is beside the headline and must never cost it: exceptions are caught; against a collective that never returns
+    # (the N > 1 RCCL path has only ever run on one rank here) a watchdog prints the headline line as it stands and ends the process ...
+    import signal
+    import threading
+    want_sharded = args.sharded_extras == 1 or (args.sharded_extras == -1 and world > 1)
+    sh = {} if want_sharded else None
+    stage = ["the RCCL rank count"]
+    watchdog, old_term = None, None
+
+    def bail(why):
+        if rank == 0:
+            line["abandoned"] = "%s during %s" % (why, stage[0])
+            if sh:
+                line["sharded"] = dict(sh)
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+    if world > 1 or want_sharded:
+        watchdog = threading.Timer(args.extras_timeout, lambda: bail("not finished within %d s: abandoned" % args.extras_timeout))
+        watchdog.daemon = True
+        watchdog.start()
+        # ... and against a PEER that dies in them: the launcher then sends the surviving ranks SIGTERM -- rank 0 prints the line first
+        old_term = signal.signal(signal.SIGTERM, lambda signum, frame: bail("terminated (signal %d: a peer rank ended)" % signum))
+    if world > 1:
+        # n_gpus = what RCCL itself reports for the library's own communicator (a mismatch is refused: SystemExit, no line)
+        try:
+            n_gpus, rccl_check = rccl_rank_count(torch, dist, rank, local_rank, world)
+        except Exception as e:                  # (n_gpus stays torch.distributed's world size, and the line says so)
+            rccl_check = {"error": "%s: %s" % (type(e).__name__, e), "n_gpus_is": "torch.distributed world size"}
+        if rank == 0:
+            line["n_gpus"] = n_gpus
+            line["rccl_check"] = rccl_check
+    stage[0] = "cfg4_replicas"
     if world > 1 and args.workload == "cfg3":
         # BASELINE config 4 as written: one 25-camera sub-problem per GPU (all ranks take part; rank 0 reports)
         try:
@@ -455,42 +491,20 @@ def main():
         if rank == 0:
             line["cfg4_replicas"] = c4
     # ---- the path with a real exchange step: one problem, points sharded over the ranks (all ranks take part) ----
-    want_sharded = args.sharded_extras == 1 or (args.sharded_extras == -1 and world > 1)
-    sh = None
     if want_sharded:
-        sh = {}
-        # The extras must never cost the headline: exceptions are caught below; against a collective that never returns (the N > 1
-        # RCCL path has only ever run on one rank here) a watchdog prints the headline line as it stands and ends the process.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                line["sharded"] = dict(sh, error="sharded extras did not finish within %d s: abandoned" % args.extras_timeout)
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(args.extras_timeout, give_up)
-        watchdog.daemon = True
-        watchdog.start()
-        # ... and against a PEER that dies in them: the launcher then sends the surviving ranks SIGTERM -- rank 0 prints the line first
-        import signal
-
-        def on_term(signum, frame):
-            if rank == 0:
-                line["sharded"] = dict(sh, error="terminated (signal %d) during the sharded extras: a peer rank ended" % signum)
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-        old_term = signal.signal(signal.SIGTERM, on_term)
         # BASELINE config 5 first, and of its four forms the row-sharded one first: should the extras run out of their time,
         # what is lost is the least interesting; one synthetic problem per workload, shared by its forms
         for wl in (["cfg5", "cfg3"] if args.workload == "cfg3" else [args.workload]):
             wl_prob = sfm.make_problem(wl)
             for variant in ("row_sharded_cg", "replicated_cg", "distributed_cg", "implicit_schur_cg"):
                 key = wl if variant == "replicated_cg" else wl + "_" + variant
+                stage[0] = "the sharded extras (%s)" % key
                 try:
                     sh[key] = sharded_run(wl, args, rank, local_rank, world, torch, dist, sfm, capi, precision, linear, steps=max(3, min(args.steps, 10)),
                                           distributed={"replicated_cg": 0, "distributed_cg": 1, "implicit_schur_cg": 2, "row_sharded_cg": 3}[variant], prob=wl_prob)
                 except Exception as e:                       # never lose the headline line to the extras
                     sh[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if watchdog is not None:
         watchdog.cancel()
         signal.signal(signal.SIGTERM, old_term)
     if rank == 0:

@@ -28,7 +28,9 @@
  * lm_trust_region() below is one function that runs both the bundle adjustment and Powell's
  * function, and on the latter it reproduces the minimizer output Ceres itself published in its
  * tutorial to every printed digit (14 rows x 6 numbers, the final cost and x, the gradient of the
- * termination message: tests/golden/ceres_powell_trace.json, tests/test_oracle_kat.py).  The
+ * termination message: tests/golden/ceres_powell_trace.json, tests/test_oracle_kat.py) -- and
+ * the tutorial's first example (f = 10 - x: three rows, ending on the PARAMETER tolerance, the
+ * brief report's iteration count and final cost: tests/golden/ceres_helloworld_trace.json).  The
  * Schur elimination underneath is cross-checked against scipy.optimize.least_squares, the KKT
  * conditions and the full normal equations (tests/test_oracle_solver.py).
  */
@@ -1168,7 +1170,8 @@ ORACLE_API int sfmba_oracle_solve(int n_cam, double* cam6, int n_pt, double* pt3
 /* ---- a DENSE model of the same loop: m residuals of n parameters with a caller-supplied evaluator; the LM step by Householder QR of the
  * stacked [J~; sqrt(D)] (DENSE_QR [Ceres-upstream]: the solver the Ceres tutorial runs Powell's function with).  This is how the loop above is
  * anchored to output Ceres itself published.  problem: 0 = Powell's function (examples/powell.cc [Ceres-upstream], four residuals of four
- * parameters: f1 = x1 + 10 x2, f2 = sqrt(5) (x3 - x4), f3 = (x2 - 2 x3)^2, f4 = sqrt(10) (x1 - x4)^2). ---- */
+ * parameters: f1 = x1 + 10 x2, f2 = sqrt(5) (x3 - x4), f3 = (x2 - 2 x3)^2, f4 = sqrt(10) (x1 - x4)^2); 1 = the tutorial's first example,
+ * f = 10 - x from x = 0.5 (examples/helloworld.cc [Ceres-upstream]; its three-row minimizer table is printed in the tutorial as well). ---- */
 enum { DENSE_MAX_N = 8, DENSE_MAX_M = 8 };
 typedef struct {
     int problem, n, m;
@@ -1190,6 +1193,11 @@ static int dense_eval(int problem, const double* x, double* r, double (*J)[DENSE
             J[2][1] = 2.0 * (x[1] - 2.0 * x[2]); J[2][2] = -4.0 * (x[1] - 2.0 * x[2]);
             J[3][0] = 2.0 * s10 * (x[0] - x[3]); J[3][3] = -2.0 * s10 * (x[0] - x[3]);
         }
+        return 0;
+    }
+    if (problem == 1) {          /* examples/helloworld.cc [Ceres-upstream]: one residual f = 10 - x */
+        r[0] = 10.0 - x[0];
+        if (J) { memset(J, 0, sizeof(double) * DENSE_MAX_M * DENSE_MAX_N); J[0][0] = -1.0; }
         return 0;
     }
     return 1;
@@ -1276,7 +1284,7 @@ static void dm_accept(void* c) { dense_model* d = (dense_model*)c; memcpy(d->x, 
 /* x [n] in-out.  The options are the solver's (the reference's: BA.cpp:171-177 + Ceres defaults); the linear solver field is ignored (dense QR). */
 ORACLE_API int sfmba_oracle_solve_dense(int problem, int n, double* x, const sfmba_options* opt_in, sfmba_summary* summary,
                                         sfmba_iteration* trace, int trace_cap, int* trace_len) {
-    if (problem != 0 || n != 4 || !x) return SFMBA_ERR_INVALID_ARG;
+    if (!x || !((problem == 0 && n == 4) || (problem == 1 && n == 1))) return SFMBA_ERR_INVALID_ARG;
     sfmba_options opt;
     if (opt_in) opt = *opt_in; else sfmba_oracle_options_default(&opt);
     sfmba_summary sum;
@@ -1285,15 +1293,15 @@ ORACLE_API int sfmba_oracle_solve_dense(int problem, int n, double* x, const sfm
     const double t_start = wall_seconds();
     dense_model d;
     memset(&d, 0, sizeof(d));
-    d.problem = problem; d.n = 4; d.m = 4;
-    memcpy(d.x, x, sizeof(double) * 4);
+    d.problem = problem; d.n = n; d.m = n;
+    memcpy(d.x, x, sizeof(double) * (size_t)n);
     const lm_model model = { &d, dm_x_norm, dm_linearise, dm_gradient_max, dm_jacobi_scale_init, dm_apply_scale, dm_lm_diagonal, dm_solve,
                              dm_model_cost_change, dm_candidate, dm_accept };
     double cost = 0.0;
     lm_trust_region(&model, &opt, &sum, &cost, trace, trace_cap, &tl, t_start);
     sum.final_cost = cost;
     sum.seconds = wall_seconds() - t_start;
-    memcpy(x, d.x, sizeof(double) * 4);
+    memcpy(x, d.x, sizeof(double) * (size_t)n);
     if (summary) *summary = sum;
     if (trace_len) *trace_len = tl;
     return SFMBA_OK;
