@@ -1007,7 +1007,7 @@ def roofline_entry(profile, prob, precision, all_kernels=False):
         if len(stage) >= 3:
             launches = max(profile["point_build"]["launches"], 1)
             us = sum(profile[k]["total_us"] for k in stage) / launches
-            alg = prob.n_obs * (8 + 2 * t) + 24 * prob.n_pt + 48 * prob.n_cam + 8 * (6 * prob.n_cam + 1) ** 2
+            alg = prob.n_obs * (8 + 2 * t) + 24 * prob.n_pt + 48 * prob.n_cam + model["schur_pairs"]["bytes"]
             moved = sum(model[k].get("moved", model[k].get("bytes", 0)) for k in stage if k in model)
             tr = {k: pmc_traffic(k) for k in stage}
             covered = [k for k in stage if tr[k] is not None]
@@ -1032,6 +1032,11 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
     nb = 64
     nblk = (d + 1 + nb - 1) // nb
     b_res = n_obs * (8 + 2 * t) + 24 * n_pt + 48 * n_cam          # one residual evaluation (B_res)
+    # the reduced matrix as this path stores it: both triangles in fp64 up to d = 1280 (the register-resident CG); above, ONE triangle
+    # (symmetric streaming CG, round 6), in fp32 when the Jacobians are (F32J)
+    sym = d > 1280
+    b_mat = (t * d * (d + 1) // 2) if sym else 8 * d * d
+    mat_txt = ("one triangle of the reduced matrix in %s (%d d (d + 1) / 2)" % ("fp32" if t == 4 else "fp64", t)) if sym else "the reduced matrix (8 d^2)"
     pa = 64 if t == 4 else 80          # PtRecA / PtRecB of the per-point table (sfmba_device.h)
     pb = 24 if t == 4 else 48
     return {
@@ -1040,9 +1045,9 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
                         "note": "algorithmic: one pass over observations, points and cameras (B_res); moved: the two observation indices and the coordinates, "
                                 "per point the scales, t, M and the table entry every other pass re-evaluates from (64 + 24 bytes); nothing is written per "
                                 "observation (rounds 1 - 3 wrote a 64-byte record each)"},
-        "schur_pairs": {"bound": "hbm", "bytes": 8 * d * d,
-                        "moved": 4 * npair + n_pt * pa + 8 * d * d,
-                        "note": "algorithmic: the reduced matrix written once (8 d^2); moved: + the pair-point list (4 bytes per pair) and the point table once "
+        "schur_pairs": {"bound": "hbm", "bytes": b_mat,
+                        "moved": 4 * npair + n_pt * pa + b_mat,
+                        "note": "algorithmic: " + mat_txt + " written once; moved: + the pair-point list (4 bytes per pair) and the point table once "
                                 "(it stays in L2: every pair re-reads its entry from there); no per-observation record is gathered"},
         "cam_diag": {"overhead_only": True, "bytes": 96 * n_cam + 8 * d,
                      "moved": n_obs * (4 + 2 * t) + n_pt * (pa + pb),
@@ -1053,10 +1058,14 @@ def kernel_models(n_obs, n_pt, n_cam, d, t):
                          "moved": n_obs * (4 + 4 + 2 * t) + n_pt * (pa + 24 + 48 + 24 + 24),
                          "note": "one residual evaluation (B_res) + the trial points written; moved: observation indices and coordinates, per point the table "
                                  "entry, t, M, the point and the trial point (no per-observation record since round 4)"},
-        "pcg_iter": {"bound": "hbm", "label": "l2_mall_latency", "bytes": 8 * d * d + 9 * 8 * d, "cache_resident": 8 * d * d <= 64 << 20,
-                     "note": "one CG iteration = one launch: reads its rows of the preconditioned reduced matrix S~ once "
-                             "(8 d^2 bytes) + the x/r/p/q vectors; launch/latency bound (d = %d): the matrix is re-read from "
-                             "L2/MALL every launch because L2 does not survive the kernel boundary" % d},
+        "pcg_iter": ({"bound": "hbm", "bytes": b_mat + 9 * 8 * d,
+                      "note": "one CG iteration = two launches (k_sy_vec + k_sy_prod): " + mat_txt + " read once, every entry used twice, + the x/r/p/q "
+                              "vectors; the event bracket spans whole batches INCLUDING their early-exit launches: compare profiles/r06_ab_sy_prod_bisect.txt "
+                              "(17.9 + 7.5 us per real iteration at d = 6001)"} if sym else
+                     {"bound": "hbm", "label": "l2_mall_latency", "bytes": 8 * d * d + 9 * 8 * d, "cache_resident": 8 * d * d <= 64 << 20,
+                      "note": "one CG iteration = one launch: reads its rows of the preconditioned reduced matrix S~ once "
+                              "(8 d^2 bytes) + the x/r/p/q vectors; launch/latency bound (d = %d): the matrix is re-read from "
+                              "L2/MALL every launch because L2 does not survive the kernel boundary" % d}),
         "chol_update": {"bound": "mfma", "flops": d * d * d / 3.0 / max(nblk - 1, 1), "peak_tflops": 78.6,
                         "note": "fp64 trailing update on v_mfma_f64_16x16x4_f64; d^3/3 flops of the factorisation spread over its launches; "
                                 "peak = fp64 matrix 78.6 TF (171 tiles of 64^3 at most: latency bound, not MFMA bound)"},
