@@ -1366,6 +1366,10 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
     if ((n_cam > 0 && !cam6) || (n_pt > 0 && !pt3) || (n_obs_new > 0 && (!obs_cam || !obs_pt || !obs_xy)))
         return fail(SFMBA_ERR_INVALID_ARG, "NULL array");
     HIP_TRY(hipSetDevice(p->device));
+    const bool at_on = std::getenv("SFMBA_BUILD_TIMING") != nullptr;
+    auto at_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double at_t = at_now();
+    auto at_mark = [&](const char* what) { if (at_on) { const double t = at_now(); std::fprintf(stderr, "[sfmba append] %-18s %.3f ms\n", what, 1e3 * (t - at_t)); at_t = at_now(); } };
     // (the observations of an added view are scattered over the points: the three loops over them cost their cache misses.  The
     // check pulls the slot entries in, the slot loop the counters of build_structure's loop.)
     p->cam_slot.resize((size_t)n_cam, -1); p->pt_slot.resize((size_t)n_pt, -1);
@@ -1374,7 +1378,9 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
             return fail(SFMBA_ERR_INVALID_ARG, "observation index out of range");
         __builtin_prefetch(&p->pt_slot[(size_t)obs_pt[k]], 1);
     }
+    at_mark("check indices");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    at_mark("sync (idle stream)");
     // (argument errors are behind us: from here on the problem is being replaced)
     p->reset_pending = false;           // the parameters are replaced by the caller's below
     // cameras / points that become observed get the next free slot (slot order = order of first observation)
@@ -1401,11 +1407,14 @@ int sfmba_problem_append(sfmba_problem* p, int n_cam, const double* cam6, int n_
     if (p->db.trace && !p->trace_mapped) { (void)hipFree(p->db.trace); }
     p->db.trace = nullptr; p->db.trace_cap = 0; p->trace_mapped = false;
     p->cur = 0;
+    at_mark("slots, arena swap");
     const int rc = build_structure(p, src, cam6, pt3, focal, false);
+    at_mark("build_structure");
     // not failure-atomic (the old structure is gone, counts and slot tables are already the new ones): a failed build leaves the
     // handle POISONED -- every entry point refuses it from here on, only sfmba_problem_destroy is valid (include/sfmba.h)
     if (rc != SFMBA_OK) { p->poisoned = true; (void)hipStreamSynchronize(p->stream); return rc; }
     if (hipStreamSynchronize(p->stream) != hipSuccess) { p->poisoned = true; return fail(SFMBA_ERR_HIP, "structure build did not complete"); }
+    at_mark("final sync");
     return rc;      // `old` releases the previous structure here
 }
 
