@@ -640,8 +640,9 @@ __global__ __launch_bounds__(256) void k_pcg_iter(int d, int ld, const FT* __res
 // ONE TILE PER WORKGROUP: every load of the product is in flight as soon as the launch starts (2 396 workgroups at d = 6001).  A row of q collects
 // sums from every tile of its row strip and of its column chunk: fp64 device-scope atomics on a zeroed q buffer, every atomic instruction on
 // CONSECUTIVE addresses (tools/micro/symv_bench.hip: the memory side retires ~6 G line-sized atomic transactions per second whatever they carry;
-// 48 k of them per product cost nothing next to the stream -- 12 - 14 us, 5.2 - 5.9 TB/s of the 72 MB, against 27.8 us for both triangles --, the
-// 2 M of a form with one flush per wave and strided lanes cost 100 us).
+// 48 k of them per product cost nothing next to the stream -- 14.7 us = 4.9 TB/s of the 72 MB under rocprofv3, against 27 - 32 us for both triangles --,
+// the 2 M of a form with one flush per wave and strided lanes cost 100 us).  In the solve: 17.9 us per launch, of which 15.0 the bare product and 1.8 the
+// epilogue below (profiles/r06_ab_sy_prod_bisect.txt: occupancy, the prologue's scalar round trips, an unmasked path for interior tiles do not move it).
 // What does NOT survive a grid of 2 396 workgroups is the vector phase of k_pcg_iter (every workgroup forms alpha, |r - alpha q|^2, beta from the
 // whole vectors: 96 KB from L2 per workgroup -- measured +5 ... +10 us at 512 ... 1 024 workgroups in the same micro-benchmark, fused forms of the
 // iteration land at 20 - 26 us).  So an iteration is TWO launches here:
