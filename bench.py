@@ -110,13 +110,31 @@ def ensure_ranks(args):
             raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing (a run on fewer devices would not be an N-GPU number)"
                              % (args.gpus, have))
     import socket
-    with socket.socket() as sk:                       # a free port on the loop-back interface for the rendezvous
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stdout.flush(); sys.stderr.flush()
-    os.execv(sys.executable, cmd)                     # does not return
+    import subprocess
+    # The ranks run as a child `python -m torch.distributed.run ...` whose stdio is this process's.  The rendezvous port is picked here and
+    # bound by the child a moment later: if somebody else takes it in between the child dies within seconds -- a launch that fails that
+    # early (before any rank could have printed a line) is repeated on a fresh port, twice at most.
+    rc = 1
+    for attempt in range(3):
+        with socket.socket() as sk:                   # a free port on the loop-back interface for the rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush(); sys.stderr.flush()
+        t0 = time.time()
+        child = subprocess.Popen(cmd)
+        import signal
+        old = {sg: signal.signal(sg, lambda signum, frame: child.send_signal(signum)) for sg in (signal.SIGTERM, signal.SIGINT)}      # (what ends this process ends the ranks)
+        try:
+            rc = child.wait()
+        finally:
+            for sg, h in old.items():
+                signal.signal(sg, h)
+        if rc == 0 or time.time() - t0 > 20.0:
+            break
+        sys.stderr.write("bench.py: the launcher exited with %d after %.1f s (attempt %d of 3)\n" % (rc, time.time() - t0, attempt + 1))
+    raise SystemExit(rc)
 
 
 def parity_vs_oracle(summ, n_obs, key, tol_rel_cost=1e-6):
