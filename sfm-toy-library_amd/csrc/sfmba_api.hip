@@ -1034,14 +1034,44 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         HIP_TRY(dev_alloc(&p->d_dup_blocks, (size_t)ncam));
         return SFMBA_OK;
     };
+    // ---- parameters.  Slot order = order of first observation; when every camera / point of the caller's arrays is observed and the slots came
+    // out in index order (the usual case: point-major observation lists), the arrays go up as they are.  Runs on the helper thread behind the host
+    // half (round 6: the helper had 0.24 ms to spare at BASELINE config 3 + one view while this thread enqueued; the copies are synchronous, NULL stream) ----
+    auto params_half = [&]() -> int {
+        bool cam_identity = (size_t)ncam == p->cam_slot.size(), pt_identity = (size_t)npt == p->pt_slot.size();
+        for (int j = 0; j < ncam && cam_identity; ++j) cam_identity = p->acam_id[j] == j;
+        for (int i = 0; i < npt && pt_identity; ++i) pt_identity = p->apt_id[i] == i;
+        p->cam_identity = cam_identity; p->pt_identity = pt_identity;
+        const double* cam_src = cam6;
+        const double* pts_src = pt3;
+        if (!cam_identity) {
+            cam0.resize((size_t)6 * ncam);
+            for (int j = 0; j < ncam; ++j) std::memcpy(&cam0[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
+            cam_src = cam0.data();
+        }
+        if (!pt_identity) {
+            pts0.resize((size_t)3 * npt);
+            for (int i = 0; i < npt; ++i) std::memcpy(&pts0[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
+            pts_src = pts0.data();
+        }
+        HIP_TRY(dev_alloc(&p->d_cam0, (size_t)6 * ncam));
+        HIP_TRY(dev_alloc(&p->d_pts0, (size_t)3 * npt));
+        if (ncam > 0) HIP_TRY(hipMemcpy(p->d_cam0, cam_src, sizeof(double) * 6 * (size_t)ncam, hipMemcpyHostToDevice));
+        if (npt > 0) HIP_TRY(hipMemcpy(p->d_pts0, pts_src, sizeof(double) * 3 * (size_t)npt, hipMemcpyHostToDevice));
+        return SFMBA_OK;
+    };
     int host_rc = SFMBA_OK;
     std::string host_msg;
     BuildHelper::Lease helper(BuildHelper::instance());
     auto host_task = [&] {
         (void)hipSetDevice(device);
         ArenaScope helper_scope(&p->arena);
+        const double th0 = bt_now();
         host_rc = host_half();
+        const double th1 = bt_now();
+        if (host_rc == SFMBA_OK && counts_state.load() > 0) host_rc = params_half();
         if (host_rc != SFMBA_OK) host_msg = g_last_error;
+        if (bt_on) std::fprintf(stderr, "[sfmba build] (helper) host half   %.3f ms + parameters %.3f ms\n", 1e3 * (th1 - th0), 1e3 * (bt_now() - th1));
     };
     if (helper.granted()) helper.post(host_task); else host_task();        // (another build has the helper: everything on this thread)
     bt_mark("post");
@@ -1101,90 +1131,14 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
         p->d_cam_obs_xy = cxy;
     }
     bt_mark("enqueue sorts");
-    {
-        // ---- parameters (on this thread: the helper has the longer half).  Slot order = order of first observation; when every
-        // camera / point of the caller's arrays is observed and the slots came out in index order (the usual case: point-major
-        // observation lists), the arrays go up as they are ----
-        bool cam_identity = (size_t)ncam == p->cam_slot.size(), pt_identity = (size_t)npt == p->pt_slot.size();
-        for (int j = 0; j < ncam && cam_identity; ++j) cam_identity = p->acam_id[j] == j;
-        for (int i = 0; i < npt && pt_identity; ++i) pt_identity = p->apt_id[i] == i;
-        p->cam_identity = cam_identity; p->pt_identity = pt_identity;
-        const double* cam_src = cam6;
-        const double* pts_src = pt3;
-        if (!cam_identity) {
-            cam0.resize((size_t)6 * ncam);
-            for (int j = 0; j < ncam; ++j) std::memcpy(&cam0[6 * (size_t)j], cam6 + 6 * (size_t)p->acam_id[j], 6 * sizeof(double));
-            cam_src = cam0.data();
-        }
-        if (!pt_identity) {
-            pts0.resize((size_t)3 * npt);
-            for (int i = 0; i < npt; ++i) std::memcpy(&pts0[3 * (size_t)i], pt3 + 3 * (size_t)p->apt_id[i], 3 * sizeof(double));
-            pts_src = pts0.data();
-        }
-        HIP_TRY(dev_alloc(&p->d_cam0, (size_t)6 * ncam));
-        HIP_TRY(dev_alloc(&p->d_pts0, (size_t)3 * npt));
-        if (ncam > 0) HIP_TRY(hipMemcpy(p->d_cam0, cam_src, sizeof(double) * 6 * (size_t)ncam, hipMemcpyHostToDevice));
-        if (npt > 0) HIP_TRY(hipMemcpy(p->d_pts0, pts_src, sizeof(double) * 3 * (size_t)npt, hipMemcpyHostToDevice));
-    }
-    bt_mark("upload params");
-    helper.wait();
-    if (host_rc != SFMBA_OK) return fail(host_rc, host_msg);
-    bt_mark("join host half");
-    // what depends on the block CSR is filled in by the device, behind the pair sort: the pair-pass descriptors and the list of
-    // diagonal blocks that contain pairs (the same camera observing a point twice; handled by a separate pass).  The number of
-    // those and the device's own pair total come back through host-mapped memory and are read after the one wait below.
-    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
-    volatile int* build_report = reinterpret_cast<volatile int*>(p->kit.pinned + 1536);      // [1536, 1568) of the mailbox slice
-    build_report[0] = -1;
-    int* d_report = reinterpret_cast<int*>(p->d_pinned + 1536);
-    build_report[1] = -1; build_report[4] = -1; build_report[5] = -1; build_report[6] = -1; build_report[7] = -1;
-    HIP_TRY(hipMemsetAsync(p->d_build_counters, 0, 4 * sizeof(int), p->stream));
-    if (pwg_blocks.empty()) {
-        build_report[4] = 0; build_report[5] = 0; build_report[7] = 0;      // (a row-sharded rank without a block row, or no pair list: no pair pass)
-    } else if (pair_lpb == 64) {
-        const int crc = build_pair_chunks(p->stream, &staging, (int)pwg_blocks.size(), SFMBA_PAIR_CHUNK, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr,
-                                          p->d_pwg_desc, p->d_pwg_chunk, p->d_multi_slots, p->d_build_counters, d_report);
-        if (crc) return fail(SFMBA_ERR_HIP, std::string("pair-chunk descriptors: ") + hipGetErrorString((hipError_t)crc));
-    } else {
-        // sixteen lanes per block: the blocks of a row grouped by rounds of sixteen pairs (a wave holds four of them and loops to the longest)
-        int* d_perm = staging.alloc_n<int>((size_t)nblock);
-        if (!d_perm) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
-        launch_row_order(p->stream, ncam, pair_lpb, p->d_blk_ptr, d_perm);
-        launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, d_perm, p->d_pwg_desc);
-    }
-    launch_block_fill(p->stream, nblock, ncam, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
-    p->d_blk_mask = nullptr;
-    if (6 * ncam + 1 > 1280 && !sharded && !no_pairs) {       // (the streaming CG kernels: a sparsely filled reduced matrix is multiplied block-sparse there)
-        HIP_TRY(dev_alloc(&p->d_blk_mask, (size_t)ncam * (size_t)((ncam + 31) / 32)));
-        launch_block_mask(p->stream, ncam, p->d_blk_ptr, p->d_blk_mask);
-    }
-    launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, d_report);
-    HIP_TRY(hipGetLastError());
-    p->focal0 = p->focal = focal;
-
+    // ---- the buffers of the solve: sized by (cameras, points, observations) alone, carved out of the arena and zeroed WHILE the helper thread finishes
+    // its half (descriptors, parameters); what depends on that half -- chunk counts, the pair-pass descriptors -- follows the join ----
     DeviceStructure& ds = p->ds;
     ds = DeviceStructure{};
     ds.ncam = ncam; ds.npt = npt; ds.nobs = nobs;
     ds.d = 6 * ncam + 1;
     ds.ld = dense_padded_dim(ds.d);
-    ds.pt_ptr = p->d_pt_ptr; ds.pt_order = p->d_pt_order; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
-    ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt; ds.cam_obs_xy = p->d_cam_obs_xy;
-    // row-sharded: a contiguous, equally sized share of the camera-major chunks per rank (every chunk is <= 256 entries of one camera)
-    p->own_chunk0 = 0; p->own_chunk1 = (int)chunks.size(); p->own_coarse0 = 0; p->own_coarse1 = (int)chunks_coarse.size();
-    if (rowsh) {
-        const long long nc_ = (long long)chunks.size(), ncc = (long long)chunks_coarse.size(), r_ = p->shard_rank, w_ = p->shard_world;
-        p->own_chunk0 = (int)(nc_ * r_ / w_); p->own_chunk1 = (int)(nc_ * (r_ + 1) / w_);
-        p->own_coarse0 = (int)(ncc * r_ / w_); p->own_coarse1 = (int)(ncc * (r_ + 1) / w_);
-    }
-    ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks; ds.chunk_order = p->d_chunk_order; ds.coarse_order = p->d_coarse_order;
-    ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
-    ds.obs_pt = p->d_obs_pt;
-    ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pair_pt = p->d_pair_pt;
-    ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
-    ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
-    ds.pwg_chunk = pair_lpb == 64 ? p->d_pwg_chunk : nullptr; ds.nmulti = 0; ds.multi_slots = p->d_multi_slots;      // counts: after the wait at the end
-    ds.ndupwg = 0; ds.dup_blocks = p->d_dup_blocks;          // count: after the wait at the end
-
+    ds.nblock = nblock;          // (shard_offdiag_len below sizes the exchange buffer from it)
     DeviceBuffers& db = p->db;
     db = DeviceBuffers{};
     for (int b = 0; b < 2; ++b) {
@@ -1234,6 +1188,75 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     db.shared_weight = 1.0;
     db.shard_blocks = nullptr; db.shard_blocks32 = nullptr; db.shard_scal = nullptr;
     HIP_TRY(dev_alloc(&db.st, 1));
+    // padding of the reduced system (rows/columns >= d) is zero apart from the identity diagonal set by k_finalize
+    HIP_TRY(hipMemsetAsync(p->d_sys, 0, sizeof(double) * sys_len, p->stream));
+    HIP_TRY(dev_alloc(&p->d_info, 2));
+    HIP_TRY(hipMemsetAsync(p->d_info, 0, 2 * sizeof(int), p->stream));
+    db.lin_info = p->d_info;
+    db.fin_counter = p->d_info + 1;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
+    db.lm_mailbox = reinterpret_cast<int*>(p->d_pinned + 1024);
+    db.st_mirror = reinterpret_cast<LMState*>(p->d_pinned);
+    db.trace = nullptr; db.trace_cap = 0; p->trace_mapped = false;
+    dense_solver_destroy(&p->solver);
+    if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
+    db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
+    db.pcg_binv = p->solver.binv;
+    HIP_TRY(dev_alloc(&db.pair_G, (size_t)36 * std::max(ncam, 1)));
+    bt_mark("alloc buffers");
+    helper.wait();
+    if (host_rc != SFMBA_OK) return fail(host_rc, host_msg);
+    bt_mark("join host half");
+    // what depends on the block CSR is filled in by the device, behind the pair sort: the pair-pass descriptors and the list of
+    // diagonal blocks that contain pairs (the same camera observing a point twice; handled by a separate pass).  The number of
+    // those and the device's own pair total come back through host-mapped memory and are read after the one wait below.
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
+    volatile int* build_report = reinterpret_cast<volatile int*>(p->kit.pinned + 1536);      // [1536, 1568) of the mailbox slice
+    build_report[0] = -1;
+    int* d_report = reinterpret_cast<int*>(p->d_pinned + 1536);
+    build_report[1] = -1; build_report[4] = -1; build_report[5] = -1; build_report[6] = -1; build_report[7] = -1;
+    HIP_TRY(hipMemsetAsync(p->d_build_counters, 0, 4 * sizeof(int), p->stream));
+    if (pwg_blocks.empty()) {
+        build_report[4] = 0; build_report[5] = 0; build_report[7] = 0;      // (a row-sharded rank without a block row, or no pair list: no pair pass)
+    } else if (pair_lpb == 64) {
+        const int crc = build_pair_chunks(p->stream, &staging, (int)pwg_blocks.size(), SFMBA_PAIR_CHUNK, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr,
+                                          p->d_pwg_desc, p->d_pwg_chunk, p->d_multi_slots, p->d_build_counters, d_report);
+        if (crc) return fail(SFMBA_ERR_HIP, std::string("pair-chunk descriptors: ") + hipGetErrorString((hipError_t)crc));
+    } else {
+        // sixteen lanes per block: the blocks of a row grouped by rounds of sixteen pairs (a wave holds four of them and loops to the longest)
+        int* d_perm = staging.alloc_n<int>((size_t)nblock);
+        if (!d_perm) return fail(SFMBA_ERR_ALLOC, "device allocation failed");
+        launch_row_order(p->stream, ncam, pair_lpb, p->d_blk_ptr, d_perm);
+        launch_pair_desc(p->stream, (int)pwg_blocks.size(), blocks_per_wg, p->d_pwg_blocks, p->d_blk_cams, p->d_blk_ptr, d_perm, p->d_pwg_desc);
+    }
+    launch_block_fill(p->stream, nblock, ncam, p->d_blk_cams, p->d_blk_ptr, p->d_build_counters, d_report);
+    p->d_blk_mask = nullptr;
+    if (6 * ncam + 1 > 1280 && !sharded && !no_pairs) {       // (the streaming CG kernels: a sparsely filled reduced matrix is multiplied block-sparse there)
+        HIP_TRY(dev_alloc(&p->d_blk_mask, (size_t)ncam * (size_t)((ncam + 31) / 32)));
+        launch_block_mask(p->stream, ncam, p->d_blk_ptr, p->d_blk_mask);
+    }
+    launch_dup_blocks(p->stream, ncam, p->d_blk_ptr, pm.pair_off + npt, p->d_dup_blocks, d_report);
+    HIP_TRY(hipGetLastError());
+    p->focal0 = p->focal = focal;
+
+    ds.pt_ptr = p->d_pt_ptr; ds.pt_order = p->d_pt_order; ds.obs_cam = p->d_obs_cam; ds.obs_xy = p->d_obs_xy;
+    ds.cam_ptr = p->d_cam_ptr; ds.cam_obs = p->d_cam_obs; ds.cam_obs_pt = p->d_cam_obs_pt; ds.cam_obs_xy = p->d_cam_obs_xy;
+    // row-sharded: a contiguous, equally sized share of the camera-major chunks per rank (every chunk is <= 256 entries of one camera)
+    p->own_chunk0 = 0; p->own_chunk1 = (int)chunks.size(); p->own_coarse0 = 0; p->own_coarse1 = (int)chunks_coarse.size();
+    if (rowsh) {
+        const long long nc_ = (long long)chunks.size(), ncc = (long long)chunks_coarse.size(), r_ = p->shard_rank, w_ = p->shard_world;
+        p->own_chunk0 = (int)(nc_ * r_ / w_); p->own_chunk1 = (int)(nc_ * (r_ + 1) / w_);
+        p->own_coarse0 = (int)(ncc * r_ / w_); p->own_coarse1 = (int)(ncc * (r_ + 1) / w_);
+    }
+    ds.nchunk = (int)chunks.size(); ds.chunks = p->d_chunks; ds.chunk_order = p->d_chunk_order; ds.coarse_order = p->d_coarse_order;
+    ds.nchunk_coarse = (int)chunks_coarse.size(); ds.chunks_coarse = p->d_chunks_coarse; ds.cam_chunk_ptr = p->d_cam_chunk_ptr;
+    ds.obs_pt = p->d_obs_pt;
+    ds.nblock = nblock; ds.blk_cams = p->d_blk_cams; ds.blk_ptr = p->d_blk_ptr; ds.pair_pt = p->d_pair_pt;
+    ds.npairwg = (int)pwg_blocks.size(); ds.pwg_blocks = p->d_pwg_blocks; ds.pair_lpb = pair_lpb;
+    ds.pwg_group = blocks_per_wg; ds.pwg_desc = p->d_pwg_desc;
+    ds.pwg_chunk = pair_lpb == 64 ? p->d_pwg_chunk : nullptr; ds.nmulti = 0; ds.multi_slots = p->d_multi_slots;      // counts: after the wait at the end
+    ds.ndupwg = 0; ds.dup_blocks = p->d_dup_blocks;          // count: after the wait at the end
+
     // Opt-in deterministic accumulation (SFMBA_DETERMINISTIC=1 when the problem is built): every workgroup of a launch owns its
     // accumulator slot and the multi-chunk camera sums are added in chunk order, so that no result depends on the order in which
     // fp64 atomics arrive -- two runs give bit-identical trajectories.  Costs ~10 % (longer slot sweeps, a serial chunk loop).
@@ -1247,23 +1270,8 @@ static int build_structure(sfmba_problem* p, const ObsSource& src, const double*
     HIP_TRY(dev_alloc(&p->d_facc, (size_t)db.nslot * SLOT_W));
     HIP_TRY(hipMemsetAsync(p->d_facc, 0, sizeof(double) * (size_t)db.nslot * SLOT_W, p->stream));
     db.slots = p->d_facc;
-    // padding of the reduced system (rows/columns >= d) is zero apart from the identity diagonal set by k_finalize
-    HIP_TRY(hipMemsetAsync(p->d_sys, 0, sizeof(double) * sys_len, p->stream));
-    HIP_TRY(dev_alloc(&p->d_info, 2));
-    HIP_TRY(hipMemsetAsync(p->d_info, 0, 2 * sizeof(int), p->stream));
-    db.lin_info = p->d_info;
-    db.fin_counter = p->d_info + 1;
-    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_pinned), p->kit.pinned, 0));
-    db.lm_mailbox = reinterpret_cast<int*>(p->d_pinned + 1024);
-    db.st_mirror = reinterpret_cast<LMState*>(p->d_pinned);
-    db.trace = nullptr; db.trace_cap = 0; p->trace_mapped = false;
-    dense_solver_destroy(&p->solver);
-    if (dense_solver_create(&p->solver, ds.d, ds.ld, &p->arena, p->kit.pinned + 2048)) return fail(SFMBA_ERR_ALLOC, "dense solver workspace allocation failed");
     p->solver.blk_mask = p->d_blk_mask;
-    db.pcg_bt = p->solver.vec + (size_t)8 * ds.ld;
-    db.pcg_binv = p->solver.binv;
-    HIP_TRY(dev_alloc(&db.pair_G, (size_t)36 * std::max(ncam, 1)));
-    bt_mark("alloc buffers");
+    bt_mark("descriptors");
     // the one wait of the build: sorts, lists and descriptors are in place; the staging arena and the host vectors may go
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (build_report[0] < 0 || (((long long)build_report[3] << 32) | (unsigned)build_report[2]) != npair_total)
