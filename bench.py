@@ -86,6 +86,13 @@ def parse():
     return ap.parse_args()
 
 
+def emit(obj):
+    """One JSON line in ONE write: torch.distributed.run starts its ranks with `python -u`, where print() hands the text and the newline to the
+    pipe separately -- two ranks' lines then come out glued together now and then."""
+    sys.stdout.write(json.dumps(obj) + "\n")
+    sys.stdout.flush()
+
+
 def ensure_ranks(args):
     """The contract is `python bench.py --gpus N`; the N > 1 form normally arrives wrapped in torch.distributed.run, but a plain invocation
     must not silently run ONE rank and print n_gpus = 1.  Returns (rank, local_rank, world) of THIS process; when N > 1 ranks
@@ -269,8 +276,8 @@ def main():
     args = parse()
     rank, local_rank, world = ensure_ranks(args)
     if args.launch_only:
-        print(json.dumps({"launch_only": True, "rank": rank, "local_rank": local_rank, "world_size": world, "gpus_arg": args.gpus,
-                          "master_addr": os.environ.get("MASTER_ADDR"), "pid": os.getpid()}), flush=True)
+        emit({"launch_only": True, "rank": rank, "local_rank": local_rank, "world_size": world, "gpus_arg": args.gpus,
+              "master_addr": os.environ.get("MASTER_ADDR"), "pid": os.getpid()})
         return
     import torch
     if not torch.cuda.is_available():
@@ -482,7 +489,7 @@ def main():
             line["abandoned"] = "%s during %s" % (why, stage[0])
             if sh:
                 line["sharded"] = dict(sh)
-            print(json.dumps(line), flush=True)
+            emit(line)
         os._exit(0)
     if world > 1 or want_sharded:
         watchdog = threading.Timer(args.extras_timeout, lambda: bail("not finished within %d s: abandoned" % args.extras_timeout))
@@ -529,7 +536,7 @@ def main():
         if sh is not None:
             line["sharded"] = sh
         _flush_c_stdio()
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -850,14 +857,14 @@ def main_sharded(args, rank, local_rank, world, torch, dist, sfm, capi, precisio
                     distributed=3 if args.row_sharded else 2 if args.implicit_cg else 1 if args.distributed_cg else 0)
     if rank == 0:
         _flush_c_stdio()
-        print(json.dumps({
+        emit({
             "metric": "BA LM iterations/sec", "value": r["value"], "unit": "LM iterations/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64" if precision == 0 else DTYPE_F32J,
             "data": "synthetic", "config": {"workload": r["workload"], "step": "one full LM solve to ceres CONVERGENCE",
                                             "lm_iterations_per_step": r["lm_iterations_per_step"], "collective": r["collective"]},
             "sharded": r, "final_rms_px": r["final_rms_px"], "final_cost": r["final_cost"], "termination": r["termination"],
-            "parity_ok": r.get("parity_ok")}), flush=True)
+            "parity_ok": r.get("parity_ok")})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
