@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Both forms run N ranks, one device each: started plain with N > 1 the script re-executes itself under torch.distributed.run (ensure_ranks), it refuses when
+Both forms run N ranks, one device each: started plain with N > 1 the script starts torch.distributed.run on itself (ensure_ranks), it refuses when
 fewer than N devices are visible or when --gpus contradicts the launcher's WORLD_SIZE, and the line's `n_gpus` is the rank count RCCL itself reports for the
 library's own communicator (rccl_rank_count).  Every number of the line -- headline, extra_workloads, cfg4, sharded.* -- carries `parity_ok` against the
 oracle's stored result for its problem (tests/golden/oracle_final_costs.json).
@@ -96,7 +96,7 @@ def emit(obj):
 def ensure_ranks(args):
     """The contract is `python bench.py --gpus N`; the N > 1 form normally arrives wrapped in torch.distributed.run, but a plain invocation
     must not silently run ONE rank and print n_gpus = 1.  Returns (rank, local_rank, world) of THIS process; when N > 1 ranks
-    are asked for and none were started, this process is REPLACED by `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`."""
+    are asked for and none were started, this process starts `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a child, waits for it and exits with its code."""
     started = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if started:
         world = int(os.environ["WORLD_SIZE"])
