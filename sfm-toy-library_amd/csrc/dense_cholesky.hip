@@ -358,10 +358,15 @@ __global__ __launch_bounds__(256, 1) void k_chol_step(double* __restrict__ A, in
 constexpr unsigned long long CHOL_X_PENDING = 0x7FF4C0DEC0DE0001ull;
 // rhs becomes row d of the matrix (the forward substitution rides along with the factorisation); its first `pending` entries are then
 // marked "not computed yet" for the back substitution, which overwrites rhs with the solution
+// ... and the padding rows d + 1 .. ld - 1 are written afresh (unit diagonal, zeros): the factorisation works in place and stores what it computes
+// for them -- zeros and ones as long as everything is finite, but a factorisation that ran into an indefinite or near-singular matrix (fp32 Jacobians on
+// a barely determined problem: tools/fuzz_parity.py found it) leaves 0 * inf = NaN there, nothing else ever rewrites those rows, and the last diagonal
+// tile of EVERY later factorisation contains them: one invalid step used to make every following step of the handle invalid.
 __global__ void k_augment(double* __restrict__ A, int ld, int d, double* __restrict__ rhs, int pending) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < d) AT(d, c) = rhs[c];
     if (c < pending) reinterpret_cast<unsigned long long*>(rhs)[c] = CHOL_X_PENDING;
+    if (c < ld) for (int i = max(c, d + 1); i < ld; ++i) AT(i, c) = i == c ? 1.0 : 0.0;
 }
 
 // y = L(d, 0:d) (forward-substituted rhs), zero in the padding
@@ -529,6 +534,7 @@ __global__ __launch_bounds__(256, 1) void k_chol_small(double* __restrict__ A, i
         const int r = idx % NB, c = idx / NB;
         double v = r >= c ? AT(r, c) : 0.0;
         if (r == d && c < d) v = rhs[c];             // the augmented row (the padded diagonal is already 1)
+        if (r > d) v = r == c ? 1.0 : 0.0;           // padding rows: never what an earlier (failed) factorisation stored there (see k_augment)
         U[r * CT_LDT + c] = v;
     }
     __syncthreads();
@@ -569,7 +575,7 @@ void dense_cholesky_solve(hipStream_t s, DenseSolver* ws, double* S, double* rhs
     const bool one_launch_back = nblk <= CHOL_FUSED_MAX_BLOCKS && nblk <= 64;
     { ProfScope ps(prof, KID_CHOL_AUGMENT, s);
       const int pending = one_launch_back ? nblk * NB : 0;
-      hipLaunchKernelGGL(k_augment, dim3((std::max(d, pending) + 255) / 256), dim3(256), 0, s, S, ld, d, rhs, pending); }
+      hipLaunchKernelGGL(k_augment, dim3((ld + 255) / 256), dim3(256), 0, s, S, ld, d, rhs, pending); }
     if (nblk <= CHOL_FUSED_MAX_BLOCKS) {
         // one launch per block column (k_chol_step); beyond ~2500 unknowns the redundant panel GEMMs of the fused step cost more than
         // the launch they save and the two-kernel form below takes over
