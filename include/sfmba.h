@@ -101,6 +101,16 @@ enum { SFMBA_PRECISION_F64  = 0,    /* everything fp64 (parity mode) */
 #define SFMBA_F32J_BUDGET_TRANSLATION  1e-5    /* 1.6e-6   camera translation / scale */
 #define SFMBA_F32J_BUDGET_FOCAL_REL    1e-6    /* 3.0e-9   the shared focal, relative */
 #define SFMBA_F32J_BUDGET_POINT_P999   2e-5    /* 1.5e-6   99.9th percentile of the point displacement / scale (the weakly constrained tracks above are the rest) */
+/* WHERE THE BUDGET DOES NOT APPLY (round 6, tests/fuzz_parity.py: 1 500 random shapes against the oracle; the fp64 modes follow it to <= 2e-8 of the
+ * final cost on every one of them, over runs of up to 343 LM iterations).  F32J is for WELL-DETERMINED problems -- several observations per point, a few
+ * hundred points per view, as every reconstruction the reference produces is.  On problems with about as many residuals as parameters (each point seen
+ * twice, a handful of points for dozens of views) or dominated by gross outliers, the LM run takes tens of iterations, the trust region grows past ~1e7,
+ * the damping falls below the rounding of the fp32 blocks and the reduced matrix stops being positive definite: steps become INVALID.  The library
+ * then divides the radius by 8 instead of Ceres' 2 (F32J only; fp64 keeps the reference's rule) and goes on, and the run converges -- but to a final
+ * cost that can differ from the fp64 one by 1e-4 .. 1e-3 relative, with a different iteration count, and not reproducibly from one run to the next (the
+ * order in which fp64 atomics arrive is enough to tip an accept / reject decision on such a landscape; SFMBA_CREATE_DETERMINISTIC fixes the order).
+ * Exactly satisfiable toy problems (final cost ~1e-8 of the initial one) end one LM iteration earlier or later than the oracle in F32J and with
+ * the CG at 1e-8: both at a cost of zero for every purpose.  Use the default -- fp64 with SFMBA_LINEAR_AUTO -- when in doubt. */
 
 /* Return codes of every entry point. */
 enum {

@@ -58,6 +58,7 @@ struct LMState {
     double max_radius, min_radius, min_relative_decrease, min_diag, max_diag;
     int max_consecutive_invalid;
     int retry;                // set by k_lm_control when it asked for more CG iterations (the LM iteration is not finished yet)
+    double invalid_shrink;    // factor on the radius after an INVALID step: 1/2 (Ceres, StepIsInvalid); 1/8 with fp32 Jacobians (init_state)
 };
 
 enum {

@@ -1652,7 +1652,7 @@ __device__ __forceinline__ void lm_control_body(const DeviceBuffers& db) {
             st->termination = SFMBA_FAILURE;
             st->message = MSG_INVALID_STEPS;
         } else {
-            st->radius *= 0.5;
+            st->radius *= st->invalid_shrink;
             st->unsuccessful++;
         }
     } else {

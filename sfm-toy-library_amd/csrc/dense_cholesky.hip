@@ -360,7 +360,7 @@ constexpr unsigned long long CHOL_X_PENDING = 0x7FF4C0DEC0DE0001ull;
 // marked "not computed yet" for the back substitution, which overwrites rhs with the solution
 // ... and the padding rows d + 1 .. ld - 1 are written afresh (unit diagonal, zeros): the factorisation works in place and stores what it computes
 // for them -- zeros and ones as long as everything is finite, but a factorisation that ran into an indefinite or near-singular matrix (fp32 Jacobians on
-// a barely determined problem: tools/fuzz_parity.py found it) leaves 0 * inf = NaN there, nothing else ever rewrites those rows, and the last diagonal
+// a barely determined problem: tests/fuzz_parity.py found it) leaves 0 * inf = NaN there, nothing else ever rewrites those rows, and the last diagonal
 // tile of EVERY later factorisation contains them: one invalid step used to make every following step of the handle invalid.
 __global__ void k_augment(double* __restrict__ A, int ld, int d, double* __restrict__ rhs, int pending) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

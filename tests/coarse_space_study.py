@@ -1,7 +1,7 @@
 """CPU study (numpy + the oracle's reduced system): how many CG iterations does the block-Jacobi-preconditioned reduced system of a
 realistic-co-visibility problem need with (a) no coarse space, (b) the 8 global gauge vectors of the product, (c) the same gauge vectors
 restricted to G contiguous groups of cameras (7 G + 1 vectors: piecewise similarity transforms, the near-null space of a camera chain)?
-    python tools/coarse_space_study.py [workload] [radius]"""
+    python tests/coarse_space_study.py [workload] [radius]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
 """F32J accuracy against the oracle on a few problems (max parameter difference, final cost, RMS), for the library selected by SFMBA_LIB.
-   python tools/f32j_accuracy.py      (runs on the GPU box)"""
+   python tests/f32j_accuracy.py      (runs on the GPU box)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -59,7 +59,7 @@ def test_incremental_sequence_matches_fresh_oracle_solves(capi, sfm, oracle, pre
             assert abs(s["final_cost"] - want[3]["final_cost"]) <= tol * want[3]["final_cost"]
             assert np.isclose(s["initial_cost"], want[3]["initial_cost"], rtol=1e-9)
             # F32J: the rounding of the fp32 Jacobian blocks moves a weakly held camera of these small sub-problems by 1e-5 .. 3e-5 at equal cost
-            # (the cost to 1e-6 above; tools/f32j_accuracy.py prints the same figures for other shapes)
+            # (the cost to 1e-6 above; tests/f32j_accuracy.py prints the same figures for other shapes)
             atol = 1e-7 if precision == 0 else 5e-5
             assert np.abs(cam - want[0]).max() <= atol and np.abs(pt - want[1]).max() <= atol
             # residual vector in the CALLER's observation order (old observations first, then each append's)
