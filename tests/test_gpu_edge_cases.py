@@ -140,3 +140,14 @@ def test_randomised_parity_sweep_finds_nothing(sfm):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "--cases", "250", "--seed", "21"], capture_output=True, text=True, timeout=900)
     tail = "\n".join(l for l in r.stdout.splitlines() if "Ceres Solver Report" not in l)[-3000:]
     assert r.returncode == 0 and "fuzz_parity: 250 cases: 0 HARD" in r.stdout, tail + r.stderr[-1500:]
+
+
+def test_randomised_sweep_of_the_handle_variants_finds_nothing(sfm):
+    """tests/fuzz_handles.py, one fixed sequence of 160 random shapes: handles that grow through sfmba_problem_append in one to four random steps (every
+    step's solve against the oracle's solve of that step's problem), deterministic handles (bit-identical twice, and on the oracle), matrix-free handles,
+    sfmba_problem_set_params with the oracle's solution."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_handles.py"), "--cases", "160", "--seed", "51"], capture_output=True, text=True, timeout=900)
+    tail = "\n".join(l for l in r.stdout.splitlines() if "Ceres Solver Report" not in l)[-3000:]
+    assert r.returncode == 0 and ": 0 mismatches" in r.stdout, tail + r.stderr[-1500:]
