@@ -151,3 +151,14 @@ def test_randomised_sweep_of_the_handle_variants_finds_nothing(sfm):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_handles.py"), "--cases", "160", "--seed", "51"], capture_output=True, text=True, timeout=900)
     tail = "\n".join(l for l in r.stdout.splitlines() if "Ceres Solver Report" not in l)[-3000:]
     assert r.returncode == 0 and ": 0 mismatches" in r.stdout, tail + r.stderr[-1500:]
+
+
+def test_randomised_sweep_of_the_sharded_forms_on_one_rank_finds_nothing(sfm):
+    """tests/fuzz_sharded.py, one fixed sequence of 120 random shapes through sfmba_problem_solve_sharded with a world of one: replicated solve,
+    distributed CG on owned blocks, implicit Schur product, sharded block rows -- every pack / transform / slice kernel of the exchange runs, the
+    collectives are the identity; options varied (plain block-Jacobi, fp64 exchange, one- / two-phase); solved twice per handle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_sharded.py"), "--cases", "120", "--seed", "61"], capture_output=True, text=True, timeout=900)
+    tail = "\n".join(l for l in r.stdout.splitlines() if "Ceres Solver Report" not in l)[-3000:]
+    assert r.returncode == 0 and ": 0 mismatches" in r.stdout, tail + r.stderr[-1500:]
