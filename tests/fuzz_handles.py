@@ -8,7 +8,7 @@ tests/fuzz_parity.py: for random shapes
 
     python tests/fuzz_handles.py [--cases N] [--seed S]
 
-Exit code 1 on any mismatch: termination, LM iteration count on runs of <= 40 iterations, final cost beyond 1e-7 (fp64, exact solver) / 1e-6 relative."""
+Exit code 1 on any mismatch: termination, LM iteration count on runs of <= 40 iterations, final cost beyond 1e-7 (fp64, exact solver) / 1e-5 relative (fp32 Jacobians, CG at 1e-8: their own bars are held by the parity tests)."""
 import argparse
 import os
 import sys
@@ -47,7 +47,7 @@ def main():
         long_run = s_o["iterations"] > LONG_RUN
         off = s["termination_name"] != s_o["termination_name"]
         if not tiny and not long_run:
-            off = off or (exact and s["iterations"] != s_o["iterations"]) or (rel > (1e-7 if exact else 1e-6) and abs(s["final_cost"] - s_o["final_cost"]) > floor)
+            off = off or (exact and s["iterations"] != s_o["iterations"]) or (rel > (1e-7 if exact else 1e-5) and abs(s["final_cost"] - s_o["final_cost"]) > floor)
         if off:
             bad += 1
             print("case %d %s MISMATCH: %s | oracle %s it %d cost %.12e | hip %s it %d cost %.12e (rel %.2e)" % (

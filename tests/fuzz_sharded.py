@@ -73,9 +73,9 @@ def main():
         tiny = s_o["final_cost"] <= 1e-9 * s_o["initial_cost"]
         off = s["termination_name"] != s_o["termination_name"]
         if not tiny and s_o["iterations"] <= LONG_RUN:
-            off = off or (exact and s["iterations"] != s_o["iterations"]) or (rel > (1e-7 if exact else 1e-6) and abs(s["final_cost"] - s_o["final_cost"]) > floor)
+            off = off or (exact and s["iterations"] != s_o["iterations"]) or (rel > (1e-7 if exact else 1e-5) and abs(s["final_cost"] - s_o["final_cost"]) > floor)
             rep = abs(s2["final_cost"] - s["final_cost"]) / scale
-            if s2["termination_name"] != s["termination_name"] or rep > 1e-6:
+            if s2["termination_name"] != s["termination_name"] or rep > 1e-5:
                 bad += 1
                 print("case %d NOT REPEATABLE after reset: %s | %s it %d cost %.12e, then %s it %d cost %.12e" % (
                     case, desc, s["termination_name"], s["iterations"], s["final_cost"], s2["termination_name"], s2["iterations"], s2["final_cost"]))
