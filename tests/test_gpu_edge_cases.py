@@ -162,3 +162,35 @@ def test_randomised_sweep_of_the_sharded_forms_on_one_rank_finds_nothing(sfm):
     distributed CG on owned blocks, implicit Schur product, sharded block rows -- every pack / transform / slice kernel of the exchange runs, the
     collectives are the identity; options varied (plain block-Jacobi, fp64 exchange, one- / two-phase); solved twice per handle."""
     _sweep("fuzz_sharded.py", 120, 61, ": 0 mismatches")
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("linear", [0, 1, 2])
+def test_a_handle_recovers_from_non_finite_parameters(capi, sfm, precision, linear):
+    """A resident handle whose parameters were non-finite (FAILURE at the initial point, BA.cpp:182-185) is given finite ones with
+    sfmba_problem_set_params: the next solve must be what a fresh handle gives -- nothing non-finite may survive in the accumulators, the reduced system or
+    the solver's workspace.  Both orders: NaN first, and NaN after a good solve."""
+    prob = sfm.make_problem("cfg2", n_cam=12, n_pt=600, views=4, seed=909)
+    opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear)
+    want = capi.solve(prob, opt)[3]
+    assert want["termination_name"] == "CONVERGENCE"
+    poisoned = prob.copy()
+    poisoned.cam6[3, 1] = np.nan
+    poisoned.pt3[17, 2] = np.inf
+    with capi.Problem(poisoned, precision=precision) as P:
+        s, _ = P.solve(opt)
+        assert s["termination_name"] == "FAILURE" and s["iterations"] == 0
+        for _ in range(2):
+            P.set_params(prob.cam6, prob.pt3, prob.focal)
+            s, _ = P.solve(opt)
+            assert s["termination_name"] == "CONVERGENCE" and s["iterations"] == want["iterations"]
+            assert abs(s["final_cost"] - want["final_cost"]) <= 1e-9 * want["final_cost"]
+            P.set_params(poisoned.cam6, poisoned.pt3, prob.focal)
+            s, _ = P.solve(opt)
+            assert s["termination_name"] == "FAILURE" and s["iterations"] == 0
+        P.set_params(prob.cam6, prob.pt3, float("nan"))
+        s, _ = P.solve(opt)
+        assert s["termination_name"] == "FAILURE"
+        P.set_params(prob.cam6, prob.pt3, prob.focal)
+        s, _ = P.solve(opt)
+        assert s["termination_name"] == "CONVERGENCE" and abs(s["final_cost"] - want["final_cost"]) <= 1e-9 * want["final_cost"]
