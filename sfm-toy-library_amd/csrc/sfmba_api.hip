@@ -492,7 +492,25 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
     p->h_lm_mail[0] = 0; p->h_lm_mail[1] = -1;
     for (;;) {
         if (o.max_seconds > 0.0 && now_seconds() - t0 >= o.max_seconds) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_TIME; break; }
-        if (host_iter >= o.max_iters) { term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS; break; }
+        if (host_iter >= o.max_iters) {
+            term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS;
+            if (host_iter == 0) {
+                // max_iters <= 0: Ceres still evaluates iteration 0 -- cost, gradient; the gradient tolerance (or a non-finite evaluation) may end the run there --
+                // before it looks at the iteration limit [Ceres-upstream: TrustRegionMinimizer::IterationZero], and reports that cost as the final one
+                // (tests/fuzz_parity.py --options: the summary used to come back with a cost of 0)
+                launch_point_build<T>(p->stream, p->ds, p->db, o.jacobi_scaling ? 1 : 2);
+                launch_cam_diag<T>(p->stream, p->ds, p->db);
+                launch_schur_pairs<T>(p->stream, p->ds, p->db, 2);
+                launch_schur_pairs<T>(p->stream, p->ds, p->db, 0);
+                launch_finalize(p->stream, p->ds, p->db, 0);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(p->stream));
+                rc = download_state(p);
+                if (rc) return rc;
+                if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; }
+            }
+            break;
+        }
         Profiler* prof = p->prof.on ? &p->prof : nullptr;
         const bool pcg = pcg_mode && !(exact_pcg && auto_prefers_cholesky);
         if (pcg) {

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="include shapes above 213 cameras (streaming CG; the oracle takes seconds each)")
+    ap.add_argument("--options", action="store_true", help="random LM options as well (the same on both sides): iteration limits 0 / 1 / 3 / 50, initial radius 1e-2 .. 1e12, "
+                                                           "tolerances 0 .. 1e-3, Jacobi scaling off, a tight diagonal clamp, min_relative_decrease, max_radius")
     ap.add_argument("--only", type=int, default=-1, help="run this case of the sequence alone (the random stream is advanced through the others) and print its traces")
     args = ap.parse_args()
     import sfm_toy_library_amd as sfm
@@ -80,9 +82,22 @@ def main():
             continue
         if args.only >= 0:
             resident = True
-        opt_o = sfm.SfmbaOptions.defaults(max_seconds=0.0)
+        okw = {}
+        if args.options:
+            if rng.random() < 0.5: okw["max_iters"] = int(rng.choice([0, 1, 3, 50]))
+            if rng.random() < 0.4: okw["initial_radius"] = float(rng.choice([1e-2, 1.0, 1e2, 1e8, 1e12]))
+            if rng.random() < 0.3: okw["function_tolerance"] = float(rng.choice([0.0, 1e-12, 1e-3]))
+            if rng.random() < 0.2: okw["gradient_tolerance"] = float(rng.choice([0.0, 1e-4, 1.0]))
+            if rng.random() < 0.2: okw["parameter_tolerance"] = float(rng.choice([0.0, 1e-4]))
+            if rng.random() < 0.2: okw["jacobi_scaling"] = 0
+            if rng.random() < 0.15: okw["min_lm_diagonal"], okw["max_lm_diagonal"] = 1e-2, 1e2
+            if rng.random() < 0.15: okw["min_relative_decrease"] = float(rng.choice([0.0, 0.25]))
+            if rng.random() < 0.15: okw["max_radius"] = float(rng.choice([1e4, 1e6]))
+            if rng.random() < 0.1: okw["max_consecutive_invalid_steps"] = 1
+            if "function_tolerance" in okw and okw["function_tolerance"] == 0.0 and "max_iters" not in okw: okw["max_iters"] = 60       # (bounded)
+        opt_o = sfm.SfmbaOptions.defaults(max_seconds=0.0, **okw)
         cam_o, pt_o, f_o, s_o, tr_o = oracle.solve(prob, opt_o)
-        opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear)
+        opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **okw)
         try:
             if not resident:
                 cam, pt, f, s, tr = capi.solve(prob, opt)
@@ -133,7 +148,7 @@ def main():
         rel = abs(s["final_cost"] - s_o["final_cost"]) / scale
         key = (precision, linear)
         worst[key] = max(worst.get(key, 0.0), rel)
-        desc = "n_cam %d n_pt %d n_obs %d views %s noise %.1f %s precision %d linear %d %s" % (n_cam, prob.n_pt, prob.n_obs, views, noise, what, precision, linear, how)
+        desc = "n_cam %d n_pt %d n_obs %d views %s noise %.1f %s precision %d linear %d %s%s" % (n_cam, prob.n_pt, prob.n_obs, views, noise, what, precision, linear, how, (" " + repr(okw)) if okw else "")
         if s["termination_name"] != s_o["termination_name"] or not (rel <= bar):
             # a cost inside the rounding floor of an exactly satisfiable problem compares against the initial cost
             floor = 1e-12 * abs(s_o["initial_cost"]) + prob.n_obs * np.sqrt(2.0 * max(s_o["final_cost"], 0.0) / max(prob.n_obs, 1)) * 1e-11
@@ -158,7 +173,7 @@ def main():
                     tr[first]["cost"], tr[first]["step_is_successful"], tr[first]["trust_region_radius"]))
             if not exact:
                 # the same problem in the reference's own arithmetic (fp64, factorised): does THAT follow the oracle?
-                c2, p2, f2, s2, tr2 = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=0))
+                c2, p2, f2, s2, tr2 = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=0, linear_solver=0, **okw))
                 rel2 = abs(s2["final_cost"] - s_o["final_cost"]) / scale
                 off = s2["termination_name"] != s_o["termination_name"] or s2["iterations"] != s_o["iterations"] or (rel2 > 1e-7 and abs(s2["final_cost"] - s_o["final_cost"]) > floor)
                 long2 = off and s_o["iterations"] > LONG_RUN and s2["termination_name"] == s_o["termination_name"] and rel2 <= 1e-3
@@ -170,7 +185,7 @@ def main():
                 for pr, li in ((1, 0), (0, 1)):
                     if (pr, li) == (precision, linear):
                         continue
-                    s3 = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=pr, linear_solver=li))[3]
+                    s3 = capi.solve(prob, capi.default_options(max_seconds=0.0, precision=pr, linear_solver=li, **okw))[3]
                     print("        precision %d linear %d: %s it %d cost %.12e (rel %.2e)" % (pr, li, s3["termination_name"], s3["iterations"], s3["final_cost"],
                                                                                        abs(s3["final_cost"] - s_o["final_cost"]) / scale))
         elif s["iterations"] != s_o["iterations"] and exact and s_o["final_cost"] > 1e-9 * s_o["initial_cost"]:

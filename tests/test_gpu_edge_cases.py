@@ -194,3 +194,27 @@ def test_a_handle_recovers_from_non_finite_parameters(capi, sfm, precision, line
         P.set_params(prob.cam6, prob.pt3, prob.focal)
         s, _ = P.solve(opt)
         assert s["termination_name"] == "CONVERGENCE" and abs(s["final_cost"] - want["final_cost"]) <= 1e-9 * want["final_cost"]
+
+
+@pytest.mark.parametrize("precision,linear", [(0, 0), (0, 2), (1, 1)])
+def test_iteration_limits_zero_and_one_follow_the_oracle(capi, sfm, oracle, precision, linear):
+    """max_iters = 0: Ceres evaluates iteration 0 before it looks at the limit -- NO_CONVERGENCE with the INITIAL cost as the final one (the summary used to
+    carry a final cost of 0: tests/fuzz_parity.py --options), or CONVERGENCE if the gradient tolerance is already met there; max_iters = 1: one step."""
+    prob = sfm.make_problem("cfg2", n_cam=9, n_pt=500, views=4, seed=4242)
+    for kw in (dict(max_iters=0), dict(max_iters=1), dict(max_iters=0, gradient_tolerance=1e30)):
+        want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0, **kw))[3]
+        for how in ("one-shot", "resident"):
+            opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **kw)
+            if how == "one-shot":
+                cam, pt, f, s, tr = capi.solve(prob, opt)
+            else:
+                with capi.Problem(prob, precision=precision) as P:
+                    P.solve(opt)
+                    P.reset()
+                    s, tr = P.solve(opt)
+                    cam, pt, f = P.get_params()
+            assert s["termination_name"] == want["termination_name"] and s["iterations"] == want["iterations"], (kw, how, s, want)
+            assert np.isclose(s["initial_cost"], want["initial_cost"], rtol=1e-9) and np.isclose(s["final_cost"], want["final_cost"], rtol=1e-6)
+            assert len(tr) == want["iterations"] + 1
+            if kw["max_iters"] == 0:
+                assert s["final_cost"] == s["initial_cost"] and np.array_equal(cam, prob.cam6) and np.array_equal(pt, prob.pt3) and f == prob.focal
