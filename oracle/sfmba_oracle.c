@@ -857,14 +857,10 @@ static void lm_trust_region(const lm_model* m, const sfmba_options* optp, sfmba_
     it.iteration = 0; it.cost = cost; it.trust_region_radius = radius;
     trace_push(trace, trace_cap, &tl, &it);
     if (opt.verbose) fprintf(stderr, "[oracle] it %3d cost %.12e |g|inf %.3e radius %.3e\n", 0, cost, it.gradient_max_norm, radius);
-    if (it.gradient_max_norm <= opt.gradient_tolerance) {
-        sum.termination = SFMBA_CONVERGENCE;
-        snprintf(sum.message, sizeof(sum.message), "Gradient tolerance reached.");
-        goto done;
-    }
-
     for (;;) {
-        /* FinalizeIterationAndCheckIfMinimizerCanContinue() */
+        /* FinalizeIterationAndCheckIfMinimizerCanContinue(): "a. run time  b. iteration count  c. max norm of the gradient  d. size of the trust region
+         * radius" [Ceres-upstream, in that order: an iteration that meets the gradient tolerance AND the iteration limit ends as NO_CONVERGENCE --
+         * tests/fuzz_parity.py --options found the two the other way round here; it.gradient_max_norm of a rejected or invalid step is the previous one] */
         if (opt.max_seconds > 0.0 && wall_seconds() - t_start >= opt.max_seconds) {
             sum.termination = SFMBA_NO_CONVERGENCE;
             snprintf(sum.message, sizeof(sum.message), "Maximum solver time reached.");
@@ -873,6 +869,16 @@ static void lm_trust_region(const lm_model* m, const sfmba_options* optp, sfmba_
         if (it.iteration >= opt.max_iters) {
             sum.termination = SFMBA_NO_CONVERGENCE;
             snprintf(sum.message, sizeof(sum.message), "Maximum number of iterations reached.");
+            break;
+        }
+        if (it.gradient_max_norm <= opt.gradient_tolerance) {
+            sum.termination = SFMBA_CONVERGENCE;
+            snprintf(sum.message, sizeof(sum.message), "Gradient tolerance reached.");
+            break;
+        }
+        if (radius <= opt.min_radius) {
+            sum.termination = SFMBA_CONVERGENCE;
+            snprintf(sum.message, sizeof(sum.message), "Minimum trust region radius reached.");
             break;
         }
         const double prev_gmax = it.gradient_max_norm;
@@ -987,17 +993,7 @@ static void lm_trust_region(const lm_model* m, const sfmba_options* optp, sfmba_
             fprintf(stderr, "[oracle] it %3d cost %.12e dcost %.3e |g|inf %.3e |step| %.3e rho %.3e radius %.3e %s\n",
                     it.iteration, cost, it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, radius,
                     it.step_is_successful ? "ok" : "rejected");
-        /* remaining checks of FinalizeIterationAndCheckIfMinimizerCanContinue() */
-        if (it.step_is_successful && it.gradient_max_norm <= opt.gradient_tolerance) {
-            sum.termination = SFMBA_CONVERGENCE;
-            snprintf(sum.message, sizeof(sum.message), "Gradient tolerance reached.");
-            break;
-        }
-        if (radius <= opt.min_radius) {
-            sum.termination = SFMBA_CONVERGENCE;
-            snprintf(sum.message, sizeof(sum.message), "Minimum trust region radius reached.");
-            break;
-        }
+        /* (the checks of FinalizeIterationAndCheckIfMinimizerCanContinue() follow at the top of the loop) */
     }
 done:
     *cost_out = cost;

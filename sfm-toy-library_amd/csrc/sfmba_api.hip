@@ -495,8 +495,9 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
         if (host_iter >= o.max_iters) {
             term = SFMBA_NO_CONVERGENCE; msg = MSG_MAX_ITERS;
             if (host_iter == 0) {
-                // max_iters <= 0: Ceres still evaluates iteration 0 -- cost, gradient; the gradient tolerance (or a non-finite evaluation) may end the run there --
-                // before it looks at the iteration limit [Ceres-upstream: TrustRegionMinimizer::IterationZero], and reports that cost as the final one
+                // max_iters <= 0: Ceres still evaluates iteration 0 [Ceres-upstream: TrustRegionMinimizer::IterationZero] -- a non-finite evaluation ends the run
+                // there as FAILURE -- and reports that cost as the final one; then the iteration limit is looked at BEFORE the gradient tolerance
+                // (FinalizeIterationAndCheckIfMinimizerCanContinue: run time, iteration count, gradient, radius): NO_CONVERGENCE even at a stationary point
                 // (tests/fuzz_parity.py --options: the summary used to come back with a cost of 0)
                 launch_point_build<T>(p->stream, p->ds, p->db, o.jacobi_scaling ? 1 : 2);
                 launch_cam_diag<T>(p->stream, p->ds, p->db);
@@ -507,7 +508,7 @@ int run_solve(sfmba_problem* p, const sfmba_options& o, sfmba_summary* summary, 
                 HIP_TRY(hipStreamSynchronize(p->stream));
                 rc = download_state(p);
                 if (rc) return rc;
-                if (p->h_state->termination != -1) { term = p->h_state->termination; msg = p->h_state->message; }
+                if (p->h_state->termination == SFMBA_FAILURE) { term = p->h_state->termination; msg = p->h_state->message; }
             }
             break;
         }

@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="shapes above 213 cameras as well (the streaming CG on one triangle; the oracle takes seconds each)")
     args = ap.parse_args()
     import sfm_toy_library_amd as sfm
     from sfm_toy_library_amd import capi
@@ -58,6 +59,9 @@ def main():
         n_cam = int(rng.choice([2, 3, 5, 8, 14, 25, 43, 44, 60, 90]))
         views = (2, min(n_cam, int(rng.integers(2, 9))))
         n_pt = int(rng.choice([40, 150, 600, 1500]))
+        if args.big and rng.random() < 0.6:
+            n_cam, n_pt = int(rng.choice([214, 230, 260])), int(rng.choice([2500, 5000]))
+            views = (3, int(rng.integers(4, 9)))
         prob = sfm.make_problem("cfg2", n_cam=n_cam, n_pt=n_pt, views=views, seed=int(rng.integers(1, 1 << 30)), noise_px=float(rng.choice([0.0, 0.5, 2.0]))).copy()
         precision = int(rng.integers(0, 2))
         linear = int(rng.integers(0, 3))

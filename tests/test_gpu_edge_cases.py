@@ -199,10 +199,19 @@ def test_a_handle_recovers_from_non_finite_parameters(capi, sfm, precision, line
 @pytest.mark.parametrize("precision,linear", [(0, 0), (0, 2), (1, 1)])
 def test_iteration_limits_zero_and_one_follow_the_oracle(capi, sfm, oracle, precision, linear):
     """max_iters = 0: Ceres evaluates iteration 0 before it looks at the limit -- NO_CONVERGENCE with the INITIAL cost as the final one (the summary used to
-    carry a final cost of 0: tests/fuzz_parity.py --options), or CONVERGENCE if the gradient tolerance is already met there; max_iters = 1: one step."""
+    carry a final cost of 0: tests/fuzz_parity.py --options) -- and it looks at the limit BEFORE the gradient tolerance (FinalizeIterationAndCheckIfMinimizerCanContinue:
+    run time, iteration count, gradient, radius): a start that already meets the gradient tolerance is NO_CONVERGENCE with max_iters = 0 and CONVERGENCE
+    at iteration 0 with max_iters = 1; a first step that lands on the gradient tolerance is NO_CONVERGENCE with max_iters = 1, CONVERGENCE with 2."""
     prob = sfm.make_problem("cfg2", n_cam=9, n_pt=500, views=4, seed=4242)
-    for kw in (dict(max_iters=0), dict(max_iters=1), dict(max_iters=0, gradient_tolerance=1e30)):
+    tr0 = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0))[4]
+    g01 = float(np.sqrt(tr0[0]["gradient_max_norm"] * tr0[1]["gradient_max_norm"]))          # between the gradient at the start and after the first step
+    assert tr0[1]["step_is_successful"] and tr0[1]["gradient_max_norm"] < 0.5 * g01 < 0.5 * tr0[0]["gradient_max_norm"]
+    cases = [(dict(max_iters=0), "NO_CONVERGENCE", 0), (dict(max_iters=1), "NO_CONVERGENCE", 1),
+             (dict(max_iters=0, gradient_tolerance=1e30), "NO_CONVERGENCE", 0), (dict(max_iters=1, gradient_tolerance=1e30), "CONVERGENCE", 0),
+             (dict(max_iters=1, gradient_tolerance=g01), "NO_CONVERGENCE", 1), (dict(max_iters=2, gradient_tolerance=g01), "CONVERGENCE", 1)]
+    for kw, term, iters in cases:
         want = oracle.solve(prob, sfm.SfmbaOptions.defaults(max_seconds=0.0, **kw))[3]
+        assert (want["termination_name"], want["iterations"]) == (term, iters), (kw, want)
         for how in ("one-shot", "resident"):
             opt = capi.default_options(max_seconds=0.0, precision=precision, linear_solver=linear, **kw)
             if how == "one-shot":
@@ -213,8 +222,8 @@ def test_iteration_limits_zero_and_one_follow_the_oracle(capi, sfm, oracle, prec
                     P.reset()
                     s, tr = P.solve(opt)
                     cam, pt, f = P.get_params()
-            assert s["termination_name"] == want["termination_name"] and s["iterations"] == want["iterations"], (kw, how, s, want)
+            assert (s["termination_name"], s["iterations"]) == (term, iters), (kw, how, s)
             assert np.isclose(s["initial_cost"], want["initial_cost"], rtol=1e-9) and np.isclose(s["final_cost"], want["final_cost"], rtol=1e-6)
-            assert len(tr) == want["iterations"] + 1
-            if kw["max_iters"] == 0:
+            assert len(tr) == iters + 1
+            if iters == 0:
                 assert s["final_cost"] == s["initial_cost"] and np.array_equal(cam, prob.cam6) and np.array_equal(pt, prob.pt3) and f == prob.focal
